@@ -1,0 +1,92 @@
+"""ctypes binding of libddp_hip.so (the C ABI declared in include/ddp_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `python -m diffdock_pocket_amd.build`.  There is NO
+fallback: if the shared object is missing or a symbol is absent, loading raises - the product never routes
+through PyTorch eager or the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libddp_hip.so")
+
+DDP_MAX_TASKS, DDP_MAX_BLOCKS, DDP_MAX_SEGS, DDP_MAX_NS, DDP_EDGE_TILE = 9, 4, 3, 64, 64
+F_SCALAR_S0, F_DOT, F_SCALAR_S1, F_VEC_S0, F_CROSS = range(5)
+FS = 68  # feature-buffer row stride of ddp_conv.hip
+
+EXPORTS = ["ddp_conv_messages", "ddp_segment_reduce", "ddp_edge_featurize", "ddp_torsion_sh", "ddp_abi_version",
+           "ddp_last_error"]
+
+
+class Seg(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("in_off", C.c_int32), ("count", C.c_int32)]
+
+
+class Block(C.Structure):
+    _fields_ = [("U", C.c_int32), ("n", C.c_int32), ("C", C.c_int32), ("out_off", C.c_int32), ("tile0", C.c_int32),
+                ("ntiles", C.c_int32), ("nsub", C.c_int32), ("ups", C.c_int32), ("nseg", C.c_int32),
+                ("seg", Seg * DDP_MAX_SEGS)]
+
+
+class ConvShape(C.Structure):
+    _fields_ = [("f_in", C.c_int32), ("hid", C.c_int32), ("kp1", C.c_int32), ("hp", C.c_int32), ("hs", C.c_int32),
+                ("nct1", C.c_int32), ("d_out", C.c_int32), ("nblocks", C.c_int32), ("fbuf_floats", C.c_int32),
+                ("blk", Block * DDP_MAX_BLOCKS)]
+
+
+class ConvTask(C.Structure):
+    _fields_ = [("x_src", C.c_void_p), ("ldx_src", C.c_int32), ("n_edges", C.c_int32), ("src", C.c_void_p),
+                ("eid", C.c_void_p), ("sh", C.c_void_p), ("seg_ptr", C.c_void_p * DDP_MAX_SEGS),
+                ("seg_idx", C.c_void_p * DDP_MAX_SEGS), ("seg_ld", C.c_int32 * DDP_MAX_SEGS),
+                ("seg_n", C.c_int32 * DDP_MAX_SEGS), ("w1p", C.c_void_p), ("b1p", C.c_void_p), ("w2p", C.c_void_p),
+                ("b2p", C.c_void_p), ("msg", C.c_void_p)]
+
+
+class ReduceSrc(C.Structure):
+    _fields_ = [("msg", C.c_void_p), ("rowptr", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p),
+                ("n_edges", C.c_int32)]
+
+
+class DdpError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libddp_hip.so (once).  Raises if it is missing: there is no non-HIP product path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DdpError(f"{LIB_PATH} not found: build it with `python -m diffdock_pocket_amd.build` "
+                       f"(hipcc --offload-arch=gfx950); there is no fallback path")
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise DdpError(f"{LIB_PATH} does not export {name}")
+    lib.ddp_abi_version.restype = C.c_int
+    lib.ddp_last_error.restype = C.c_char_p
+    lib.ddp_conv_messages.argtypes = [C.POINTER(ConvShape), C.POINTER(ConvTask), C.c_int, C.c_void_p]
+    lib.ddp_conv_messages.restype = C.c_int
+    lib.ddp_segment_reduce.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(ReduceSrc), C.c_int, C.c_int,
+                                       C.c_void_p]
+    lib.ddp_segment_reduce.restype = C.c_int
+    lib.ddp_edge_featurize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                       C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ddp_edge_featurize.restype = C.c_int
+    lib.ddp_torsion_sh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.ddp_torsion_sh.restype = C.c_int
+    if lib.ddp_abi_version() != 1:
+        raise DdpError("libddp_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise DdpError(f"{what} failed (rc={rc}): {load().ddp_last_error().decode()}")

@@ -1,0 +1,36 @@
+"""Build libddp_hip.so in-tree for gfx950:  python -m diffdock_pocket_amd.build
+(hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the gpurun snapshot)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SOURCES = ["ddp_conv.hip", "ddp_misc.hip", "ddp_capi.hip"]
+OUT = os.path.join(HERE, "libddp_hip.so")
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(HERE, "csrc", s) for s in SOURCES] + [os.path.join(HERE, "csrc", "ddp_internal.h"),
+                                                               os.path.join(ROOT, "include", "ddp_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), "-o", OUT]
+    cmd += [os.path.join(HERE, "csrc", s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

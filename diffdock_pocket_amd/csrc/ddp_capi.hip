@@ -1,0 +1,21 @@
+// ddp_capi.hip - error bookkeeping and ABI version of libddp_hip.so.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+#include "ddp_hip.h"
+#include "ddp_internal.h"
+
+static thread_local char g_err[256] = "ok";
+
+int ddp_fail(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+
+int ddp_fail_hip(hipError_t err, const char* where) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(err));
+  return (int)err;
+}
+
+extern "C" int ddp_abi_version(void) { return DDP_ABI_VERSION; }
+extern "C" const char* ddp_last_error(void) { return g_err; }

@@ -1,0 +1,202 @@
+// ddp_misc.hip - the HBM-bound kernels around the fused conv (gfx950):
+//   ddp_segment_reduce   CSR segmented mean + e3nn BatchNorm(eval) + residual accumulate
+//   ddp_edge_featurize   edge vector -> RBF -> 2-layer MLP, spherical harmonics (lmax = 1)
+//   ddp_torsion_sh       closed-form 1o block of FullTensorProduct(sh, Y2(bond))
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ddp_hip.h"
+#include "ddp_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------ segment reduce
+// Replaces torch_scatter.scatter(reduce='mean') (reference models/score_model.py:117), e3nn BatchNorm in eval
+// mode (:123-124) and the pad + add residual (models/all_atom_score_model.py:315-324).
+// One workgroup per receiving node, one thread per output channel: the node's incoming messages are consecutive
+// rows of `msg` (CSR order), so every row read is a fully coalesced d_out*4-byte burst and the sum order is the
+// CSR order (deterministic).  Algorithmic bytes: 4*d_out per edge read + 8*d_out per node (x read + write).
+struct ReduceLaunch {
+  ddp_reduce_src_t src[3];
+  int nsrc;
+};
+
+__global__ void ddp_segment_reduce_kernel(float* __restrict__ x, int ldx, int n_nodes, int d_out, ReduceLaunch L,
+                                          int accumulate) {
+  const int node = blockIdx.x;
+  const int ch = threadIdx.x;
+  if (ch >= d_out) return;
+  float* dst = x + (size_t)node * ldx + ch;
+  // same association as the reference's `x + u_a + u_b + u_c` (all_atom_score_model.py:316,320,324)
+  float total = accumulate ? *dst : 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (k < L.nsrc) {
+      const ddp_reduce_src_t& s = L.src[k];
+      const int p0 = s.rowptr[node], p1 = s.rowptr[node + 1];
+      float sum = 0.f;
+      for (int p = p0; p < p1; ++p) sum += s.msg[(size_t)p * d_out + ch];
+      const int cnt = p1 - p0;
+      const float mean = sum / (float)(cnt > 1 ? cnt : 1);
+      total += mean * s.bn_scale[ch] + s.bn_shift[ch];
+    }
+  }
+  *dst = total;
+}
+
+extern "C" int ddp_segment_reduce(float* x, int ldx, int n_nodes, int d_out, const ddp_reduce_src_t* srcs, int nsrc,
+                                  int accumulate, void* stream) {
+  if (!x || (!srcs && nsrc > 0)) return ddp_fail(DDP_EINVAL, "ddp_segment_reduce: null argument");
+  if (nsrc < 0 || nsrc > 3) return ddp_fail(DDP_ELIMIT, "ddp_segment_reduce: nsrc > 3");
+  if (d_out < 1 || d_out > 1024) return ddp_fail(DDP_ELIMIT, "ddp_segment_reduce: d_out");
+  if (n_nodes <= 0) return 0;
+  ReduceLaunch L;
+  L.nsrc = 0;
+  for (int i = 0; i < nsrc; ++i)
+    if (srcs[i].n_edges > 0) L.src[L.nsrc++] = srcs[i];  // an empty conv contributes exactly 0 (score_model.py:109-111)
+  if (L.nsrc == 0 && accumulate) return 0;
+  const int threads = ((d_out + 63) / 64) * 64;
+  hipLaunchKernelGGL(ddp_segment_reduce_kernel, dim3(n_nodes), dim3(threads), 0, (hipStream_t)stream, x, ldx, n_nodes,
+                     d_out, L, accumulate);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return ddp_fail_hip(err, "ddp_segment_reduce launch");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ edge featurise
+// One thread per edge; the (zero-padded to 64) MLP weights live in LDS and are read as wave-wide broadcasts.
+// Output rows are transposed through LDS so the [E, ns] store is coalesced.
+#define EF_NS 64
+__global__ __launch_bounds__(256) void ddp_edge_featurize_kernel(
+    const float* __restrict__ pos_a, const int* __restrict__ ia, const float* __restrict__ pos_b,
+    const int* __restrict__ ib, int n_edges, const float* __restrict__ offset, int k_rbf, float coeff,
+    const float* __restrict__ pre, const int* __restrict__ pre_idx, int ld_pre, const float* __restrict__ w1d,
+    const float* __restrict__ w2, const float* __restrict__ b2, int ns, float* __restrict__ out,
+    float* __restrict__ sh) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_w1 = smem;                       // [k_rbf][64]
+  float* s_w2 = s_w1 + k_rbf * EF_NS;       // [64][64]
+  float* s_b2 = s_w2 + EF_NS * EF_NS;       // [64]
+  float* s_off = s_b2 + EF_NS;              // [k_rbf]
+  float* s_out = s_off + ((k_rbf + 3) & ~3);  // [4 waves][64 edges][65]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < k_rbf * EF_NS; i += 256) s_w1[i] = w1d[i];
+  for (int i = tid; i < EF_NS * EF_NS; i += 256) s_w2[i] = w2[i];
+  if (tid < EF_NS) s_b2[tid] = b2[tid];
+  for (int i = tid; i < k_rbf; i += 256) s_off[i] = offset[i];
+  __syncthreads();
+
+  const int wave = tid >> 6, lane = tid & 63;
+  float* my_out = s_out + wave * 64 * 65;
+  for (int base = blockIdx.x * 256; base < n_edges; base += gridDim.x * 256) {
+    const int e = base + tid;
+    const bool live = e < n_edges;
+    const int ec = live ? e : n_edges - 1;
+    const int a = ia[ec], b = ib[ec];
+    const float vx = pos_b[3 * b] - pos_a[3 * a], vy = pos_b[3 * b + 1] - pos_a[3 * a + 1],
+                vz = pos_b[3 * b + 2] - pos_a[3 * a + 2];
+    const float d = sqrtf(vx * vx + vy * vy + vz * vz);
+    const float inv = 1.7320508075688772f / fmaxf(d, 1e-12f);  // sqrt(3) / max(|v|, eps)  (F.normalize eps)
+    if (live) reinterpret_cast<f32x4*>(sh)[e] = f32x4{1.0f, vx * inv, vy * inv, vz * inv};
+
+    float hid[EF_NS];
+    const float* prow = pre + (size_t)pre_idx[ec] * ld_pre;
+#pragma unroll
+    for (int j = 0; j < EF_NS; ++j) hid[j] = (j < ns) ? prow[j] : 0.f;
+    for (int k = 0; k < k_rbf; ++k) {
+      const float t = d - s_off[k];
+      const float rb = expf(coeff * (t * t));
+      const f32x4* wrow = reinterpret_cast<const f32x4*>(s_w1 + k * EF_NS);
+#pragma unroll
+      for (int j4 = 0; j4 < EF_NS / 4; ++j4) {
+        const f32x4 w = wrow[j4];
+        hid[4 * j4 + 0] += rb * w[0];
+        hid[4 * j4 + 1] += rb * w[1];
+        hid[4 * j4 + 2] += rb * w[2];
+        hid[4 * j4 + 3] += rb * w[3];
+      }
+    }
+    // second layer, 16 outputs at a time to bound register use; results go to LDS transposed
+#pragma unroll
+    for (int oc = 0; oc < EF_NS / 16; ++oc) {
+      float o[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) o[q] = s_b2[16 * oc + q];
+#pragma unroll
+      for (int j = 0; j < EF_NS; ++j) {
+        const float hj = fmaxf(hid[j], 0.f);
+        const f32x4* wrow = reinterpret_cast<const f32x4*>(s_w2 + j * EF_NS + 16 * oc);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const f32x4 w = wrow[q4];
+          o[4 * q4 + 0] += hj * w[0];
+          o[4 * q4 + 1] += hj * w[1];
+          o[4 * q4 + 2] += hj * w[2];
+          o[4 * q4 + 3] += hj * w[3];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) my_out[lane * 65 + 16 * oc + q] = o[q];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // coalesced store of this wave's 64 rows x ns columns
+    const int ebase = base + wave * 64;
+    for (int i = lane; i < 64 * ns; i += 64) {
+      const int row = i / ns, col = i - row * ns;
+      if (ebase + row < n_edges) out[(size_t)(ebase + row) * ns + col] = my_out[row * 65 + col];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+extern "C" int ddp_edge_featurize(const float* pos_a, const int32_t* ia, const float* pos_b, const int32_t* ib,
+                                  int n_edges, const float* offset, int k_rbf, float coeff, const float* pre,
+                                  const int32_t* pre_idx, int ld_pre, const float* w1d, const float* w2, const float* b2,
+                                  int ns, float* out, float* sh, void* stream) {
+  if (n_edges <= 0) return 0;
+  if (!pos_a || !ia || !pos_b || !ib || !offset || !pre || !pre_idx || !w1d || !w2 || !b2 || !out || !sh)
+    return ddp_fail(DDP_EINVAL, "ddp_edge_featurize: null argument");
+  if (ns < 1 || ns > EF_NS) return ddp_fail(DDP_ELIMIT, "ddp_edge_featurize: ns > 64");
+  if (k_rbf < 2 || k_rbf > 256) return ddp_fail(DDP_ELIMIT, "ddp_edge_featurize: k_rbf");
+  const size_t lds = (size_t)(k_rbf * EF_NS + EF_NS * EF_NS + EF_NS + ((k_rbf + 3) & ~3) + 4 * 64 * 65) * sizeof(float);
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(ddp_edge_featurize_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (err != hipSuccess) return ddp_fail_hip(err, "hipFuncSetAttribute(edge_featurize)");
+  int blocks = (n_edges + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(ddp_edge_featurize_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, pos_a, ia, pos_b, ib,
+                     n_edges, offset, k_rbf, coeff, pre, pre_idx, ld_pre, w1d, w2, b2, ns, out, sh);
+  err = hipGetLastError();
+  if (err != hipSuccess) return ddp_fail_hip(err, "ddp_edge_featurize launch");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ torsion sh
+// t = sqrt(3/2) * (3 (n.v) v - n): the 1o block of o3.FullTensorProduct(sh(lmax=1), "2e") applied to
+// (sh(edge), Y2(bond)) (reference models/all_atom_score_model.py:394-395,418-419).
+__global__ void ddp_torsion_sh_kernel(const float* __restrict__ sh_edge, const float* __restrict__ bond_vec,
+                                      const int* __restrict__ bond_of_edge, int n_edges, float* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  const f32x4 s = reinterpret_cast<const f32x4*>(sh_edge)[e];
+  const float inv3 = 0.57735026918962576f;
+  const float nx = s[1] * inv3, ny = s[2] * inv3, nz = s[3] * inv3;  // unit edge vector
+  const int b = bond_of_edge[e];
+  float vx = bond_vec[3 * b], vy = bond_vec[3 * b + 1], vz = bond_vec[3 * b + 2];
+  const float vin = 1.0f / fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), 1e-12f);
+  vx *= vin; vy *= vin; vz *= vin;
+  const float dot3 = 3.0f * (nx * vx + ny * vy + nz * vz);
+  const float k = 1.2247448713915890f;  // sqrt(3/2)
+  reinterpret_cast<f32x4*>(out)[e] = f32x4{0.f, k * (dot3 * vx - nx), k * (dot3 * vy - ny), k * (dot3 * vz - nz)};
+}
+
+extern "C" int ddp_torsion_sh(const float* sh_edge, const float* bond_vec, const int32_t* bond_of_edge, int n_edges,
+                              float* out, void* stream) {
+  if (n_edges <= 0) return 0;
+  if (!sh_edge || !bond_vec || !bond_of_edge || !out) return ddp_fail(DDP_EINVAL, "ddp_torsion_sh: null argument");
+  hipLaunchKernelGGL(ddp_torsion_sh_kernel, dim3((n_edges + 255) / 256), dim3(256), 0, (hipStream_t)stream, sh_edge,
+                     bond_vec, bond_of_edge, n_edges, out);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return ddp_fail_hip(err, "ddp_torsion_sh launch");
+  return 0;
+}

@@ -1,0 +1,145 @@
+/*
+ * ddp_hip.h - C ABI of the MI355X-native DiffDock-Pocket score-model hot path (libddp_hip.so).
+ *
+ * The reference (plainerman/DiffDock-Pocket) is 100 % Python and has NO native boundary of its own: its
+ * "plugin API" for this path is the Python class TensorProductScoreModel
+ * (models/all_atom_score_model.py:21-436).  This header is the C-ABI layer underneath our drop-in for that
+ * class; each entry point names the reference code it replaces.  All pointers are DEVICE pointers owned by
+ * the caller (fp32 / int32), all launches are stream-ordered on `stream` (a hipStream_t passed as void*),
+ * no entry point allocates, frees or synchronises.  Return value: 0 on success, otherwise a hipError_t
+ * (>0) or a negative DDP_E* code; ddp_last_error() returns a static description.
+ *
+ * INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ */
+#ifndef DDP_HIP_H
+#define DDP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDP_ABI_VERSION 1
+#define DDP_EINVAL (-1)   /* bad argument (shape not supported, null pointer, ...) */
+#define DDP_ELIMIT (-2)   /* exceeds a compiled-in limit (see DDP_MAX_*) */
+
+#define DDP_MAX_TASKS 9   /* convs fused in one launch = the 9 convs of one layer (all_atom_score_model.py:118) */
+#define DDP_MAX_BLOCKS 4  /* weight blocks 0e,1o,1e,0o of FasterTensorProduct (models/layers.py:26-31) */
+#define DDP_MAX_SEGS 3
+#define DDP_MAX_NS 64     /* scalar multiplicity supported by the fixed-size register tiles */
+#define DDP_EDGE_TILE 64  /* edges per workgroup */
+
+/* How one group of tensor-product basis features is built from the gathered node irreps a[.] and the edge's
+ * spherical harmonics sh = [s0 | s1(3)]  (models/layers.py:40-53). */
+enum ddp_feat_kind {
+  DDP_F_SCALAR_S0 = 0, /* a[u] * s0                       scalar in -> scalar feature (:41, :53) */
+  DDP_F_DOT = 1,       /* dot(a3[u], s1) / sqrt(3)        vector in -> scalar feature (:44, :50) */
+  DDP_F_SCALAR_S1 = 2, /* a[u] * s1[c]                    scalar in -> vector feature (:42, :52) */
+  DDP_F_VEC_S0 = 3,    /* a3[u][c] * s0                   vector in -> vector feature (:45, :49) */
+  DDP_F_CROSS = 4      /* cross(a3[u], s1)[c] / sqrt(2)   vector in -> vector feature (:46, :48) */
+};
+
+typedef struct {
+  int32_t kind;   /* ddp_feat_kind */
+  int32_t in_off; /* first column of the input irreps block inside a node row */
+  int32_t count;  /* multiplicity (number of features this segment contributes) */
+} ddp_seg_t;
+
+/* One weight block: out[e, n(,c)] = sum_u F[e, u(,c)] * w[e, u, n]  (models/layers.py:55-80). */
+typedef struct {
+  int32_t U;       /* number of basis features (rows of the per-edge weight block) */
+  int32_t n;       /* output multiplicity */
+  int32_t C;       /* 1 = scalar block (0e/0o), 3 = vector block (1o/1e) */
+  int32_t out_off; /* first output column of this block in a message row */
+  int32_t tile0;   /* first 32-column tile of this block in the packed fc2 weight */
+  int32_t ntiles;  /* number of tiles */
+  int32_t nsub;    /* n > 32: tiles per feature (n split in 32-column pieces); else 1 */
+  int32_t ups;     /* n <= 32: features packed per tile = 32 / n; else 1 */
+  int32_t nseg;
+  ddp_seg_t seg[DDP_MAX_SEGS];
+} ddp_block_t;
+
+/* Static shape of a TensorProductConvLayer (models/score_model.py:84-107); shared by all tasks of a launch. */
+typedef struct {
+  int32_t f_in;  /* n_edge_features = width of edge_attr_ (3*ns, final_conv: 2*ns) */
+  int32_t hid;   /* hidden_features of fc (= n_edge_features) */
+  int32_t kp1;   /* f_in rounded up to 8 */
+  int32_t hp;    /* hid rounded up to 8 */
+  int32_t hs;    /* LDS row stride (floats) of the staged edge_attr_/h tiles */
+  int32_t nct1;  /* 32-column tiles of fc layer 1 = ceil(hid/32) */
+  int32_t d_out; /* message width */
+  int32_t nblocks;
+  int32_t fbuf_floats; /* LDS floats reserved for the per-block feature / reduction buffer */
+  ddp_block_t blk[DDP_MAX_BLOCKS];
+} ddp_conv_shape_t;
+
+/* One conv = one edge set + one set of weights.  Edge arrays are in CSR order of the RECEIVING node
+ * (edge_index[0], models/score_model.py:113,117). */
+typedef struct {
+  const float* x_src;   /* node features gathered by edge_index[1]          [n_src, ldx_src] */
+  int32_t ldx_src;
+  int32_t n_edges;
+  const int32_t* src;   /* edge_index[1] per CSR position                    [E] */
+  const int32_t* eid;   /* row of edge_sh / seg[0] for this CSR position     [E] */
+  const float* sh;      /* edge spherical harmonics, 4 floats per edge        [E_canonical, 4] */
+  /* edge_attr_ = cat(seg0[idx0], seg1[idx1], seg2[idx2]) (all_atom_score_model.py:273-312) */
+  const float* seg_ptr[DDP_MAX_SEGS];
+  const int32_t* seg_idx[DDP_MAX_SEGS];
+  int32_t seg_ld[DDP_MAX_SEGS];
+  int32_t seg_n[DDP_MAX_SEGS]; /* 0 = segment unused */
+  const float* w1p;     /* fc.0 weight, packed by ddp_pack (tile-major, K-interleaved) */
+  const float* b1p;
+  const float* w2p;     /* fc.3 weight, packed, 1/sqrt(U) folded in */
+  const float* b2p;
+  float* msg;           /* per-edge messages, CSR order                       [E, d_out] */
+} ddp_conv_task_t;
+
+/* Fused fc -> tensor product -> per-edge message for up to 9 convs that share one shape.
+ * Replaces: TensorProductConvLayer.forward up to (not including) the scatter
+ * (models/score_model.py:108-114) + FasterTensorProduct.forward (models/layers.py:34-85) + the edge_attr_
+ * concatenations (models/all_atom_score_model.py:273-312).  The [E, weight_numel] tensor never exists. */
+int ddp_conv_messages(const ddp_conv_shape_t* shape, const ddp_conv_task_t* tasks, int ntasks, void* stream);
+
+/* Segmented mean over CSR rows + e3nn BatchNorm (eval) + residual accumulate:
+ *   x[n, :d_out] (+)= sum_k ( mean_{p in rowptr_k[n]..rowptr_k[n+1]} msg_k[p, :] * bn_scale_k + bn_shift_k )
+ * for up to 3 incoming convs k whose n_edges > 0 (an empty conv contributes exactly 0, models/score_model.py:109-111).
+ * Replaces torch_scatter.scatter(reduce='mean') (score_model.py:117), e3nn BatchNorm (score_model.py:123-124)
+ * and the pad+add residual (all_atom_score_model.py:315-324).  accumulate=0 overwrites x instead. */
+typedef struct {
+  const float* msg;
+  const int32_t* rowptr; /* [n_nodes + 1] */
+  const float* bn_scale; /* [d_out]  weight / sqrt(running_var + eps), broadcast over vector components */
+  const float* bn_shift; /* [d_out]  bias - running_mean * scale on 0e channels, 0 elsewhere */
+  int32_t n_edges;
+} ddp_reduce_src_t;
+int ddp_segment_reduce(float* x, int ldx, int n_nodes, int d_out, const ddp_reduce_src_t* srcs, int nsrc,
+                       int accumulate, void* stream);
+
+/* Edge featurisation: edge vector -> length -> Gaussian RBF -> 2-layer MLP, and spherical harmonics (lmax=1).
+ *   vec = pos_b[ib[e]] - pos_a[ia[e]];  d = |vec|;  rbf_k = exp(coeff * (d - offset[k])^2)
+ *   hidden = relu(pre[pre_idx[e]] + W1d^T rbf);  out[e] = W2^T hidden + b2;  sh[e] = [1, sqrt(3) vec/|vec|]
+ * `pre` holds the part of the first Linear that does not depend on the distance (sigma embedding, bond type, bias).
+ * Replaces GaussianSmearing (models/score_model.py:661-671), o3.spherical_harmonics and the *_edge_embedding MLPs
+ * (models/all_atom_score_model.py:71-81,164-169,187-192,212-217 and the builders :444-636).
+ * w1d: [k_rbf, 64] (zero padded columns), w2: [64, 64] (zero padded), b2: [64]; out: [E, ns]; sh: [E, 4]; vec_out
+ * (optional, may be null): [E, 4] = (vec, d). */
+int ddp_edge_featurize(const float* pos_a, const int32_t* ia, const float* pos_b, const int32_t* ib, int n_edges,
+                       const float* offset, int k_rbf, float coeff, const float* pre, const int32_t* pre_idx, int ld_pre,
+                       const float* w1d, const float* w2, const float* b2, int ns, float* out, float* sh,
+                       void* stream);
+
+/* Torsion-head edge harmonics: the 1o block of FullTensorProduct(sh(edge), Y2(bond)) in closed form,
+ *   t[e] = sqrt(3/2) * (3 (n.v) v - n),  n = unit(sh edge vector), v = unit(bond vector of bond ib[e])
+ * written as [0, t] so the conv kernel reads it like an edge_sh row.
+ * Replaces all_atom_score_model.py:394-395,418-419 (o3.spherical_harmonics("2e") + o3.FullTensorProduct). */
+int ddp_torsion_sh(const float* sh_edge, const float* bond_vec, const int32_t* bond_of_edge, int n_edges, float* out,
+                   void* stream);
+
+int ddp_abi_version(void);
+const char* ddp_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDP_HIP_H */

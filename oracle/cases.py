@@ -1,0 +1,119 @@
+"""Seeded parity cases shared by the golden-vector generator and the tests (TEST INFRASTRUCTURE, oracle/).
+
+A case = (model configuration, synthetic-weight seed, a deterministic recipe for the input batch).  Everything
+is regenerated from seeds on whatever machine runs the test (same torch build in the container and on the GPU
+box); the golden files hold the reference's outputs, checksums of the regenerated inputs and the state_dict key
+layout.
+"""
+from __future__ import annotations
+
+import functools
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+from diffdock_pocket_amd.batch import HeteroBatch, collate, set_time
+from diffdock_pocket_amd.diffusion import SigmaRanges, get_timestep_embedding, t_to_sigma
+from diffdock_pocket_amd.synthetic import make_3dpf_complex
+
+from .ref_model import OracleConfig
+
+
+@dataclass
+class Case:
+    name: str
+    ns: int = 16
+    nv: int = 4
+    num_conv_layers: int = 2
+    embed: int = 32                       # sigma / distance / cross-distance embedding width
+    flexible_sidechains: bool = True
+    fixed_center_conv: bool = True
+    use_old_atom_encoder: bool = False
+    no_torsion: bool = False
+    n_graphs: int = 2
+    n_lig: Optional[int] = None           # truncation of the 3dpf complex (None = full)
+    n_rec: Optional[int] = None
+    n_atom: Optional[int] = None
+    t: List[float] = field(default_factory=lambda: [0.7, 0.35])   # per-graph diffusion time
+    lig_shift: float = 0.0                # extra translation of the ligand (A) to empty the lig-atom graph
+    drop_rotatable: bool = False          # edge_mask all False -> tor_pred empty
+    weight_seed: int = 0
+    data_seed: int = 0
+
+    def model_kwargs(self) -> Dict:
+        """kwargs for TensorProductScoreModel (reference ctor signature, README.md:72 settings)."""
+        return dict(sh_lmax=1, ns=self.ns, nv=self.nv, num_conv_layers=self.num_conv_layers,
+                    sigma_embed_dim=self.embed, distance_embed_dim=self.embed, cross_distance_embed_dim=self.embed,
+                    lig_max_radius=5.0, cross_max_distance=80.0, dynamic_max_cross=True, scale_by_sigma=True,
+                    batch_norm=True, dropout=0.0, lm_embedding_type="esm", fixed_center_conv=self.fixed_center_conv,
+                    atom_max_neighbors=8, flexible_sidechains=self.flexible_sidechains, no_torsion=self.no_torsion,
+                    use_old_atom_encoder=self.use_old_atom_encoder)
+
+    def oracle_config(self) -> OracleConfig:
+        return OracleConfig(ns=self.ns, nv=self.nv, num_conv_layers=self.num_conv_layers, sigma_embed_dim=self.embed,
+                            distance_embed_dim=self.embed, cross_distance_embed_dim=self.embed,
+                            flexible_sidechains=self.flexible_sidechains, fixed_center_conv=self.fixed_center_conv,
+                            use_old_atom_encoder=self.use_old_atom_encoder, no_torsion=self.no_torsion,
+                            embedding_scale=1000.0)
+
+    def ctor_extras(self):
+        sig = SigmaRanges()
+        return dict(t_to_sigma=functools.partial(t_to_sigma, args=sig), device=torch.device("cpu"),
+                    timestep_emb_func=get_timestep_embedding("sinusoidal", self.embed, 1000.0))
+
+    def make_batch(self) -> HeteroBatch:
+        """n_graphs copies of the (possibly truncated) 3dpf complex with different seeded ligand poses and
+        side-chain perturbations, per-graph times `t`."""
+        g = torch.Generator().manual_seed(1000 + self.data_seed)
+        graphs = []
+        for i in range(self.n_graphs):
+            c = make_3dpf_complex(seed=self.data_seed, flexible_sidechains=self.flexible_sidechains, n_lig=self.n_lig,
+                                  n_rec=self.n_rec, n_atom=self.n_atom)
+            pos = c["ligand"].pos
+            ctr = pos.mean(0, keepdim=True)
+            axis = torch.randn(3, generator=g)
+            axis = axis / axis.norm()
+            ang = float(torch.rand(1, generator=g)) * 0.6
+            K = torch.tensor([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+            R = torch.eye(3) + math.sin(ang) * K + (1 - math.cos(ang)) * (K @ K)
+            c["ligand"].pos = (pos - ctr) @ R.T + ctr + torch.randn(1, 3, generator=g) * 0.8 + self.lig_shift
+            c["atom"].pos = c["atom"].pos + torch.randn(c["atom"].pos.shape, generator=g) * 0.05
+            if self.drop_rotatable:
+                c["ligand"].edge_mask = torch.zeros_like(c["ligand"].edge_mask)
+            graphs.append(c)
+        batch = collate(graphs)
+        set_time(batch, 0.0, 0.0, 0.0, 0.0)
+        tt = torch.tensor(self.t[:self.n_graphs], dtype=torch.float32)
+        for nt in ("ligand", "receptor", "atom"):
+            b = batch[nt].batch
+            batch[nt].node_t = {k: tt[b].clone() for k in ("tr", "rot", "tor", "sc_tor")}
+        batch.complex_t = {k: tt.clone() for k in ("tr", "rot", "tor", "sc_tor")}
+        return batch
+
+
+CASES: Dict[str, Case] = {c.name: c for c in [
+    # BASELINE configs[0]: the reference's own CPU-runnable configuration on the full 3dpf complex
+    Case("cfg1_full", n_graphs=2),
+    # BASELINE configs[1]/[2] architecture (ns=60 nv=10 L=6, embeds 64) on a truncated pocket so the CPU oracle
+    # finishes in seconds
+    Case("cfg2_small", ns=60, nv=10, num_conv_layers=6, embed=64, n_graphs=2, n_rec=28, t=[0.9, 0.2]),
+    # no flexible side chains: last-layer atom/receptor convs are skipped, sc_tor_pred is empty
+    Case("cfg2_noflex", ns=60, nv=10, num_conv_layers=4, embed=64, flexible_sidechains=False, n_graphs=1, n_rec=20,
+         t=[0.5]),
+    # edge cases: ligand far from every atom (empty lig-atom conv -> scalar 0), no rotatable bond, three graphs at
+    # three times, legacy encoder and the non-fixed centre conv
+    Case("cfg1_edge", n_graphs=3, n_rec=24, t=[1.0, 0.5, 0.05], lig_shift=9.0, drop_rotatable=True,
+         use_old_atom_encoder=True, fixed_center_conv=False, data_seed=3),
+    Case("ns24_l3", ns=24, nv=6, num_conv_layers=3, embed=32, n_graphs=2, n_rec=24, t=[0.6, 0.4], weight_seed=5),
+]}
+
+
+def input_checksums(batch: HeteroBatch) -> Dict[str, float]:
+    return {
+        "lig_pos": float(batch["ligand"].pos.double().sum()), "atom_pos": float(batch["atom"].pos.double().abs().sum()),
+        "rec_x": float(batch["receptor"].x.double().abs().sum()), "lig_x": float(batch["ligand"].x.double().sum()),
+        "atom_x": float(batch["atom"].x.double().sum()), "n_lig": float(batch["ligand"].pos.shape[0]),
+        "n_atom": float(batch["atom"].pos.shape[0]), "n_rec": float(batch["receptor"].pos.shape[0]),
+    }
