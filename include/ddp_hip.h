@@ -88,7 +88,7 @@ typedef struct {
   const int32_t* seg_idx[DDP_MAX_SEGS];
   int32_t seg_ld[DDP_MAX_SEGS];
   int32_t seg_n[DDP_MAX_SEGS]; /* 0 = segment unused */
-  const float* w1p;     /* fc.0 weight, packed by ddp_pack (tile-major, K-interleaved) */
+  const float* w1p;     /* fc.0 weight, packed by packing.py (tile-major, K-interleaved) */
   const float* b1p;
   const float* w2p;     /* fc.3 weight, packed, 1/sqrt(U) folded in */
   const float* b2p;

@@ -1,0 +1,220 @@
+"""CPU tests of the host side: weight packing / shape descriptors (through a pure-torch emulation of the kernel's
+documented data flow), graph construction against the oracle's restated torch_cluster semantics, state_dict layout,
+C-ABI exports, and the no-fallback rule."""
+import ctypes
+import functools
+import os
+import re
+
+import pytest
+import torch
+
+from diffdock_pocket_amd import _lib as L
+from diffdock_pocket_amd import graph as G
+from diffdock_pocket_amd import packing as P
+from diffdock_pocket_amd.batch import collate
+from diffdock_pocket_amd.score_model import TensorProductScoreModel
+from oracle import thirdparty as tp
+from oracle.cases import CASES
+from oracle.ref_model import OracleConfig, faster_tensor_product
+
+from helpers import load_golden, golden_state_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def unpack_tiles(flat, ntiles, kp):
+    """inverse of the layout documented in csrc/ddp_conv.hip: -> [ntiles*32 columns, kp]"""
+    W = flat.reshape(ntiles, kp // 8, 2, 32, 4)            # [tile, m, hh, j, i]
+    return W.permute(0, 3, 1, 2, 4).reshape(ntiles * 32, kp)
+
+
+def emulate_conv(spec, w1p, b1p, w2p, b2p, edge_attr, x_src_rows, sh):
+    """What ddp_conv_messages_kernel computes for one conv, written with dense torch ops on the PACKED weights."""
+    E = edge_attr.shape[0]
+    W1 = unpack_tiles(w1p, spec.nct1, spec.kp1)            # [cols, kp1]
+    ea = torch.zeros(E, spec.kp1, dtype=torch.float64)
+    ea[:, :spec.f_in] = edge_attr
+    h = torch.relu(ea @ W1.double().T + b1p.double())[:, :spec.hp]
+    hp = torch.zeros(E, spec.hp, dtype=torch.float64)
+    hp[:, :h.shape[1]] = h
+    hp[:, spec.hid:] = 0
+    W2 = unpack_tiles(w2p, spec.ntiles, spec.hp).double()
+    acc = hp @ W2.T + b2p.double()                          # [E, ntiles*32]
+    out = torch.zeros(E, spec.d_out, dtype=torch.float64)
+    s0, s1 = sh[:, 0].double(), sh[:, 1:4].double()
+    x = x_src_rows.double()
+    for b in spec.blocks:
+        feats = []
+        for kind, off, cnt in b.segs:
+            if kind == L.F_SCALAR_S0:
+                feats.append((x[:, off:off + cnt] * s0[:, None])[:, :, None])
+            elif kind == L.F_DOT:
+                a = x[:, off:off + 3 * cnt].reshape(E, cnt, 3)
+                feats.append(((a * s1[:, None]).sum(-1) / 3 ** 0.5)[:, :, None])
+            elif kind == L.F_SCALAR_S1:
+                feats.append(x[:, off:off + cnt, None] * s1[:, None, :])
+            elif kind == L.F_VEC_S0:
+                feats.append(x[:, off:off + 3 * cnt].reshape(E, cnt, 3) * s0[:, None, None])
+            else:
+                a = x[:, off:off + 3 * cnt].reshape(E, cnt, 3)
+                feats.append(torch.linalg.cross(a, s1[:, None].expand_as(a), dim=-1) / 2 ** 0.5)
+        F = torch.cat(feats, 1)                             # [E, U, C]
+        assert F.shape[1] == b.U and F.shape[2] == b.C
+        for t in range(b.ntiles):
+            for j in range(32):
+                if b.nsub > 1:
+                    u, sub = divmod(t, b.nsub)
+                    ncol = sub * 32 + j
+                    valid = ncol < b.n and u < b.U
+                else:
+                    us, ncol = divmod(j, b.n)
+                    u = t * b.ups + us
+                    valid = us < b.ups and u < b.U
+                if not valid:
+                    assert float(acc[:, (b.tile0 + t) * 32 + j].abs().max()) == 0.0  # padded columns are exactly zero
+                    continue
+                for c in range(b.C):
+                    out[:, b.out_off + ncol * b.C + c] += F[:, u, c] * acc[:, (b.tile0 + t) * 32 + j]
+    return out
+
+
+@pytest.mark.parametrize("ns,nv,layer", [(16, 4, 0), (16, 4, 1), (24, 6, 2), (60, 10, 3), (60, 10, 0), (32, 6, 3)])
+def test_packed_conv_matches_faster_tensor_product(ns, nv, layer):
+    torch.manual_seed(layer + ns)
+    mi, mo = P.irreps_muls(ns, nv, layer), P.irreps_muls(ns, nv, layer + 1)
+    spec = P.faster_tp_spec(mi, mo, 3 * ns)
+    cfg = OracleConfig(ns=ns, nv=nv)
+    E = 7
+    fc0_w, fc0_b = torch.randn(3 * ns, 3 * ns) / (3 * ns) ** 0.5, torch.randn(3 * ns) * 0.1
+    fc3_w, fc3_b = torch.randn(spec.weight_numel, 3 * ns) / (3 * ns) ** 0.5, torch.randn(spec.weight_numel) * 0.1
+    ea, x, sh = torch.randn(E, 3 * ns), torch.randn(E, P.irreps_dim(mi)), torch.randn(E, 4)
+    w1p, b1p = P.pack_fc1(spec, fc0_w, fc0_b)
+    w2p, b2p = P.pack_fc2(spec, fc3_w, fc3_b)
+    got = emulate_conv(spec, w1p, b1p, w2p, b2p, ea, x, sh)
+    w = torch.relu(ea.double() @ fc0_w.double().T + fc0_b.double()) @ fc3_w.double().T + fc3_b.double()
+    want = faster_tensor_product(cfg.irreps(layer), cfg.irreps(layer + 1), x.double(), sh.double(), w)
+    assert torch.allclose(got, want, rtol=2e-5, atol=2e-6)
+    assert spec.weight_numel == fc3_w.shape[0]
+
+
+def test_final_conv_and_torsion_specs():
+    ns, nv = 16, 4
+    m = P.irreps_muls(ns, nv, 3)
+    spec = P.faster_tp_spec(m, (0, 2, 2, 0), 2 * ns)
+    assert spec.d_out == 12 and [b.ups for b in spec.blocks] == [16, 16]
+    E = 5
+    torch.manual_seed(0)
+    fc0_w, fc0_b = torch.randn(2 * ns, 2 * ns), torch.randn(2 * ns)
+    fc3_w, fc3_b = torch.randn(spec.weight_numel, 2 * ns), torch.randn(spec.weight_numel)
+    ea, x, sh = torch.randn(E, 2 * ns), torch.randn(E, P.irreps_dim(m)), torch.randn(E, 4)
+    got = emulate_conv(spec, *P.pack_fc1(spec, fc0_w, fc0_b), *P.pack_fc2(spec, fc3_w, fc3_b), ea, x, sh)
+    w = torch.relu(ea.double() @ fc0_w.double().T + fc0_b.double()) @ fc3_w.double().T + fc3_b.double()
+    want = faster_tensor_product(OracleConfig(ns=ns, nv=nv).irreps(3), "2x1o+2x1e", x.double(), sh.double(), w)
+    assert torch.allclose(got, want, rtol=2e-5, atol=2e-6)
+    # torsion conv against the restated e3nn FullyConnectedTensorProduct
+    tspec = P.torsion_tp_spec(m, ns, 3 * ns)
+    fctp = tp.FullyConnectedTensorProduct(OracleConfig(ns=ns, nv=nv).irreps(3), "1x1o+1x2e+1x2o+1x3o", f"{ns}x0o+{ns}x0e")
+    assert tspec.weight_numel == fctp.weight_numel
+    fc0_w, fc0_b = torch.randn(3 * ns, 3 * ns), torch.randn(3 * ns)
+    fc3_w, fc3_b = torch.randn(tspec.weight_numel, 3 * ns), torch.randn(tspec.weight_numel)
+    ea = torch.randn(E, 3 * ns)
+    t = torch.randn(E, 3)
+    tor_sh20 = torch.cat([t, torch.zeros(E, 17)], 1)
+    got = emulate_conv(tspec, *P.pack_fc1(tspec, fc0_w, fc0_b), *P.pack_fc2(tspec, fc3_w, fc3_b), ea, x,
+                       torch.cat([torch.zeros(E, 1), t], 1))
+    w = torch.relu(ea.double() @ fc0_w.double().T + fc0_b.double()) @ fc3_w.double().T + fc3_b.double()
+    want = fctp(x.double(), tor_sh20.double(), w)
+    assert torch.allclose(got, want, rtol=2e-5, atol=2e-6)
+
+
+def test_bn_affine_matches_restated_batchnorm():
+    torch.manual_seed(1)
+    ns, nv = 8, 3
+    blocks = [(ns, 1, True), (nv, 3, False), (nv, 3, False), (ns, 1, False)]
+    nf, nsc = 2 * ns + 2 * nv, ns
+    rm, rv, w, b = torch.randn(nsc), torch.rand(nf) + 0.5, torch.rand(nf) + 0.5, torch.randn(nsc)
+    x = torch.randn(11, 2 * ns + 6 * nv)
+    sc, sh = P.bn_affine(blocks, rm, rv, w, b)
+    want = tp.batch_norm_eval(f"{ns}x0e+{nv}x1o+{nv}x1e+{ns}x0o", x, rm, rv, w, b)
+    assert torch.allclose(x * sc + sh, want, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("uniform", [True, False])
+def test_graph_builders_match_oracle_semantics(uniform):
+    torch.manual_seed(2)
+    sizes_x = [40, 40, 40] if uniform else [40, 17, 33]
+    sizes_y = [9, 9, 9] if uniform else [9, 4, 12]
+    x = torch.cat([torch.randn(n, 3) * 4 for n in sizes_x])
+    y = torch.cat([torch.randn(n, 3) * 4 for n in sizes_y])
+    bx = torch.repeat_interleave(torch.arange(3), torch.tensor(sizes_x))
+    by = torch.repeat_interleave(torch.arange(3), torch.tensor(sizes_y))
+    lx, ly = G.DenseLayout.build(bx, 3), G.DenseLayout.build(by, 3)
+    for cap in (10000, 5):
+        a = G.radius(x, y, 3.0, lx, ly, max_num_neighbors=cap)
+        b = tp.radius(x, y, 3.0, bx, by, max_num_neighbors=cap)
+        assert torch.equal(a, b)
+    assert torch.equal(G.radius_graph(x, 3.0, lx), tp.radius_graph(x, 3.0, bx))
+    a, b = G.knn_graph(x, 8, lx), tp.knn_graph(x, 8, bx)
+    assert torch.equal(a, b)
+    csr = G.build_csr(a[0], a[1], x.shape[0])
+    assert int(csr.rowptr[-1]) == a.shape[1]
+    assert torch.equal(csr.recv.long(), a[0][csr.eid.long()]) and torch.equal(csr.src.long(), a[1][csr.eid.long()])
+    assert bool((csr.recv[1:] >= csr.recv[:-1]).all())
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_state_dict_layout_matches_reference(name):
+    """Keys and shapes equal those of the reference's own module tree (captured in the golden file): reference
+    checkpoints load with strict=True."""
+    case, gold = CASES[name], load_golden(name)
+    kw = dict(case.model_kwargs())
+    kw.update(case.ctor_extras())
+    model = TensorProductScoreModel(**kw)
+    mine = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert mine == gold["state_dict_shapes"]
+    sd = golden_state_dict(gold, case.weight_seed)
+    sd["final_tp_tor.some_e3nn_buffer"] = torch.zeros(3)       # e3nn-internal buffers of real checkpoints are ignored
+    model.load_state_dict(sd, strict=True)
+    for k, v in gold["offsets"].items():
+        assert torch.equal(model.state_dict()[k], v)
+
+
+def test_unsupported_configs_raise():
+    case = CASES["cfg1_full"]
+    for bad in ({"sh_lmax": 2}, {"use_second_order_repr": True}, {"smooth_edges": True}, {"confidence_mode": True}):
+        kw = dict(case.model_kwargs())
+        kw.update(case.ctor_extras())
+        kw.update(bad)
+        with pytest.raises(NotImplementedError):
+            TensorProductScoreModel(**kw)
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly off-GPU instead of computing somewhere else."""
+    case = CASES["cfg1_edge"]
+    kw = dict(case.model_kwargs())
+    kw.update(case.ctor_extras())
+    model = TensorProductScoreModel(**kw).eval()
+    with pytest.raises(L.DdpError):
+        model(case.make_batch())
+    src = open(os.path.join(ROOT, "diffdock_pocket_amd", "score_model.py")).read()
+    assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# ", "")
+    for fn in os.listdir(os.path.join(ROOT, "diffdock_pocket_amd")):
+        if fn.endswith(".py"):
+            body = open(os.path.join(ROOT, "diffdock_pocket_amd", fn)).read()
+            assert "import oracle" not in body and "from oracle" not in body, fn
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from diffdock_pocket_amd import build
+    build.build(verbose=False)
+    header = open(os.path.join(ROOT, "include", "ddp_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(ddp_[a-z_]+)\s*\(", header, flags=re.M))
+    assert declared == set(L.EXPORTS)
+    lib = ctypes.CDLL(L.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.ddp_abi_version.restype = ctypes.c_int
+    assert lib.ddp_abi_version() == 1
+    assert ctypes.sizeof(L.ConvShape) == 9 * 4 + 4 * (9 * 4 + 3 * 12)
