@@ -1,0 +1,221 @@
+"""Reverse-diffusion sampling loop around the score model: the caller of the hot path.
+
+Counterpart of reference utils/sampling.py:16-60 (`randomize_position`) and :70-286 (`sampling`) for the default
+inference settings (SDE with low-temperature sampling, no SVGD, no confidence model), restructured for the
+MI355X: the N sample graphs of one complex are collated ONCE into a device-resident batch (the reference
+re-collates a python list on the CPU every step, utils/sampling.py:100,112-114) and the pose update
+(utils/diffusion_utils.py:37-70, utils/torsion.py:68-94,251-278, utils/geometry.py:72-86,209-243) is batched over
+the N samples in PyTorch-ROCm instead of a per-sample numpy/scipy loop.  North-star keeps this side in Python.
+
+Random numbers are drawn for ALL n_total samples of the job from one seeded CPU generator and sliced by
+`sample_slice`, so results do not depend on how samples are sharded over GPUs.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .batch import HeteroBatch, collate, set_time
+from .diffusion import SigmaRanges, get_t_schedule
+
+# defaults of reference inference.py:93-101
+TEMP_SAMPLING = (0.9766350103728372, 6.077432837220868, 6.761568162335063, 1.4487910576602347)
+TEMP_PSI = (1.5102572175711826, 0.8141168207563049, 0.7661845361370018, 1.339614553802453)
+TEMP_SIGMA_DATA = 0.48884149503636976
+
+
+def rotvec_to_matrix(v: torch.Tensor) -> torch.Tensor:
+    """Rodrigues formula, [...,3] -> [...,3,3]; equals scipy Rotation.from_rotvec(v).as_matrix() and
+    reference utils/geometry.py:72-86 (axis_angle_to_matrix)."""
+    ang = v.norm(dim=-1, keepdim=True)
+    small = ang < 1e-6
+    safe = torch.where(small, torch.ones_like(ang), ang)
+    a = torch.where(small, 1.0 - ang * ang / 6.0, torch.sin(safe) / safe)                 # sin(t)/t
+    b = torch.where(small, 0.5 - ang * ang / 24.0, (1.0 - torch.cos(safe)) / (safe * safe))  # (1-cos t)/t^2
+    x, y, z = v.unbind(-1)
+    zero = torch.zeros_like(x)
+    K = torch.stack([zero, -z, y, z, zero, -x, -y, x, zero], -1).reshape(v.shape[:-1] + (3, 3))
+    eye = torch.eye(3, dtype=v.dtype, device=v.device).expand(K.shape)
+    return eye + a.unsqueeze(-1) * K + b.unsqueeze(-1) * (K @ K)
+
+
+def kabsch(A: torch.Tensor, B: torch.Tensor):
+    """Batched rigid_transform_Kabsch_3D_torch (reference utils/geometry.py:209-243): A, B [N, n, 3] point sets;
+    returns R [N,3,3], t [N,1,3] with  A @ R^T + t ~ B."""
+    ca, cb = A.mean(1, keepdim=True), B.mean(1, keepdim=True)
+    H = (A - ca).transpose(1, 2) @ (B - cb)
+    U, S, Vt = torch.linalg.svd(H)
+    R = Vt.transpose(1, 2) @ U.transpose(1, 2)
+    neg = torch.linalg.det(R) < 0
+    if bool(neg.any()):
+        D = torch.diag(torch.tensor([1.0, 1.0, -1.0], dtype=A.dtype, device=A.device))
+        R = torch.where(neg.reshape(-1, 1, 1), (Vt.transpose(1, 2) @ D) @ U.transpose(1, 2), R)
+    t = cb - ca @ R.transpose(1, 2)
+    return R, t
+
+
+def apply_torsions(pos: torch.Tensor, bonds: torch.Tensor, mask_rotate: torch.Tensor, angles: torch.Tensor):
+    """Batched modify_conformer_torsion_angles (reference utils/torsion.py:68-94).
+    pos [N,n,3]; bonds [T,2] (u,v); mask_rotate [T,n] bool; angles [N,T]."""
+    pos = pos.clone()
+    for j in range(bonds.shape[0]):
+        u, v = int(bonds[j, 0]), int(bonds[j, 1])
+        axis = pos[:, u] - pos[:, v]
+        rot = rotvec_to_matrix(axis * (angles[:, j:j + 1] / axis.norm(dim=-1, keepdim=True)))
+        m = mask_rotate[j]
+        pv = pos[:, v:v + 1]
+        pos[:, m] = (pos[:, m] - pv) @ rot.transpose(1, 2) + pv
+    return pos
+
+
+def apply_sidechain_torsions(pos, edge_idx, subcomponents, mapping, angles):
+    """Batched modify_sidechains (reference utils/diffusion_utils.py:63-70, utils/torsion.py:251-278): bonds are
+    applied sequentially in list order.  pos [N,n,3]; angles [N,S]."""
+    pos = pos.clone()
+    for j in range(edge_idx.shape[0]):
+        u, v = int(edge_idx[j, 0]), int(edge_idx[j, 1])
+        idx = subcomponents[int(mapping[j, 0]):int(mapping[j, 1])]
+        axis = pos[:, u] - pos[:, v]
+        rot = rotvec_to_matrix(axis * (angles[:, j:j + 1] / axis.norm(dim=-1, keepdim=True)))
+        pv = pos[:, v:v + 1]
+        pos[:, idx] = (pos[:, idx] - pv) @ rot.transpose(1, 2) + pv
+    return pos
+
+
+def modify_conformer(pos, tr, rot, tor, bonds, mask_rotate):
+    """Batched modify_conformer (reference utils/diffusion_utils.py:37-60), pivot=None.
+    pos [N,n,3]; tr, rot [N,3]; tor [N,T] or None."""
+    center = pos.mean(1, keepdim=True)
+    R = rotvec_to_matrix(rot)
+    rigid = (pos - center) @ R.transpose(1, 2) + tr.unsqueeze(1) + center
+    if tor is None or tor.shape[1] == 0:
+        return rigid
+    flex = apply_torsions(rigid, bonds, mask_rotate, tor)
+    Rk, tk = kabsch(flex, rigid)
+    return flex @ Rk.transpose(1, 2) + tk
+
+
+@dataclass
+class SamplerConfig:
+    inference_steps: int = 20
+    sigma: SigmaRanges = field(default_factory=SigmaRanges)
+    temp_sampling: Sequence[float] = TEMP_SAMPLING
+    temp_psi: Sequence[float] = TEMP_PSI
+    temp_sigma_data: float = TEMP_SIGMA_DATA
+    no_final_step_noise: bool = False
+    no_random: bool = False
+    ode: bool = False
+    flexible_sidechains: bool = True
+    no_torsion: bool = False
+
+
+class Sampler:
+    """Holds the device-resident batch of `n_local` samples of one complex (samples `sample_slice` of `n_total`)."""
+
+    def __init__(self, model, complex_graph: HeteroBatch, n_total: int, device, cfg: SamplerConfig, seed: int = 0,
+                 sample_slice: Optional[slice] = None):
+        self.model, self.cfg, self.device = model, cfg, device
+        self.n_total = n_total
+        self.slice = sample_slice or slice(0, n_total)
+        self.n = len(range(*self.slice.indices(n_total)))
+        self.gen = torch.Generator().manual_seed(seed)
+        g = complex_graph
+        self.n_l, self.n_a = g["ligand"].pos.shape[0], g["atom"].pos.shape[0]
+        em = g["ligand"].edge_mask.bool()
+        self.bonds = g["ligand", "ligand"].edge_index.t()[em].clone()             # [T,2] (u,v)
+        mr = g["ligand"].mask_rotate
+        self.mask_rotate = torch.as_tensor(np.asarray(mr if isinstance(mr, np.ndarray) else mr[0])).bool().to(device)
+        self.T = int(self.bonds.shape[0])
+        self.has_flex = cfg.flexible_sidechains and ("flexResidues" in g) and len(g["flexResidues"]) > 0
+        if self.has_flex:
+            fr = g["flexResidues"]
+            self.sc_edge_idx, self.sc_sub = fr.edge_idx.clone(), fr.subcomponents.clone().to(device)
+            self.sc_map = fr.subcomponentsMapping.clone()
+            self.S = int(self.sc_edge_idx.shape[0])
+        else:
+            self.S = 0
+        self.batch = collate([g] * self.n).to(device)
+        self.lig_pos = self.batch["ligand"].pos.reshape(self.n, self.n_l, 3).clone()
+        self.atom_pos = self.batch["atom"].pos.reshape(self.n, self.n_a, 3).clone()
+
+    # -- randomize_position (reference utils/sampling.py:16-60), pocket_knowledge=False -----------------------
+    def randomize(self):
+        cfg, N, sl = self.cfg, self.n_total, self.slice
+        if not cfg.no_torsion and self.T > 0:
+            ang = (torch.rand((N, self.T), generator=self.gen) * 2 - 1) * math.pi
+            self.lig_pos = apply_torsions(self.lig_pos, self.bonds, self.mask_rotate, ang[sl].to(self.device))
+        if self.has_flex:
+            ang = (torch.rand((N, self.S), generator=self.gen) * 2 - 1) * math.pi
+            self.atom_pos = apply_sidechain_torsions(self.atom_pos, self.sc_edge_idx, self.sc_sub, self.sc_map,
+                                                     ang[sl].to(self.device))
+        # uniform random rotations from normalised gaussian quaternions (scipy Rotation.random)
+        q = torch.randn((N, 4), generator=self.gen)
+        q = (q / q.norm(dim=1, keepdim=True))[sl].to(self.device)
+        w, x, y, z = q.unbind(1)
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                         2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                         2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+        center = self.lig_pos.mean(1, keepdim=True)
+        self.lig_pos = (self.lig_pos - center) @ R.transpose(1, 2)
+        if not cfg.no_random:
+            tr = torch.randn((N, 1, 3), generator=self.gen) * cfg.sigma.tr_sigma_max
+            self.lig_pos = self.lig_pos + tr[sl].to(self.device)
+
+    # -- one denoising step (reference utils/sampling.py:93-251) ------------------------------------------------
+    def step(self, t_idx: int, schedule: np.ndarray):
+        cfg, sg, N, sl, dev = self.cfg, self.cfg.sigma, self.n_total, self.slice, self.device
+        steps = len(schedule)
+        t = float(schedule[t_idx])
+        dt = float(schedule[t_idx] - schedule[t_idx + 1]) if t_idx < steps - 1 else float(schedule[t_idx])
+        tr_s = sg.tr_sigma_min ** (1 - t) * sg.tr_sigma_max ** t
+        rot_s = sg.rot_sigma_min ** (1 - t) * sg.rot_sigma_max ** t
+        tor_s = sg.tor_sigma_min ** (1 - t) * sg.tor_sigma_max ** t
+        sc_s = sg.sidechain_tor_sigma_min ** (1 - t) * sg.sidechain_tor_sigma_max ** t
+
+        b = self.batch
+        b["ligand"].pos = self.lig_pos.reshape(-1, 3)
+        b["atom"].pos = self.atom_pos.reshape(-1, 3)
+        set_time(b, t, t, t, t, device=dev)
+        tr_score, rot_score, tor_score, sc_score = self.model(b)
+
+        noise_off = cfg.no_random or (cfg.no_final_step_noise and t_idx == steps - 1)
+
+        def z(shape):  # drawn for all samples of the job, sliced to this shard
+            full = torch.zeros(shape) if noise_off else torch.randn(shape, generator=self.gen)
+            return full[sl].to(dev)
+
+        def perturb(score, g, sigma, lo, hi, k, zz):
+            if cfg.ode:
+                return 0.5 * g ** 2 * dt * score
+            if cfg.temp_sampling[k] != 1.0:
+                sigma_data = math.exp(cfg.temp_sigma_data * math.log(hi) + (1 - cfg.temp_sigma_data) * math.log(lo))
+                lam = (sigma_data + sigma) / (sigma_data + sigma / cfg.temp_sampling[k])
+                return (g ** 2 * dt * (lam + cfg.temp_sampling[k] * cfg.temp_psi[k] / 2) * score
+                        + g * math.sqrt(dt * (1 + cfg.temp_psi[k])) * zz)
+            return g ** 2 * dt * score + g * math.sqrt(dt) * zz
+
+        tr_g = tr_s * math.sqrt(2 * math.log(sg.tr_sigma_max / sg.tr_sigma_min))
+        rot_g = 2 * rot_s * math.sqrt(math.log(sg.rot_sigma_max / sg.rot_sigma_min))
+        tr_p = perturb(tr_score, tr_g, tr_s, sg.tr_sigma_min, sg.tr_sigma_max, 0, z((N, 3)))
+        rot_p = perturb(rot_score, rot_g, rot_s, sg.rot_sigma_min, sg.rot_sigma_max, 1, z((N, 3)))
+        tor_p = None
+        if not cfg.no_torsion and self.T > 0:
+            tor_g = tor_s * math.sqrt(2 * math.log(sg.tor_sigma_max / sg.tor_sigma_min))
+            tor_p = perturb(tor_score.reshape(self.n, self.T), tor_g, tor_s, sg.tor_sigma_min, sg.tor_sigma_max, 2,
+                            z((N, self.T)))
+        if self.has_flex:
+            sc_g = sc_s * math.sqrt(2 * math.log(sg.sidechain_tor_sigma_max / sg.sidechain_tor_sigma_min))
+            sc_p = perturb(sc_score.reshape(self.n, self.S), sc_g, sc_s, sg.sidechain_tor_sigma_min,
+                           sg.sidechain_tor_sigma_max, 3, z((N, self.S)))
+            self.atom_pos = apply_sidechain_torsions(self.atom_pos, self.sc_edge_idx, self.sc_sub, self.sc_map, sc_p)
+        self.lig_pos = modify_conformer(self.lig_pos, tr_p, rot_p, tor_p, self.bonds, self.mask_rotate)
+
+    def run(self, schedule: Optional[np.ndarray] = None):
+        schedule = get_t_schedule(self.cfg.inference_steps) if schedule is None else schedule
+        for i in range(len(schedule)):
+            self.step(i, schedule)
+        return self.lig_pos, self.atom_pos

@@ -210,13 +210,41 @@ def _make_task(pk: _PackedConv, x_src, ldx_src, csr: G.CSR, sh, segs, msg) -> L.
     return t
 
 
+class ConvProfiler:
+    """Times every ddp_conv_messages launch with HIP events on the launch stream and tallies its algorithmic FLOPs
+    (BASELINE.md §3 formula x the launch's actual edge count).  Used by bench.py for the roofline entry."""
+
+    def __init__(self):
+        self.events, self.flops = [], []
+
+    def summary(self):
+        ms = sum(a.elapsed_time(b) for a, b in self.events)
+        return len(self.events), float(sum(self.flops)), float(ms)
+
+
+_PROFILER: Optional[ConvProfiler] = None
+
+
+def set_conv_profiler(p: Optional[ConvProfiler]):
+    global _PROFILER
+    _PROFILER = p
+
+
 def _launch_convs(spec: P.ConvSpec, tasks: List[L.ConvTask]):
     lib = L.load()
     if not tasks:
         return
     arr = (L.ConvTask * len(tasks))(*tasks)
     shape = spec.ctypes_shape()
+    prof = _PROFILER
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     L.check(lib.ddp_conv_messages(C.byref(shape), arr, len(tasks), _stream()), "ddp_conv_messages")
+    if prof is not None:
+        e1.record()
+        prof.events.append((e0, e1))
+        prof.flops.append(spec.flops_per_edge() * sum(t.n_edges for t in tasks))
 
 
 def _launch_reduce(x, ldx, n_nodes, d_out, sources, accumulate=True):
@@ -602,7 +630,8 @@ class TensorProductScoreModel(nn.Module):
                                     torch.zeros(E, device=dev, dtype=torch.int32))
         bond_vec = (pos[bonds[1]] - pos[bonds[0]]).contiguous()
         tor_sh = torch.empty((E, 4), device=dev)
-        L.check(lib.ddp_torsion_sh(_ptr(sh_e), _ptr(bond_vec), _ptr(i32(ei[0])), E, _ptr(tor_sh), _stream()), "ddp_torsion_sh")
+        bond_of_edge = i32(ei[0])
+        L.check(lib.ddp_torsion_sh(_ptr(sh_e), _ptr(bond_vec), _ptr(bond_of_edge), E, _ptr(tor_sh), _stream()), "ddp_torsion_sh")
         bond_attr = (x[bonds[0], :ns] + x[bonds[1], :ns]).contiguous()
         csr = G.build_csr(ei[0], ei[1], T, presorted=True)
         spec, pkc = conv.spec, conv.packed(dev)

@@ -127,6 +127,6 @@ def test_edge_featurize_and_torsion_sh():
     y2 = tp.spherical_harmonics("2e", bv)
     want_t = tp.FullTensorProduct("1x0e+1x1o", "2e")(want_sh, y2[boe])[:, :3]
     got_t = torch.empty(E, 4, device=dev)
-    L.check(L.load().ddp_torsion_sh(_ptr(sh), _ptr(bv.to(dev).contiguous()), _ptr(boe.int().to(dev)), E, _ptr(got_t),
-                                    _stream()), "ddp_torsion_sh")
+    bv_d, boe_d = bv.to(dev).contiguous(), boe.int().to(dev)   # keep the device buffers alive across the launch
+    L.check(L.load().ddp_torsion_sh(_ptr(sh), _ptr(bv_d), _ptr(boe_d), E, _ptr(got_t), _stream()), "ddp_torsion_sh")
     assert float((got_t.cpu()[:, 1:] - want_t).abs().max()) < 1e-5 and float(got_t[:, 0].abs().max()) == 0.0
