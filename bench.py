@@ -73,7 +73,7 @@ def cpu_baseline(args, model, kw, complex_graph):
                         flexible_sidechains=kw["flexible_sidechains"], embedding_scale=1000.0)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     oracle = OracleScoreModel(ocfg, sd)
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, args.cpu_threads))
     gs = []
     g = torch.Generator().manual_seed(7)
     for _ in range(n):
@@ -104,8 +104,9 @@ def main():
     ap.add_argument("--cfg", default="cfg2", choices=["cfg1", "cfg2"])
     ap.add_argument("--flex", action="store_true", help="flexible side chains (BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-samples", type=int, default=2)
+    ap.add_argument("--cpu-samples", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--cpu-threads", type=int, default=32)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
