@@ -10,7 +10,7 @@
 // the tensor-product basis features straight from the accumulator registers:  w never leaves the CU.
 //
 // Work decomposition (one launch = the <=9 convs of a layer, they share one shape):
-//   workgroup = 256 threads = 4 waves (one per SIMD, whole register file), 64 edges.
+//   workgroup = 512 threads = 8 waves (two per SIMD, 256 registers each), 64 edges.
 //   phase 0  stage edge_attr_ rows (3 gathers) into LDS
 //   phase 1  h = relu(edge_attr_ @ W1 + b1)  via MFMA, to LDS [64][hs]
 //   per weight block (0e,1o,1e,0o):
@@ -34,6 +34,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define FS 68  // LDS row stride (floats) of the feature buffer F[u*C + c][e], e < 64
+#define DDP_CONV_THREADS 512  // 8 waves: two per SIMD
 
 struct ConvLaunch {
   ddp_conv_shape_t shape;
@@ -60,7 +61,7 @@ __device__ __forceinline__ void build_features(const ddp_block_t& B, const ddp_c
   int ubase = 0;
   for (int si = 0; si < B.nseg; ++si) {
     const int kind = B.seg[si].kind, off = B.seg[si].in_off, cnt = B.seg[si].count;
-    for (int ul = wave; ul < cnt; ul += 4) {
+    for (int ul = wave; ul < cnt; ul += DDP_CONV_THREADS / 64) {
       const int u = ubase + ul;
       if (kind == DDP_F_SCALAR_S0) {
         fbuf[u * FS + e] = xrow[off + ul] * s0;
@@ -105,43 +106,41 @@ __device__ __forceinline__ void tile_lane_map(const ddp_block_t& B, int t, int r
 }
 
 // ------------------------------------------------------------------------------------------------ phases 3+4
-// C = 1: scalar block, tiles processed in pairs (2x2 register blocking: 64 edges x 64 columns per wave step)
-// C = 3: vector block, single tiles (2x1 blocking) with three output accumulators (x,y,z) per edge row
+// 8 waves = 2 per SIMD.  Wave w owns the 32 edges of row-tile rt = w >> 2 and, inside the block, the tile groups
+// g = (w & 3), (w & 3) + 4, ...  (so the two waves of a SIMD cover each other's waits and epilogues).
+// C = 1: scalar block, tiles in pairs (1x2 register blocking: 32 edges x 64 columns per wave step)
+// C = 3: vector block, single tiles with three output accumulators (x,y,z) per edge row
 template <int C>
 __device__ __forceinline__ void run_block(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
                                           const float* hbuf, float* fbuf, int tid, int p0, int nvalid) {
   constexpr int CT = (C == 1) ? 2 : 1;
   const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int rt = wave >> 2, wq = wave & 3;
   const int nm = S.hp >> 3;
   const int ngroups = B.ntiles / CT;  // host pads scalar blocks to an even tile count
   const f32x4* __restrict__ w2p = reinterpret_cast<const f32x4*>(T.w2p);
+  const float* arow = &hbuf[(rt * 32 + r) * S.hs + 4 * hh];
 
-  f32x16 out[2][CT][C];
+  f32x16 out[CT][C];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int s = 0; s < CT; ++s)
 #pragma unroll
-    for (int s = 0; s < CT; ++s)
-#pragma unroll
-      for (int c = 0; c < C; ++c) out[rt][s][c] = splat16(0.f);
+    for (int c = 0; c < C; ++c) out[s][c] = splat16(0.f);
 
   // B-operand prefetch, flattened over (group, m)
   f32x4 bnext[CT];
-  if (wave < ngroups) {
+  if (wq < ngroups) {
 #pragma unroll
     for (int s = 0; s < CT; ++s) {
-      const int tile = B.tile0 + wave * CT + s;
+      const int tile = B.tile0 + wq * CT + s;
       bnext[s] = w2p[((size_t)tile * nm * 2 + hh) * 32 + r];
     }
   }
-
-  for (int g = wave; g < ngroups; g += 4) {
-    f32x16 acc[2][CT];
+  f32x4 anext = *reinterpret_cast<const f32x4*>(arow);
+  for (int g = wq; g < ngroups; g += 4) {
+    f32x16 acc[CT];
 #pragma unroll
-    for (int s = 0; s < CT; ++s) {
-      const float bias = T.b2p[(B.tile0 + g * CT + s) * 32 + r];
-      acc[0][s] = splat16(bias);
-      acc[1][s] = splat16(bias);
-    }
+    for (int s = 0; s < CT; ++s) acc[s] = splat16(T.b2p[(B.tile0 + g * CT + s) * 32 + r]);
     for (int m = 0; m < nm; ++m) {
       f32x4 bcur[CT];
 #pragma unroll
@@ -157,16 +156,12 @@ __device__ __forceinline__ void run_block(const ddp_conv_shape_t& S, const ddp_b
           }
         }
       }
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(&hbuf[r * S.hs + 8 * m + 4 * hh]);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(&hbuf[(32 + r) * S.hs + 8 * m + 4 * hh]);
+      const f32x4 a = anext;
+      anext = *reinterpret_cast<const f32x4*>(arow + 8 * ((m + 1 == nm) ? 0 : m + 1));  // h is tile independent: wrap
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int s = 0; s < CT; ++s) {
-          acc[0][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], bcur[s][i], acc[0][s], 0, 0, 0);
-          acc[1][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], bcur[s][i], acc[1][s], 0, 0, 0);
-        }
-      }
+        for (int s = 0; s < CT; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[s][i], acc[s], 0, 0, 0);
     }
     // contraction with the basis features, in the MFMA C/D layout: reg i <-> edge row (i&3) + 8*(i>>2) + 4*hh
 #pragma unroll
@@ -175,71 +170,67 @@ __device__ __forceinline__ void run_block(const ddp_conv_shape_t& S, const ddp_b
       bool valid;
       tile_lane_map(B, g * CT + s, r, u, ncol, us, valid);
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
+      for (int c = 0; c < C; ++c) {
+        const float* frow = &fbuf[(u * C + c) * FS + rt * 32 + 4 * hh];
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-          const float* frow = &fbuf[(u * C + c) * FS + rt * 32 + 4 * hh];
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const f32x4 f = *reinterpret_cast<const f32x4*>(frow + 8 * q4);
 #pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            const f32x4 f = *reinterpret_cast<const f32x4*>(frow + 8 * q4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) out[rt][s][c][4 * q4 + q] += f[q] * acc[rt][s][4 * q4 + q];
-          }
+          for (int q = 0; q < 4; ++q) out[s][c][4 * q4 + q] += f[q] * acc[s][4 * q4 + q];
         }
       }
     }
   }
 
-  // ---- phase 4: deterministic reduction (fixed wave order, fixed lane-group order) into red[e][RS]
+  // ---- phase 4: deterministic cross-wave / cross-lane reduction.  Every wave parks its 32-row partial tile in its own
+  // LDS region with plain stores (all waves concurrently); then all threads sum the 4 regions of a row-tile (and, for
+  // n <= 32, the `ups` lane groups and both tile slots) in a FIXED order and store the block's message columns
+  // coalesced.  Vector blocks do this in two passes (row-tile 0, then 1) to stay inside fbuf.
+  constexpr int NP = (C == 1) ? 1 : 2;            // passes
+  constexpr int RW = CT * 32 * C;                 // floats per edge row in a wave region: [c][slot*32 + r]
+  constexpr int REGION = 32 * RW;                 // 2048 (scalar) / 3072 (vector) floats per wave
   const int nc = B.n * C;
-  const int RS = nc | 1;
-  float* red = fbuf;
-  __syncthreads();  // everyone is done reading F
-  for (int i = tid; i < 64 * RS; i += 256) red[i] = 0.f;
-  __syncthreads();
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
+  float* part = fbuf;
 #pragma unroll
-      for (int s = 0; s < CT; ++s) {
-        // slot s always sees the same column->channel map (pairs start at even tiles; nsub is 1 or 2)
-        int ncol, us;
-        bool valid;
-        if (B.nsub > 1) {
-          ncol = s * 32 + r;
-          us = 0;
-          valid = ncol < B.n;
-        } else {
-          us = r / B.n;
-          ncol = r - us * B.n;
-          valid = us < B.ups;
-        }
-        for (int k = 0; k < B.ups; ++k) {
-          if (valid && us == k) {
+  for (int pass = 0; pass < NP; ++pass) {
+    __syncthreads();  // F (or the previous pass's partials) no longer needed
+    if (NP == 1 || rt == pass) {
+      float* mine = part + ((NP == 1) ? wave : wq) * REGION;
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
+      for (int s = 0; s < CT; ++s)
 #pragma unroll
-              for (int c = 0; c < C; ++c)
+        for (int c = 0; c < C; ++c)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                  const int row = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                  red[row * RS + ncol * C + c] += out[rt][s][c][i];
-                }
+          for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+            mine[row * RW + c * (CT * 32) + s * 32 + r] = out[s][c][i];
           }
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
     }
     __syncthreads();
-  }
-  for (int i = tid; i < 64 * nc; i += 256) {
-    const int e = i / nc, cc = i - e * nc;
-    if (e < nvalid) T.msg[(size_t)(p0 + e) * S.d_out + B.out_off + cc] = red[e * RS + cc];
+    const int rows = (NP == 1) ? 64 : 32;
+    for (int idx = tid; idx < rows * nc; idx += DDP_CONV_THREADS) {
+      const int el = idx / nc, cc = idx - el * nc;
+      const int ncol = cc / C, c = cc - ncol * C;
+      const int e = (NP == 1) ? el : pass * 32 + el;
+      const int wbase = (NP == 1) ? (e >> 5) * 4 : 0;
+      float sum = 0.f;
+      for (int w = 0; w < 4; ++w) {
+        const float* reg = part + (wbase + w) * REGION + (e & 31) * RW + c * (CT * 32);
+        if (B.nsub > 1) {
+          sum += reg[ncol];                       // column = sub*32 + r = ncol
+        } else {
+          for (int sl = 0; sl < CT; ++sl)
+            for (int k = 0; k < B.ups; ++k) sum += reg[sl * 32 + k * B.n + ncol];
+        }
+      }
+      if (e < nvalid) T.msg[(size_t)(p0 + e) * S.d_out + B.out_off + cc] = sum;
+    }
   }
   __syncthreads();  // fbuf is rewritten by the next block's features
 }
 
 // ------------------------------------------------------------------------------------------------ kernel
-__global__ __launch_bounds__(256) void ddp_conv_messages_kernel(const ConvLaunch L) {
+__global__ __launch_bounds__(DDP_CONV_THREADS, 2) void ddp_conv_messages_kernel(const ConvLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int s_src[64], s_eid[64];
   const ddp_conv_shape_t& S = L.shape;
@@ -267,7 +258,7 @@ __global__ __launch_bounds__(256) void ddp_conv_messages_kernel(const ConvLaunch
       const float* __restrict__ ptr = T.seg_ptr[sg];
       const int* __restrict__ idx = T.seg_idx[sg];
       const int ld = T.seg_ld[sg];
-      for (int i = tid; i < 64 * n; i += 256) {
+      for (int i = tid; i < 64 * n; i += DDP_CONV_THREADS) {
         const int e = i / n, c = i - e * n;
         const int row = idx[p0 + min(e, nvalid - 1)];
         xa[e * S.hs + col0 + c] = ptr[(size_t)row * ld + c];
@@ -277,38 +268,33 @@ __global__ __launch_bounds__(256) void ddp_conv_messages_kernel(const ConvLaunch
   }
   {
     const int npad = S.kp1 - S.f_in;
-    for (int i = tid; i < 64 * npad; i += 256) {
+    for (int i = tid; i < 64 * npad; i += DDP_CONV_THREADS) {
       const int e = i / npad, c = i - e * npad;
       xa[e * S.hs + S.f_in + c] = 0.f;
     }
   }
   __syncthreads();
 
-  // ---- phase 1: h = relu(edge_attr_ @ W1 + b1)
+  // ---- phase 1: h = relu(edge_attr_ @ W1 + b1); wave w: row-tile w >> 2, column tiles (w & 3), (w & 3) + 4, ...
   {
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int rt = wave >> 2;
     const int nm1 = S.kp1 >> 3;
     const f32x4* __restrict__ w1p = reinterpret_cast<const f32x4*>(T.w1p);
-    for (int ct = wave; ct < S.nct1; ct += 4) {
-      const float bias = T.b1p[ct * 32 + r];
-      f32x16 acc0 = splat16(bias), acc1 = splat16(bias);
+    for (int ct = wave & 3; ct < S.nct1; ct += 4) {
+      f32x16 acc = splat16(T.b1p[ct * 32 + r]);
       for (int m = 0; m < nm1; ++m) {
         const f32x4 b = w1p[(((size_t)ct * nm1 + m) * 2 + hh) * 32 + r];
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(&xa[r * S.hs + 8 * m + 4 * hh]);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(&xa[(32 + r) * S.hs + 8 * m + 4 * hh]);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(&xa[(rt * 32 + r) * S.hs + 8 * m + 4 * hh]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b[i], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b[i], acc1, 0, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
       }
       const int col = ct * 32 + r;
       if (col < S.hp) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-          hbuf[row * S.hs + col] = fmaxf(acc0[i], 0.f);
-          hbuf[(32 + row) * S.hs + col] = fmaxf(acc1[i], 0.f);
+          const int row = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          hbuf[row * S.hs + col] = fmaxf(acc[i], 0.f);
         }
       }
     }
@@ -340,7 +326,7 @@ extern "C" int ddp_conv_messages(const ddp_conv_shape_t* shape, const ddp_conv_t
     if (B.n < 1 || B.n > 64 || (B.C == 3 && B.n > 32)) return ddp_fail(DDP_ELIMIT, "ddp_conv_messages: block n too large");
     if (B.nsub < 1 || B.nsub > 2 || B.ups < 1) return ddp_fail(DDP_ELIMIT, "ddp_conv_messages: nsub/ups");
     if (B.C == 1 && (B.ntiles & 1)) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: scalar blocks need an even tile count");
-    if (B.U * B.C * FS > shape->fbuf_floats || 64 * ((B.n * B.C) | 1) > shape->fbuf_floats)
+    if (B.U * B.C * FS > shape->fbuf_floats || 4 * 4096 > shape->fbuf_floats)
       return ddp_fail(DDP_EINVAL, "ddp_conv_messages: fbuf_floats too small");
     if (B.nseg < 0 || B.nseg > DDP_MAX_SEGS) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: nseg");
   }
@@ -363,7 +349,7 @@ extern "C" int ddp_conv_messages(const ddp_conv_shape_t* shape, const ddp_conv_t
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(ddp_conv_messages_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (err != hipSuccess) return ddp_fail_hip(err, "hipFuncSetAttribute(conv)");
-  hipLaunchKernelGGL(ddp_conv_messages_kernel, dim3(tiles), dim3(256), lds_bytes, (hipStream_t)stream, L);
+  hipLaunchKernelGGL(ddp_conv_messages_kernel, dim3(tiles), dim3(DDP_CONV_THREADS), lds_bytes, (hipStream_t)stream, L);
   err = hipGetLastError();
   if (err != hipSuccess) return ddp_fail_hip(err, "ddp_conv_messages launch");
   return 0;

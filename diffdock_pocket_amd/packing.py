@@ -77,9 +77,9 @@ class ConvSpec:
         for b in self.blocks:
             t = b.finalize(t)
         self.ntiles = t
-        fb = 64 * self.hs
+        fb = max(64 * self.hs, 4 * 4096)      # staging tile / the four per-wave partial regions of phase 4
         for b in self.blocks:
-            fb = max(fb, b.U * b.C * L.FS, 64 * ((b.n * b.C) | 1))
+            fb = max(fb, b.U * b.C * L.FS)
         self.fbuf_floats = (fb + 3) // 4 * 4
         if any(b.n > 64 or (b.C == 3 and b.n > 32) for b in self.blocks):
             raise NotImplementedError("HIP conv supports ns <= 64 and nv <= 32")
