@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libddp_hip.so")
+LIB_PATH = os.environ.get("DDP_HIP_LIB", os.path.join(HERE, "libddp_hip.so"))  # override: diagnostic builds only
 
 DDP_MAX_TASKS, DDP_MAX_BLOCKS, DDP_MAX_SEGS, DDP_MAX_NS, DDP_EDGE_TILE = 9, 4, 3, 64, 64
 F_SCALAR_S0, F_DOT, F_SCALAR_S1, F_VEC_S0, F_CROSS = range(5)

@@ -19,7 +19,21 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, stamps=False, ablate=0):
+    if ablate:  # timing-only diagnostic variants (tools/ablate_conv.py)
+        out = os.path.join(HERE, f"libddp_hip_ablate{ablate}.so")
+        cmd = [os.environ.get("HIPCC", "hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+               f"-DDDP_ABLATE={ablate}", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), "-o", out]
+        cmd += [os.path.join(HERE, "csrc", s) for s in SOURCES]
+        subprocess.check_call(cmd)
+        return out
+    if stamps:  # diagnostic library with in-kernel phase stamps (tools/stamp_conv.py); never loaded by the product
+        out = os.path.join(HERE, "libddp_hip_stamps.so")
+        cmd = [os.environ.get("HIPCC", "hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+               "-DDDP_STAMPS", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), "-o", out]
+        cmd += [os.path.join(HERE, "csrc", s) for s in SOURCES]
+        subprocess.check_call(cmd)
+        return out
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "hipcc")
@@ -33,4 +47,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, stamps="--stamps" in sys.argv)

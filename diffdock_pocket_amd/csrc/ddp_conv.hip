@@ -36,6 +36,50 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define FS 68  // LDS row stride (floats) of the feature buffer F[u*C + c][e], e < 64
 #define DDP_CONV_THREADS 512  // 8 waves: two per SIMD
 
+#ifdef DDP_STAMPS
+// Diagnostic build only (python -m diffdock_pocket_amd.build --stamps): thread 0 of every workgroup records
+// s_memtime at the phase boundaries into a device buffer that no kernel code reads (tools/stamp_conv.py).
+#define DDP_STAMP_SLOTS 40
+#define DDP_STAMP_WGS 32768
+__device__ unsigned long long ddp_stamp_buf[DDP_STAMP_WGS * DDP_STAMP_SLOTS];
+__device__ __forceinline__ unsigned long long ddp_stamp_now(bool realtime) {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  if (realtime)
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  else
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define STAMP(k)                                                                                          \
+  do {                                                                                                    \
+    const unsigned long long t_ = ddp_stamp_now((k) >= 22);                                               \
+    if (threadIdx.x == 0 && blockIdx.x < DDP_STAMP_WGS) ddp_stamp_buf[blockIdx.x * DDP_STAMP_SLOTS + (k)] = t_; \
+  } while (0)
+extern "C" int ddp_debug_read_stamps(unsigned long long* host_dst, int n_wgs) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(ddp_stamp_buf),
+                                  sizeof(unsigned long long) * DDP_STAMP_SLOTS * (size_t)n_wgs);
+}
+#define STAMP_SYNC() __syncthreads()
+#else
+#define STAMP(k) do {} while (0)
+#define STAMP_SYNC() do {} while (0)
+#endif
+
+// Timing-only ablations for tools/ablate_conv.py (never defined in the product build): DDP_ABLATE=1 drops the weight
+// loads of the scalar-block main loop, =2 drops its LDS A-operand reads; results are then wrong by construction.
+#if defined(DDP_ABLATE) && DDP_ABLATE == 1
+#define DDP_ABL_B(x) (f32x4{1.f, 2.f, 3.f, 4.f} * (float)(mn + 1))
+#else
+#define DDP_ABL_B(x) (x)
+#endif
+#if defined(DDP_ABLATE) && DDP_ABLATE == 2
+#define DDP_ABL_A(x, old) ((old) * 1.0001f)
+#else
+#define DDP_ABL_A(x, old) (x)
+#endif
+
 struct ConvLaunch {
   ddp_conv_shape_t shape;
   int ntasks;
@@ -106,15 +150,185 @@ __device__ __forceinline__ void tile_lane_map(const ddp_block_t& B, int t, int r
 }
 
 // ------------------------------------------------------------------------------------------------ phases 3+4
-// 8 waves = 2 per SIMD.  Wave w owns the 32 edges of row-tile rt = w >> 2 and, inside the block, the tile groups
-// g = (w & 3), (w & 3) + 4, ...  (so the two waves of a SIMD cover each other's waits and epilogues).
-// C = 1: scalar block, tiles in pairs (1x2 register blocking: 32 edges x 64 columns per wave step)
-// C = 3: vector block, single tiles with three output accumulators (x,y,z) per edge row
+// 8 waves = 2 per SIMD (they cover each other's waits and epilogues).  Wave w owns the tile groups g = w, w+8, ...
+// of the block for ALL 64 edges (both 32-row tiles), so every packed weight tile is fetched from L2 exactly once per
+// workgroup and each 16-byte B load feeds 4 MFMA k-steps x 2 row tiles.
+// C = 1: scalar block, tiles in pairs (2x2 register blocking: 64 edges x 64 columns per wave step)
+// C = 3: vector block, single tiles (2x1) with three output accumulators (x,y,z) per edge row
+// Two register-blocking variants of phases 3+4 (both 8 waves = 2 per SIMD, which cover each other's waits/epilogues):
+//  run_block_full  wave w owns tile groups w, w+8, .. for ALL 64 edges: each packed weight tile leaves L2 once per
+//                  workgroup and one 16-byte B load feeds 4 k-steps x 2 row tiles (used for the scalar blocks, 84 % of
+//                  the MFMA work; 128 accumulator registers)
+//  run_block_rows  wave w owns row tile w >> 2 and tile groups (w & 3), +4, ..: half the registers per wave (used for
+//                  the vector blocks whose three (x,y,z) output accumulators would not fit next to a 2-row-tile acc)
 template <int C>
-__device__ __forceinline__ void run_block(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
-                                          const float* hbuf, float* fbuf, int tid, int p0, int nvalid) {
+__device__ __forceinline__ void run_block_full(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
+                                          const float* hbuf, float* fbuf, int tid, int p0, int nvalid, int sbase) {
   constexpr int CT = (C == 1) ? 2 : 1;
-  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  constexpr int NW = DDP_CONV_THREADS / 64;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps tile/loop indices in SGPRs
+  const int lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int nm = S.hp >> 3;
+  const int ngroups = B.ntiles / CT;  // host pads scalar blocks to an even tile count
+  const f32x4* __restrict__ w2p = reinterpret_cast<const f32x4*>(T.w2p);
+  const float* arow0 = &hbuf[r * S.hs + 4 * hh];
+  const float* arow1 = &hbuf[(32 + r) * S.hs + 4 * hh];
+
+  f32x16 out[2][CT][C];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int s = 0; s < CT; ++s)
+#pragma unroll
+      for (int c = 0; c < C; ++c) out[rt][s][c] = splat16(0.f);
+
+  // B-operand prefetch, flattened over (group, m): the 16-byte weight fragments of the next k-group are requested
+  // before the 16 MFMAs of the current one.  sched_barriers pin the requests and the LDS A-operand prefetch where they
+  // are written: hipcc otherwise sinks both to just before their first use, which exposes their latency on every k-group.
+  // (Measured alternatives, tools/stamp_conv.py + tools/ablate_loop.py: deeper weight prefetch (3 k-groups per step,
+  // register ring) and dropping the loads altogether change the launch time by < 5 %: the loop is not latency bound.)
+  f32x4 bnext[CT];
+  {
+    const int g0 = (wave < ngroups) ? wave : ngroups - 1;
+#pragma unroll
+    for (int s = 0; s < CT; ++s) bnext[s] = w2p[(((size_t)(B.tile0 + g0 * CT + s) * nm) * 2 + hh) * 32 + r];
+  }
+  f32x4 anext0 = *reinterpret_cast<const f32x4*>(arow0);
+  f32x4 anext1 = *reinterpret_cast<const f32x4*>(arow1);
+  float bias_next[CT];
+#pragma unroll
+  for (int s = 0; s < CT; ++s) bias_next[s] = (wave < ngroups) ? T.b2p[(B.tile0 + wave * CT + s) * 32 + r] : 0.f;
+#ifdef DDP_SOLO   // diagnostic: only one wave per SIMD works (timing of a lone wave)
+  for (int g = (wave < 4 ? wave : ngroups); g < ngroups; g += NW) {
+#else
+  for (int g = wave; g < ngroups; g += NW) {
+#endif
+    // The SIMD arbitrates its two waves by priority, then age: left alone, the older wave (w < 4) takes the matrix pipe,
+    // finishes all its groups first and the younger one then runs the rest of the block by itself at ~80 % efficiency
+    // (tools/stamp_conv.py).  Alternating a static priority per tile group between the partners keeps them in step.
+    if (((g / NW) + (wave >> 2)) & 1)
+      __builtin_amdgcn_s_setprio(1);
+    else
+      __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc[2][CT];
+#pragma unroll
+    for (int s = 0; s < CT; ++s) {
+      acc[0][s] = splat16(bias_next[s]);
+      acc[1][s] = splat16(bias_next[s]);
+      bias_next[s] = (g + NW < ngroups) ? T.b2p[(B.tile0 + (g + NW) * CT + s) * 32 + r] : 0.f;
+    }
+    for (int m = 0; m < nm; ++m) {
+      f32x4 bcur[CT];
+#pragma unroll
+      for (int s = 0; s < CT; ++s) bcur[s] = bnext[s];
+      {  // request the next (group, m); clamped and unconditional
+        int gn = g, mn = m + 1;
+        if (mn == nm) { mn = 0; gn = (g + NW < ngroups) ? g + NW : g; }
+#pragma unroll
+        for (int s = 0; s < CT; ++s)
+          bnext[s] = DDP_ABL_B(w2p[(((size_t)(B.tile0 + gn * CT + s) * nm + mn) * 2 + hh) * 32 + r]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const f32x4 a0 = anext0, a1 = anext1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int s = 0; s < CT; ++s) {
+          acc[0][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], bcur[s][i], acc[0][s], 0, 0, 0);
+          acc[1][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], bcur[s][i], acc[1][s], 0, 0, 0);
+        }
+        if (i == 0) {  // A operand of the next k-group, behind the first 4 MFMAs (h is tile independent: wrap around)
+          __builtin_amdgcn_sched_barrier(0);
+          const int mn = (m + 1 == nm) ? 0 : m + 1;
+          anext0 = DDP_ABL_A(*reinterpret_cast<const f32x4*>(arow0 + 8 * mn), anext0);
+          anext1 = DDP_ABL_A(*reinterpret_cast<const f32x4*>(arow1 + 8 * mn), anext1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    // contraction with the basis features, in the MFMA C/D layout: reg i <-> edge row (i&3) + 8*(i>>2) + 4*hh
+#pragma unroll
+    for (int s = 0; s < CT; ++s) {
+      int u, ncol, us;
+      bool valid;
+      tile_lane_map(B, g * CT + s, r, u, ncol, us, valid);
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float* frow = &fbuf[(u * C + c) * FS + rt * 32 + 4 * hh];
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 f = *reinterpret_cast<const f32x4*>(frow + 8 * q4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out[rt][s][c][4 * q4 + q] += f[q] * acc[rt][s][4 * q4 + q];
+          }
+        }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_setprio(0);
+
+#ifdef DDP_STAMPS
+  if (sbase == 4) {  // block 0: per-wave finish time of the tile loop (slots 8..15 are otherwise blocks 1/2 stamps -> use 24..31)
+    const unsigned long long tw = ddp_stamp_now(false);
+    if (lane == 0 && blockIdx.x < DDP_STAMP_WGS) ddp_stamp_buf[blockIdx.x * DDP_STAMP_SLOTS + 24 + wave] = tw;
+  }
+#endif
+  static_assert(C == 1, "run_block_full is instantiated for scalar blocks only");
+  STAMP(sbase);        // wave 0 done with its tiles
+  STAMP_SYNC();
+  STAMP(sbase + 1);    // all waves done
+  constexpr int RW = CT * 32;                     // floats per edge row in a wave region: [slot*32 + r]
+  constexpr int REGION = 64 * RW;                 // 4096 floats per wave
+  const int nc = B.n;
+  float* part = fbuf;
+  float* carry = fbuf + 4 * REGION;
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();  // F (or the previous pass's partials) no longer needed
+    if ((wave >> 2) == half) {
+      float* mine = part + (wave & 3) * REGION;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int s = 0; s < CT; ++s)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            mine[row * RW + s * 32 + r] = out[rt][s][0][i];
+          }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * nc; idx += DDP_CONV_THREADS) {
+      const int e = idx / nc, ncol = idx - e * nc;
+      float sum = (half == 0) ? 0.f : carry[idx];
+      for (int w = 0; w < 4; ++w) {
+        const float* reg = part + w * REGION + e * RW;
+        if (B.nsub > 1) {
+          sum += reg[ncol];                       // column = sub*32 + r = ncol
+        } else {
+          for (int sl = 0; sl < CT; ++sl)
+            for (int q = 0; q < B.ups; ++q) sum += reg[sl * 32 + q * B.n + ncol];
+        }
+      }
+      if (half == 0)
+        carry[idx] = sum;
+      else if (e < nvalid)
+        T.msg[(size_t)(p0 + e) * S.d_out + B.out_off + ncol] = sum;
+    }
+  }
+  __syncthreads();  // fbuf is rewritten by the next block's features
+  STAMP(sbase + 2);
+}
+
+template <int C>
+__device__ __forceinline__ void run_block_rows(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
+                                          const float* hbuf, float* fbuf, int tid, int p0, int nvalid, int sbase) {
+  constexpr int CT = (C == 1) ? 2 : 1;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps tile/loop indices in SGPRs
+  const int lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int rt = wave >> 2, wq = wave & 3;
   const int nm = S.hp >> 3;
   const int ngroups = B.ntiles / CT;  // host pads scalar blocks to an even tile count
@@ -186,6 +400,9 @@ __device__ __forceinline__ void run_block(const ddp_conv_shape_t& S, const ddp_b
   // LDS region with plain stores (all waves concurrently); then all threads sum the 4 regions of a row-tile (and, for
   // n <= 32, the `ups` lane groups and both tile slots) in a FIXED order and store the block's message columns
   // coalesced.  Vector blocks do this in two passes (row-tile 0, then 1) to stay inside fbuf.
+  STAMP(sbase);        // wave 0 done with its tiles
+  STAMP_SYNC();
+  STAMP(sbase + 1);    // all waves done
   constexpr int NP = (C == 1) ? 1 : 2;            // passes
   constexpr int RW = CT * 32 * C;                 // floats per edge row in a wave region: [c][slot*32 + r]
   constexpr int REGION = 32 * RW;                 // 2048 (scalar) / 3072 (vector) floats per wave
@@ -227,6 +444,7 @@ __device__ __forceinline__ void run_block(const ddp_conv_shape_t& S, const ddp_b
     }
   }
   __syncthreads();  // fbuf is rewritten by the next block's features
+  STAMP(sbase + 2);
 }
 
 // ------------------------------------------------------------------------------------------------ kernel
@@ -244,6 +462,8 @@ __global__ __launch_bounds__(DDP_CONV_THREADS, 2) void ddp_conv_messages_kernel(
   float* fbuf = lds + 64 * S.hs;
   float* xa = fbuf;  // edge_attr_ staging aliases the feature buffer
 
+  STAMP(0);
+  STAMP(22);  // s_memrealtime (100 MHz) at entry
   // ---- phase 0: indices + edge_attr_ rows
   if (tid < 64) {
     const int p = p0 + min(tid, nvalid - 1);
@@ -274,20 +494,34 @@ __global__ __launch_bounds__(DDP_CONV_THREADS, 2) void ddp_conv_messages_kernel(
     }
   }
   __syncthreads();
+  STAMP(1);
 
   // ---- phase 1: h = relu(edge_attr_ @ W1 + b1); wave w: row-tile w >> 2, column tiles (w & 3), (w & 3) + 4, ...
   {
-    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps tile/loop indices in SGPRs
+  const int lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int rt = wave >> 2;
     const int nm1 = S.kp1 >> 3;
     const f32x4* __restrict__ w1p = reinterpret_cast<const f32x4*>(T.w1p);
     for (int ct = wave & 3; ct < S.nct1; ct += 4) {
       f32x16 acc = splat16(T.b1p[ct * 32 + r]);
-      for (int m = 0; m < nm1; ++m) {
-        const f32x4 b = w1p[(((size_t)ct * nm1 + m) * 2 + hh) * 32 + r];
-        const f32x4 a = *reinterpret_cast<const f32x4*>(&xa[(rt * 32 + r) * S.hs + 8 * m + 4 * hh]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
+      const f32x4* __restrict__ wp = w1p + ((size_t)ct * nm1 * 2 + hh) * 32 + r;
+      // the whole K panel of this column tile is 23 KiB per wave: request 4 k-groups ahead (the loop is short and
+      // latency bound otherwise: 4 MFMAs = 256 cycles per k-group)
+      f32x4 q0 = wp[0], q1 = wp[64 * min(1, nm1 - 1)], q2 = wp[64 * min(2, nm1 - 1)], q3 = wp[64 * min(3, nm1 - 1)];
+      for (int m = 0; m < nm1; m += 4) {
+#define DDP_FC1_STEP(Q, K)                                                                                   \
+        if (m + K < nm1) {                                                                                   \
+          const f32x4 b = Q;                                                                                 \
+          Q = wp[64 * min(m + K + 4, nm1 - 1)];                                                              \
+          const f32x4 a = *reinterpret_cast<const f32x4*>(&xa[(rt * 32 + r) * S.hs + 8 * (m + K) + 4 * hh]); \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0); \
+        }
+        DDP_FC1_STEP(q0, 0)
+        DDP_FC1_STEP(q1, 1)
+        DDP_FC1_STEP(q2, 2)
+        DDP_FC1_STEP(q3, 3)
+#undef DDP_FC1_STEP
       }
       const int col = ct * 32 + r;
       if (col < S.hp) {
@@ -300,17 +534,28 @@ __global__ __launch_bounds__(DDP_CONV_THREADS, 2) void ddp_conv_messages_kernel(
     }
   }
   __syncthreads();
+  STAMP(2);
 
   // ---- per weight block
   for (int bi = 0; bi < S.nblocks; ++bi) {
     const ddp_block_t& B = S.blk[bi];
     build_features(B, T, s_src, s_eid, fbuf, tid);
     __syncthreads();
+    STAMP(3 + 4 * bi);
     if (B.C == 1)
-      run_block<1>(S, B, T, hbuf, fbuf, tid, p0, nvalid);
+      run_block_full<1>(S, B, T, hbuf, fbuf, tid, p0, nvalid, 4 + 4 * bi);
     else
-      run_block<3>(S, B, T, hbuf, fbuf, tid, p0, nvalid);
+      run_block_rows<3>(S, B, T, hbuf, fbuf, tid, p0, nvalid, 4 + 4 * bi);
   }
+  STAMP(23);  // s_memrealtime at exit
+#ifdef DDP_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < DDP_STAMP_WGS) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    ddp_stamp_buf[blockIdx.x * DDP_STAMP_SLOTS + 21] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -326,7 +571,7 @@ extern "C" int ddp_conv_messages(const ddp_conv_shape_t* shape, const ddp_conv_t
     if (B.n < 1 || B.n > 64 || (B.C == 3 && B.n > 32)) return ddp_fail(DDP_ELIMIT, "ddp_conv_messages: block n too large");
     if (B.nsub < 1 || B.nsub > 2 || B.ups < 1) return ddp_fail(DDP_ELIMIT, "ddp_conv_messages: nsub/ups");
     if (B.C == 1 && (B.ntiles & 1)) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: scalar blocks need an even tile count");
-    if (B.U * B.C * FS > shape->fbuf_floats || 4 * 4096 > shape->fbuf_floats)
+    if (B.U * B.C * FS > shape->fbuf_floats || 5 * 4096 > shape->fbuf_floats)
       return ddp_fail(DDP_EINVAL, "ddp_conv_messages: fbuf_floats too small");
     if (B.nseg < 0 || B.nseg > DDP_MAX_SEGS) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: nseg");
   }

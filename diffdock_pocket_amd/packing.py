@@ -77,7 +77,7 @@ class ConvSpec:
         for b in self.blocks:
             t = b.finalize(t)
         self.ntiles = t
-        fb = max(64 * self.hs, 4 * 4096)      # staging tile / the four per-wave partial regions of phase 4
+        fb = max(64 * self.hs, 5 * 4096)      # staging tile / four per-wave partial regions + carry of phase 4
         for b in self.blocks:
             fb = max(fb, b.U * b.C * L.FS)
         self.fbuf_floats = (fb + 3) // 4 * 4

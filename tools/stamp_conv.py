@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Diagnostic: where does a conv workgroup spend its cycles?  Builds libddp_hip_stamps.so (-DDDP_STAMPS), runs a few
+bench steps with it and prints the mean s_memtime deltas between the phase stamps of the LAST conv launch of layer 3
+(the shape with all four weight blocks).  Usage on the GPU box:  python tools/stamp_conv.py"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from diffdock_pocket_amd import build  # noqa: E402
+
+os.environ["DDP_HIP_LIB"] = os.environ.get("DDP_STAMP_LIB") or build.build(stamps=True)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from diffdock_pocket_amd import _lib as L  # noqa: E402
+from diffdock_pocket_amd import score_model as sm  # noqa: E402
+from diffdock_pocket_amd.diffusion import get_t_schedule  # noqa: E402
+from diffdock_pocket_amd.sampler import Sampler, SamplerConfig  # noqa: E402
+from diffdock_pocket_amd.synthetic import make_3dpf_complex  # noqa: E402
+
+dev = torch.device("cuda:0")
+model, kw = bench.build_model("cfg2", False, dev)
+g = make_3dpf_complex(seed=0, flexible_sidechains=False)
+smp = Sampler(model, g, 40, dev, SamplerConfig(flexible_sidechains=False), seed=0)
+smp.randomize()
+lib = L.load()
+lib.ddp_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
+orig = sm._launch_convs
+captured = {}
+
+
+def hooked(spec, tasks):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    orig(spec, tasks)
+    e1.record()
+    torch.cuda.synchronize()
+    if len(spec.blocks) == 4 and len(tasks) == 9:
+        captured["ms"] = e0.elapsed_time(e1)
+    if len(spec.blocks) == 4 and len(tasks) == 9 and "done" not in captured:
+        torch.cuda.synchronize()
+        n = sum((t.n_edges + 63) // 64 for t in tasks)
+        n = min(n, 32768)
+        buf = np.zeros((n, 40), dtype=np.uint64)
+        rc = lib.ddp_debug_read_stamps(buf.ctypes.data_as(C.c_void_p), n)
+        assert rc == 0
+        captured["done"] = buf
+
+
+sm._launch_convs = hooked
+smp.step(0, get_t_schedule(20))
+smp.step(1, get_t_schedule(20))
+captured.pop("done", None)
+smp.step(2, get_t_schedule(20))
+st = captured["done"].astype(np.int64)
+names = ["stage edge_attr_", "fc1"]
+for b in range(4):
+    names += [f"blk{b} features", f"blk{b} wave0 tiles", f"blk{b} wait other waves", f"blk{b} reduce+store"]
+idx = [0, 1, 2]
+for b in range(4):
+    idx += [3 + 4 * b, 4 + 4 * b, 5 + 4 * b, 6 + 4 * b]
+d = np.diff(st[:, idx], axis=1)
+tot = (st[:, idx[-1]] - st[:, 0]).mean()
+hw = captured["done"][:, 21]
+xcc = (hw >> np.uint64(32)).astype(np.int64) & 0xF
+hwid = (hw & np.uint64(0xFFFFFFFF)).astype(np.int64)
+cu = (hwid >> 8) & 0xF
+sh = (hwid >> 12) & 0x1
+se = (hwid >> 13) & 0x7
+unit = xcc * 1000 + se * 100 + sh * 16 + cu
+span = (st[:, 23].max() - st[:, 22].min()) / 100.0
+busy = (st[:, 23] - st[:, 22]).sum() / 100.0
+print(f"HIP-event time of this launch: {captured['ms']:.2f} ms  => s_memrealtime runs at {span * 100 / (captured['ms'] * 1e3):.1f} MHz")
+print(f"launch span {span:.0f} us (if 100 MHz); distinct (xcc,se,sh,cu) units {len(np.unique(unit))}; distinct xcc {len(np.unique(xcc))}; "
+      f"sum of workgroup times / span = {busy / span:.1f} concurrently resident workgroups")
+rt = (st[:, 23] - st[:, 22]).mean()
+print(f"in-kernel clock = {tot / rt * 100:.0f} MHz (s_memtime / s_memrealtime x 100 MHz); mean workgroup {rt / 100:.1f} us")
+print(f"workgroups {len(st)}  mean total ticks {tot:.0f} (s_memtime ticks; 100 MHz constant clock on gfx950 => x24 for 2.4 GHz cycles)")
+for n_, m in zip(names, d.mean(0)):
+    print(f"  {n_:26s} {m:10.0f}  {100 * m / tot:5.1f} %")
+
+pw = st[:, 24:32] - st[:, 3:4]
+print("blk0 per-wave tile-loop finish (cycles after the feature barrier), mean over workgroups:")
+print("  " + "  ".join(f"w{w}:{pw[:, w].mean():.0f}" for w in range(8)))
+
+for name, o in (("wave 4 (priority)", 32), ("wave 0", 36)):
+    d = st[:, o:o + 4].astype(np.float64)
+    ng = d[:, 3].mean()
+    print(f"blk0 {name}: groups {ng:.1f}; per group: acc init {d[:,0].mean()/ng:.0f}, k-loop {d[:,1].mean()/ng:.0f} "
+          f"(MFMA-only would be {16 * 64 * 24}), epilogue {d[:,2].mean()/ng:.0f} cycles")
