@@ -27,13 +27,13 @@ class Seg(C.Structure):
 class Block(C.Structure):
     _fields_ = [("U", C.c_int32), ("n", C.c_int32), ("C", C.c_int32), ("out_off", C.c_int32), ("tile0", C.c_int32),
                 ("ntiles", C.c_int32), ("nsub", C.c_int32), ("ups", C.c_int32), ("nseg", C.c_int32),
-                ("seg", Seg * DDP_MAX_SEGS)]
+                ("seg", Seg * DDP_MAX_SEGS), ("g_slot", C.c_int32), ("g_col0", C.c_int32)]
 
 
 class ConvShape(C.Structure):
     _fields_ = [("f_in", C.c_int32), ("hid", C.c_int32), ("kp1", C.c_int32), ("hp", C.c_int32), ("hs", C.c_int32),
                 ("nct1", C.c_int32), ("d_out", C.c_int32), ("nblocks", C.c_int32), ("fbuf_floats", C.c_int32),
-                ("blk", Block * DDP_MAX_BLOCKS)]
+                ("g_cols", C.c_int32 * 2), ("blk", Block * DDP_MAX_BLOCKS)]
 
 
 class ConvTask(C.Structure):
@@ -41,7 +41,8 @@ class ConvTask(C.Structure):
                 ("eid", C.c_void_p), ("sh", C.c_void_p), ("seg_ptr", C.c_void_p * DDP_MAX_SEGS),
                 ("seg_idx", C.c_void_p * DDP_MAX_SEGS), ("seg_ld", C.c_int32 * DDP_MAX_SEGS),
                 ("seg_n", C.c_int32 * DDP_MAX_SEGS), ("w1p", C.c_void_p), ("b1p", C.c_void_p), ("w2p", C.c_void_p),
-                ("b2p", C.c_void_p), ("msg", C.c_void_p)]
+                ("b2p", C.c_void_p), ("msg", C.c_void_p), ("g", C.c_void_p * 2), ("gb", C.c_void_p * 2),
+                ("pos", C.c_void_p)]
 
 
 class ReduceSrc(C.Structure):
@@ -81,7 +82,7 @@ def load():
     lib.ddp_edge_featurize.restype = C.c_int
     lib.ddp_torsion_sh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.ddp_torsion_sh.restype = C.c_int
-    if lib.ddp_abi_version() != 1:
+    if lib.ddp_abi_version() != 2:
         raise DdpError("libddp_hip.so ABI version mismatch")
     _lib = lib
     return lib

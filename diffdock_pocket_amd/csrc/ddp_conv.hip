@@ -96,11 +96,10 @@ __device__ __forceinline__ f32x16 splat16(float v) {
 
 // ------------------------------------------------------------------------------------------------ phase 2
 __device__ __forceinline__ void build_features(const ddp_block_t& B, const ddp_conv_task_t& T, const int* s_src,
-                                               const int* s_eid, float* fbuf, int tid) {
+                                               const float (*s_sh)[4], float* fbuf, int tid) {
   const int e = tid & 63, wave = tid >> 6;
   const float* xrow = T.x_src + (size_t)s_src[e] * T.ldx_src;
-  const f32x4 shv = reinterpret_cast<const f32x4*>(T.sh)[s_eid[e]];
-  const float s0 = shv[0], sx = shv[1], sy = shv[2], sz = shv[3];
+  const float s0 = s_sh[e][0], sx = s_sh[e][1], sy = s_sh[e][2], sz = s_sh[e][3];
   const float inv_sqrt3 = 0.57735026918962576f, inv_sqrt2 = 0.70710678118654752f;
   int ubase = 0;
   for (int si = 0; si < B.nseg; ++si) {
@@ -155,6 +154,85 @@ __device__ __forceinline__ void tile_lane_map(const ddp_block_t& B, int t, int r
 // workgroup and each 16-byte B load feeds 4 MFMA k-steps x 2 row tiles.
 // C = 1: scalar block, tiles in pairs (2x2 register blocking: 64 edges x 64 columns per wave step)
 // C = 3: vector block, single tiles (2x1) with three output accumulators (x,y,z) per edge row
+// ------------------------------------------------------------------------------------------------ factorised part
+// Per-edge part of the source-node factorisation (include/ddp_hip.h, ddp_block_t::g_slot):
+//   tv[e, n] = Gb[src(e)][n] + sum_k h[e,k] * G[src(e)][k][n]      for the block's n columns of the G row.
+// The tile's edges are listed in source order; `units` are runs of <= 8 edges with one source node.  A wave takes a
+// unit, lanes = output columns (coalesced G rows, streamed once), the run's h rows come from LDS as wave-wide broadcasts
+// and the 8 running sums live in registers.  VALU work: 2*hid*n flops per edge (vs 2*hid*U*n on the MFMA path).
+struct TileAux {
+  int src[64], eid[64], pos[64], ustart[65];
+  int nunits;
+  float sh[64][4];
+};
+
+__device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, const ddp_conv_task_t& T, const float* hbuf,
+                                        float* tvbuf, const TileAux& aux, int wave, int lane) {
+  // One pass per G slot covers all its columns (<= 64 + 64): lane l owns column l and, if it exists, column 64 + l.
+  // The k loop is software pipelined in chunks of KC rows: the next chunk's G values are requested before the FMAs of
+  // the current one (a G row is touched once per workgroup, i.e. every request is an HBM / Infinity-Cache miss).
+  constexpr int KC = 12;
+  const int gc = S.g_cols[slot];
+  const float* __restrict__ G = T.g[slot];
+  const float* __restrict__ Gb = T.gb[slot];
+  const bool act0 = lane < gc, act1 = 64 + lane < gc;
+  const int c0 = act0 ? lane : 0, c1 = act1 ? 64 + lane : 0;
+  const int nch = (S.hid + KC - 1) / KC;   // h is zero beyond hid (LDS rows are padded to hp >= hid and cleared)
+  for (int u = wave; u < aux.nunits; u += DDP_CONV_THREADS / 64) {
+    const int e0 = aux.ustart[u], len = aux.ustart[u + 1] - e0;
+    const int node = aux.src[e0];
+    const float* __restrict__ gp = G + (size_t)node * S.hid * gc;
+    float tv0[8], tv1[8];
+    {
+      const float b0 = Gb[(size_t)node * gc + c0], b1 = Gb[(size_t)node * gc + c1];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { tv0[i] = b0; tv1[i] = b1; }
+    }
+    float ga[KC], gb2[KC];
+#pragma unroll
+    for (int q = 0; q < KC; ++q) {
+      const int k = min(q, S.hid - 1);
+      ga[q] = gp[(size_t)k * gc + c0];
+      gb2[q] = gp[(size_t)k * gc + c1];
+    }
+    for (int ch = 0; ch < nch; ++ch) {
+      float ca[KC], cb[KC];
+#pragma unroll
+      for (int q = 0; q < KC; ++q) { ca[q] = ga[q]; cb[q] = gb2[q]; }
+#pragma unroll
+      for (int q = 0; q < KC; ++q) {   // request the next chunk (clamped, unconditional)
+        const int k = min((ch + 1) * KC + q, S.hid - 1);
+        ga[q] = gp[(size_t)k * gc + c0];
+        gb2[q] = gp[(size_t)k * gc + c1];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const int k0 = ch * KC;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i < len) {
+          const float* hrow = &hbuf[(e0 + i) * S.hs + k0];
+#pragma unroll
+          for (int q4 = 0; q4 < KC / 4; ++q4) {
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(hrow + 4 * q4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              // rows k >= hid of the last chunk: h is 0 there only up to hp; mask explicitly
+              const float hq = (k0 + 4 * q4 + q < S.hid) ? hv[q] : 0.f;
+              tv0[i] += hq * ca[4 * q4 + q];
+              tv1[i] += hq * cb[4 * q4 + q];
+            }
+          }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < len) {
+        if (act0) tvbuf[(e0 + i) * gc + lane] = tv0[i];
+        if (act1) tvbuf[(e0 + i) * gc + 64 + lane] = tv1[i];
+      }
+  }
+}
+
 // Two register-blocking variants of phases 3+4 (both 8 waves = 2 per SIMD, which cover each other's waits/epilogues):
 //  run_block_full  wave w owns tile groups w, w+8, .. for ALL 64 edges: each packed weight tile leaves L2 once per
 //                  workgroup and one 16-byte B load feeds 4 k-steps x 2 row tiles (used for the scalar blocks, 84 % of
@@ -163,7 +241,7 @@ __device__ __forceinline__ void tile_lane_map(const ddp_block_t& B, int t, int r
 //                  the vector blocks whose three (x,y,z) output accumulators would not fit next to a 2-row-tile acc)
 template <int C>
 __device__ __forceinline__ void run_block_full(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
-                                          const float* hbuf, float* fbuf, int tid, int p0, int nvalid, int sbase) {
+                                          const float* hbuf, float* fbuf, int tid, const TileAux& aux, int nvalid, int sbase) {
   constexpr int CT = (C == 1) ? 2 : 1;
   constexpr int NW = DDP_CONV_THREADS / 64;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps tile/loop indices in SGPRs
@@ -187,8 +265,8 @@ __device__ __forceinline__ void run_block_full(const ddp_conv_shape_t& S, const 
   // are written: hipcc otherwise sinks both to just before their first use, which exposes their latency on every k-group.
   // (Measured alternatives, tools/stamp_conv.py + tools/ablate_loop.py: deeper weight prefetch (3 k-groups per step,
   // register ring) and dropping the loads altogether change the launch time by < 5 %: the loop is not latency bound.)
-  f32x4 bnext[CT];
-  {
+  f32x4 bnext[CT] = {};
+  if (ngroups > 0) {  // (a fully factorised block has no tiles at all)
     const int g0 = (wave < ngroups) ? wave : ngroups - 1;
 #pragma unroll
     for (int s = 0; s < CT; ++s) bnext[s] = w2p[(((size_t)(B.tile0 + g0 * CT + s) * nm) * 2 + hh) * 32 + r];
@@ -285,6 +363,7 @@ __device__ __forceinline__ void run_block_full(const ddp_conv_shape_t& S, const 
   const int nc = B.n;
   float* part = fbuf;
   float* carry = fbuf + 4 * REGION;
+  const float* tvbuf = fbuf + 5 * 4096;
 #pragma unroll 1
   for (int half = 0; half < 2; ++half) {
     __syncthreads();  // F (or the previous pass's partials) no longer needed
@@ -313,10 +392,12 @@ __device__ __forceinline__ void run_block_full(const ddp_conv_shape_t& S, const 
             for (int q = 0; q < B.ups; ++q) sum += reg[sl * 32 + q * B.n + ncol];
         }
       }
-      if (half == 0)
+      if (half == 0) {
         carry[idx] = sum;
-      else if (e < nvalid)
-        T.msg[(size_t)(p0 + e) * S.d_out + B.out_off + ncol] = sum;
+      } else if (e < nvalid) {
+        if (B.g_slot >= 0) sum += aux.sh[e][0] * tvbuf[e * S.g_cols[B.g_slot] + B.g_col0 + ncol];   // factorised features
+        T.msg[(size_t)aux.pos[e] * S.d_out + B.out_off + ncol] = sum;
+      }
     }
   }
   __syncthreads();  // fbuf is rewritten by the next block's features
@@ -325,7 +406,7 @@ __device__ __forceinline__ void run_block_full(const ddp_conv_shape_t& S, const 
 
 template <int C>
 __device__ __forceinline__ void run_block_rows(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
-                                          const float* hbuf, float* fbuf, int tid, int p0, int nvalid, int sbase) {
+                                          const float* hbuf, float* fbuf, int tid, const TileAux& aux, int nvalid, int sbase) {
   constexpr int CT = (C == 1) ? 2 : 1;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps tile/loop indices in SGPRs
   const int lane = tid & 63, r = lane & 31, hh = lane >> 5;
@@ -440,7 +521,11 @@ __device__ __forceinline__ void run_block_rows(const ddp_conv_shape_t& S, const 
             for (int k = 0; k < B.ups; ++k) sum += reg[sl * 32 + k * B.n + ncol];
         }
       }
-      if (e < nvalid) T.msg[(size_t)(p0 + e) * S.d_out + B.out_off + cc] = sum;
+      if (e < nvalid) {
+        if (B.g_slot >= 0)
+          sum += ((C == 1) ? aux.sh[e][0] : aux.sh[e][1 + c]) * (fbuf + 5 * 4096)[e * S.g_cols[B.g_slot] + B.g_col0 + ncol];
+        T.msg[(size_t)aux.pos[e] * S.d_out + B.out_off + cc] = sum;
+      }
     }
   }
   __syncthreads();  // fbuf is rewritten by the next block's features
@@ -450,7 +535,7 @@ __device__ __forceinline__ void run_block_rows(const ddp_conv_shape_t& S, const 
 // ------------------------------------------------------------------------------------------------ kernel
 __global__ __launch_bounds__(DDP_CONV_THREADS, 2) void ddp_conv_messages_kernel(const ConvLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ int s_src[64], s_eid[64];
+  __shared__ TileAux aux;
   const ddp_conv_shape_t& S = L.shape;
   const int tid = threadIdx.x;
   int t = 0;
@@ -467,8 +552,24 @@ __global__ __launch_bounds__(DDP_CONV_THREADS, 2) void ddp_conv_messages_kernel(
   // ---- phase 0: indices + edge_attr_ rows
   if (tid < 64) {
     const int p = p0 + min(tid, nvalid - 1);
-    s_src[tid] = T.src[p];
-    s_eid[tid] = T.eid[p];
+    aux.src[tid] = T.src[p];
+    const int eid = T.eid[p];
+    aux.eid[tid] = eid;
+    aux.pos[tid] = T.pos ? T.pos[p] : p;
+    const f32x4 shv = reinterpret_cast<const f32x4*>(T.sh)[eid];
+    aux.sh[tid][0] = shv[0]; aux.sh[tid][1] = shv[1]; aux.sh[tid][2] = shv[2]; aux.sh[tid][3] = shv[3];
+  }
+  if (tid == 64 && (S.g_cols[0] | S.g_cols[1])) {  // runs of <= 8 valid edges with one source node (edges are source sorted)
+    int nu = 0, start = 0;
+    const int* __restrict__ srcp = T.src + p0;
+    for (int e = 1; e <= nvalid; ++e) {
+      if (e == nvalid || srcp[e] != srcp[start] || e - start == 8) {
+        aux.ustart[nu++] = start;
+        start = e;
+      }
+    }
+    aux.ustart[nu] = nvalid;
+    aux.nunits = nu;
   }
   int col0 = 0;
 #pragma unroll
@@ -539,13 +640,15 @@ __global__ __launch_bounds__(DDP_CONV_THREADS, 2) void ddp_conv_messages_kernel(
   // ---- per weight block
   for (int bi = 0; bi < S.nblocks; ++bi) {
     const ddp_block_t& B = S.blk[bi];
-    build_features(B, T, s_src, s_eid, fbuf, tid);
+    build_features(B, T, aux.src, aux.sh, fbuf, tid);
+    if (B.g_slot >= 0 && (bi == 0 || S.blk[bi - 1].g_slot != B.g_slot))   // one pass per G slot, shared by its blocks
+      g_stage(S, B.g_slot, T, hbuf, fbuf + 5 * 4096, aux, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
     __syncthreads();
     STAMP(3 + 4 * bi);
     if (B.C == 1)
-      run_block_full<1>(S, B, T, hbuf, fbuf, tid, p0, nvalid, 4 + 4 * bi);
+      run_block_full<1>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
     else
-      run_block_rows<3>(S, B, T, hbuf, fbuf, tid, p0, nvalid, 4 + 4 * bi);
+      run_block_rows<3>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
   }
   STAMP(23);  // s_memrealtime at exit
 #ifdef DDP_STAMPS
@@ -574,6 +677,9 @@ extern "C" int ddp_conv_messages(const ddp_conv_shape_t* shape, const ddp_conv_t
     if (B.U * B.C * FS > shape->fbuf_floats || 5 * 4096 > shape->fbuf_floats)
       return ddp_fail(DDP_EINVAL, "ddp_conv_messages: fbuf_floats too small");
     if (B.nseg < 0 || B.nseg > DDP_MAX_SEGS) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: nseg");
+    if (B.g_slot > 1 || (B.g_slot >= 0 && (shape->g_cols[B.g_slot] < B.g_col0 + B.n || shape->g_cols[B.g_slot] > 128 ||
+                          5 * 4096 + 64 * shape->g_cols[B.g_slot] > shape->fbuf_floats)))
+      return ddp_fail(DDP_EINVAL, "ddp_conv_messages: factorised block outside its G row / fbuf too small");
   }
   if (64 * shape->hs > shape->fbuf_floats) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: fbuf_floats < staging tile");
   ConvLaunch L;
@@ -582,6 +688,9 @@ extern "C" int ddp_conv_messages(const ddp_conv_shape_t* shape, const ddp_conv_t
   int tiles = 0;
   for (int i = 0; i < ntasks; ++i) {
     if (tasks[i].n_edges <= 0) continue;  // an empty conv sends no message (models/score_model.py:109-111)
+    for (int gs = 0; gs < 2; ++gs)
+      if (shape->g_cols[gs] > 0 && (!tasks[i].g[gs] || !tasks[i].gb[gs]))
+        return ddp_fail(DDP_EINVAL, "ddp_conv_messages: factorised shape but task.g / task.gb is null");
     L.tile_start[L.ntasks] = tiles;
     L.task[L.ntasks] = tasks[i];
     tiles += (tasks[i].n_edges + DDP_EDGE_TILE - 1) / DDP_EDGE_TILE;

@@ -131,3 +131,22 @@ def build_csr(recv: torch.Tensor, src: torch.Tensor, n_recv: int, presorted: boo
     rowptr = torch.zeros(n_recv + 1, dtype=torch.int32, device=dev)
     rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
     return CSR(E, r_sorted.to(torch.int32), src[perm].to(torch.int32), perm.to(torch.int32), rowptr)
+
+
+@dataclass
+class SourceOrder:
+    """The edges of a CSR view re-listed in SOURCE-node order (for the factorised conv, which streams one G[j] per
+    source node): same fields as CSR plus `pos`, the row of each listed edge in the receiver-CSR message array."""
+    n_edges: int
+    recv: torch.Tensor
+    src: torch.Tensor
+    eid: torch.Tensor
+    pos: torch.Tensor
+
+
+def source_order(csr: CSR) -> SourceOrder:
+    if csr.n_edges == 0:
+        return SourceOrder(0, csr.recv, csr.src, csr.eid, csr.eid)
+    _, order = torch.sort(csr.src.long(), stable=True)
+    return SourceOrder(csr.n_edges, csr.recv[order].contiguous(), csr.src[order].contiguous(),
+                       csr.eid[order].contiguous(), order.to(torch.int32).contiguous())

@@ -31,6 +31,13 @@ class BlockSpec:
     ntiles: int = 0
     nsub: int = 1
     ups: int = 1
+    u_map: List[int] = None         # original feature index of each kept feature (None = identity)
+    # source-node factorisation of the block's scalar-input segment (see faster_tp_spec(factorized=True))
+    g_slot: int = -1                # -1 none, 0 = G array built from the 0e inputs, 1 = from the 0o inputs
+    g_col0: int = 0                 # first column of this block inside a G row
+    g_in_off: int = 0               # first column of the scalar inputs inside a node row
+    g_count: int = 0                # number of scalar inputs (= rows of the factorised weight slab)
+    g_u0: int = 0                   # original feature index of the first factorised feature
 
     def finalize(self, tile0):
         if self.n > 32:
@@ -56,6 +63,9 @@ class BlockSpec:
             us, ncol = j // self.n, j % self.n
             u = t * self.ups + us
             valid = (us < self.ups) & (u < self.U)
+        if self.u_map is not None:
+            um = torch.tensor(self.u_map + [0], dtype=torch.long)
+            u = um[torch.clamp(u, max=len(self.u_map))]
         rows = self.w_off + u * self.n + ncol
         return torch.where(valid, rows, torch.full_like(rows, -1))
 
@@ -81,6 +91,13 @@ class ConvSpec:
         for b in self.blocks:
             fb = max(fb, b.U * b.C * L.FS)
         self.fbuf_floats = (fb + 3) // 4 * 4
+        self.g_cols = [0, 0]
+        for b in self.blocks:
+            if b.g_slot >= 0:
+                self.g_cols[b.g_slot] = max(self.g_cols[b.g_slot], b.g_col0 + b.n)
+        self.factorized = any(b.g_slot >= 0 for b in self.blocks)
+        if self.factorized:
+            self.fbuf_floats += (64 * max(self.g_cols) + 3) // 4 * 4   # + the tv[64][g_cols] region of the factorised part
         if any(b.n > 64 or (b.C == 3 and b.n > 32) for b in self.blocks):
             raise NotImplementedError("HIP conv supports ns <= 64 and nv <= 32")
 
@@ -88,10 +105,12 @@ class ConvSpec:
         s = L.ConvShape()
         s.f_in, s.hid, s.kp1, s.hp, s.hs, s.nct1 = self.f_in, self.hid, self.kp1, self.hp, self.hs, self.nct1
         s.d_out, s.nblocks, s.fbuf_floats = self.d_out, len(self.blocks), self.fbuf_floats
+        s.g_cols[0], s.g_cols[1] = self.g_cols
         for i, b in enumerate(self.blocks):
             cb = s.blk[i]
             cb.U, cb.n, cb.C, cb.out_off = b.U, b.n, b.C, b.out_off
             cb.tile0, cb.ntiles, cb.nsub, cb.ups, cb.nseg = b.tile0, b.ntiles, b.nsub, b.ups, len(b.segs)
+            cb.g_slot, cb.g_col0 = b.g_slot, b.g_col0
             for k, (kind, off, cnt) in enumerate(b.segs):
                 cb.seg[k].kind, cb.seg[k].in_off, cb.seg[k].count = kind, off, cnt
         return s
@@ -115,8 +134,14 @@ def irreps_dim(m):
     return m[0] + 3 * m[1] + 3 * m[2] + m[3]
 
 
-def faster_tp_spec(in_mul: Sequence[int], out_mul: Sequence[int], n_edge_features: int) -> ConvSpec:
-    """Blocks of FasterTensorProduct (reference models/layers.py:26-31,40-53,82-85)."""
+def faster_tp_spec(in_mul: Sequence[int], out_mul: Sequence[int], n_edge_features: int, factorized: bool = False) -> ConvSpec:
+    """Blocks of FasterTensorProduct (reference models/layers.py:26-31,40-53,82-85).
+
+    factorized=True: the basis features built from SCALAR inputs (a0e*s0, a0e*s1, a0o*s1, a0o*s0) depend on the
+    edge only through sh, so their part of the message is  sh-factor(e) * sum_k h[e,k] * G[src(e)][k, n]  with the
+    per-SOURCE-NODE tensor  G[j][k, n] = sum_u a[j,u] * W2[(u,n), k] / sqrt(U)   (exact algebra, fp32).  Those features
+    (84 % of the fc.3 weight at ns=60) leave the per-edge MFMA work; G is produced by one plain GEMM per conv
+    (`factor_weights` below gives its right-hand side).  Only the vector-input features stay in `segs`/`u_map`."""
     m0e, m1o, m1e, m0o = in_mul
     n0e, n1o, n1e, n0o = out_mul
     o0e, o1o, o1e, o0o = 0, m0e, m0e + 3 * m1o, m0e + 3 * m1o + 3 * m1e          # input column offsets
@@ -129,13 +154,52 @@ def faster_tp_spec(in_mul: Sequence[int], out_mul: Sequence[int], n_edge_feature
         (m1e + m0o, n0o, 1, q0o, [(L.F_DOT, o1e, m1e), (L.F_SCALAR_S0, o0o, m0o)]),
     ]
     blocks, w_off = [], 0
+    gcol = [0, 0]
     for U, n, C, out_off, segs in table:
         if U * n > 0:
-            blocks.append(BlockSpec(U=U, n=n, C=C, out_off=out_off, w_off=w_off, scale=1.0 / math.sqrt(U),
-                                    segs=[s for s in segs if s[2] > 0]))
+            segs = [s for s in segs if s[2] > 0]
+            blk = BlockSpec(U=U, n=n, C=C, out_off=out_off, w_off=w_off, scale=1.0 / math.sqrt(U), segs=segs)
+            if factorized:
+                keep, umap, u0 = [], [], 0
+                for kind, off, cnt in segs:
+                    if kind in (L.F_SCALAR_S0, L.F_SCALAR_S1):
+                        slot = 0 if off == o0e else 1
+                        blk.g_slot, blk.g_col0, blk.g_in_off, blk.g_count, blk.g_u0 = slot, gcol[slot], off, cnt, u0
+                        gcol[slot] += n
+                    else:
+                        keep.append((kind, off, cnt))
+                        umap += list(range(u0, u0 + cnt))
+                    u0 += cnt
+                blk.segs, blk.u_map, blk.U = keep, umap, len(umap)
+            blocks.append(blk)
         w_off += U * n
     return ConvSpec(f_in=n_edge_features, hid=n_edge_features, d_out=irreps_dim(out_mul), weight_numel=w_off,
                     blocks=blocks)
+
+
+def factor_weights(spec: ConvSpec, weight: torch.Tensor, bias: torch.Tensor):
+    """Right-hand sides of the per-source-node GEMMs of a factorised conv, per G slot s (0: 0e inputs, 1: 0o inputs):
+         Wg[s]  [n_in, hid * g_cols[s]]   G[j].reshape(hid, g_cols) = x[j, in_off:in_off+n_in] @ Wg[s]
+         Bg[s]  [n_in, g_cols[s]]         Gb[j] = x[j, in_off:in_off+n_in] @ Bg[s]     (the fc.3 bias part)
+       with the block scale 1/sqrt(U_orig) folded in.  Returns ([Wg0, Wg1], [Bg0, Bg1], [in_off0, in_off1]); entries
+       of unused slots are None."""
+    weight = weight.detach().float().cpu()
+    bias = bias.detach().float().cpu()
+    Wg, Bg, offs = [None, None], [None, None], [0, 0]
+    for slot in (0, 1):
+        blks = [b for b in spec.blocks if b.g_slot == slot]
+        if not blks:
+            continue
+        n_in = blks[0].g_count
+        assert all(b.g_count == n_in and b.g_in_off == blks[0].g_in_off for b in blks)
+        W = torch.zeros(n_in, spec.hid, spec.g_cols[slot])
+        Bm = torch.zeros(n_in, spec.g_cols[slot])
+        for b in blks:
+            rows = b.w_off + (b.g_u0 + torch.arange(n_in)).reshape(-1, 1) * b.n + torch.arange(b.n).reshape(1, -1)
+            W[:, :, b.g_col0:b.g_col0 + b.n] = (weight[rows] * b.scale).permute(0, 2, 1)     # [u, n, hid] -> [u, hid, n]
+            Bm[:, b.g_col0:b.g_col0 + b.n] = bias[rows] * b.scale
+        Wg[slot], Bg[slot], offs[slot] = W.reshape(n_in, -1).contiguous(), Bm.contiguous(), blks[0].g_in_off
+    return Wg, Bg, offs
 
 
 def torsion_tp_spec(in_mul: Sequence[int], ns: int, n_edge_features: int) -> ConvSpec:

@@ -125,7 +125,7 @@ def _mlp(n_in, n_hidden, n_out, dropout):
 
 
 class _PackedConv:
-    __slots__ = ("w1p", "b1p", "w2p", "b2p", "bn_scale", "bn_shift")
+    __slots__ = ("w1p", "b1p", "w2p", "b2p", "bn_scale", "bn_shift", "wg", "bg", "g_in_off")
 
 
 class TensorProductConvLayer(nn.Module):
@@ -133,13 +133,46 @@ class TensorProductConvLayer(nn.Module):
     the HIP kernels.  `forward` keeps the reference call signature for a single conv (used by the parity tests);
     the score model itself batches the nine convs of a layer into one launch."""
 
-    def __init__(self, spec: P.ConvSpec, out_blocks, batch_norm=True, dropout=0.0):
+    def __init__(self, spec: P.ConvSpec, out_blocks, batch_norm=True, dropout=0.0, spec_g: Optional[P.ConvSpec] = None):
         super().__init__()
         self.spec = spec
+        self.spec_g = spec_g          # source-node factorised variant of the same conv (None: not available)
         self.out_blocks = list(out_blocks)
         self.fc = _mlp(spec.f_in, spec.hid, spec.weight_numel, dropout)
         self.batch_norm = IrrepsBatchNorm(out_blocks) if batch_norm else None
         self._packed: Optional[_PackedConv] = None
+        self._packed_g: Optional[_PackedConv] = None
+
+    def packed_g(self, device) -> _PackedConv:
+        """Weights for the factorised path: fc.3 tiles of the vector-input features only + the GEMM right-hand sides
+        that turn source-node scalars into G / Gb (packing.factor_weights)."""
+        if self._packed_g is None or self._packed_g.w1p.device != device:
+            base = self.packed(device)
+            pk = _PackedConv()
+            pk.w1p, pk.b1p, pk.bn_scale, pk.bn_shift = base.w1p, base.b1p, base.bn_scale, base.bn_shift
+            w2p, b2p = P.pack_fc2(self.spec_g, self.fc[3].weight, self.fc[3].bias)
+            if w2p.numel() == 0:
+                w2p, b2p = torch.zeros(64), torch.zeros(32)
+            pk.w2p, pk.b2p = w2p.to(device), b2p.to(device)
+            wg, bg, offs = P.factor_weights(self.spec_g, self.fc[3].weight, self.fc[3].bias)
+            pk.wg = [w.to(device) if w is not None else None for w in wg]
+            pk.bg = [b.to(device) if b is not None else None for b in bg]
+            pk.g_in_off = offs
+            self._packed_g = pk
+        return self._packed_g
+
+    def node_tensors(self, pk: _PackedConv, x_src: torch.Tensor):
+        """Stage A of the factorised conv: per-source-node G = x_scalar @ Wg (one plain GEMM per slot, rocBLAS through
+        torch.mm - a library GEMM, not a hand-written kernel) and its bias part Gb."""
+        g, gb = [None, None], [None, None]
+        for slot in (0, 1):
+            if pk.wg[slot] is None:
+                continue
+            n_in = pk.wg[slot].shape[0]
+            xs = x_src[:, pk.g_in_off[slot]:pk.g_in_off[slot] + n_in]
+            g[slot] = torch.mm(xs, pk.wg[slot])
+            gb[slot] = torch.mm(xs, pk.bg[slot])
+        return g, gb
 
     def packed(self, device) -> _PackedConv:
         if self._packed is None or self._packed.w1p.device != device:
@@ -156,7 +189,8 @@ class TensorProductConvLayer(nn.Module):
             self._packed = pk
         return self._packed
 
-    def forward(self, node_attr, edge_index, edge_attr, edge_sh, out_nodes=None, reduce="mean", edge_weight=1.0):
+    def forward(self, node_attr, edge_index, edge_attr, edge_sh, out_nodes=None, reduce="mean", edge_weight=1.0,
+                factorized=False):
         if reduce != "mean" or not (isinstance(edge_weight, (int, float)) and edge_weight == 1.0):
             raise NotImplementedError("HIP conv implements reduce='mean', edge_weight=1")
         if edge_index.numel() == 0:
@@ -171,8 +205,17 @@ class TensorProductConvLayer(nn.Module):
         if sh.shape[1] != 4:
             raise NotImplementedError("edge_sh must be [E,4] (lmax=1) or pre-contracted torsion harmonics [0,t]")
         msg = torch.empty((csr.n_edges, self.spec.d_out), device=dev, dtype=torch.float32)
-        task = _make_task(self.packed(dev), x, x.shape[1], csr, sh, [(ea, csr.eid, ea.shape[1], ea.shape[1])], msg)
-        _launch_convs(self.spec, [task])
+        if factorized:
+            if self.spec_g is None:
+                raise NotImplementedError("this conv has no factorised variant")
+            pk = self.packed_g(dev)
+            so = G.source_order(csr)
+            g, gb = self.node_tensors(pk, x)
+            task = _make_task(pk, x, x.shape[1], so, sh, [(ea, so.eid, ea.shape[1], ea.shape[1])], msg, g=g, gb=gb, pos=so.pos)
+            _launch_convs(self.spec_g, [task], flops_spec=self.spec)
+        else:
+            task = _make_task(self.packed(dev), x, x.shape[1], csr, sh, [(ea, csr.eid, ea.shape[1], ea.shape[1])], msg)
+            _launch_convs(self.spec, [task])
         out = torch.zeros((n_out, self.spec.d_out), device=dev, dtype=torch.float32)
         _launch_reduce(out, self.spec.d_out, n_out, self.spec.d_out, [(msg, csr, self.packed(dev))], accumulate=False)
         return out
@@ -194,7 +237,7 @@ def _ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def _make_task(pk: _PackedConv, x_src, ldx_src, csr: G.CSR, sh, segs, msg) -> L.ConvTask:
+def _make_task(pk: _PackedConv, x_src, ldx_src, csr, sh, segs, msg, g=None, gb=None, pos=None) -> L.ConvTask:
     """segs: [(tensor, idx_int32[E], ld, ncols)], concatenated into edge_attr_ in this order."""
     t = L.ConvTask()
     t.x_src, t.ldx_src, t.n_edges = x_src.data_ptr(), ldx_src, csr.n_edges
@@ -207,6 +250,10 @@ def _make_task(pk: _PackedConv, x_src, ldx_src, csr: G.CSR, sh, segs, msg) -> L.
             t.seg_ptr[k], t.seg_idx[k], t.seg_ld[k], t.seg_n[k] = 0, 0, 0, 0
     t.w1p, t.b1p, t.w2p, t.b2p = pk.w1p.data_ptr(), pk.b1p.data_ptr(), pk.w2p.data_ptr(), pk.b2p.data_ptr()
     t.msg = msg.data_ptr()
+    for k in range(2):
+        t.g[k] = g[k].data_ptr() if (g is not None and g[k] is not None) else 0
+        t.gb[k] = gb[k].data_ptr() if (gb is not None and gb[k] is not None) else 0
+    t.pos = pos.data_ptr() if pos is not None else 0
     return t
 
 
@@ -230,7 +277,7 @@ def set_conv_profiler(p: Optional[ConvProfiler]):
     _PROFILER = p
 
 
-def _launch_convs(spec: P.ConvSpec, tasks: List[L.ConvTask]):
+def _launch_convs(spec: P.ConvSpec, tasks: List[L.ConvTask], flops_spec: Optional[P.ConvSpec] = None):
     lib = L.load()
     if not tasks:
         return
@@ -244,7 +291,7 @@ def _launch_convs(spec: P.ConvSpec, tasks: List[L.ConvTask]):
     if prof is not None:
         e1.record()
         prof.events.append((e0, e1))
-        prof.flops.append(spec.flops_per_edge() * sum(t.n_edges for t in tasks))
+        prof.flops.append((flops_spec or spec).flops_per_edge() * sum(t.n_edges for t in tasks))
 
 
 def _launch_reduce(x, ldx, n_nodes, d_out, sources, accumulate=True):
@@ -359,13 +406,20 @@ class TensorProductScoreModel(nn.Module):
                     if mul > 0]
 
         convs = []
-        self._layer_specs = []
+        self._layer_specs, self._layer_specs_g = [], []
+        # Source-node factorisation (packing.faster_tp_spec(factorized=True)): used for a conv when its edge set has on
+        # average at least `factorize_min_degree` edges per source node (then streaming one G[j] per node is cheaper
+        # than the per-edge MFMA work it replaces).  0 disables it (every conv on the direct path).
+        self.factorize_min_degree = 3.0
         for i in range(num_conv_layers):
             mi, mo = P.irreps_muls(ns, nv, i), P.irreps_muls(ns, nv, i + 1)
             spec = P.faster_tp_spec(mi, mo, 3 * ns)
+            spec_g = P.faster_tp_spec(mi, mo, 3 * ns, factorized=True)
             self._layer_specs.append(spec)
+            self._layer_specs_g.append(spec_g)
             for _ in range(9):
-                convs.append(TensorProductConvLayer(spec, out_blocks(mo), batch_norm=batch_norm, dropout=dropout))
+                convs.append(TensorProductConvLayer(spec, out_blocks(mo), batch_norm=batch_norm, dropout=dropout,
+                                                    spec_g=spec_g))
         self.conv_layers = nn.ModuleList(convs)
         m_final = P.irreps_muls(ns, nv, num_conv_layers)
         self._d_final = P.irreps_dim(m_final)
@@ -537,12 +591,20 @@ class TensorProductScoreModel(nn.Module):
         nodes = {"l": (xl, Nl), "a": (xa, Na), "r": (xr, Nr)}
         # summation order of the residual update (:316,:320,:324): lig u0+u2+u1, atom u3+u4+u5, rec u6+u8+u7
         order = {"l": [0, 2, 1], "a": [3, 4, 5], "r": [6, 8, 7]}
+        # source-ordered views for the factorised convs (built once per forward, reused by every layer)
+        n_src_nodes = {"l": Nl, "a": Na, "r": Nr}
+        src_type = {0: "l", 1: "r", 2: "a", 3: "a", 4: "l", 5: "r", 6: "r", 7: "l", 8: "a"}
+        so_views = {}
+        if self.factorize_min_degree > 0:
+            for k, csr, *_ in plan:
+                if csr.n_edges > 0 and csr.n_edges >= self.factorize_min_degree * n_src_nodes[src_type[k]]:
+                    so_views[k] = G.source_order(csr)
         for l in range(L_):
-            spec = self._layer_specs[l]
+            spec, spec_g = self._layer_specs[l], self._layer_specs_g[l]
             do_atom = self.flexible_sidechains or l != L_ - 1
             do_rec = do_atom and l != L_ - 1
             active = {"l": True, "a": do_atom, "r": do_rec}
-            tasks, msgs = [], {}
+            tasks, tasks_g, msgs, keep = [], [], {}, []
             for k, csr, x_recv, x_src, e_base, sh, rt in plan:
                 if not active[rt]:
                     continue
@@ -552,8 +614,16 @@ class TensorProductScoreModel(nn.Module):
                 msgs[k] = (msg, csr, pkc)
                 if csr.n_edges == 0:
                     continue
-                segs = [(e_base, csr.eid, ns, ns), (x_recv, csr.recv, ldx, ns), (x_src, csr.src, ldx, ns)]
-                tasks.append(_make_task(pkc, x_src, ldx, csr, sh, segs, msg))
+                if k in so_views:
+                    so, pkg = so_views[k], conv.packed_g(dev)
+                    g, gb = conv.node_tensors(pkg, x_src)
+                    keep.append((g, gb))
+                    segs = [(e_base, so.eid, ns, ns), (x_recv, so.recv, ldx, ns), (x_src, so.src, ldx, ns)]
+                    tasks_g.append(_make_task(pkg, x_src, ldx, so, sh, segs, msg, g=g, gb=gb, pos=so.pos))
+                else:
+                    segs = [(e_base, csr.eid, ns, ns), (x_recv, csr.recv, ldx, ns), (x_src, csr.src, ldx, ns)]
+                    tasks.append(_make_task(pkc, x_src, ldx, csr, sh, segs, msg))
+            _launch_convs(spec_g, tasks_g, flops_spec=spec)
             _launch_convs(spec, tasks)
             for rt in ("l", "a", "r"):
                 if active[rt]:

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DDP_ABI_VERSION 1
+#define DDP_ABI_VERSION 2
 #define DDP_EINVAL (-1)   /* bad argument (shape not supported, null pointer, ...) */
 #define DDP_ELIMIT (-2)   /* exceeds a compiled-in limit (see DDP_MAX_*) */
 
@@ -58,6 +58,12 @@ typedef struct {
   int32_t ups;     /* n <= 32: features packed per tile = 32 / n; else 1 */
   int32_t nseg;
   ddp_seg_t seg[DDP_MAX_SEGS];
+  /* Source-node factorisation of the block's scalar-input features (a0e*s0, a0e*s1[c], a0o*s1[c], a0o*s0):
+   *   out[e, n(,c)] += (C == 1 ? s0 : s1[c]) * ( sum_k h[e,k] * G[src(e)][k][g_col0 + n] + Gb[src(e)][g_col0 + n] )
+   * with G = task.g[g_slot], a per-SOURCE-NODE tensor produced by one plain GEMM per conv (host side).  U / seg[] then
+   * describe only the remaining (vector-input) features, which stay on the per-edge MFMA path.  g_slot = -1: none. */
+  int32_t g_slot;
+  int32_t g_col0;
 } ddp_block_t;
 
 /* Static shape of a TensorProductConvLayer (models/score_model.py:84-107); shared by all tasks of a launch. */
@@ -71,6 +77,7 @@ typedef struct {
   int32_t d_out; /* message width */
   int32_t nblocks;
   int32_t fbuf_floats; /* LDS floats reserved for the per-block feature / reduction buffer */
+  int32_t g_cols[2];   /* columns per (node, k) row of the two G arrays (0 = unused) */
   ddp_block_t blk[DDP_MAX_BLOCKS];
 } ddp_conv_shape_t;
 
@@ -93,9 +100,15 @@ typedef struct {
   const float* w2p;     /* fc.3 weight, packed, 1/sqrt(U) folded in */
   const float* b2p;
   float* msg;           /* per-edge messages, CSR order                       [E, d_out] */
+  /* factorised convs only (shape.g_cols != 0): edges are then listed in SOURCE-node order (so that a workgroup streams
+   * each G[j] once) and `pos` gives the message row (= position in the receiver-CSR order) of every listed edge */
+  const float* g[2];    /* G[s]:  [n_src, hid, g_cols[s]] */
+  const float* gb[2];   /* Gb[s]: [n_src, g_cols[s]]      (fc.3 bias part) */
+  const int32_t* pos;   /* [E] message row per listed edge; NULL = identity */
 } ddp_conv_task_t;
 
 /* Fused fc -> tensor product -> per-edge message for up to 9 convs that share one shape.
+ * All tasks of one call share `shape` (factorised and plain convs therefore go in separate calls).
  * Replaces: TensorProductConvLayer.forward up to (not including) the scatter
  * (models/score_model.py:108-114) + FasterTensorProduct.forward (models/layers.py:34-85) + the edge_attr_
  * concatenations (models/all_atom_score_model.py:273-312).  The [E, weight_numel] tensor never exists. */

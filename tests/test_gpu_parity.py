@@ -53,6 +53,17 @@ def test_forward_matches_oracle_and_golden(name):
     assert st["E_ll"] == int(oracle.record["ll"].shape[1])
 
 
+@pytest.mark.parametrize("name", ["cfg2_small", "cfg1_edge"])
+def test_forward_direct_path_matches_too(name):
+    """factorize_min_degree = 0 forces every conv onto the direct (per-edge MFMA) path; both paths are kept correct."""
+    case, gold, batch, sd = case_inputs(name)
+    model = _model_for(case, sd)
+    model.factorize_min_degree = 0
+    got = model(batch.to(_dev()))
+    for g, k in zip(got, ("tr", "rot", "tor", "sc_tor")):
+        assert rel_err(g.float().cpu(), gold["outputs"][k]) < TOL, (name, k)
+
+
 def test_forward_is_deterministic():
     case, gold, batch, sd = case_inputs("cfg1_full")
     model = _model_for(case, sd)
@@ -65,7 +76,8 @@ def test_forward_is_deterministic():
 @pytest.mark.parametrize("ns,nv,layer,E,N", [(16, 4, 0, 1, 3), (16, 4, 1, 63, 10), (16, 4, 2, 64, 10), (24, 6, 3, 65, 7),
                                               (60, 10, 3, 200, 23), (60, 10, 0, 129, 5), (32, 6, 3, 500, 40),
                                               (64, 32, 3, 70, 9)])
-def test_single_conv_layer(ns, nv, layer, E, N):
+@pytest.mark.parametrize("factorized", [False, True])
+def test_single_conv_layer(ns, nv, layer, E, N, factorized):
     """TensorProductConvLayer.forward with the reference call signature (models/score_model.py:108) on ragged
     edge sets: partial tiles, receivers without edges, repeated receivers."""
     from diffdock_pocket_amd import packing as P
@@ -74,7 +86,7 @@ def test_single_conv_layer(ns, nv, layer, E, N):
     mi, mo = P.irreps_muls(ns, nv, layer), P.irreps_muls(ns, nv, layer + 1)
     spec = P.faster_tp_spec(mi, mo, 3 * ns)
     blocks = [(m, d, s) for m, d, s in ((mo[0], 1, True), (mo[1], 3, False), (mo[2], 3, False), (mo[3], 1, False)) if m]
-    conv = TensorProductConvLayer(spec, blocks)
+    conv = TensorProductConvLayer(spec, blocks, spec_g=P.faster_tp_spec(mi, mo, 3 * ns, factorized=True))
     with torch.no_grad():
         conv.batch_norm.running_mean.normal_(0, 0.2)
         conv.batch_norm.running_var.uniform_(0.5, 2)
@@ -89,7 +101,7 @@ def test_single_conv_layer(ns, nv, layer, E, N):
     want = OracleScoreModel(cfg, sd)._conv("c", cfg.irreps(layer), cfg.irreps(layer + 1), x, ei, ea, sh)
     dev = _dev()
     conv = conv.to(dev)
-    got = conv(x.to(dev), ei.to(dev), ea.to(dev), sh.to(dev)).cpu()
+    got = conv(x.to(dev), ei.to(dev), ea.to(dev), sh.to(dev), factorized=factorized).cpu()
     assert got.shape == want.shape
     assert rel_err(got, want) < 2e-5, rel_err(got, want)
     # empty edge set: scalar zero, like the reference (models/score_model.py:109-111)

@@ -29,7 +29,7 @@ def unpack_tiles(flat, ntiles, kp):
     return W.permute(0, 3, 1, 2, 4).reshape(ntiles * 32, kp)
 
 
-def emulate_conv(spec, w1p, b1p, w2p, b2p, edge_attr, x_src_rows, sh):
+def emulate_conv(spec, w1p, b1p, w2p, b2p, edge_attr, x_src_rows, sh, fact=None):
     """What ddp_conv_messages_kernel computes for one conv, written with dense torch ops on the PACKED weights."""
     E = edge_attr.shape[0]
     W1 = unpack_tiles(w1p, spec.nct1, spec.kp1)            # [cols, kp1]
@@ -44,7 +44,22 @@ def emulate_conv(spec, w1p, b1p, w2p, b2p, edge_attr, x_src_rows, sh):
     out = torch.zeros(E, spec.d_out, dtype=torch.float64)
     s0, s1 = sh[:, 0].double(), sh[:, 1:4].double()
     x = x_src_rows.double()
+    if fact is not None:   # source-node factorised part: tv[e] = h[e] . G[src(e)] + Gb[src(e)], times s0 / s1[c]
+        Wg, Bg, offs = fact
+        for b in spec.blocks:
+            if b.g_slot < 0:
+                continue
+            xs = x[:, offs[b.g_slot]:offs[b.g_slot] + Wg[b.g_slot].shape[0]]
+            G = (xs @ Wg[b.g_slot].double()).reshape(E, spec.hid, spec.g_cols[b.g_slot])
+            Gb = xs @ Bg[b.g_slot].double()
+            tv = torch.einsum("ek,ekn->en", hp[:, :spec.hid], G) + Gb
+            tv = tv[:, b.g_col0:b.g_col0 + b.n]
+            for c in range(b.C):
+                fac = s0 if b.C == 1 else s1[:, c]
+                out[:, b.out_off + torch.arange(b.n) * b.C + c] += fac[:, None] * tv
     for b in spec.blocks:
+        if b.U == 0:
+            continue
         feats = []
         for kind, off, cnt in b.segs:
             if kind == L.F_SCALAR_S0:
@@ -79,11 +94,12 @@ def emulate_conv(spec, w1p, b1p, w2p, b2p, edge_attr, x_src_rows, sh):
     return out
 
 
+@pytest.mark.parametrize("factorized", [False, True])
 @pytest.mark.parametrize("ns,nv,layer", [(16, 4, 0), (16, 4, 1), (24, 6, 2), (60, 10, 3), (60, 10, 0), (32, 6, 3)])
-def test_packed_conv_matches_faster_tensor_product(ns, nv, layer):
+def test_packed_conv_matches_faster_tensor_product(ns, nv, layer, factorized):
     torch.manual_seed(layer + ns)
     mi, mo = P.irreps_muls(ns, nv, layer), P.irreps_muls(ns, nv, layer + 1)
-    spec = P.faster_tp_spec(mi, mo, 3 * ns)
+    spec = P.faster_tp_spec(mi, mo, 3 * ns, factorized=factorized)
     cfg = OracleConfig(ns=ns, nv=nv)
     E = 7
     fc0_w, fc0_b = torch.randn(3 * ns, 3 * ns) / (3 * ns) ** 0.5, torch.randn(3 * ns) * 0.1
@@ -91,7 +107,8 @@ def test_packed_conv_matches_faster_tensor_product(ns, nv, layer):
     ea, x, sh = torch.randn(E, 3 * ns), torch.randn(E, P.irreps_dim(mi)), torch.randn(E, 4)
     w1p, b1p = P.pack_fc1(spec, fc0_w, fc0_b)
     w2p, b2p = P.pack_fc2(spec, fc3_w, fc3_b)
-    got = emulate_conv(spec, w1p, b1p, w2p, b2p, ea, x, sh)
+    fact = P.factor_weights(spec, fc3_w, fc3_b) if factorized else None
+    got = emulate_conv(spec, w1p, b1p, w2p, b2p, ea, x, sh, fact)
     w = torch.relu(ea.double() @ fc0_w.double().T + fc0_b.double()) @ fc3_w.double().T + fc3_b.double()
     want = faster_tensor_product(cfg.irreps(layer), cfg.irreps(layer + 1), x.double(), sh.double(), w)
     assert torch.allclose(got, want, rtol=2e-5, atol=2e-6)
@@ -216,5 +233,5 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.ddp_abi_version.restype = ctypes.c_int
-    assert lib.ddp_abi_version() == 1
-    assert ctypes.sizeof(L.ConvShape) == 9 * 4 + 4 * (9 * 4 + 3 * 12)
+    assert lib.ddp_abi_version() == 2
+    assert ctypes.sizeof(L.ConvShape) == 11 * 4 + 4 * (11 * 4 + 3 * 12)

@@ -23,6 +23,8 @@ from diffdock_pocket_amd.synthetic import make_3dpf_complex  # noqa: E402
 
 dev = torch.device("cuda:0")
 model, kw = bench.build_model("cfg2", False, dev)
+if "--direct" in sys.argv:
+    model.factorize_min_degree = 0
 g = make_3dpf_complex(seed=0, flexible_sidechains=False)
 smp = Sampler(model, g, 40, dev, SamplerConfig(flexible_sidechains=False), seed=0)
 smp.randomize()
@@ -32,15 +34,20 @@ orig = sm._launch_convs
 captured = {}
 
 
-def hooked(spec, tasks):
+WANT_G = "--direct" not in sys.argv
+
+
+def hooked(spec, tasks, flops_spec=None):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    orig(spec, tasks)
+    orig(spec, tasks, flops_spec)
     e1.record()
     torch.cuda.synchronize()
-    if len(spec.blocks) == 4 and len(tasks) == 9:
+    sel = len(spec.blocks) == 4 and len(tasks) >= 5 and spec.factorized == WANT_G and spec.blocks[3].n == 60 and spec.blocks[2].n == 10 \
+        and (spec.blocks[3].ntiles in (20, 140))
+    if sel:
         captured["ms"] = e0.elapsed_time(e1)
-    if len(spec.blocks) == 4 and len(tasks) == 9 and "done" not in captured:
+    if sel and "done" not in captured:
         torch.cuda.synchronize()
         n = sum((t.n_edges + 63) // 64 for t in tasks)
         n = min(n, 32768)
