@@ -34,6 +34,20 @@ import torch  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 
 
+def _load_traffic():
+    """HBM bytes per conv launch from the rocprofv3 PMC passes (profiles/*_traffic.json, written by
+    tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs with the gfx950 corrections); None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except OSError:
+        return None
+
+
+TRAFFIC_BYTES_PER_LAUNCH = None
+
+
 def model_kwargs(cfg, flex):
     if cfg == "cfg2":
         ns, nv, L, emb = 60, 10, 6, 64
@@ -172,14 +186,22 @@ def main():
     assert torch.isfinite(sampler.lig_pos).all(), "non-finite poses"
 
     if rank == 0:
+        global TRAFFIC_BYTES_PER_LAUNCH
+        TRAFFIC_BYTES_PER_LAUNCH = _load_traffic()
         poses = n_total * args.steps / 20.0
         launches, flops, ms = prof.summary()
         roof = None
         if launches:
             ach = flops / launches / (ms / launches * 1e-3) / 1e12
+            exe = prof.executed_flops() / launches / (ms / launches * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "ddp_conv_messages_kernel", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": TRAFFIC_BYTES_PER_LAUNCH,
                     "launches": launches, "avg_launch_ms": ms / launches, "algorithmic_gflop_per_launch": flops / launches / 1e9,
+                    "executed_tflops": exe, "executed_frac": exe / FP32_MFMA_PEAK_TFLOPS,
+                    "note": "achieved = ALGORITHMIC FLOPs of the reference formulation (BASELINE.md section 3: 2FH + 2HW + 2C per edge) / "
+                            "kernel time; frac > 1 is possible because the kernel does not execute that formulation: the scalar-input "
+                            "tensor-product features are factorised per source node (exact fp32 algebra, DESIGN.md section 4), so only "
+                            "executed_tflops of fp32 MFMA/VALU work are issued",
                     "conv_share_of_wall": ms * 1e-3 / elapsed}
         line = {"metric": "ligand poses/sec (40 samples x 20 steps) on 3dpf", "value": poses / elapsed, "unit": "poses/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,

@@ -262,11 +262,15 @@ class ConvProfiler:
     (BASELINE.md §3 formula x the launch's actual edge count).  Used by bench.py for the roofline entry."""
 
     def __init__(self):
-        self.events, self.flops = [], []
+        self.events, self.flops, self.executed = [], [], []
 
     def summary(self):
         ms = sum(a.elapsed_time(b) for a, b in self.events)
         return len(self.events), float(sum(self.flops)), float(ms)
+
+    def executed_flops(self):
+        """FLOPs the kernel actually issued (padded MFMA tiles + the VALU part of factorised convs)."""
+        return float(sum(self.executed))
 
 
 _PROFILER: Optional[ConvProfiler] = None
@@ -291,7 +295,9 @@ def _launch_convs(spec: P.ConvSpec, tasks: List[L.ConvTask], flops_spec: Optiona
     if prof is not None:
         e1.record()
         prof.events.append((e0, e1))
-        prof.flops.append((flops_spec or spec).flops_per_edge() * sum(t.n_edges for t in tasks))
+        ne = sum(t.n_edges for t in tasks)
+        prof.flops.append((flops_spec or spec).flops_per_edge() * ne)
+        prof.executed.append((spec.mfma_flops_per_edge_executed() + 2 * spec.hid * sum(spec.g_cols)) * ne)
 
 
 def _launch_reduce(x, ldx, n_nodes, d_out, sources, accumulate=True):
