@@ -214,6 +214,19 @@ class Sampler:
             self.atom_pos = apply_sidechain_torsions(self.atom_pos, self.sc_edge_idx, self.sc_sub, self.sc_map, sc_p)
         self.lig_pos = modify_conformer(self.lig_pos, tr_p, rot_p, tor_p, self.bonds, self.mask_rotate)
 
+    # -- confidence pass + ranking (reference utils/sampling.py:263-283, inference.py:212-219) ------------------------
+    def confidence(self, confidence_model):
+        """Runs the confidence model (TensorProductScoreModel(confidence_mode=True)) on the final poses at t = 0 and
+        returns (confidence [n] or [n, k], order) with `order` = sample indices from most to least confident (for a
+        multi-output head the reference ranks by the first column, inference.py:213-216)."""
+        b = self.batch
+        b["ligand"].pos = self.lig_pos.reshape(-1, 3)
+        b["atom"].pos = self.atom_pos.reshape(-1, 3)
+        set_time(b, 0.0, 0.0, 0.0, 0.0, device=self.device)
+        conf = confidence_model(b)
+        key = conf[:, 0] if conf.dim() == 2 else conf
+        return conf, torch.argsort(key, descending=True)
+
     def run(self, schedule: Optional[np.ndarray] = None):
         schedule = get_t_schedule(self.cfg.inference_steps) if schedule is None else schedule
         for i in range(len(schedule)):

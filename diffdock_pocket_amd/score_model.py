@@ -15,7 +15,8 @@ reference checkpoints load with `load_state_dict`.  What runs where:
 
 There is no eager/CPU fallback: `forward` raises if the inputs are not on a HIP device or the library is missing.
 Configurations outside the README models (sh_lmax != 1, second-order irreps, smooth_edges, odd_parity, separate or
-asynchronous noise schedules, confidence mode, parallel > 1) raise NotImplementedError instead of silently differing.
+asynchronous noise schedules, affinity prediction, parallel > 1) raise NotImplementedError instead of silently differing.
+`confidence_mode=True` builds the confidence model (same convs, scalar-mean + MLP head).
 """
 from __future__ import annotations
 
@@ -364,7 +365,7 @@ class TensorProductScoreModel(nn.Module):
         unsupported = {"sh_lmax != 1": sh_lmax != 1, "use_second_order_repr": use_second_order_repr,
                        "smooth_edges": smooth_edges, "odd_parity": odd_parity,
                        "separate_noise_schedule": separate_noise_schedule,
-                       "asyncronous_noise_schedule": asyncronous_noise_schedule, "confidence_mode": confidence_mode,
+                       "asyncronous_noise_schedule": asyncronous_noise_schedule,
                        "affinity_prediction": affinity_prediction, "parallel > 1": parallel != 1,
                        "include_miscellaneous_atoms": include_miscellaneous_atoms}
         bad = [k for k, v in unsupported.items() if v]
@@ -390,7 +391,7 @@ class TensorProductScoreModel(nn.Module):
         self.atom_max_neighbors = atom_max_neighbors
         self.no_aminoacid_identities = no_aminoacid_identities
         self.flexible_sidechains = flexible_sidechains
-        self.confidence_mode = False
+        self.confidence_mode = bool(confidence_mode)
 
         enc = OldAtomEncoder if use_old_atom_encoder else AtomEncoder
         sd, dd, cd = sigma_embed_dim, distance_embed_dim, cross_distance_embed_dim
@@ -431,25 +432,34 @@ class TensorProductScoreModel(nn.Module):
         self._d_final = P.irreps_dim(m_final)
         self._ldx = (P.irreps_dim(P.irreps_muls(ns, nv, num_conv_layers)) + 3) // 4 * 4
 
-        self.center_distance_expansion = GaussianSmearing(0.0, center_max_distance, dd)
-        self.center_edge_embedding = _mlp(dd + sd, ns, ns, dropout)
-        self.final_conv = TensorProductConvLayer(P.faster_tp_spec(m_final, (0, 2, 2, 0), 2 * ns),
-                                                 [(2, 3, False), (2, 3, False)], batch_norm=batch_norm, dropout=dropout)
-        self.tr_final_layer = nn.Sequential(nn.Linear(1 + sd, ns), nn.Dropout(dropout), nn.ReLU(), nn.Linear(ns, 1))
-        self.rot_final_layer = nn.Sequential(nn.Linear(1 + sd, ns), nn.Dropout(dropout), nn.ReLU(), nn.Linear(ns, 1))
-        tor_blocks = [(ns, 1, False), (ns, 1, True)]   # "ns x0o + ns x0e": 0o first
-        if not no_torsion:
-            self.final_edge_embedding = _mlp(dd, ns, ns, dropout)
-            self.tor_bond_conv = TensorProductConvLayer(P.torsion_tp_spec(m_final, ns, 3 * ns), tor_blocks,
-                                                        batch_norm=batch_norm, dropout=dropout)
-            self.tor_final_layer = nn.Sequential(nn.Linear(2 * ns, ns, bias=False), nn.Tanh(), nn.Dropout(dropout),
-                                                 nn.Linear(ns, 1, bias=False))
-        if flexible_sidechains:
-            self.sidechain_final_edge_embedding = _mlp(dd, ns, ns, dropout)
-            self.sc_tor_bond_conv = TensorProductConvLayer(P.torsion_tp_spec(m_final, ns, 3 * ns), tor_blocks,
-                                                           batch_norm=batch_norm, dropout=dropout)
-            self.sc_tor_final_layer = nn.Sequential(nn.Linear(2 * ns, ns, bias=False), nn.Tanh(), nn.Dropout(dropout),
-                                                    nn.Linear(ns, 1, bias=False))
+        if self.confidence_mode:
+            # confidence head (reference models/all_atom_score_model.py:124-146); host-side PyTorch: a [B, <=4ns] MLP
+            conf_in = (2 * ns if num_conv_layers >= 3 else ns) * (2 if flexible_sidechains else 1)
+            bn = (lambda: nn.Identity()) if confidence_no_batchnorm else (lambda: nn.BatchNorm1d(ns))
+            self.confidence_predictor = nn.Sequential(
+                nn.Linear(conf_in, ns), bn(), nn.ReLU(), nn.Dropout(confidence_dropout),
+                nn.Linear(ns, ns), bn(), nn.ReLU(), nn.Dropout(confidence_dropout),
+                nn.Linear(ns, num_confidence_outputs))
+        else:
+            self.center_distance_expansion = GaussianSmearing(0.0, center_max_distance, dd)
+            self.center_edge_embedding = _mlp(dd + sd, ns, ns, dropout)
+            self.final_conv = TensorProductConvLayer(P.faster_tp_spec(m_final, (0, 2, 2, 0), 2 * ns),
+                                                     [(2, 3, False), (2, 3, False)], batch_norm=batch_norm, dropout=dropout)
+            self.tr_final_layer = nn.Sequential(nn.Linear(1 + sd, ns), nn.Dropout(dropout), nn.ReLU(), nn.Linear(ns, 1))
+            self.rot_final_layer = nn.Sequential(nn.Linear(1 + sd, ns), nn.Dropout(dropout), nn.ReLU(), nn.Linear(ns, 1))
+            tor_blocks = [(ns, 1, False), (ns, 1, True)]   # "ns x0o + ns x0e": 0o first
+            if not no_torsion:
+                self.final_edge_embedding = _mlp(dd, ns, ns, dropout)
+                self.tor_bond_conv = TensorProductConvLayer(P.torsion_tp_spec(m_final, ns, 3 * ns), tor_blocks,
+                                                            batch_norm=batch_norm, dropout=dropout)
+                self.tor_final_layer = nn.Sequential(nn.Linear(2 * ns, ns, bias=False), nn.Tanh(), nn.Dropout(dropout),
+                                                     nn.Linear(ns, 1, bias=False))
+            if flexible_sidechains:
+                self.sidechain_final_edge_embedding = _mlp(dd, ns, ns, dropout)
+                self.sc_tor_bond_conv = TensorProductConvLayer(P.torsion_tp_spec(m_final, ns, 3 * ns), tor_blocks,
+                                                               batch_norm=batch_norm, dropout=dropout)
+                self.sc_tor_final_layer = nn.Sequential(nn.Linear(2 * ns, ns, bias=False), nn.Tanh(), nn.Dropout(dropout),
+                                                        nn.Linear(ns, 1, bias=False))
         with np.load(os.path.join(ASSETS, "score_norm_tables.npz")) as z:
             self._so3_table = torch.from_numpy(z["so3_exp_score_norms"]).float()
             self._torus_table = torch.from_numpy(z["torus_score_norm"]).float()
@@ -510,7 +520,10 @@ class TensorProductScoreModel(nn.Module):
         B = int(data.num_graphs)
         if self.no_aminoacid_identities:
             rec.x = rec.x * 0
-        tr_sigma, rot_sigma, tor_sigma, sc_sigma = self.t_to_sigma(*[data.complex_t[k] for k in ("tr", "rot", "tor", "sc_tor")])
+        if self.confidence_mode:   # (:245) the times are used as they are
+            tr_sigma, rot_sigma, tor_sigma, sc_sigma = [data.complex_t[k] for k in ("tr", "rot", "tor", "sc_tor")]
+        else:
+            tr_sigma, rot_sigma, tor_sigma, sc_sigma = self.t_to_sigma(*[data.complex_t[k] for k in ("tr", "rot", "tor", "sc_tor")])
 
         lpos, rpos, apos = lig.pos.float().contiguous(), rec.pos.float().contiguous(), atom.pos.float().contiguous()
         lbatch, rbatch, abatch = lig.batch.long(), rec.batch.long(), atom.batch.long()
@@ -639,6 +652,25 @@ class TensorProductScoreModel(nn.Module):
         num_flex = 0
         if self.flexible_sidechains and ("flexResidues" in data) and len(data["flexResidues"]) > 0:
             num_flex = int(data["flexResidues"].edge_idx.shape[0])
+
+        if self.confidence_mode:   # (:329-353) mean of the scalar channels per graph -> MLP
+            def scalars(x):
+                return torch.cat([x[:, :ns], x[:, self._d_final - ns:self._d_final]], dim=1) if L_ >= 3 else x[:, :ns]
+
+            def graph_mean(v, b):
+                out = torch.zeros((B, v.shape[1]), device=dev).index_add_(0, b, v)
+                return out / torch.bincount(b, minlength=B).clamp(min=1).unsqueeze(1)
+
+            conf_in = graph_mean(scalars(xl), lbatch)
+            if self.flexible_sidechains:
+                if num_flex > 0:
+                    fr = data["flexResidues"]
+                    bonds = lay_a.starts[fr.batch.long()] + fr.edge_idx.t().long()
+                    flex_atoms = torch.unique(bonds)
+                    conf_in = torch.cat([conf_in, graph_mean(scalars(xa)[flex_atoms], abatch[flex_atoms])], dim=1)
+                else:
+                    conf_in = torch.cat([conf_in, torch.zeros_like(conf_in)], dim=1)
+            return self.confidence_predictor(conf_in).squeeze(dim=-1)
 
         # ---- translation / rotation head (:357-384)
         ar_l = torch.arange(Nl, device=dev)

@@ -32,6 +32,8 @@ class Case:
     fixed_center_conv: bool = True
     use_old_atom_encoder: bool = False
     no_torsion: bool = False
+    confidence_mode: bool = False
+    num_confidence_outputs: int = 1
     n_graphs: int = 2
     n_lig: Optional[int] = None           # truncation of the 3dpf complex (None = full)
     n_rec: Optional[int] = None
@@ -49,14 +51,15 @@ class Case:
                     lig_max_radius=5.0, cross_max_distance=80.0, dynamic_max_cross=True, scale_by_sigma=True,
                     batch_norm=True, dropout=0.0, lm_embedding_type="esm", fixed_center_conv=self.fixed_center_conv,
                     atom_max_neighbors=8, flexible_sidechains=self.flexible_sidechains, no_torsion=self.no_torsion,
-                    use_old_atom_encoder=self.use_old_atom_encoder)
+                    use_old_atom_encoder=self.use_old_atom_encoder, confidence_mode=self.confidence_mode,
+                    num_confidence_outputs=self.num_confidence_outputs)
 
     def oracle_config(self) -> OracleConfig:
         return OracleConfig(ns=self.ns, nv=self.nv, num_conv_layers=self.num_conv_layers, sigma_embed_dim=self.embed,
                             distance_embed_dim=self.embed, cross_distance_embed_dim=self.embed,
                             flexible_sidechains=self.flexible_sidechains, fixed_center_conv=self.fixed_center_conv,
                             use_old_atom_encoder=self.use_old_atom_encoder, no_torsion=self.no_torsion,
-                            embedding_scale=1000.0)
+                            confidence_mode=self.confidence_mode, embedding_scale=1000.0)
 
     def ctor_extras(self):
         sig = SigmaRanges()
@@ -107,6 +110,12 @@ CASES: Dict[str, Case] = {c.name: c for c in [
     Case("cfg1_edge", n_graphs=3, n_rec=24, t=[1.0, 0.5, 0.05], lig_shift=9.0, drop_rotatable=True,
          use_old_atom_encoder=True, fixed_center_conv=False, data_seed=3),
     Case("ns24_l3", ns=24, nv=6, num_conv_layers=3, embed=32, n_graphs=2, n_rec=24, t=[0.6, 0.4], weight_seed=5),
+    # confidence model (README.md:88 architecture ns=24 nv=6 L=5, flexible side chains): t = 0 as in
+    # reference utils/sampling.py:269-281, two classification outputs
+    Case("conf_ns24_l5", ns=24, nv=6, num_conv_layers=5, embed=32, n_graphs=3, n_rec=24, t=[0.0, 0.0, 0.0],
+         confidence_mode=True, num_confidence_outputs=2, weight_seed=7, data_seed=2),
+    Case("conf_noflex", ns=16, nv=4, num_conv_layers=2, embed=32, n_graphs=2, n_rec=20, t=[0.0, 0.0],
+         confidence_mode=True, flexible_sidechains=False, weight_seed=8),
 ]}
 
 

@@ -56,10 +56,15 @@ def run_case(case):
         if hasattr(model, name):
             getattr(model, name).register_forward_hook(hook(name))
     with torch.no_grad():
-        tr, rot, tor, sc = model(batch)
+        res = model(batch)
+    if case.confidence_mode:
+        outputs = {"confidence": res}
+    else:
+        tr, rot, tor, sc = res
+        outputs = {"tr": tr, "rot": rot, "tor": tor, "sc_tor": sc}
     gold = {
         "case": case.name,
-        "outputs": {"tr": tr, "rot": rot, "tor": tor, "sc_tor": sc},
+        "outputs": outputs,
         "conv_stats": {k: {"shape": list(v.shape), "mean_abs": float(v.abs().mean()) if v.numel() else 0.0,
                            "sample": sample_of(v)} for k, v in conv_out.items()},
         "state_dict_shapes": {k: list(v.shape) for k, v in template.items()},
@@ -78,8 +83,8 @@ def main():
         path = os.path.join(OUT_DIR, f"{n}.pt")
         torch.save(gold, path)
         o = gold["outputs"]
-        print(f"{n}: tr {o['tr'].flatten()[:3].tolist()} tor {o['tor'].flatten()[:3].tolist()} "
-              f"sc {o['sc_tor'].flatten()[:3].tolist()} -> {path} ({os.path.getsize(path) / 1e3:.0f} kB)")
+        print(f"{n}: " + " ".join(f"{k} {v.flatten()[:3].tolist()}" for k, v in o.items())
+              + f" -> {path} ({os.path.getsize(path) / 1e3:.0f} kB)")
 
 
 if __name__ == "__main__":

@@ -60,6 +60,7 @@ class OracleConfig:
     atom_max_neighbors: Optional[int] = 8
     flexible_sidechains: bool = True
     use_old_atom_encoder: bool = False
+    confidence_mode: bool = False
     lm_embedding_type: Optional[str] = "esm"
     embedding_scale: float = 1000.0
     tr_sigma_min: float = 0.1
@@ -326,10 +327,18 @@ class OracleScoreModel:
         return h.squeeze(1)
 
     # ---- forward (all_atom_score_model.py:238-436)
-    def forward(self, data):
+    def _forward_confidence(self, data, sig):
+        return self.forward(data, _conf=True)
+
+    def forward(self, data, _conf=False):
         c, ns = self.cfg, self.cfg.ns
+        conf = _conf
         rec = self.record = {}
         sig = {k: data.complex_t[k].to(self.dtype) for k in ("tr", "rot", "tor", "sc_tor")}
+        if c.confidence_mode and not conf:   # (:245) sigmas = times; only the cross cutoff uses them
+            return self._forward_confidence(data, sig)
+        if conf:
+            sig = {k: sig[k] for k in sig}
         tr_sigma = c.tr_sigma_min ** (1 - sig["tr"]) * c.tr_sigma_max ** sig["tr"]
         rot_sigma = c.rot_sigma_min ** (1 - sig["rot"]) * c.rot_sigma_max ** sig["rot"]
         tor_sigma = c.tor_sigma_min ** (1 - sig["tor"]) * c.tor_sigma_max ** sig["tor"]
@@ -347,7 +356,7 @@ class OracleScoreModel:
 
         # the neighbour search always runs on float32 inputs (as in the reference), also in the fp64 oracle
         t32 = data.complex_t["tr"].float()
-        tr_sigma32 = c.tr_sigma_min ** (1 - t32) * c.tr_sigma_max ** t32
+        tr_sigma32 = t32 if conf else c.tr_sigma_min ** (1 - t32) * c.tr_sigma_max ** t32
         cutoff = (tr_sigma32 * 3 + 20).unsqueeze(1) if c.dynamic_max_cross else c.cross_max_distance
         lr, lr_attr, lr_sh, la, la_attr, la_sh, ar, ar_attr, ar_sh = self._cross_graphs(data, cutoff)
         lr_attr = self._mlp("lr_edge_embedding", lr_attr)
@@ -390,6 +399,26 @@ class OracleScoreModel:
         final_irreps = c.irreps(L)
         has_flex = c.flexible_sidechains and ("flexResidues" in data) and len(data["flexResidues"]) > 0
         n_flex = data["flexResidues"].edge_idx.shape[0] if has_flex else 0
+        if conf:   # confidence head (:329-353)
+            def scal(x):
+                return torch.cat([x[:, :ns], x[:, -ns:]], dim=1) if L >= 3 else x[:, :ns]
+            cin = tp.scatter_mean(scal(lig_x), data["ligand"].batch, dim=0)
+            if c.flexible_sidechains:
+                if n_flex > 0:
+                    fa = self._sc_tor_bonds(data).unique()
+                    sa = tp.scatter_mean(scal(atom_x)[fa], data["atom"].batch[fa], dim=0, dim_size=cin.shape[0])
+                else:
+                    sa = torch.zeros_like(cin)
+                cin = torch.cat([cin, sa], dim=1)
+            p = "confidence_predictor"
+            def bn(i, x):
+                if f"{p}.{i}.running_mean" not in self.sd:
+                    return x
+                return ((x - self.sd[f"{p}.{i}.running_mean"]) / torch.sqrt(self.sd[f"{p}.{i}.running_var"] + 1e-5)
+                        * self.sd[f"{p}.{i}.weight"] + self.sd[f"{p}.{i}.bias"])
+            h = torch.relu(bn(1, self._lin(f"{p}.0", cin)))
+            h = torch.relu(bn(5, self._lin(f"{p}.4", h)))
+            return self._lin(f"{p}.8", h).squeeze(dim=-1)
 
         # translation / rotation head (:357-384)
         ce, ce_attr, ce_sh = self._center_graph(data)

@@ -26,7 +26,7 @@ def synth_tensor(key, shape, seed):
         return torch.randn(shape, generator=g) * 0.1
     if key.endswith("num_batches_tracked"):
         return torch.zeros(shape, dtype=torch.long)
-    if "batch_norm" in key or re_bn1d(key):
+    if "batch_norm" in key or (len(shape) == 1 and "confidence_predictor" in key and key.endswith("weight")):
         if key.endswith("weight"):
             return uni(0.5, 1.5)
         return torch.randn(shape, generator=g) * 0.1

@@ -17,10 +17,12 @@ TOL = 2e-5  # fp32 restatement vs fp32 reference: only summation-order noise is 
 def test_oracle_matches_reference_outputs(name):
     case, gold, batch, sd = case_inputs(name)
     model = OracleScoreModel(case.oracle_config(), sd)
-    tr, rot, tor, sc = model(batch)
+    res = model(batch)
     g = gold["outputs"]
-    assert tr.shape == g["tr"].shape and tor.shape == g["tor"].shape and sc.shape == g["sc_tor"].shape
-    for got, key in ((tr, "tr"), (rot, "rot"), (tor, "tor"), (sc, "sc_tor")):
+    named = {"confidence": res} if case.confidence_mode else dict(zip(("tr", "rot", "tor", "sc_tor"), res))
+    assert set(named) == set(g)
+    for key, got in named.items():
+        assert got.shape == g[key].shape, key
         assert rel_err(got, g[key]) < TOL, (key, rel_err(got, g[key]))
     assert int(batch["atom", "atom"].edge_index.shape[1]) == gold["edge_counts"]["aa"]
 
