@@ -404,10 +404,9 @@ __device__ __forceinline__ void run_block_full(const ddp_conv_shape_t& S, const 
   STAMP(sbase + 2);
 }
 
-template <int C>
+template <int C, int CT>
 __device__ __forceinline__ void run_block_rows(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
                                           const float* hbuf, float* fbuf, int tid, const TileAux& aux, int nvalid, int sbase) {
-  constexpr int CT = (C == 1) ? 2 : 1;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps tile/loop indices in SGPRs
   const int lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int rt = wave >> 2, wq = wave & 3;
@@ -515,7 +514,12 @@ __device__ __forceinline__ void run_block_rows(const ddp_conv_shape_t& S, const 
       for (int w = 0; w < 4; ++w) {
         const float* reg = part + (wbase + w) * REGION + (e & 31) * RW + c * (CT * 32);
         if (B.nsub > 1) {
-          sum += reg[ncol];                       // column = sub*32 + r = ncol
+          // pairs (CT = 2): column = sub*32 + r = ncol.  Single tiles (CT = 1): the wave's tiles w, w+4, ... all have
+          // the same parity, i.e. wave w only ever holds sub-block (w & 1) of the n columns
+          if (CT == 2)
+            sum += reg[ncol];
+          else if ((w & 1) == (ncol >> 5))
+            sum += reg[ncol & 31];
         } else {
           for (int sl = 0; sl < CT; ++sl)
             for (int k = 0; k < B.ups; ++k) sum += reg[sl * 32 + k * B.n + ncol];
@@ -645,10 +649,14 @@ __global__ __launch_bounds__(DDP_CONV_THREADS, 2) void ddp_conv_messages_kernel(
       g_stage(S, B.g_slot, T, hbuf, fbuf + 5 * 4096, aux, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
     __syncthreads();
     STAMP(3 + 4 * bi);
-    if (B.C == 1)
+    // scalar blocks with many tiles (direct path: 140): 2x2 full-row blocking, 8-way tile split; with few tiles
+    // (factorised path: 20) single tiles over (4 column groups x 2 row tiles) balance the four SIMDs better
+    if (B.C == 1 && B.ntiles >= 64)
       run_block_full<1>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
+    else if (B.C == 1)
+      run_block_rows<1, 1>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
     else
-      run_block_rows<3>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
+      run_block_rows<3, 1>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
   }
   STAMP(23);  // s_memrealtime at exit
 #ifdef DDP_STAMPS
