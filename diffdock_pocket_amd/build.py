@@ -20,17 +20,13 @@ def needs_build():
 
 
 def build(force=False, verbose=True, stamps=False, ablate=0):
-    if ablate:  # timing-only diagnostic variants (tools/ablate_conv.py)
-        out = os.path.join(HERE, f"libddp_hip_ablate{ablate}.so")
+    if ablate or stamps:
+        # diagnostic variants, never loaded by the product: -DDDP_STAMPS = in-kernel phase stamps (tools/stamp_conv.py),
+        # -DDDP_ABLATE=n = timing-only ablations whose results are wrong by construction (tools/ablate_conv.py)
+        out = os.path.join(HERE, "libddp_hip" + ("_stamps" if stamps else "") + (f"_ablate{ablate}" if ablate else "") + ".so")
         cmd = [os.environ.get("HIPCC", "hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-               f"-DDDP_ABLATE={ablate}", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), "-o", out]
-        cmd += [os.path.join(HERE, "csrc", s) for s in SOURCES]
-        subprocess.check_call(cmd)
-        return out
-    if stamps:  # diagnostic library with in-kernel phase stamps (tools/stamp_conv.py); never loaded by the product
-        out = os.path.join(HERE, "libddp_hip_stamps.so")
-        cmd = [os.environ.get("HIPCC", "hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-               "-DDDP_STAMPS", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), "-o", out]
+               "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), "-o", out]
+        cmd += (["-DDDP_STAMPS"] if stamps else []) + ([f"-DDDP_ABLATE={ablate}"] if ablate else [])
         cmd += [os.path.join(HERE, "csrc", s) for s in SOURCES]
         subprocess.check_call(cmd)
         return out

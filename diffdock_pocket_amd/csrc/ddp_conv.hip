@@ -32,6 +32,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define FS 68  // LDS row stride (floats) of the feature buffer F[u*C + c][e], e < 64
 #define DDP_CONV_THREADS 512  // 8 waves: two per SIMD
@@ -62,7 +63,16 @@ extern "C" int ddp_debug_read_stamps(unsigned long long* host_dst, int n_wgs) {
                                   sizeof(unsigned long long) * DDP_STAMP_SLOTS * (size_t)n_wgs);
 }
 #define STAMP_SYNC() __syncthreads()
+// running stamps of wave 0 inside g_stage (slot 0 pass only): slots 24..31 (s_memtime)
+#define GSTAMP()                                                                                          \
+  do {                                                                                                    \
+    const unsigned long long t_ = ddp_stamp_now(false);                                                   \
+    if (slot == 0 && threadIdx.x == 0 && blockIdx.x < DDP_STAMP_WGS && gstamp_i < 8)                      \
+      ddp_stamp_buf[blockIdx.x * DDP_STAMP_SLOTS + 24 + gstamp_i] = t_;                                   \
+    ++gstamp_i;                                                                                           \
+  } while (0)
 #else
+#define GSTAMP() do {} while (0)
 #define STAMP(k) do {} while (0)
 #define STAMP_SYNC() do {} while (0)
 #endif
@@ -73,6 +83,16 @@ extern "C" int ddp_debug_read_stamps(unsigned long long* host_dst, int n_wgs) {
 #define DDP_ABL_B(x) (f32x4{1.f, 2.f, 3.f, 4.f} * (float)(mn + 1))
 #else
 #define DDP_ABL_B(x) (x)
+#endif
+#if defined(DDP_ABLATE) && DDP_ABLATE == 3   // G pass without its global loads
+#define DDP_ABL_G(x, q) ((float)((q) + lane) * 1e-12f)
+#else
+#define DDP_ABL_G(x, q) (x)
+#endif
+#if defined(DDP_ABLATE) && DDP_ABLATE == 4   // G pass with 1/9 of its FMAs and LDS reads
+#define DDP_ABL_NQ(n) 1
+#else
+#define DDP_ABL_NQ(n) (n)
 #endif
 #if defined(DDP_ABLATE) && DDP_ABLATE == 2
 #define DDP_ABL_A(x, old) ((old) * 1.0001f)
@@ -168,69 +188,176 @@ struct TileAux {
 
 __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, const ddp_conv_task_t& T, const float* hbuf,
                                         float* tvbuf, const TileAux& aux, int wave, int lane) {
-  // One pass per G slot covers all its columns (<= 64 + 64): lane l owns column l and, if it exists, column 64 + l.
-  // The k loop is software pipelined in chunks of KC rows: the next chunk's G values are requested before the FMAs of
-  // the current one (a G row is touched once per workgroup, i.e. every request is an HBM / Infinity-Cache miss).
-  constexpr int KC = 12;
+  // One pass per G slot; a wave takes units wave, wave + 8, ...  For a unit (<= 8 edges of one source node)
+  //   tv[i, c] = Gb[c] + sum_k h[e0 + i, k] * G[k, c]
+  // is a [8 x hid] x [hid x gc] product with the 8 rows in LDS and the G rows streamed from memory exactly once.
+  //  * columns c < 64: v_mfma_f32_4x4x1 (16 blocks of 4x4, k = 1): block b = column group 4b..4b+3, so the B operand is
+  //    simply G[k][lane] (coalesced row) and D[i] lands as tv[i][lane]; the A operand h[e0 + (lane & 3)][k] is the same
+  //    for all blocks, i.e. ONE 16-byte LDS read per lane serves 4 edges x 4 k for all 64 columns.  (A VALU formulation
+  //    needs one wave-wide broadcast read per edge and 4 k: 4x the LDS traffic, which was its bound.)
+  //  * extra columns 64.. : if there are at most 8 of them (6 of the 70 at ns = 60, nv = 10) the 16 MFMA blocks are
+  //    used as nb = 1|2 column blocks x 16/nb K-slices and the slices are summed across lanes at the end of the unit
+  //    (shfl_xor butterfly, fixed order): 1/8 of the MFMAs of a full pass.  Otherwise a second full pass.
+  // Every G value is requested exactly once per wave (HBM / Infinity-Cache / L2), so the (unit, chunk) steps of a wave
+  // are flattened into one sequence and run through a 3-deep register ring: the loads of steps s+1 and s+2 are in
+  // flight while step s computes; the A operands of a step are read up front (the uniform k < hp branches would
+  // otherwise pin every LDS read right before its MFMAs and expose its latency 10 times per step).
+  constexpr int KC = 20, XK = 24, NW = DDP_CONV_THREADS / 64;
   const int gc = S.g_cols[slot];
   const float* __restrict__ G = T.g[slot];
   const float* __restrict__ Gb = T.gb[slot];
-  const bool act0 = lane < gc, act1 = 64 + lane < gc;
-  const int c0 = act0 ? lane : 0, c1 = act1 ? 64 + lane : 0;
-  const int nch = (S.hid + KC - 1) / KC;   // h is zero beyond hid (LDS rows are padded to hp >= hid and cleared)
-  for (int u = wave; u < aux.nunits; u += DDP_CONV_THREADS / 64) {
-    const int e0 = aux.ustart[u], len = aux.ustart[u + 1] - e0;
-    const int node = aux.src[e0];
-    const float* __restrict__ gp = G + (size_t)node * S.hid * gc;
-    float tv0[8], tv1[8];
-    {
-      const float b0 = Gb[(size_t)node * gc + c0], b1 = Gb[(size_t)node * gc + c1];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { tv0[i] = b0; tv1[i] = b1; }
+  const int nmain = min(gc, 64), nx = gc - nmain;
+  const int xnb = nx <= 4 ? 1 : 2, xnsl = 16 / xnb;                       // K-slice layout of the extra columns
+  const int xkper = (((S.hid + xnsl - 1) / xnsl) + 3) & ~3;
+  const bool kslice = nx > 0 && nx <= 8 && xkper <= XK;
+  const int npass = (nx > 0 && !kslice) ? 2 : 1;
+  const int nch = (S.hid + KC - 1) / KC;
+  const int nmine = (aux.nunits > wave) ? (aux.nunits - wave + NW - 1) / NW : 0;
+  const int nsteps = nmine * nch;
+  const size_t gstride = (size_t)S.hid * gc;
+#ifdef DDP_STAMPS
+  int gstamp_i = 0;
+#endif
+  GSTAMP();   // 0: entry
+
+  for (int pass = 0; pass < npass; ++pass) {
+    const int cb = 64 * pass;
+    const bool act0 = lane < (pass ? nx : nmain);
+    const int c0 = cb + (act0 ? lane : 0);
+    float bufA[KC], bufB[KC], bufC[KC], biasA = 0.f, biasB = 0.f, biasC = 0.f;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+
+#define DDP_G_ISSUE(STEP, BUF, BIAS)                                                                          \
+    if ((STEP) < nsteps) {                                                                                    \
+      const int ui_ = (STEP) / nch, ch_ = (STEP) - ui_ * nch;                                                 \
+      const int node_ = aux.src[aux.ustart[wave + NW * ui_]];                                                 \
+      const float* __restrict__ gp_ = G + (size_t)node_ * gstride;                                            \
+      _Pragma("unroll") for (int q = 0; q < KC; ++q)                                                          \
+        BUF[q] = DDP_ABL_G(gp_[(size_t)min(ch_ * KC + q, S.hid - 1) * gc + c0], q);                           \
+      if (ch_ == 0) BIAS = Gb[(size_t)node_ * gc + c0];                                                       \
     }
-    float ga[KC], gb2[KC];
-#pragma unroll
-    for (int q = 0; q < KC; ++q) {
-      const int k = min(q, S.hid - 1);
-      ga[q] = gp[(size_t)k * gc + c0];
-      gb2[q] = gp[(size_t)k * gc + c1];
+
+#define DDP_G_COMPUTE(STEP, BUF, BIAS)                                                                        \
+    if ((STEP) < nsteps) {                                                                                    \
+      const int ui_ = (STEP) / nch, ch_ = (STEP) - ui_ * nch;                                                 \
+      const int u_ = wave + NW * ui_;                                                                         \
+      const int e0 = aux.ustart[u_], len = aux.ustart[u_ + 1] - e0;                                           \
+      const int k0 = ch_ * KC;                                                                                \
+      if (ch_ == 0) {                                                                                         \
+        acc0 = f32x4{BIAS, BIAS, BIAS, BIAS};                                                                 \
+        acc1 = acc0;                                                                                          \
+      }                                                                                                       \
+      const float* hrow0 = &hbuf[(e0 + (lane & 3)) * S.hs + k0];                                              \
+      const float* hrow1 = hrow0 + 4 * S.hs;                                                                  \
+      f32x4 a0[KC / 4], a1[KC / 4];                                                                           \
+      _Pragma("unroll") for (int q4 = 0; q4 < KC / 4; ++q4) {                                                 \
+        a0[q4] = *reinterpret_cast<const f32x4*>(hrow0 + 4 * q4);                                             \
+        a1[q4] = *reinterpret_cast<const f32x4*>(hrow1 + 4 * q4);                                             \
+      }                                                                                                       \
+      _Pragma("unroll") for (int q4 = 0; q4 < DDP_ABL_NQ(KC / 4); ++q4)                                       \
+        if (k0 + 4 * q4 < S.hp) {   /* h is exactly 0 on [hid, hp) and the G rows are clamped there */        \
+          _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                  \
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q4][kk], BUF[4 * q4 + kk], acc0, 0, 0, 0);           \
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q4][kk], BUF[4 * q4 + kk], acc1, 0, 0, 0);           \
+          }                                                                                                   \
+        }                                                                                                     \
+      if (ch_ == nch - 1 && act0) {   /* rows >= len of the two 4-edge groups are never stored */             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+          if (i < len) tvbuf[(e0 + i) * gc + cb + lane] = acc0[i];                                            \
+          if (4 + i < len) tvbuf[(e0 + 4 + i) * gc + cb + lane] = acc1[i];                                    \
+        }                                                                                                     \
+      }                                                                                                       \
     }
-    for (int ch = 0; ch < nch; ++ch) {
-      float ca[KC], cb[KC];
-#pragma unroll
-      for (int q = 0; q < KC; ++q) { ca[q] = ga[q]; cb[q] = gb2[q]; }
-#pragma unroll
-      for (int q = 0; q < KC; ++q) {   // request the next chunk (clamped, unconditional)
-        const int k = min((ch + 1) * KC + q, S.hid - 1);
-        ga[q] = gp[(size_t)k * gc + c0];
-        gb2[q] = gp[(size_t)k * gc + c1];
-      }
+
+    DDP_G_ISSUE(0, bufA, biasA)
+    DDP_G_ISSUE(1, bufB, biasB)
+    GSTAMP();   // 1: prologue requests issued
+    for (int s0 = 0; s0 < nsteps; s0 += 3) {
+      DDP_G_ISSUE(s0 + 2, bufC, biasC)
       __builtin_amdgcn_sched_barrier(0);
-      const int k0 = ch * KC;
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (i < len) {
-          const float* hrow = &hbuf[(e0 + i) * S.hs + k0];
-#pragma unroll
-          for (int q4 = 0; q4 < KC / 4; ++q4) {
-            const f32x4 hv = *reinterpret_cast<const f32x4*>(hrow + 4 * q4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              // rows k >= hid of the last chunk: h is 0 there only up to hp; mask explicitly
-              const float hq = (k0 + 4 * q4 + q < S.hid) ? hv[q] : 0.f;
-              tv0[i] += hq * ca[4 * q4 + q];
-              tv1[i] += hq * cb[4 * q4 + q];
-            }
-          }
-        }
+      DDP_G_COMPUTE(s0, bufA, biasA)
+      __builtin_amdgcn_sched_barrier(0);
+      if (s0 == 0) GSTAMP();   // 2: first step done
+      DDP_G_ISSUE(s0 + 3, bufA, biasA)
+      __builtin_amdgcn_sched_barrier(0);
+      DDP_G_COMPUTE(s0 + 1, bufB, biasB)
+      __builtin_amdgcn_sched_barrier(0);
+      if (s0 == 0) GSTAMP();   // 3: second step done
+      DDP_G_ISSUE(s0 + 4, bufB, biasB)
+      __builtin_amdgcn_sched_barrier(0);
+      DDP_G_COMPUTE(s0 + 2, bufC, biasC)
+      __builtin_amdgcn_sched_barrier(0);
+      if (s0 == 0 || s0 == 3) GSTAMP();   // 4, 5: steps 3 and 6 done
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (i < len) {
-        if (act0) tvbuf[(e0 + i) * gc + lane] = tv0[i];
-        if (act1) tvbuf[(e0 + i) * gc + 64 + lane] = tv1[i];
-      }
+    if (nsteps <= 3) GSTAMP();
+    GSTAMP();   // 6: main loop done
+#undef DDP_G_ISSUE
+#undef DDP_G_COMPUTE
   }
+
+  if (kslice) {
+    // lane = (block b, j): K-slice p = b / xnb, extra column cj = 4 * (b % xnb) + j; A rows as in the main pass
+    const int b = lane >> 2, p = b / xnb, cj = 4 * (b - p * xnb) + (lane & 3);
+    const bool colv = cj < nx;
+    const int kx0 = p * xkper, cx = 64 + (colv ? cj : 0);
+    float gx[XK], gn[XK], bx = 0.f, bn = 0.f;
+#define DDP_GX_LOAD(UI, DST, BDST)                                                                            \
+    if ((UI) < nmine) {                                                                                       \
+      const int node_ = aux.src[aux.ustart[wave + NW * (UI)]];                                                \
+      const float* __restrict__ gp_ = G + (size_t)node_ * gstride;                                            \
+      _Pragma("unroll") for (int q = 0; q < XK; ++q) DST[q] = gp_[(size_t)min(kx0 + q, S.hid - 1) * gc + cx]; \
+      BDST = Gb[(size_t)node_ * gc + cx];                                                                     \
+    }
+    DDP_GX_LOAD(0, gn, bn)
+    for (int ui = 0; ui < nmine; ++ui) {
+#pragma unroll
+      for (int q = 0; q < XK; ++q) gx[q] = gn[q];
+      bx = bn;
+      DDP_GX_LOAD(ui + 1, gn, bn)
+      __builtin_amdgcn_sched_barrier(0);
+      const int u = wave + NW * ui;
+      const int e0 = aux.ustart[u], len = aux.ustart[u + 1] - e0;
+      const float* hrow0 = &hbuf[(e0 + (lane & 3)) * S.hs + kx0];
+      const float* hrow1 = hrow0 + 4 * S.hs;
+      f32x4 a0[XK / 4], a1[XK / 4];
+#pragma unroll
+      for (int q4 = 0; q4 < XK / 4; ++q4) {
+        a0[q4] = *reinterpret_cast<const f32x4*>(hrow0 + 4 * q4);
+        a1[q4] = *reinterpret_cast<const f32x4*>(hrow1 + 4 * q4);
+      }
+      f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < XK; ++q) {
+        // rows of the slice beyond hid (and idle columns) contribute exactly 0: both operands are zeroed there (the
+        // LDS words behind a row's hp columns are not h values)
+        const bool ok = colv && (q < xkper) && (kx0 + q < S.hid);
+        const float bq = ok ? gx[q] : 0.f;
+        const float aq0 = (kx0 + q < S.hid) ? a0[q >> 2][q & 3] : 0.f;
+        const float aq1 = (kx0 + q < S.hid) ? a1[q >> 2][q & 3] : 0.f;
+        x0 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq0, bq, x0, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq1, bq, x1, 0, 0, 0);
+      }
+      for (int m = 4 * xnb; m < 64; m <<= 1) {   // sum the K-slices (lane stride 4 * xnb), fixed order
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          x0[i] += __shfl_xor(x0[i], m);
+          x1[i] += __shfl_xor(x1[i], m);
+        }
+      }
+      if (lane < nx) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (i < len) tvbuf[(e0 + i) * gc + 64 + lane] = bx + x0[i];
+          if (4 + i < len) tvbuf[(e0 + 4 + i) * gc + 64 + lane] = bx + x1[i];
+        }
+      }
+    }
+#undef DDP_GX_LOAD
+  }
+  GSTAMP();   // 7: extras done
+#ifdef DDP_STAMPS
+  if (slot == 0 && threadIdx.x == 0 && blockIdx.x < DDP_STAMP_WGS) ddp_stamp_buf[blockIdx.x * DDP_STAMP_SLOTS + 36] = nsteps;
+#endif
 }
 
 // Two register-blocking variants of phases 3+4 (both 8 waves = 2 per SIMD, which cover each other's waits/epilogues):
@@ -645,8 +772,12 @@ __global__ __launch_bounds__(DDP_CONV_THREADS, 2) void ddp_conv_messages_kernel(
   for (int bi = 0; bi < S.nblocks; ++bi) {
     const ddp_block_t& B = S.blk[bi];
     build_features(B, T, aux.src, aux.sh, fbuf, tid);
+    if (bi == 0) STAMP(35);
+    if (bi == 2) STAMP(32);
     if (B.g_slot >= 0 && (bi == 0 || S.blk[bi - 1].g_slot != B.g_slot))   // one pass per G slot, shared by its blocks
       g_stage(S, B.g_slot, T, hbuf, fbuf + 5 * 4096, aux, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
+    if (bi == 0) STAMP(33);
+    if (bi == 2) STAMP(34);
     __syncthreads();
     STAMP(3 + 4 * bi);
     // scalar blocks with many tiles (direct path: 140): 2x2 full-row blocking, 8-way tile split; with few tiles

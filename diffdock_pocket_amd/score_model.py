@@ -277,6 +277,30 @@ class ConvProfiler:
 _PROFILER: Optional[ConvProfiler] = None
 
 
+class SectionTimer:
+    """Diagnostic: `model.section_timer = SectionTimer()` records a device event and the host clock at each section
+    boundary of forward; `summary()` gives per-section (gpu_ms, host_ms) summed over the recorded calls."""
+
+    def __init__(self):
+        self.marks = []
+
+    def mark(self, name):
+        import time
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.marks.append((name, ev, time.perf_counter()))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for (n0, e0, t0), (n1, e1, t1) in zip(self.marks[:-1], self.marks[1:]):
+            if n1 == "start":
+                continue
+            g, h = out.get(n1, (0.0, 0.0))
+            out[n1] = (g + e0.elapsed_time(e1), h + (t1 - t0) * 1e3)
+        return out
+
+
 def set_conv_profiler(p: Optional[ConvProfiler]):
     global _PROFILER
     _PROFILER = p
@@ -418,6 +442,7 @@ class TensorProductScoreModel(nn.Module):
         # average at least `factorize_min_degree` edges per source node (then streaming one G[j] per node is cheaper
         # than the per-edge MFMA work it replaces).  0 disables it (every conv on the direct path).
         self.factorize_min_degree = 3.0
+        self.section_timer = None      # optional SectionTimer (tools/time_sections.py): per-section GPU + host time
         for i in range(num_conv_layers):
             mi, mo = P.irreps_muls(ns, nv, i), P.irreps_muls(ns, nv, i + 1)
             spec = P.faster_tp_spec(mi, mo, 3 * ns)
@@ -518,6 +543,8 @@ class TensorProductScoreModel(nn.Module):
         dev = lig.pos.device
         ns, L_ = self.ns, self.num_conv_layers
         B = int(data.num_graphs)
+        mark = self.section_timer.mark if self.section_timer is not None else (lambda name: None)
+        mark("start")
         if self.no_aminoacid_identities:
             rec.x = rec.x * 0
         if self.confidence_mode:   # (:245) the times are used as they are
@@ -542,6 +569,7 @@ class TensorProductScoreModel(nn.Module):
         xr[:, :ns] = self.rec_node_embedding(rec.x[:, :ncat_r], torch.cat([rec.x[:, ncat_r:].float(), rec.node_sigma_emb], 1))
         xa[:, :ns] = self.atom_node_embedding(atom.x, atom.node_sigma_emb)
 
+        mark("node_embed")
         # ---- graphs (:444-583)
         i32 = lambda t: t.to(torch.int32).contiguous()
         bond_ei = data["ligand", "ligand"].edge_index.long()
@@ -560,6 +588,7 @@ class TensorProductScoreModel(nn.Module):
         self.last_stats = {"E_ll": ll.shape[1], "E_rr": rr.shape[1], "E_aa": aa.shape[1], "E_lr": lr.shape[1],
                            "E_la": la.shape[1], "E_ar": ar.shape[1], "N_l": Nl, "N_r": Nr, "N_a": Na, "B": B}
 
+        mark("graphs")
         # ---- edge featurisation: per-node / per-edge `pre` tables hold the non-RBF part of the first Linear
         sd_, dd, cd = self.sigma_embed_dim, self.distance_embed_dim, self.cross_distance_embed_dim
         nf = self.in_lig_edge_features
@@ -590,6 +619,7 @@ class TensorProductScoreModel(nn.Module):
         e_ar, sh_ar = _edge_featurize(pk, self.rec_distance_expansion, apos, i32(ar[0]), rpos, i32(ar[1]),
                                       sigma_pre(pk, atom.node_sigma_emb, slice(0, sd_)), i32(ar[0]))
 
+        mark("edge_featurize")
         # ---- CSR per conv direction (receiver = edge_index[0] of the conv call)
         c_ll = G.build_csr(ll[0], ll[1], Nl)
         c_lr = G.build_csr(lr[0], lr[1], Nl, presorted=True)
@@ -618,6 +648,7 @@ class TensorProductScoreModel(nn.Module):
             for k, csr, *_ in plan:
                 if csr.n_edges > 0 and csr.n_edges >= self.factorize_min_degree * n_src_nodes[src_type[k]]:
                     so_views[k] = G.source_order(csr)
+        mark("csr")
         for l in range(L_):
             spec, spec_g = self._layer_specs[l], self._layer_specs_g[l]
             do_atom = self.flexible_sidechains or l != L_ - 1
@@ -642,12 +673,15 @@ class TensorProductScoreModel(nn.Module):
                 else:
                     segs = [(e_base, csr.eid, ns, ns), (x_recv, csr.recv, ldx, ns), (x_src, csr.src, ldx, ns)]
                     tasks.append(_make_task(pkc, x_src, ldx, csr, sh, segs, msg))
+            mark("conv_prep")
             _launch_convs(spec_g, tasks_g, flops_spec=spec)
             _launch_convs(spec, tasks)
+            mark("conv_launch")
             for rt in ("l", "a", "r"):
                 if active[rt]:
                     x, n = nodes[rt]
                     _launch_reduce(x, ldx, n, spec.d_out, [msgs[k] for k in order[rt]], accumulate=True)
+            mark("reduce")
 
         num_flex = 0
         if self.flexible_sidechains and ("flexResidues" in data) and len(data["flexResidues"]) > 0:
@@ -698,6 +732,7 @@ class TensorProductScoreModel(nn.Module):
             tr_pred = tr_pred / tr_sigma.unsqueeze(1)
             rot_pred = rot_pred * self._so3_score_norm(rot_sigma).unsqueeze(1)
 
+        mark("center_head")
         # ---- torsion heads (:386-434)
         edge_mask = lig.edge_mask.bool()
         if self.no_torsion or int(edge_mask.sum()) == 0:
@@ -718,6 +753,7 @@ class TensorProductScoreModel(nn.Module):
                                          xa, apos, lay_a, bonds, fr.batch.long(), B, dev)
             if self.scale_by_sigma:
                 sc_pred = sc_pred * torch.sqrt(self._torus_score_norm(sc_sigma[fr.batch.long()]))
+        mark("tor_heads")
         return tr_pred, rot_pred, tor_pred, sc_pred
 
     def _torsion_head(self, conv: TensorProductConvLayer, final_layer, edge_mlp_name, x, pos, lay, bonds, bond_batch, B, dev):

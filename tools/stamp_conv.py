@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from diffdock_pocket_amd import build  # noqa: E402
 
-os.environ["DDP_HIP_LIB"] = os.environ.get("DDP_STAMP_LIB") or build.build(stamps=True)
+ABL = int(os.environ.get("DDP_STAMP_ABLATE", "0"))
+os.environ["DDP_HIP_LIB"] = os.environ.get("DDP_STAMP_LIB") or build.build(stamps=True, ablate=ABL)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -44,7 +45,7 @@ def hooked(spec, tasks, flops_spec=None):
     e1.record()
     torch.cuda.synchronize()
     sel = len(spec.blocks) == 4 and len(tasks) >= 5 and spec.factorized == WANT_G and spec.blocks[3].n == 60 and spec.blocks[2].n == 10 \
-        and (spec.blocks[3].ntiles in (20, 140))
+        and (spec.blocks[3].ntiles in (20, 140)) and (not WANT_G or min(spec.g_cols) > 0)
     if sel:
         captured["ms"] = e0.elapsed_time(e1)
     if sel and "done" not in captured:
@@ -55,6 +56,7 @@ def hooked(spec, tasks, flops_spec=None):
         rc = lib.ddp_debug_read_stamps(buf.ctypes.data_as(C.c_void_p), n)
         assert rc == 0
         captured["done"] = buf
+        captured["tiles"] = [(t.n_edges + 63) // 64 for t in tasks]
 
 
 sm._launch_convs = hooked
@@ -89,12 +91,29 @@ print(f"workgroups {len(st)}  mean total ticks {tot:.0f} (s_memtime ticks; 100 M
 for n_, m in zip(names, d.mean(0)):
     print(f"  {n_:26s} {m:10.0f}  {100 * m / tot:5.1f} %")
 
-pw = st[:, 24:32] - st[:, 3:4]
-print("blk0 per-wave tile-loop finish (cycles after the feature barrier), mean over workgroups:")
-print("  " + "  ".join(f"w{w}:{pw[:, w].mean():.0f}" for w in range(8)))
-
-for name, o in (("wave 4 (priority)", 32), ("wave 0", 36)):
-    d = st[:, o:o + 4].astype(np.float64)
-    ng = d[:, 3].mean()
-    print(f"blk0 {name}: groups {ng:.1f}; per group: acc init {d[:,0].mean()/ng:.0f}, k-loop {d[:,1].mean()/ng:.0f} "
-          f"(MFMA-only would be {16 * 64 * 24}), epilogue {d[:,2].mean()/ng:.0f} cycles")
+print(f"blk0 g_stage wave0 {(st[:,33]-st[:,35]).mean()*23.76:.0f} cycles; blk2 g_stage wave0 {(st[:,34]-st[:,32]).mean()*23.76:.0f} cycles")
+gph = (st[:, 3] - st[:, 2]).astype(np.float64)
+tot_wg = (st[:, 18] - st[:, 0]).astype(np.float64)
+start = (st[:, 22] - st[:, 22].min()) / 100.0
+o = 0
+print("per task (launch order): workgroups, mean blk0-features+G phase, mean workgroup total, mean start time us")
+for ti, nt in enumerate(captured["tiles"]):
+    sl = slice(o, o + nt)
+    print(f"  task {ti}: {nt:6d} wgs  G phase {gph[sl].mean():9.0f}  total {tot_wg[sl].mean():9.0f}  start {start[sl].mean():8.0f}")
+    o += nt
+order = np.argsort(st[:, 22])
+dec = np.array_split(order, 10)
+print("G phase by start-time decile:", " ".join(f"{gph[d].mean():.0f}" for d in dec))
+print(f"mean units per workgroup: n/a; edges {len(st)*64}")
+gs = st[:, 24:32]
+ns_ = st[:, 36]
+print(f"g_stage wave 0 (slot 0): mean steps {ns_.mean():.1f}; cycles: prologue issue {(gs[:,1]-gs[:,0]).mean():.0f}, step0 {(gs[:,2]-gs[:,1]).mean():.0f}, "
+      f"step1 {(gs[:,3]-gs[:,2]).mean():.0f}, step2 {(gs[:,4]-gs[:,3]).mean():.0f}, steps3-5 {(gs[:,5]-gs[:,4]).mean():.0f}, "
+      f"rest of main loop {(gs[:,6]-gs[:,5]).mean():.0f}, extras {(gs[:,7]-gs[:,6]).mean():.0f}, total {(gs[:,7]-gs[:,0]).mean():.0f}")
+o = 0
+for ti, nt in enumerate(captured["tiles"]):
+    sl = slice(o, o + nt)
+    g = gs[sl]
+    print(f"  task {ti}: steps {ns_[sl].mean():.1f} prologue {(g[:,1]-g[:,0]).mean():.0f} step0 {(g[:,2]-g[:,1]).mean():.0f} step1 {(g[:,3]-g[:,2]).mean():.0f} "
+          f"step2 {(g[:,4]-g[:,3]).mean():.0f} steps3-5 {(g[:,5]-g[:,4]).mean():.0f} rest {(g[:,6]-g[:,5]).mean():.0f} extras {(g[:,7]-g[:,6]).mean():.0f}")
+    o += nt
