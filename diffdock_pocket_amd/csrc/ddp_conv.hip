@@ -85,7 +85,7 @@ extern "C" int ddp_debug_read_stamps(unsigned long long* host_dst, int n_wgs) {
 #define DDP_ABL_B(x) (x)
 #endif
 #if defined(DDP_ABLATE) && DDP_ABLATE == 3   // G pass without its global loads
-#define DDP_ABL_G(x, q) ((float)((q) + lane) * 1e-12f)
+#define DDP_ABL_G(x, q) (f32x4{1e-12f, 2e-12f, 3e-12f, 4e-12f} * (float)((q) + lane))
 #else
 #define DDP_ABL_G(x, q) (x)
 #endif
@@ -184,6 +184,7 @@ struct TileAux {
   int src[64], eid[64], pos[64], ustart[65];
   int nunits;
   float sh[64][4];
+  int segi[DDP_MAX_SEGS][64];   // row of every edge in each edge_attr_ segment
 };
 
 __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, const ddp_conv_task_t& T, const float* hbuf,
@@ -211,10 +212,21 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
   const int xkper = (((S.hid + xnsl - 1) / xnsl) + 3) & ~3;
   const bool kslice = nx > 0 && nx <= 8 && xkper <= XK;
   const int npass = (nx > 0 && !kslice) ? 2 : 1;
-  const int nch = (S.hid + KC - 1) / KC;
+  const int nq = (S.hid + 3) >> 2;                                        // k quads of a G row: G[j][k/4][c][k%4]
+  const int nch = (4 * nq + KC - 1) / KC;
   const int nmine = (aux.nunits > wave) ? (aux.nunits - wave + NW - 1) / NW : 0;
   const int nsteps = nmine * nch;
-  const size_t gstride = (size_t)S.hid * gc;
+  const size_t gstride = (size_t)nq * gc;                                 // in 16-byte quads
+  const f32x4* __restrict__ G4 = reinterpret_cast<const f32x4*>(G);
+  // unit table of this wave in lanes 0..7 (a wave has at most 8 units): read with v_readlane instead of dependent LDS
+  // round trips at every step
+  int my_e0 = 0, my_len = 0, my_node = 0;
+  if (lane < 8 && wave + NW * lane < aux.nunits) {
+    const int u = wave + NW * lane;
+    my_e0 = aux.ustart[u];
+    my_len = aux.ustart[u + 1] - my_e0;
+    my_node = aux.src[my_e0];
+  }
 #ifdef DDP_STAMPS
   int gstamp_i = 0;
 #endif
@@ -224,28 +236,30 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
     const int cb = 64 * pass;
     const bool act0 = lane < (pass ? nx : nmain);
     const int c0 = cb + (act0 ? lane : 0);
-    float bufA[KC], bufB[KC], bufC[KC], biasA = 0.f, biasB = 0.f, biasC = 0.f;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bufA[KC / 4], bufB[KC / 4], bufC[KC / 4];
+    float biasA = 0.f, biasB = 0.f, biasC = 0.f;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    int i_ui = 0, i_ch = 0, c_ui = 0, c_ch = 0;   // (unit, chunk) of the next step to request / to compute
 
 #define DDP_G_ISSUE(STEP, BUF, BIAS)                                                                          \
     if ((STEP) < nsteps) {                                                                                    \
-      const int ui_ = (STEP) / nch, ch_ = (STEP) - ui_ * nch;                                                 \
-      const int node_ = aux.src[aux.ustart[wave + NW * ui_]];                                                 \
-      const float* __restrict__ gp_ = G + (size_t)node_ * gstride;                                            \
-      _Pragma("unroll") for (int q = 0; q < KC; ++q)                                                          \
-        BUF[q] = DDP_ABL_G(gp_[(size_t)min(ch_ * KC + q, S.hid - 1) * gc + c0], q);                           \
-      if (ch_ == 0) BIAS = Gb[(size_t)node_ * gc + c0];                                                       \
+      const int node_ = __builtin_amdgcn_readlane(my_node, i_ui);                                             \
+      const f32x4* __restrict__ gp_ = G4 + (size_t)node_ * gstride + c0;                                      \
+      _Pragma("unroll") for (int q4 = 0; q4 < KC / 4; ++q4)                                                   \
+        BUF[q4] = DDP_ABL_G(gp_[(size_t)min(i_ch * (KC / 4) + q4, nq - 1) * gc], q4);                         \
+      if (i_ch == 0) BIAS = Gb[(size_t)node_ * gc + c0];                                                      \
+      if (++i_ch == nch) { i_ch = 0; ++i_ui; }                                                                \
     }
 
 #define DDP_G_COMPUTE(STEP, BUF, BIAS)                                                                        \
     if ((STEP) < nsteps) {                                                                                    \
-      const int ui_ = (STEP) / nch, ch_ = (STEP) - ui_ * nch;                                                 \
-      const int u_ = wave + NW * ui_;                                                                         \
-      const int e0 = aux.ustart[u_], len = aux.ustart[u_ + 1] - e0;                                           \
-      const int k0 = ch_ * KC;                                                                                \
-      if (ch_ == 0) {                                                                                         \
+      const int e0 = __builtin_amdgcn_readlane(my_e0, c_ui), len = __builtin_amdgcn_readlane(my_len, c_ui);   \
+      const int k0 = c_ch * KC;                                                                               \
+      if (c_ch == 0) {                                                                                        \
         acc0 = f32x4{BIAS, BIAS, BIAS, BIAS};                                                                 \
         acc1 = acc0;                                                                                          \
+        acc2 = f32x4{0.f, 0.f, 0.f, 0.f};                                                                     \
+        acc3 = acc2;                                                                                          \
       }                                                                                                       \
       const float* hrow0 = &hbuf[(e0 + (lane & 3)) * S.hs + k0];                                              \
       const float* hrow1 = hrow0 + 4 * S.hs;                                                                  \
@@ -255,18 +269,24 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
         a1[q4] = *reinterpret_cast<const f32x4*>(hrow1 + 4 * q4);                                             \
       }                                                                                                       \
       _Pragma("unroll") for (int q4 = 0; q4 < DDP_ABL_NQ(KC / 4); ++q4)                                       \
-        if (k0 + 4 * q4 < S.hp) {   /* h is exactly 0 on [hid, hp) and the G rows are clamped there */        \
-          _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                  \
-            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q4][kk], BUF[4 * q4 + kk], acc0, 0, 0, 0);           \
-            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q4][kk], BUF[4 * q4 + kk], acc1, 0, 0, 0);           \
-          }                                                                                                   \
+        if (c_ch * (KC / 4) + q4 < nq) {   /* (h and G are exactly 0 on [hid, 4 nq)) */                       \
+          /* four independent accumulation chains (even / odd k per 4-edge group) keep the matrix pipe issuing */ \
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q4][0], BUF[q4][0], acc0, 0, 0, 0);                    \
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q4][0], BUF[q4][0], acc1, 0, 0, 0);                    \
+          acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q4][1], BUF[q4][1], acc2, 0, 0, 0);                    \
+          acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q4][1], BUF[q4][1], acc3, 0, 0, 0);                    \
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q4][2], BUF[q4][2], acc0, 0, 0, 0);                    \
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q4][2], BUF[q4][2], acc1, 0, 0, 0);                    \
+          acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q4][3], BUF[q4][3], acc2, 0, 0, 0);                    \
+          acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q4][3], BUF[q4][3], acc3, 0, 0, 0);                    \
         }                                                                                                     \
-      if (ch_ == nch - 1 && act0) {   /* rows >= len of the two 4-edge groups are never stored */             \
+      if (c_ch == nch - 1 && act0) {   /* rows >= len of the two 4-edge groups are never stored */            \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
-          if (i < len) tvbuf[(e0 + i) * gc + cb + lane] = acc0[i];                                            \
-          if (4 + i < len) tvbuf[(e0 + 4 + i) * gc + cb + lane] = acc1[i];                                    \
+          if (i < len) tvbuf[(e0 + i) * gc + cb + lane] = acc0[i] + acc2[i];                                  \
+          if (4 + i < len) tvbuf[(e0 + 4 + i) * gc + cb + lane] = acc1[i] + acc3[i];                          \
         }                                                                                                     \
       }                                                                                                       \
+      if (++c_ch == nch) { c_ch = 0; ++c_ui; }                                                                \
     }
 
     DDP_G_ISSUE(0, bufA, biasA)
@@ -300,23 +320,24 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
     const int b = lane >> 2, p = b / xnb, cj = 4 * (b - p * xnb) + (lane & 3);
     const bool colv = cj < nx;
     const int kx0 = p * xkper, cx = 64 + (colv ? cj : 0);
-    float gx[XK], gn[XK], bx = 0.f, bn = 0.f;
+    const int qx0 = kx0 >> 2;
+    f32x4 gx[XK / 4], gn[XK / 4];
+    float bx = 0.f, bn = 0.f;
 #define DDP_GX_LOAD(UI, DST, BDST)                                                                            \
     if ((UI) < nmine) {                                                                                       \
-      const int node_ = aux.src[aux.ustart[wave + NW * (UI)]];                                                \
-      const float* __restrict__ gp_ = G + (size_t)node_ * gstride;                                            \
-      _Pragma("unroll") for (int q = 0; q < XK; ++q) DST[q] = gp_[(size_t)min(kx0 + q, S.hid - 1) * gc + cx]; \
+      const int node_ = __builtin_amdgcn_readlane(my_node, (UI));                                             \
+      const f32x4* __restrict__ gp_ = G4 + (size_t)node_ * gstride + cx;                                      \
+      _Pragma("unroll") for (int q4 = 0; q4 < XK / 4; ++q4) DST[q4] = gp_[(size_t)min(qx0 + q4, nq - 1) * gc]; \
       BDST = Gb[(size_t)node_ * gc + cx];                                                                     \
     }
     DDP_GX_LOAD(0, gn, bn)
     for (int ui = 0; ui < nmine; ++ui) {
 #pragma unroll
-      for (int q = 0; q < XK; ++q) gx[q] = gn[q];
+      for (int q4 = 0; q4 < XK / 4; ++q4) gx[q4] = gn[q4];
       bx = bn;
       DDP_GX_LOAD(ui + 1, gn, bn)
       __builtin_amdgcn_sched_barrier(0);
-      const int u = wave + NW * ui;
-      const int e0 = aux.ustart[u], len = aux.ustart[u + 1] - e0;
+      const int e0 = __builtin_amdgcn_readlane(my_e0, ui), len = __builtin_amdgcn_readlane(my_len, ui);
       const float* hrow0 = &hbuf[(e0 + (lane & 3)) * S.hs + kx0];
       const float* hrow1 = hrow0 + 4 * S.hs;
       f32x4 a0[XK / 4], a1[XK / 4];
@@ -327,15 +348,16 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
       }
       f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < XK; ++q) {
-        // rows of the slice beyond hid (and idle columns) contribute exactly 0: both operands are zeroed there (the
-        // LDS words behind a row's hp columns are not h values)
-        const bool ok = colv && (q < xkper) && (kx0 + q < S.hid);
-        const float bq = ok ? gx[q] : 0.f;
-        const float aq0 = (kx0 + q < S.hid) ? a0[q >> 2][q & 3] : 0.f;
-        const float aq1 = (kx0 + q < S.hid) ? a1[q >> 2][q & 3] : 0.f;
-        x0 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq0, bq, x0, 0, 0, 0);
-        x1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq1, bq, x1, 0, 0, 0);
+      for (int q4 = 0; q4 < XK / 4; ++q4) {
+        // quads of the slice beyond the row (and idle columns) contribute exactly 0: both operands are zeroed there
+        // (the LDS words behind a row's hp columns are not h values; a NaN there would survive a multiplication by 0)
+        const bool okk = (4 * q4 < xkper) && (qx0 + q4 < nq);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const float bq = (okk && colv) ? gx[q4][kk] : 0.f;
+          x0 = __builtin_amdgcn_mfma_f32_4x4x1f32(okk ? a0[q4][kk] : 0.f, bq, x0, 0, 0, 0);
+          x1 = __builtin_amdgcn_mfma_f32_4x4x1f32(okk ? a1[q4][kk] : 0.f, bq, x1, 0, 0, 0);
+        }
       }
       for (int m = 4 * xnb; m < 64; m <<= 1) {   // sum the K-slices (lane stride 4 * xnb), fixed order
 #pragma unroll
@@ -702,18 +724,32 @@ __global__ __launch_bounds__(DDP_CONV_THREADS, 2) void ddp_conv_messages_kernel(
     aux.ustart[nu] = nvalid;
     aux.nunits = nu;
   }
+  if (tid >= 256 && tid < 256 + 64 * DDP_MAX_SEGS) {
+    const int sg = (tid - 256) >> 6, e = tid & 63;
+    if (T.seg_n[sg] > 0) aux.segi[sg][e] = T.seg_idx[sg][p0 + min(e, nvalid - 1)];
+  }
+  __syncthreads();
+  // The row indices are staged first so that the row gathers below are independent requests (one round trip for the
+  // whole tile instead of an index -> data dependency per element); 16-byte pieces when the segment allows it.
   int col0 = 0;
 #pragma unroll
   for (int sg = 0; sg < DDP_MAX_SEGS; ++sg) {
     const int n = T.seg_n[sg];
     if (n > 0) {
       const float* __restrict__ ptr = T.seg_ptr[sg];
-      const int* __restrict__ idx = T.seg_idx[sg];
       const int ld = T.seg_ld[sg];
-      for (int i = tid; i < 64 * n; i += DDP_CONV_THREADS) {
-        const int e = i / n, c = i - e * n;
-        const int row = idx[p0 + min(e, nvalid - 1)];
-        xa[e * S.hs + col0 + c] = ptr[(size_t)row * ld + c];
+      if (((n | ld | col0) & 3) == 0 && (reinterpret_cast<size_t>(ptr) & 15) == 0) {
+        const int n4 = n >> 2;
+        for (int i = tid; i < 64 * n4; i += DDP_CONV_THREADS) {
+          const int e = i / n4, c4 = i - e * n4;
+          const f32x4 v = reinterpret_cast<const f32x4*>(ptr + (size_t)aux.segi[sg][e] * ld)[c4];
+          *reinterpret_cast<f32x4*>(&xa[e * S.hs + col0 + 4 * c4]) = v;
+        }
+      } else {
+        for (int i = tid; i < 64 * n; i += DDP_CONV_THREADS) {
+          const int e = i / n, c = i - e * n;
+          xa[e * S.hs + col0 + c] = ptr[(size_t)aux.segi[sg][e] * ld + c];
+        }
       }
       col0 += n;
     }
@@ -732,10 +768,12 @@ __global__ __launch_bounds__(DDP_CONV_THREADS, 2) void ddp_conv_messages_kernel(
   {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps tile/loop indices in SGPRs
   const int lane = tid & 63, r = lane & 31, hh = lane >> 5;
-    const int rt = wave >> 2;
     const int nm1 = S.kp1 >> 3;
     const f32x4* __restrict__ w1p = reinterpret_cast<const f32x4*>(T.w1p);
-    for (int ct = wave & 3; ct < S.nct1; ct += 4) {
+    // 2 * nct1 (row tile, column tile) pairs over 8 waves: pair t -> wave t % 8, i.e. SIMD t % 4, so the four matrix
+    // pipes get the same number of tiles (12 tiles at hid = 180: 3 per SIMD)
+    for (int t1 = wave; t1 < 2 * S.nct1; t1 += DDP_CONV_THREADS / 64) {
+      const int rt = t1 & 1, ct = t1 >> 1;
       f32x16 acc = splat16(T.b1p[ct * 32 + r]);
       const f32x4* __restrict__ wp = w1p + ((size_t)ct * nm1 * 2 + hh) * 32 + r;
       // the whole K panel of this column tile is 23 KiB per wave: request 4 k-groups ahead (the loop is short and
@@ -838,7 +876,7 @@ extern "C" int ddp_conv_messages(const ddp_conv_shape_t* shape, const ddp_conv_t
   L.tile_start[L.ntasks] = tiles;
   if (tiles == 0) return 0;
   const size_t lds_bytes = (size_t)(64 * shape->hs + shape->fbuf_floats) * sizeof(float);
-  if (lds_bytes > 160 * 1024 - 1024) return ddp_fail(DDP_ELIMIT, "ddp_conv_messages: LDS budget exceeded");
+  if (lds_bytes > 160 * 1024 - 4096) return ddp_fail(DDP_ELIMIT, "ddp_conv_messages: LDS budget exceeded");
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(ddp_conv_messages_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (err != hipSuccess) return ddp_fail_hip(err, "hipFuncSetAttribute(conv)");

@@ -102,7 +102,7 @@ typedef struct {
   float* msg;           /* per-edge messages, CSR order                       [E, d_out] */
   /* factorised convs only (shape.g_cols != 0): edges are then listed in SOURCE-node order (so that a workgroup streams
    * each G[j] once) and `pos` gives the message row (= position in the receiver-CSR order) of every listed edge */
-  const float* g[2];    /* G[s]:  [n_src, hid, g_cols[s]] */
+  const float* g[2];    /* G[s]:  [n_src, hg/4, g_cols[s], 4], hg = hid rounded up to 4: G[j][k/4][c][k%4] (16-byte aligned) */
   const float* gb[2];   /* Gb[s]: [n_src, g_cols[s]]      (fc.3 bias part) */
   const int32_t* pos;   /* [E] message row per listed edge; NULL = identity */
 } ddp_conv_task_t;

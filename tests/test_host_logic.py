@@ -50,7 +50,9 @@ def emulate_conv(spec, w1p, b1p, w2p, b2p, edge_attr, x_src_rows, sh, fact=None)
             if b.g_slot < 0:
                 continue
             xs = x[:, offs[b.g_slot]:offs[b.g_slot] + Wg[b.g_slot].shape[0]]
-            G = (xs @ Wg[b.g_slot].double()).reshape(E, spec.hid, spec.g_cols[b.g_slot])
+            hg = (spec.hid + 3) // 4 * 4      # G[j][k/4][c][k%4] -> [E, hid, g_cols]
+            G = (xs @ Wg[b.g_slot].double()).reshape(E, hg // 4, spec.g_cols[b.g_slot], 4).permute(0, 1, 3, 2)
+            G = G.reshape(E, hg, spec.g_cols[b.g_slot])[:, :spec.hid]
             Gb = xs @ Bg[b.g_slot].double()
             tv = torch.einsum("ek,ekn->en", hp[:, :spec.hid], G) + Gb
             tv = tv[:, b.g_col0:b.g_col0 + b.n]
