@@ -34,8 +34,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-#define FS 68  // LDS row stride (floats) of the feature buffer F[u*C + c][e], e < 64
-#define DDP_CONV_THREADS 512  // 8 waves: two per SIMD
+// Two workgroup shapes (template parameter ET = edges per workgroup):
+//   ET = 64: 512 threads = 8 waves, one workgroup per CU (130 KiB of LDS), 2x2 register blocking of the scalar
+//            blocks - the direct path, whose 140-tile scalar blocks are MFMA bound;
+//   ET = 32: 256 threads = 4 waves (one per SIMD), ~50 KiB of LDS, three workgroups per CU - the factorised path, where
+//            half of a workgroup's time is staging, the G pass and LDS reductions: co-resident workgroups in different
+//            phases keep the matrix pipe busy meanwhile.
+#define FS64 68  // ET = 64: LDS row stride (floats) of the feature buffer F[u*C + c][e], e < 64  (ET + 4 in general)
+#define DDP_CONV_THREADS 512  // ET = 64: 8 waves, two per SIMD
 
 #ifdef DDP_STAMPS
 // Diagnostic build only (python -m diffdock_pocket_amd.build --stamps): thread 0 of every workgroup records
@@ -102,6 +108,7 @@ extern "C" int ddp_debug_read_stamps(unsigned long long* host_dst, int n_wgs) {
 
 struct ConvLaunch {
   ddp_conv_shape_t shape;
+  int tv_off;   // offset (floats) of the tv[ET][g_cols] region of the factorised part inside fbuf
   int ntasks;
   int tile_start[DDP_MAX_TASKS + 1];
   ddp_conv_task_t task[DDP_MAX_TASKS];
@@ -115,16 +122,18 @@ __device__ __forceinline__ f32x16 splat16(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------ phase 2
+template <int ET>
 __device__ __forceinline__ void build_features(const ddp_block_t& B, const ddp_conv_task_t& T, const int* s_src,
                                                const float (*s_sh)[4], float* fbuf, int tid) {
-  const int e = tid & 63, wave = tid >> 6;
+  constexpr int FS = ET + 4;
+  const int e = tid & (ET - 1), wave = tid / ET;   // 8 thread groups of ET threads
   const float* xrow = T.x_src + (size_t)s_src[e] * T.ldx_src;
   const float s0 = s_sh[e][0], sx = s_sh[e][1], sy = s_sh[e][2], sz = s_sh[e][3];
   const float inv_sqrt3 = 0.57735026918962576f, inv_sqrt2 = 0.70710678118654752f;
   int ubase = 0;
   for (int si = 0; si < B.nseg; ++si) {
     const int kind = B.seg[si].kind, off = B.seg[si].in_off, cnt = B.seg[si].count;
-    for (int ul = wave; ul < cnt; ul += DDP_CONV_THREADS / 64) {
+    for (int ul = wave; ul < cnt; ul += 8) {
       const int u = ubase + ul;
       if (kind == DDP_F_SCALAR_S0) {
         fbuf[u * FS + e] = xrow[off + ul] * s0;
@@ -180,16 +189,18 @@ __device__ __forceinline__ void tile_lane_map(const ddp_block_t& B, int t, int r
 // The tile's edges are listed in source order; `units` are runs of <= 8 edges with one source node.  A wave takes a
 // unit, lanes = output columns (coalesced G rows, streamed once), the run's h rows come from LDS as wave-wide broadcasts
 // and the 8 running sums live in registers.  VALU work: 2*hid*n flops per edge (vs 2*hid*U*n on the MFMA path).
+template <int ET>
 struct TileAux {
-  int src[64], eid[64], pos[64], ustart[65];
+  int src[ET], eid[ET], pos[ET], ustart[ET + 1];
   int nunits;
-  float sh[64][4];
-  int segi[DDP_MAX_SEGS][64];   // row of every edge in each edge_attr_ segment
+  float sh[ET][4];
+  int segi[DDP_MAX_SEGS][ET];   // row of every edge in each edge_attr_ segment
 };
 
+template <int ET>
 __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, const ddp_conv_task_t& T, const float* hbuf,
-                                        float* tvbuf, const TileAux& aux, int wave, int lane) {
-  // One pass per G slot; a wave takes units wave, wave + 8, ...  For a unit (<= 8 edges of one source node)
+                                        float* tvbuf, const TileAux<ET>& aux, int wave, int lane) {
+  // One pass per G slot; a wave takes units wave, wave + NW, ...  For a unit (<= 8 edges of one source node)
   //   tv[i, c] = Gb[c] + sum_k h[e0 + i, k] * G[k, c]
   // is a [8 x hid] x [hid x gc] product with the 8 rows in LDS and the G rows streamed from memory exactly once.
   //  * columns c < 64: v_mfma_f32_4x4x1 (16 blocks of 4x4, k = 1): block b = column group 4b..4b+3, so the B operand is
@@ -203,7 +214,7 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
   // are flattened into one sequence and run through a 3-deep register ring: the loads of steps s+1 and s+2 are in
   // flight while step s computes; the A operands of a step are read up front (the uniform k < hp branches would
   // otherwise pin every LDS read right before its MFMAs and expose its latency 10 times per step).
-  constexpr int KC = 20, XK = 24, NW = DDP_CONV_THREADS / 64;
+  constexpr int KC = 20, XK = 24, NW = ET / 8;   // NW waves per workgroup, at most 8 units per wave
   const int gc = S.g_cols[slot];
   const float* __restrict__ G = T.g[slot];
   const float* __restrict__ Gb = T.gb[slot];
@@ -390,8 +401,10 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
 //                  the vector blocks whose three (x,y,z) output accumulators would not fit next to a 2-row-tile acc)
 template <int C>
 __device__ __forceinline__ void run_block_full(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
-                                          const float* hbuf, float* fbuf, int tid, const TileAux& aux, int nvalid, int sbase) {
+                                          const float* hbuf, float* fbuf, const float* tvbuf, int tid,
+                                          const TileAux<64>& aux, int nvalid, int sbase) {
   constexpr int CT = (C == 1) ? 2 : 1;
+  constexpr int FS = FS64;
   constexpr int NW = DDP_CONV_THREADS / 64;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps tile/loop indices in SGPRs
   const int lane = tid & 63, r = lane & 31, hh = lane >> 5;
@@ -512,7 +525,6 @@ __device__ __forceinline__ void run_block_full(const ddp_conv_shape_t& S, const 
   const int nc = B.n;
   float* part = fbuf;
   float* carry = fbuf + 4 * REGION;
-  const float* tvbuf = fbuf + 5 * 4096;
 #pragma unroll 1
   for (int half = 0; half < 2; ++half) {
     __syncthreads();  // F (or the previous pass's partials) no longer needed
@@ -553,131 +565,136 @@ __device__ __forceinline__ void run_block_full(const ddp_conv_shape_t& S, const 
   STAMP(sbase + 2);
 }
 
-template <int C, int CT>
+template <int ET, int C>
 __device__ __forceinline__ void run_block_rows(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
-                                          const float* hbuf, float* fbuf, int tid, const TileAux& aux, int nvalid, int sbase) {
+                                          const float* hbuf, float* fbuf, const float* tvbuf, int tid,
+                                          const TileAux<ET>& aux, int nvalid, int sbase) {
+  constexpr int FS = ET + 4, NT = ET * 8;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps tile/loop indices in SGPRs
   const int lane = tid & 63, r = lane & 31, hh = lane >> 5;
-  const int rt = wave >> 2, wq = wave & 3;
+  const int rt = wave >> 2, wq = wave & 3;   // ET = 32: four waves, all on row tile 0
   const int nm = S.hp >> 3;
-  const int ngroups = B.ntiles / CT;  // host pads scalar blocks to an even tile count
+  const int ngroups = B.ntiles;
   const f32x4* __restrict__ w2p = reinterpret_cast<const f32x4*>(T.w2p);
   const float* arow = &hbuf[(rt * 32 + r) * S.hs + 4 * hh];
 
-  f32x16 out[CT][C];
+  f32x16 out[C];
 #pragma unroll
-  for (int s = 0; s < CT; ++s)
-#pragma unroll
-    for (int c = 0; c < C; ++c) out[s][c] = splat16(0.f);
+  for (int c = 0; c < C; ++c) out[c] = splat16(0.f);
 
   // B-operand prefetch, flattened over (group, m)
-  f32x4 bnext[CT];
-  if (wq < ngroups) {
-#pragma unroll
-    for (int s = 0; s < CT; ++s) {
-      const int tile = B.tile0 + wq * CT + s;
-      bnext[s] = w2p[((size_t)tile * nm * 2 + hh) * 32 + r];
-    }
-  }
+  f32x4 bnext = {0.f, 0.f, 0.f, 0.f};
+  if (wq < ngroups) bnext = w2p[((size_t)(B.tile0 + wq) * nm * 2 + hh) * 32 + r];
   f32x4 anext = *reinterpret_cast<const f32x4*>(arow);
   for (int g = wq; g < ngroups; g += 4) {
-    f32x16 acc[CT];
-#pragma unroll
-    for (int s = 0; s < CT; ++s) acc[s] = splat16(T.b2p[(B.tile0 + g * CT + s) * 32 + r]);
+    f32x16 acc = splat16(T.b2p[(B.tile0 + g) * 32 + r]);
     for (int m = 0; m < nm; ++m) {
-      f32x4 bcur[CT];
-#pragma unroll
-      for (int s = 0; s < CT; ++s) bcur[s] = bnext[s];
+      const f32x4 bcur = bnext;
       {  // prefetch the next (group, m)
         int gn = g, mn = m + 1;
         if (mn == nm) { gn = g + 4; mn = 0; }
-        if (gn < ngroups) {
-#pragma unroll
-          for (int s = 0; s < CT; ++s) {
-            const int tile = B.tile0 + gn * CT + s;
-            bnext[s] = w2p[(((size_t)tile * nm + mn) * 2 + hh) * 32 + r];
-          }
-        }
+        if (gn < ngroups) bnext = w2p[(((size_t)(B.tile0 + gn) * nm + mn) * 2 + hh) * 32 + r];
       }
       const f32x4 a = anext;
       anext = *reinterpret_cast<const f32x4*>(arow + 8 * ((m + 1 == nm) ? 0 : m + 1));  // h is tile independent: wrap
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int s = 0; s < CT; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[s][i], acc[s], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[i], acc, 0, 0, 0);
     }
     // contraction with the basis features, in the MFMA C/D layout: reg i <-> edge row (i&3) + 8*(i>>2) + 4*hh
+    int u, ncol, us;
+    bool valid;
+    tile_lane_map(B, g, r, u, ncol, us, valid);
 #pragma unroll
-    for (int s = 0; s < CT; ++s) {
-      int u, ncol, us;
-      bool valid;
-      tile_lane_map(B, g * CT + s, r, u, ncol, us, valid);
+    for (int c = 0; c < C; ++c) {
+      const float* frow = &fbuf[(u * C + c) * FS + rt * 32 + 4 * hh];
 #pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const float* frow = &fbuf[(u * C + c) * FS + rt * 32 + 4 * hh];
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 f = *reinterpret_cast<const f32x4*>(frow + 8 * q4);
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const f32x4 f = *reinterpret_cast<const f32x4*>(frow + 8 * q4);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) out[s][c][4 * q4 + q] += f[q] * acc[s][4 * q4 + q];
-        }
+        for (int q = 0; q < 4; ++q) out[c][4 * q4 + q] += f[q] * acc[4 * q4 + q];
       }
     }
   }
 
-  // ---- phase 4: deterministic cross-wave / cross-lane reduction.  Every wave parks its 32-row partial tile in its own
-  // LDS region with plain stores (all waves concurrently); then all threads sum the 4 regions of a row-tile (and, for
-  // n <= 32, the `ups` lane groups and both tile slots) in a FIXED order and store the block's message columns
-  // coalesced.  Vector blocks do this in two passes (row-tile 0, then 1) to stay inside fbuf.
+  // ---- phase 4: deterministic cross-wave / cross-lane reduction.  Every wave parks a 32-row partial tile in its own
+  // LDS region with plain stores (all waves concurrently); then all threads sum the 4 regions of a row tile (and, for
+  // n <= 32, the `ups` lane groups) in a FIXED order and store the block's message columns.
+  //   ET = 64: regions hold all C components (RW = 32 C floats per row); scalar blocks in one pass (8 regions), vector
+  //            blocks in two (row tile 0, then 1)
+  //   ET = 32: one pass per component (4 regions of 32 x 32 floats = 16 KiB), to stay inside a 3-per-CU LDS budget
   STAMP(sbase);        // wave 0 done with its tiles
   STAMP_SYNC();
   STAMP(sbase + 1);    // all waves done
-  constexpr int NP = (C == 1) ? 1 : 2;            // passes
-  constexpr int RW = CT * 32 * C;                 // floats per edge row in a wave region: [c][slot*32 + r]
-  constexpr int REGION = 32 * RW;                 // 2048 (scalar) / 3072 (vector) floats per wave
-  const int nc = B.n * C;
   float* part = fbuf;
+  const int gcs = (B.g_slot >= 0) ? S.g_cols[B.g_slot] : 0;
+  if constexpr (ET == 64) {
+    constexpr int NP = (C == 1) ? 1 : 2;            // passes
+    constexpr int RW = 32 * C;                      // floats per edge row in a wave region: [c][r]
+    constexpr int REGION = 32 * RW;                 // 1024 (scalar) / 3072 (vector) floats per wave
+    const int nc = B.n * C;
 #pragma unroll
-  for (int pass = 0; pass < NP; ++pass) {
-    __syncthreads();  // F (or the previous pass's partials) no longer needed
-    if (NP == 1 || rt == pass) {
-      float* mine = part + ((NP == 1) ? wave : wq) * REGION;
-#pragma unroll
-      for (int s = 0; s < CT; ++s)
+    for (int pass = 0; pass < NP; ++pass) {
+      __syncthreads();  // F (or the previous pass's partials) no longer needed
+      if (NP == 1 || rt == pass) {
+        float* mine = part + ((NP == 1) ? wave : wq) * REGION;
 #pragma unroll
         for (int c = 0; c < C; ++c)
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-            mine[row * RW + c * (CT * 32) + s * 32 + r] = out[s][c][i];
+            mine[row * RW + c * 32 + r] = out[c][i];
           }
-    }
-    __syncthreads();
-    const int rows = (NP == 1) ? 64 : 32;
-    for (int idx = tid; idx < rows * nc; idx += DDP_CONV_THREADS) {
-      const int el = idx / nc, cc = idx - el * nc;
-      const int ncol = cc / C, c = cc - ncol * C;
-      const int e = (NP == 1) ? el : pass * 32 + el;
-      const int wbase = (NP == 1) ? (e >> 5) * 4 : 0;
-      float sum = 0.f;
-      for (int w = 0; w < 4; ++w) {
-        const float* reg = part + (wbase + w) * REGION + (e & 31) * RW + c * (CT * 32);
-        if (B.nsub > 1) {
-          // pairs (CT = 2): column = sub*32 + r = ncol.  Single tiles (CT = 1): the wave's tiles w, w+4, ... all have
-          // the same parity, i.e. wave w only ever holds sub-block (w & 1) of the n columns
-          if (CT == 2)
-            sum += reg[ncol];
-          else if ((w & 1) == (ncol >> 5))
-            sum += reg[ncol & 31];
-        } else {
-          for (int sl = 0; sl < CT; ++sl)
-            for (int k = 0; k < B.ups; ++k) sum += reg[sl * 32 + k * B.n + ncol];
+      }
+      __syncthreads();
+      const int rows = (NP == 1) ? 64 : 32;
+      for (int idx = tid; idx < rows * nc; idx += NT) {
+        const int el = idx / nc, cc = idx - el * nc;
+        const int ncol = cc / C, c = cc - ncol * C;
+        const int e = (NP == 1) ? el : pass * 32 + el;
+        const int wbase = (NP == 1) ? (e >> 5) * 4 : 0;
+        float sum = 0.f;
+        for (int w = 0; w < 4; ++w) {
+          const float* reg = part + (wbase + w) * REGION + (e & 31) * RW + c * 32;
+          if (B.nsub > 1) {
+            // the wave's tiles w, w+4, ... all have the same parity, i.e. wave w only holds sub-block (w & 1) of the n columns
+            if ((w & 1) == (ncol >> 5)) sum += reg[ncol & 31];
+          } else {
+            for (int k = 0; k < B.ups; ++k) sum += reg[k * B.n + ncol];
+          }
+        }
+        if (e < nvalid) {
+          if (B.g_slot >= 0) sum += ((C == 1) ? aux.sh[e][0] : aux.sh[e][1 + c]) * tvbuf[e * gcs + B.g_col0 + ncol];
+          T.msg[(size_t)aux.pos[e] * S.d_out + B.out_off + cc] = sum;
         }
       }
-      if (e < nvalid) {
-        if (B.g_slot >= 0)
-          sum += ((C == 1) ? aux.sh[e][0] : aux.sh[e][1 + c]) * (fbuf + 5 * 4096)[e * S.g_cols[B.g_slot] + B.g_col0 + ncol];
-        T.msg[(size_t)aux.pos[e] * S.d_out + B.out_off + cc] = sum;
+    }
+  } else {
+    constexpr int REGION = 32 * 32;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      __syncthreads();  // F (or the previous component's partials) no longer needed
+      float* mine = part + wave * REGION;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+        mine[row * 32 + r] = out[c][i];
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 32 * B.n; idx += NT) {
+        const int e = idx / B.n, ncol = idx - e * B.n;
+        float sum = 0.f;
+        for (int w = 0; w < 4; ++w) {
+          const float* reg = part + w * REGION + e * 32;
+          if (B.nsub > 1) {
+            if ((w & 1) == (ncol >> 5)) sum += reg[ncol & 31];
+          } else {
+            for (int k = 0; k < B.ups; ++k) sum += reg[k * B.n + ncol];
+          }
+        }
+        if (e < nvalid) {
+          if (B.g_slot >= 0) sum += ((C == 1) ? aux.sh[e][0] : aux.sh[e][1 + c]) * tvbuf[e * gcs + B.g_col0 + ncol];
+          T.msg[(size_t)aux.pos[e] * S.d_out + B.out_off + ncol * C + c] = sum;
+        }
       }
     }
   }
@@ -686,46 +703,58 @@ __device__ __forceinline__ void run_block_rows(const ddp_conv_shape_t& S, const 
 }
 
 // ------------------------------------------------------------------------------------------------ kernel
-__global__ __launch_bounds__(DDP_CONV_THREADS, 2) void ddp_conv_messages_kernel(const ConvLaunch L) {
+template <int ET>
+__global__ __launch_bounds__(ET * 8, (ET == 64) ? 2 : 3) void ddp_conv_messages_kernel(const ConvLaunch L) {
+  constexpr int NT = ET * 8, NW = ET / 8, RT = ET / 32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ TileAux aux;
+  __shared__ TileAux<ET> aux;
   const ddp_conv_shape_t& S = L.shape;
   const int tid = threadIdx.x;
   int t = 0;
   while (t + 1 < L.ntasks && (int)blockIdx.x >= L.tile_start[t + 1]) ++t;
   const ddp_conv_task_t& T = L.task[t];
-  const int p0 = ((int)blockIdx.x - L.tile_start[t]) * DDP_EDGE_TILE;
-  const int nvalid = min(DDP_EDGE_TILE, T.n_edges - p0);
+  const int p0 = ((int)blockIdx.x - L.tile_start[t]) * ET;
+  const int nvalid = min(ET, T.n_edges - p0);
   float* hbuf = lds;
-  float* fbuf = lds + 64 * S.hs;
+  float* fbuf = lds + ET * S.hs;
   float* xa = fbuf;  // edge_attr_ staging aliases the feature buffer
+  float* tvbuf = fbuf + L.tv_off;
 
   STAMP(0);
   STAMP(22);  // s_memrealtime (100 MHz) at entry
   // ---- phase 0: indices + edge_attr_ rows
-  if (tid < 64) {
+  if (tid < 64) {   // wave 0, lane = edge
+    const bool valid = tid < nvalid;
     const int p = p0 + min(tid, nvalid - 1);
-    aux.src[tid] = T.src[p];
-    const int eid = T.eid[p];
-    aux.eid[tid] = eid;
-    aux.pos[tid] = T.pos ? T.pos[p] : p;
-    const f32x4 shv = reinterpret_cast<const f32x4*>(T.sh)[eid];
-    aux.sh[tid][0] = shv[0]; aux.sh[tid][1] = shv[1]; aux.sh[tid][2] = shv[2]; aux.sh[tid][3] = shv[3];
-  }
-  if (tid == 64 && (S.g_cols[0] | S.g_cols[1])) {  // runs of <= 8 valid edges with one source node (edges are source sorted)
-    int nu = 0, start = 0;
-    const int* __restrict__ srcp = T.src + p0;
-    for (int e = 1; e <= nvalid; ++e) {
-      if (e == nvalid || srcp[e] != srcp[start] || e - start == 8) {
-        aux.ustart[nu++] = start;
-        start = e;
+    const int src = T.src[p];
+    if (tid < ET) {
+      aux.src[tid] = src;
+      const int eid = T.eid[p];
+      aux.eid[tid] = eid;
+      aux.pos[tid] = T.pos ? T.pos[p] : p;
+      const f32x4 shv = reinterpret_cast<const f32x4*>(T.sh)[eid];
+      aux.sh[tid][0] = shv[0]; aux.sh[tid][1] = shv[1]; aux.sh[tid][2] = shv[2]; aux.sh[tid][3] = shv[3];
+    }
+    if (S.g_cols[0] | S.g_cols[1]) {
+      // units = runs of <= 8 valid edges with one source node (the edges are source sorted), found with two ballots:
+      // run starts, then every 8th edge of a run
+      const int prev = __shfl_up(src, 1);
+      const bool runstart = valid && (tid == 0 || src != prev);
+      const unsigned long long rmask = __ballot(runstart);
+      const unsigned long long upto = (tid == 63) ? ~0ull : ((2ull << tid) - 1ull);
+      const int rs = 63 - __clzll((long long)(rmask & upto));       // lane 0 is always a run start
+      const bool ustart = valid && (((tid - rs) & 7) == 0);
+      const unsigned long long umask = __ballot(ustart);
+      if (ustart) aux.ustart[__popcll(umask & ((1ull << tid) - 1ull))] = tid;
+      if (tid == 0) {
+        const int nu = __popcll(umask);
+        aux.nunits = nu;
+        aux.ustart[nu] = nvalid;
       }
     }
-    aux.ustart[nu] = nvalid;
-    aux.nunits = nu;
   }
-  if (tid >= 256 && tid < 256 + 64 * DDP_MAX_SEGS) {
-    const int sg = (tid - 256) >> 6, e = tid & 63;
+  for (int i = tid; i < ET * DDP_MAX_SEGS; i += NT) {
+    const int sg = i / ET, e = i - sg * ET;
     if (T.seg_n[sg] > 0) aux.segi[sg][e] = T.seg_idx[sg][p0 + min(e, nvalid - 1)];
   }
   __syncthreads();
@@ -740,13 +769,13 @@ __global__ __launch_bounds__(DDP_CONV_THREADS, 2) void ddp_conv_messages_kernel(
       const int ld = T.seg_ld[sg];
       if (((n | ld | col0) & 3) == 0 && (reinterpret_cast<size_t>(ptr) & 15) == 0) {
         const int n4 = n >> 2;
-        for (int i = tid; i < 64 * n4; i += DDP_CONV_THREADS) {
+        for (int i = tid; i < ET * n4; i += NT) {
           const int e = i / n4, c4 = i - e * n4;
           const f32x4 v = reinterpret_cast<const f32x4*>(ptr + (size_t)aux.segi[sg][e] * ld)[c4];
           *reinterpret_cast<f32x4*>(&xa[e * S.hs + col0 + 4 * c4]) = v;
         }
       } else {
-        for (int i = tid; i < 64 * n; i += DDP_CONV_THREADS) {
+        for (int i = tid; i < ET * n; i += NT) {
           const int e = i / n, c = i - e * n;
           xa[e * S.hs + col0 + c] = ptr[(size_t)aux.segi[sg][e] * ld + c];
         }
@@ -756,7 +785,7 @@ __global__ __launch_bounds__(DDP_CONV_THREADS, 2) void ddp_conv_messages_kernel(
   }
   {
     const int npad = S.kp1 - S.f_in;
-    for (int i = tid; i < 64 * npad; i += DDP_CONV_THREADS) {
+    for (int i = tid; i < ET * npad; i += NT) {
       const int e = i / npad, c = i - e * npad;
       xa[e * S.hs + S.f_in + c] = 0.f;
     }
@@ -764,16 +793,16 @@ __global__ __launch_bounds__(DDP_CONV_THREADS, 2) void ddp_conv_messages_kernel(
   __syncthreads();
   STAMP(1);
 
-  // ---- phase 1: h = relu(edge_attr_ @ W1 + b1); wave w: row-tile w >> 2, column tiles (w & 3), (w & 3) + 4, ...
+  // ---- phase 1: h = relu(edge_attr_ @ W1 + b1)
   {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps tile/loop indices in SGPRs
-  const int lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int nm1 = S.kp1 >> 3;
     const f32x4* __restrict__ w1p = reinterpret_cast<const f32x4*>(T.w1p);
-    // 2 * nct1 (row tile, column tile) pairs over 8 waves: pair t -> wave t % 8, i.e. SIMD t % 4, so the four matrix
-    // pipes get the same number of tiles (12 tiles at hid = 180: 3 per SIMD)
-    for (int t1 = wave; t1 < 2 * S.nct1; t1 += DDP_CONV_THREADS / 64) {
-      const int rt = t1 & 1, ct = t1 >> 1;
+    // RT * nct1 (row tile, column tile) pairs over the waves: pair t -> wave t % NW, i.e. SIMD t % 4, so the four matrix
+    // pipes get the same number of tiles (ET = 64: 12 tiles at hid = 180, 3 per SIMD)
+    for (int t1 = wave; t1 < RT * S.nct1; t1 += NW) {
+      const int rt = t1 % RT, ct = t1 / RT;
       f32x16 acc = splat16(T.b1p[ct * 32 + r]);
       const f32x4* __restrict__ wp = w1p + ((size_t)ct * nm1 * 2 + hh) * 32 + r;
       // the whole K panel of this column tile is 23 KiB per wave: request 4 k-groups ahead (the loop is short and
@@ -809,23 +838,32 @@ __global__ __launch_bounds__(DDP_CONV_THREADS, 2) void ddp_conv_messages_kernel(
   // ---- per weight block
   for (int bi = 0; bi < S.nblocks; ++bi) {
     const ddp_block_t& B = S.blk[bi];
-    build_features(B, T, aux.src, aux.sh, fbuf, tid);
+    build_features<ET>(B, T, aux.src, aux.sh, fbuf, tid);
     if (bi == 0) STAMP(35);
     if (bi == 2) STAMP(32);
-    if (B.g_slot >= 0 && (bi == 0 || S.blk[bi - 1].g_slot != B.g_slot))   // one pass per G slot, shared by its blocks
-      g_stage(S, B.g_slot, T, hbuf, fbuf + 5 * 4096, aux, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
+    if constexpr (ET == 32) {   // (factorised shapes are always launched with 32-edge workgroups)
+      if (B.g_slot >= 0 && (bi == 0 || S.blk[bi - 1].g_slot != B.g_slot))   // one pass per G slot, shared by its blocks
+        g_stage<ET>(S, B.g_slot, T, hbuf, tvbuf, aux, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
+    }
     if (bi == 0) STAMP(33);
     if (bi == 2) STAMP(34);
     __syncthreads();
     STAMP(3 + 4 * bi);
-    // scalar blocks with many tiles (direct path: 140): 2x2 full-row blocking, 8-way tile split; with few tiles
-    // (factorised path: 20) single tiles over (4 column groups x 2 row tiles) balance the four SIMDs better
-    if (B.C == 1 && B.ntiles >= 64)
-      run_block_full<1>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
-    else if (B.C == 1)
-      run_block_rows<1, 1>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
-    else
-      run_block_rows<3, 1>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
+    // ET = 64, scalar blocks with many tiles (direct path: 140): 2x2 full-row blocking, 8-way tile split; otherwise
+    // single tiles over (4 column groups x RT row tiles)
+    if constexpr (ET == 64) {
+      if (B.C == 1 && B.ntiles >= 64)
+        run_block_full<1>(S, B, T, hbuf, fbuf, tvbuf, tid, aux, nvalid, 4 + 4 * bi);
+      else if (B.C == 1)
+        run_block_rows<ET, 1>(S, B, T, hbuf, fbuf, tvbuf, tid, aux, nvalid, 4 + 4 * bi);
+      else
+        run_block_rows<ET, 3>(S, B, T, hbuf, fbuf, tvbuf, tid, aux, nvalid, 4 + 4 * bi);
+    } else {
+      if (B.C == 1)
+        run_block_rows<ET, 1>(S, B, T, hbuf, fbuf, tvbuf, tid, aux, nvalid, 4 + 4 * bi);
+      else
+        run_block_rows<ET, 3>(S, B, T, hbuf, fbuf, tvbuf, tid, aux, nvalid, 4 + 4 * bi);
+    }
   }
   STAMP(23);  // s_memrealtime at exit
 #ifdef DDP_STAMPS
@@ -839,49 +877,75 @@ __global__ __launch_bounds__(DDP_CONV_THREADS, 2) void ddp_conv_messages_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------ host
+template <int ET>
+static int launch_conv(ConvLaunch& L, const ddp_conv_task_t* tasks, int ntasks, int fbuf_floats, void* stream) {
+  const ddp_conv_shape_t* shape = &L.shape;
+  L.ntasks = 0;
+  int tiles = 0;
+  for (int i = 0; i < ntasks; ++i) {
+    if (tasks[i].n_edges <= 0) continue;  // an empty conv sends no message (models/score_model.py:109-111)
+    for (int gs = 0; gs < 2; ++gs)
+      if (shape->g_cols[gs] > 0 && (!tasks[i].g[gs] || !tasks[i].gb[gs] || (reinterpret_cast<size_t>(tasks[i].g[gs]) & 15)))
+        return ddp_fail(DDP_EINVAL, "ddp_conv_messages: factorised shape but task.g / task.gb is null (or g not 16-byte aligned)");
+    L.tile_start[L.ntasks] = tiles;
+    L.task[L.ntasks] = tasks[i];
+    tiles += (tasks[i].n_edges + ET - 1) / ET;
+    ++L.ntasks;
+  }
+  L.tile_start[L.ntasks] = tiles;
+  if (tiles == 0) return 0;
+  const size_t lds_bytes = (size_t)(ET * shape->hs + fbuf_floats) * sizeof(float);
+  const size_t budget = (ET == 64) ? (160 * 1024 - 4096) : (160 * 1024 / 3 - 2560);   // minus the static TileAux
+  if (lds_bytes > 160 * 1024 - 4096) return ddp_fail(DDP_ELIMIT, "ddp_conv_messages: LDS budget exceeded");
+  (void)budget;   // ET = 32 beyond a third of the LDS still runs, at two workgroups per CU
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(ddp_conv_messages_kernel<ET>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (err != hipSuccess) return ddp_fail_hip(err, "hipFuncSetAttribute(conv)");
+  hipLaunchKernelGGL(ddp_conv_messages_kernel<ET>, dim3(tiles), dim3(ET * 8), lds_bytes, (hipStream_t)stream, L);
+  err = hipGetLastError();
+  if (err != hipSuccess) return ddp_fail_hip(err, "ddp_conv_messages launch");
+  return 0;
+}
+
 extern "C" int ddp_conv_messages(const ddp_conv_shape_t* shape, const ddp_conv_task_t* tasks, int ntasks, void* stream) {
   if (!shape || !tasks) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: null argument");
   if (ntasks < 0 || ntasks > DDP_MAX_TASKS) return ddp_fail(DDP_ELIMIT, "ddp_conv_messages: ntasks > DDP_MAX_TASKS");
   if (shape->nblocks < 1 || shape->nblocks > DDP_MAX_BLOCKS) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: nblocks");
   if ((shape->kp1 & 7) || (shape->hp & 7) || (shape->hs & 3) || shape->hs < shape->kp1 || shape->hs < shape->hp)
     return ddp_fail(DDP_EINVAL, "ddp_conv_messages: kp1/hp must be multiples of 8 and hs >= both");
+  const bool fact = (shape->g_cols[0] | shape->g_cols[1]) != 0;
+  int max_uc = 0, max_gc = shape->g_cols[0] > shape->g_cols[1] ? shape->g_cols[0] : shape->g_cols[1];
   for (int b = 0; b < shape->nblocks; ++b) {
     const ddp_block_t& B = shape->blk[b];
     if (B.C != 1 && B.C != 3) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: block C must be 1 or 3");
     if (B.n < 1 || B.n > 64 || (B.C == 3 && B.n > 32)) return ddp_fail(DDP_ELIMIT, "ddp_conv_messages: block n too large");
     if (B.nsub < 1 || B.nsub > 2 || B.ups < 1) return ddp_fail(DDP_ELIMIT, "ddp_conv_messages: nsub/ups");
     if (B.C == 1 && (B.ntiles & 1)) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: scalar blocks need an even tile count");
-    if (B.U * B.C * FS > shape->fbuf_floats || 5 * 4096 > shape->fbuf_floats)
-      return ddp_fail(DDP_EINVAL, "ddp_conv_messages: fbuf_floats too small");
     if (B.nseg < 0 || B.nseg > DDP_MAX_SEGS) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: nseg");
-    if (B.g_slot > 1 || (B.g_slot >= 0 && (shape->g_cols[B.g_slot] < B.g_col0 + B.n || shape->g_cols[B.g_slot] > 128 ||
-                          5 * 4096 + 64 * shape->g_cols[B.g_slot] > shape->fbuf_floats)))
-      return ddp_fail(DDP_EINVAL, "ddp_conv_messages: factorised block outside its G row / fbuf too small");
+    if (B.g_slot > 1 || (B.g_slot >= 0 && (shape->g_cols[B.g_slot] < B.g_col0 + B.n || shape->g_cols[B.g_slot] > 128)))
+      return ddp_fail(DDP_EINVAL, "ddp_conv_messages: factorised block outside its G row");
+    if (B.U * B.C > max_uc) max_uc = B.U * B.C;
   }
-  if (64 * shape->hs > shape->fbuf_floats) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: fbuf_floats < staging tile");
   ConvLaunch L;
   L.shape = *shape;
-  L.ntasks = 0;
-  int tiles = 0;
-  for (int i = 0; i < ntasks; ++i) {
-    if (tasks[i].n_edges <= 0) continue;  // an empty conv sends no message (models/score_model.py:109-111)
-    for (int gs = 0; gs < 2; ++gs)
-      if (shape->g_cols[gs] > 0 && (!tasks[i].g[gs] || !tasks[i].gb[gs]))
-        return ddp_fail(DDP_EINVAL, "ddp_conv_messages: factorised shape but task.g / task.gb is null");
-    L.tile_start[L.ntasks] = tiles;
-    L.task[L.ntasks] = tasks[i];
-    tiles += (tasks[i].n_edges + DDP_EDGE_TILE - 1) / DDP_EDGE_TILE;
-    ++L.ntasks;
+  if (fact) {
+    // 32-edge workgroups.  fbuf: [0, tv_off) features / per-component partials (4 x 32 x 32), tv behind them; the
+    // edge_attr_ staging tile (32 x hs) may overlap tv, which is written after fc1.
+    const int ET = 32;
+    int tv_off = max_uc * (ET + 4);
+    if (tv_off < 4 * 1024) tv_off = 4 * 1024;
+    tv_off = (tv_off + 3) & ~3;
+    int fbuf = tv_off + ET * max_gc;
+    if (fbuf < ET * shape->hs) fbuf = ET * shape->hs;
+    L.tv_off = tv_off;
+    return launch_conv<32>(L, tasks, ntasks, fbuf, stream);
   }
-  L.tile_start[L.ntasks] = tiles;
-  if (tiles == 0) return 0;
-  const size_t lds_bytes = (size_t)(64 * shape->hs + shape->fbuf_floats) * sizeof(float);
-  if (lds_bytes > 160 * 1024 - 4096) return ddp_fail(DDP_ELIMIT, "ddp_conv_messages: LDS budget exceeded");
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(ddp_conv_messages_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (err != hipSuccess) return ddp_fail_hip(err, "hipFuncSetAttribute(conv)");
-  hipLaunchKernelGGL(ddp_conv_messages_kernel, dim3(tiles), dim3(DDP_CONV_THREADS), lds_bytes, (hipStream_t)stream, L);
-  err = hipGetLastError();
-  if (err != hipSuccess) return ddp_fail_hip(err, "ddp_conv_messages launch");
-  return 0;
+  // 64-edge workgroups: the host-provided fbuf_floats covers features, the 5 x 4096 partial regions of the 2x2 variant
+  // and (never used on this path, kept for shapes built by older hosts) a tv region behind them
+  for (int b = 0; b < shape->nblocks; ++b)
+    if (shape->blk[b].U * shape->blk[b].C * FS64 > shape->fbuf_floats || 5 * 4096 > shape->fbuf_floats)
+      return ddp_fail(DDP_EINVAL, "ddp_conv_messages: fbuf_floats too small");
+  if (64 * shape->hs > shape->fbuf_floats) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: fbuf_floats < staging tile");
+  L.tv_off = 5 * 4096;
+  return launch_conv<64>(L, tasks, ntasks, shape->fbuf_floats, stream);
 }

@@ -50,13 +50,14 @@ def hooked(spec, tasks, flops_spec=None):
         captured["ms"] = e0.elapsed_time(e1)
     if sel and "done" not in captured:
         torch.cuda.synchronize()
-        n = sum((t.n_edges + 63) // 64 for t in tasks)
+        ET = 32 if spec.factorized else 64
+        n = sum((t.n_edges + ET - 1) // ET for t in tasks)
         n = min(n, 32768)
         buf = np.zeros((n, 40), dtype=np.uint64)
         rc = lib.ddp_debug_read_stamps(buf.ctypes.data_as(C.c_void_p), n)
         assert rc == 0
         captured["done"] = buf
-        captured["tiles"] = [(t.n_edges + 63) // 64 for t in tasks]
+        captured["tiles"] = [(t.n_edges + ET - 1) // ET for t in tasks]
 
 
 sm._launch_convs = hooked
@@ -104,7 +105,7 @@ for ti, nt in enumerate(captured["tiles"]):
 order = np.argsort(st[:, 22])
 dec = np.array_split(order, 10)
 print("G phase by start-time decile:", " ".join(f"{gph[d].mean():.0f}" for d in dec))
-print(f"mean units per workgroup: n/a; edges {len(st)*64}")
+print(f"workgroups {len(st)}")
 gs = st[:, 24:32]
 ns_ = st[:, 36]
 print(f"g_stage wave 0 (slot 0): mean steps {ns_.mean():.1f}; cycles: prologue issue {(gs[:,1]-gs[:,0]).mean():.0f}, step0 {(gs[:,2]-gs[:,1]).mean():.0f}, "
