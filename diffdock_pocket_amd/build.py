@@ -19,7 +19,14 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True, stamps=False, ablate=0):
+def build(force=False, verbose=True, stamps=False, ablate=0, defs=(), tag=""):
+    if defs:   # tuning variants (tools/): extra -D flags, library name suffixed with `tag`
+        out = os.path.join(HERE, f"libddp_hip_{tag}.so")
+        cmd = [os.environ.get("HIPCC", "hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+               "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), "-o", out]
+        cmd += [f"-D{d}" for d in defs] + [os.path.join(HERE, "csrc", s) for s in SOURCES]
+        subprocess.check_call(cmd)
+        return out
     if ablate or stamps:
         # diagnostic variants, never loaded by the product: -DDDP_STAMPS = in-kernel phase stamps (tools/stamp_conv.py),
         # -DDDP_ABLATE=n = timing-only ablations whose results are wrong by construction (tools/ablate_conv.py)

@@ -9,8 +9,9 @@
 // (v_mfma_f32_32x32x2_f32, exact fp32 FMA chains) one 32-column tile at a time and contracts each tile with
 // the tensor-product basis features straight from the accumulator registers:  w never leaves the CU.
 //
-// Work decomposition (one launch = the <=9 convs of a layer, they share one shape):
-//   workgroup = 512 threads = 8 waves (two per SIMD, 256 registers each), 64 edges.
+// Work decomposition (one launch = the convs of a layer that share one shape):
+//   workgroup = ET edges x 8 ET threads: ET = 64 (8 waves, one workgroup per CU) for direct shapes, ET = 32 (4 waves,
+//   three workgroups per CU) for factorised shapes - see the note at FS64 below.
 //   phase 0  stage edge_attr_ rows (3 gathers) into LDS
 //   phase 1  h = relu(edge_attr_ @ W1 + b1)  via MFMA, to LDS [64][hs]
 //   per weight block (0e,1o,1e,0o):
@@ -26,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "ddp_hip.h"
 #include "ddp_internal.h"
@@ -710,10 +712,18 @@ __global__ __launch_bounds__(ET * 8, (ET == 64) ? 2 : 3) void ddp_conv_messages_
   __shared__ TileAux<ET> aux;
   const ddp_conv_shape_t& S = L.shape;
   const int tid = threadIdx.x;
+  // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), so id -> tile is
+  // remapped to give every XCD one contiguous range of tiles: neighbouring tiles share source nodes (G rows, x rows)
+  // and all tiles of a conv share its packed weights.
+  int tile;
+  {
+    const int ntl = (int)gridDim.x, q = ntl >> 3, rem = ntl & 7, x = (int)blockIdx.x & 7;
+    tile = ((x < rem) ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + ((int)blockIdx.x >> 3);
+  }
   int t = 0;
-  while (t + 1 < L.ntasks && (int)blockIdx.x >= L.tile_start[t + 1]) ++t;
+  while (t + 1 < L.ntasks && tile >= L.tile_start[t + 1]) ++t;
   const ddp_conv_task_t& T = L.task[t];
-  const int p0 = ((int)blockIdx.x - L.tile_start[t]) * ET;
+  const int p0 = (tile - L.tile_start[t]) * ET;
   const int nvalid = min(ET, T.n_edges - p0);
   float* hbuf = lds;
   float* fbuf = lds + ET * S.hs;
@@ -872,6 +882,7 @@ __global__ __launch_bounds__(ET * 8, (ET == 64) ? 2 : 3) void ddp_conv_messages_
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     ddp_stamp_buf[blockIdx.x * DDP_STAMP_SLOTS + 21] = ((unsigned long long)xcc << 32) | hw;
+    ddp_stamp_buf[blockIdx.x * DDP_STAMP_SLOTS + 37] = (unsigned long long)tile;
   }
 #endif
 }
@@ -928,7 +939,8 @@ extern "C" int ddp_conv_messages(const ddp_conv_shape_t* shape, const ddp_conv_t
   }
   ConvLaunch L;
   L.shape = *shape;
-  if (fact) {
+  static const bool force32 = getenv("DDP_FORCE_ET32") != nullptr;   // diagnostic: direct shapes on the 32-edge kernel too
+  if (fact || force32) {
     // 32-edge workgroups.  fbuf: [0, tv_off) features / per-component partials (4 x 32 x 32), tv behind them; the
     // edge_attr_ staging tile (32 x hs) may overlap tv, which is written after fc1.
     const int ET = 32;

@@ -263,15 +263,18 @@ class ConvProfiler:
     (BASELINE.md §3 formula x the launch's actual edge count).  Used by bench.py for the roofline entry."""
 
     def __init__(self):
-        self.events, self.flops, self.executed = [], [], []
+        self.events, self.flops, self.executed, self.kernel = [], [], [], []
 
-    def summary(self):
-        ms = sum(a.elapsed_time(b) for a, b in self.events)
-        return len(self.events), float(sum(self.flops)), float(ms)
+    def summary(self, kernel=None):
+        """(launches, algorithmic FLOPs, ms) over all launches or over those of one kernel instantiation
+        ("ddp_conv_messages_kernel<32>": factorised shapes, "ddp_conv_messages_kernel<64>": direct shapes)."""
+        sel = [i for i, k in enumerate(self.kernel) if kernel is None or k == kernel]
+        ms = sum(self.events[i][0].elapsed_time(self.events[i][1]) for i in sel)
+        return len(sel), float(sum(self.flops[i] for i in sel)), float(ms)
 
-    def executed_flops(self):
-        """FLOPs the kernel actually issued (padded MFMA tiles + the VALU part of factorised convs)."""
-        return float(sum(self.executed))
+    def executed_flops(self, kernel=None):
+        """FLOPs the kernel actually issued (padded MFMA tiles + the G pass of factorised convs)."""
+        return float(sum(e for e, k in zip(self.executed, self.kernel) if kernel is None or k == kernel))
 
 
 _PROFILER: Optional[ConvProfiler] = None
@@ -323,6 +326,7 @@ def _launch_convs(spec: P.ConvSpec, tasks: List[L.ConvTask], flops_spec: Optiona
         ne = sum(t.n_edges for t in tasks)
         prof.flops.append((flops_spec or spec).flops_per_edge() * ne)
         prof.executed.append((spec.mfma_flops_per_edge_executed() + 2 * spec.hid * sum(spec.g_cols)) * ne)
+        prof.kernel.append("ddp_conv_messages_kernel<32>" if spec.factorized else "ddp_conv_messages_kernel<64>")
 
 
 def _launch_reduce(x, ldx, n_nodes, d_out, sources, accumulate=True):

@@ -10,28 +10,33 @@ exactly half of the bytes of a wide coalesced streaming read (MI355X_MICROARCH.m
 exact for 16-byte-per-lane streaming stores.  The result is averaged per ddp_conv_messages_kernel launch.
 """
 import glob
+import os
 import json
 import sys
 
 import pandas as pd
 
 
-def per_launch(d, counter):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+KERNELS = {"ddp_conv_messages_kernel<32>": "ddp_conv_messages_kernel<32>", "ddp_conv_messages_kernel<64>": "ddp_conv_messages_kernel<64>"}
+
+
+def per_launch(d, counter, kernel):
+    f = max(glob.glob(d + "/*/*counter_collection.csv"), key=os.path.getmtime)   # newest pass in the directory
     c = pd.read_csv(f)
-    c = c[c.Kernel_Name.str.contains("ddp_conv_messages") & (c.Counter_Name == counter)]
+    c = c[c.Kernel_Name.str.contains(kernel, regex=False) & (c.Counter_Name == counter)]
     per = c.groupby("Dispatch_Id").Counter_Value.sum()
     return float(per.mean()), int(per.shape[0])
 
 
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
-    fetch_kb, n1 = per_launch(fetch_dir, "FETCH_SIZE")
-    write_kb, n2 = per_launch(write_dir, "WRITE_SIZE")
-    res = {"kernel": "ddp_conv_messages_kernel", "launches_sampled": [n1, n2],
-           "FETCH_SIZE_kb_per_launch_raw": fetch_kb, "WRITE_SIZE_kb_per_launch_raw": write_kb,
-           "corrections": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B), WRITE_SIZE x1; units of 1024 B",
-           "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0}
+    res = {"corrections": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B), WRITE_SIZE x1; units of 1024 B", "kernels": {}}
+    for name, pat in KERNELS.items():
+        fetch_kb, n1 = per_launch(fetch_dir, "FETCH_SIZE", pat)
+        write_kb, n2 = per_launch(write_dir, "WRITE_SIZE", pat)
+        res["kernels"][name] = {"launches_sampled": [n1, n2], "FETCH_SIZE_kb_per_launch_raw": fetch_kb,
+                                "WRITE_SIZE_kb_per_launch_raw": write_kb,
+                                "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0}
     json.dump(res, open(out, "w"), indent=1)
     print(res)
 

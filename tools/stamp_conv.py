@@ -66,6 +66,8 @@ smp.step(1, get_t_schedule(20))
 captured.pop("done", None)
 smp.step(2, get_t_schedule(20))
 st = captured["done"].astype(np.int64)
+st = st[np.argsort(st[:, 37], kind="stable")]      # rows in tile order (workgroup ids are remapped per XCD)
+captured["done"] = captured["done"][np.argsort(captured["done"][:, 37].astype(np.int64), kind="stable")]
 names = ["stage edge_attr_", "fc1"]
 for b in range(4):
     names += [f"blk{b} features", f"blk{b} wave0 tiles", f"blk{b} wait other waves", f"blk{b} reduce+store"]
