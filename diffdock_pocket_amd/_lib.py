@@ -16,8 +16,9 @@ DDP_MAX_TASKS, DDP_MAX_BLOCKS, DDP_MAX_SEGS, DDP_MAX_NS, DDP_EDGE_TILE = 9, 4, 3
 F_SCALAR_S0, F_DOT, F_SCALAR_S1, F_VEC_S0, F_CROSS = range(5)
 FS = 68  # feature-buffer row stride of ddp_conv.hip
 
-EXPORTS = ["ddp_conv_messages", "ddp_segment_reduce", "ddp_edge_featurize", "ddp_torsion_sh", "ddp_abi_version",
-           "ddp_last_error"]
+DDP_MAX_GEMM_BATCH = 16
+EXPORTS = ["ddp_conv_messages", "ddp_segment_reduce", "ddp_edge_featurize", "ddp_torsion_sh", "ddp_stage_a",
+           "ddp_abi_version", "ddp_last_error"]
 
 
 class Seg(C.Structure):
@@ -48,6 +49,11 @@ class ConvTask(C.Structure):
 class ReduceSrc(C.Structure):
     _fields_ = [("msg", C.c_void_p), ("rowptr", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p),
                 ("n_edges", C.c_int32)]
+
+
+def g_ld(hid: int, gcols: int) -> int:
+    """DDP_G_LD of include/ddp_hip.h: floats per node of a G array (rows start on 128-byte boundaries)."""
+    return ((hid + 3) // 4 * 4 * gcols + 31) // 32 * 32
 
 
 class DdpError(RuntimeError):
@@ -82,7 +88,10 @@ def load():
     lib.ddp_edge_featurize.restype = C.c_int
     lib.ddp_torsion_sh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.ddp_torsion_sh.restype = C.c_int
-    if lib.ddp_abi_version() != 2:
+    lib.ddp_stage_a.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                C.c_void_p, C.c_int, C.c_void_p]
+    lib.ddp_stage_a.restype = C.c_int
+    if lib.ddp_abi_version() != 3:
         raise DdpError("libddp_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -229,7 +229,7 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
   const int nch = (4 * nq + KC - 1) / KC;
   const int nmine = (aux.nunits > wave) ? (aux.nunits - wave + NW - 1) / NW : 0;
   const int nsteps = nmine * nch;
-  const size_t gstride = (size_t)nq * gc;                                 // in 16-byte quads
+  const size_t gstride = (size_t)(DDP_G_LD(S.hid, gc) / 4);               // node stride in 16-byte quads (128-byte aligned rows)
   const f32x4* __restrict__ G4 = reinterpret_cast<const f32x4*>(G);
   // unit table of this wave in lanes 0..7 (a wave has at most 8 units): read with v_readlane instead of dependent LDS
   // round trips at every step

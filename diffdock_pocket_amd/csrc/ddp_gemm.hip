@@ -1,0 +1,265 @@
+// ddp_gemm.hip - stage A of the source-node factorisation (include/ddp_hip.h, ddp_stage_a):
+//   out[b][j * ldo + n] = sum_u x[j, off[b] + u] * w[b][u, n]      b < nbatch, j < nrows, n < ncols, K = n_in (= ns <= 64)
+// i.e. G = x_scalar @ Wg per conv and G slot, [n_src, ncols] with ncols = hg * g_cols (12600 at
+// ns = 60): 120 FLOPs and 4 bytes written per output element, so the product is bound by the HBM write of G.
+//
+// Weight-stationary on the VECTOR ALU, on purpose: a lane owns two output columns and keeps their K weights in
+// registers (2 x K VGPRs, loaded once per workgroup); the x row of the current node is wave-uniform, so it arrives
+// through the SCALAR cache (s_load_dwordx16) and enters v_pk_fma_f32 as an SGPR pair: no LDS, no per-lane x traffic, one
+// 8-byte store per lane and row (512 contiguous bytes per wave).  Per row and wave: K v_pk_fma_f32 = 4K cycles for 512
+// bytes, i.e. 8.5 B/clk/CU = 5.2 TB/s over the chip at ns = 60 - the same as an fp32-MFMA formulation would reach (both
+// 64 FLOP/clk/SIMD) and above what HBM takes in writes, but it leaves the matrix pipe to the conv kernels and needs only
+// 128 registers and no LDS, so its workgroups fit beside theirs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "ddp_hip.h"
+#include "ddp_internal.h"
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DDP_GEMM_THREADS 256
+#define DDP_GEMM_ROWS 128   // rows per workgroup (the weight columns are re-read from L2 once per 128 rows)
+
+struct GemmOffs {
+  int off[DDP_MAX_GEMM_BATCH];
+};
+
+// KT > 0: K is the compile-time constant KT (fully unrolled, no guards); KT == 0: any even K <= 64 (guarded pairs).
+// CPL = output columns per lane: 4 (K = 60: 240 weight registers, two waves per SIMD, 16-byte stores; needs ncols % 4
+// == 0) halves the scalar-cache traffic per output byte against 2, which is what bounds the 2-column form.
+// x / w / out are direct __restrict__ kernel arguments: only then does the compiler treat the x row as invariant and
+// fetch it with scalar loads (through a pointer read from a struct it falls back to 60 per-lane loads per row: 5x slower).
+template <int KT, int CPL>
+__global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_kernel(const float* __restrict__ x, int ldx, int nrows,
+                                                                           const GemmOffs offs, const float* __restrict__ w,
+                                                                           int k, int ncols, float* __restrict__ out, int ldo) {
+  constexpr int KP = (KT > 0) ? KT / 2 : 32;                  // k pairs held in registers
+  const int K = (KT > 0) ? KT : k;
+  const int z = (int)blockIdx.z;
+  const int r0 = (int)blockIdx.y * DDP_GEMM_ROWS;
+  const int r1 = min(nrows, r0 + DDP_GEMM_ROWS);
+  const int col = ((int)blockIdx.x * DDP_GEMM_THREADS + (int)threadIdx.x) * CPL;
+  bool act[CPL];
+  int cc[CPL];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    act[q] = col + q < ncols;
+    cc[q] = act[q] ? col + q : 0;
+  }
+  const float* __restrict__ W = w + (size_t)z * K * ncols;
+  f32x2 wr[CPL][KP];
+#pragma unroll
+  for (int u = 0; u < KP; ++u) {
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      if (KT > 0 || 2 * u < K)
+        wr[q][u] = f32x2{W[(size_t)(2 * u) * ncols + cc[q]], W[(size_t)(2 * u + 1) * ncols + cc[q]]};
+      else
+        wr[q][u] = f32x2{0.f, 0.f};
+    }
+  }
+  const bool vec = act[CPL - 1] && ((ldo & (CPL - 1)) == 0);     // aligned CPL-wide store
+  float* __restrict__ o = out + ((size_t)z * nrows + r0) * ldo + col;
+  const float* __restrict__ xr = x + (size_t)r0 * ldx + offs.off[z];   // wave-uniform: scalar loads
+  for (int j = r0; j < r1; ++j, xr += ldx, o += ldo) {
+    f32x2 acc[CPL];                                             // even / odd k partial sums
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) acc[q] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < KP; ++u) {
+      if (KT > 0 || 2 * u < K) {
+        const f32x2 xv = {xr[2 * u], xr[2 * u + 1]};
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) acc[q] = __builtin_elementwise_fma(xv, wr[q][u], acc[q]);
+      }
+    }
+    if (vec) {
+      if constexpr (CPL == 4)
+        *reinterpret_cast<f32x4*>(o) = f32x4{acc[0][0] + acc[0][1], acc[1][0] + acc[1][1], acc[2][0] + acc[2][1], acc[3][0] + acc[3][1]};
+      else
+        *reinterpret_cast<f32x2*>(o) = f32x2{acc[0][0] + acc[0][1], acc[1][0] + acc[1][1]};
+    } else {
+#pragma unroll
+      for (int q = 0; q < CPL; ++q)
+        if (act[q]) o[q] = acc[q][0] + acc[q][1];
+    }
+  }
+}
+
+// ---- MFMA form (used for wide outputs): weight-stationary on v_mfma_f32_32x32x2_f32.
+// A wave owns CT = 4 column tiles of 32 and keeps their K x 32 weights as B operands in registers (K/2 VGPRs per tile:
+// lane (r, hh) holds w[k = hh*K/2 + s][col r], the k order of the K/2 MFMA steps is (s, K/2 + s)); it streams 32-row tiles
+// of x as the A operand (lane (r, hh): x[row r][off + hh*K/2 + s], K/2 contiguous floats, next tile requested one tile
+// ahead) and stores each accumulator register as two 128-byte row segments.  4 independent accumulators per wave keep
+// the matrix pipe issuing; per 32 x 128 output block K/2 * 4 MFMAs = 7680 cycles for 16 KiB at K = 60, i.e. the same
+// 8.5 B/clk/CU bound as above, but the VALU form stalls at ~1/3 of its nominal rate (1.5 TB/s measured, rocBLAS 2.2-2.4).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef DDP_GEMM_MROWS
+#define DDP_GEMM_MROWS 256
+#endif //  // rows per workgroup of the MFMA form
+
+#ifndef DDP_SA_CT
+#define DDP_SA_CT 4      // column tiles (of 32) per wave
+#define DDP_SA_WPE 2     // waves per SIMD the register budget is set for
+#endif
+template <int KT>
+__global__ __launch_bounds__(DDP_GEMM_THREADS, DDP_SA_WPE) void ddp_stage_a_mfma_kernel(const float* __restrict__ x, int ldx, int nrows,
+                                                                                const GemmOffs offs, const float* __restrict__ w,
+                                                                                int ncols, float* __restrict__ out, int ldo) {
+  constexpr int KH = KT / 2, CT = DDP_SA_CT;
+  constexpr int XS = KT + 1;                                    // odd LDS row stride: conflict-free ds_read_b32 down a column
+  constexpr int NV = (32 * KT / 4 + DDP_GEMM_THREADS - 1) / DDP_GEMM_THREADS;   // 16-byte pieces of an x tile per thread
+  constexpr int TS = 36;                                        // LDS row stride of the per-wave store tile
+  __shared__ float xt[2][32 * XS];
+  __shared__ __attribute__((aligned(16))) float st[4][32 * TS];
+  const bool wide = ((ncols & 3) == 0) && ((ldo & 3) == 0) && ((reinterpret_cast<size_t>(out) & 15) == 0);
+  const int z = (int)blockIdx.z, tid = (int)threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int col0 = ((int)blockIdx.x * 4 + wave) * (32 * CT);
+  const float* __restrict__ W = w + (size_t)z * KT * ncols;
+  float wr[CT][KH];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) {
+    const int c = min(col0 + 32 * t + r, ncols - 1);
+#pragma unroll
+    for (int s2 = 0; s2 < KH; ++s2) wr[t][s2] = W[(size_t)(hh * KH + s2) * ncols + c];
+  }
+  const int R0 = (int)blockIdx.y * DDP_GEMM_MROWS;
+  const int R1 = min(nrows, R0 + DDP_GEMM_MROWS);
+  const float* __restrict__ xb = x + offs.off[z];
+  const bool al4 = ((ldx | offs.off[z]) & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0;
+
+  // The 32 x K tile of x rows is fetched ONCE per workgroup with coalesced 16-byte loads (each wave fetching its own A
+  // operand straight from memory is 64 scattered 4-byte pieces per load instruction, 4x redundant: the L1 tag rate then
+  // bounds the kernel at ~40 % of the matrix pipe), parked in LDS (double buffered) and read per lane as the A operand.
+  f32x4 xv[NV];
+  auto fetch = [&](int row0) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int i = tid + v * DDP_GEMM_THREADS;                 // piece i = (row i / (KT/4), quad i % (KT/4))
+      const int rr = min(i / (KT / 4), 31), q = i % (KT / 4);
+      const float* __restrict__ p = xb + (size_t)min(row0 + rr, nrows - 1) * ldx + 4 * q;
+      if (al4)
+        xv[v] = *reinterpret_cast<const f32x4*>(p);
+      else
+        xv[v] = f32x4{p[0], p[1], p[2], p[3]};
+    }
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int i = tid + v * DDP_GEMM_THREADS;
+      if (i < 32 * (KT / 4)) {
+        const int rr = i / (KT / 4), q = i % (KT / 4);
+        float* d = &xt[buf][rr * XS + 4 * q];
+        d[0] = xv[v][0]; d[1] = xv[v][1]; d[2] = xv[v][2]; d[3] = xv[v][3];
+      }
+    }
+  };
+  fetch(R0);
+  park(0);
+  __syncthreads();
+  int buf = 0;
+  for (int row0 = R0; row0 < R1; row0 += 32, buf ^= 1) {
+    const bool more = row0 + 32 < R1;
+    if (more) fetch(row0 + 32);                                 // in flight during this tile's MFMAs
+    float a[KH];
+    {
+      const float* ar = &xt[buf][r * XS + hh * KH];
+#pragma unroll
+      for (int s2 = 0; s2 < KH; ++s2) a[s2] = ar[s2];
+    }
+    // one column tile at a time: its 32 x 32 block is stored while the next tile's MFMAs run (a single accumulator
+    // chain already issues at the full rate: issue interval = dependent latency = 64 cycles); C/D layout: register i of
+    // lane (r, hh) = out[row0 + (i&3) + 8*(i>>2) + 4*hh][col r], i.e. every store instruction writes two 128-byte row pieces
+    float* __restrict__ ob = out + ((size_t)z * nrows + row0) * ldo;
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+#if defined(DDP_SA_ABL) && DDP_SA_ABL == 3
+      for (int s2 = 0; s2 < 1; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], wr[t][s2], acc, 0, 0, 0);
+#else
+      for (int s2 = 0; s2 < KH; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], wr[t][s2], acc, 0, 0, 0);
+#endif
+      if (wide) {
+        // through a per-wave LDS tile: a lane then writes 16 bytes, an instruction 8 rows x 128 bytes (4 store
+        // instructions per 32 x 32 block instead of 16)
+        float* tl = st[wave];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tl[((i & 3) + 8 * (i >> 2) + 4 * hh) * TS + r] = acc[i];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int rr = 8 * p + (lane >> 3), q = lane & 7, c = col0 + 32 * t + 4 * q;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(&tl[rr * TS + 4 * q]);
+#if defined(DDP_SA_ABL) && DDP_SA_ABL == 1
+          if (row0 + rr < R1 && c < ncols && v[0] == 1.2345e30f)
+#else
+          if (row0 + rr < R1 && c < ncols)
+#endif
+            *reinterpret_cast<f32x4*>(&ob[(size_t)rr * ldo + c]) = v;
+        }
+      } else {
+        const int c = col0 + 32 * t + r;
+        if (c < ncols) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int rr = (i & 3) + 8 * (i >> 2) + 4 * hh;
+            if (row0 + rr < R1) ob[(size_t)rr * ldo + c] = acc[i];
+          }
+        }
+      }
+    }
+    if (more) park(buf ^ 1);
+    __syncthreads();
+  }
+}
+
+extern "C" int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* offs, int nbatch, const float* w, int k, int ncols,
+                           float* out, int ldo, void* stream) {
+  if (nbatch < 0 || nbatch > DDP_MAX_GEMM_BATCH) return ddp_fail(DDP_ELIMIT, "ddp_stage_a: nbatch > DDP_MAX_GEMM_BATCH");
+  if (k < 2 || k > 64 || (k & 1)) return ddp_fail(DDP_ELIMIT, "ddp_stage_a: K must be even and in [2, 64]");
+  if (ncols < 1 || nrows < 0 || ldo < ncols) return ddp_fail(DDP_EINVAL, "ddp_stage_a: ncols / nrows / ldo");
+  if (nbatch == 0 || nrows == 0) return 0;
+  if (!x || !offs || !w || !out) return ddp_fail(DDP_EINVAL, "ddp_stage_a: null argument");
+  if ((reinterpret_cast<size_t>(x) & 3) || (reinterpret_cast<size_t>(out) & 7))   // scalar loads: dword aligned
+    return ddp_fail(DDP_EINVAL, "ddp_stage_a: x must be 4-byte aligned, out 8-byte aligned");
+  GemmOffs O;
+  for (int i = 0; i < DDP_MAX_GEMM_BATCH; ++i) O.off[i] = (i < nbatch) ? offs[i] : 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int nry = (nrows + DDP_GEMM_ROWS - 1) / DDP_GEMM_ROWS;
+#define DDP_GEMM_LAUNCH(KT, CPL)                                                                                 \
+  hipLaunchKernelGGL((ddp_stage_a_kernel<KT, CPL>), dim3((ncols + CPL * DDP_GEMM_THREADS - 1) / (CPL * DDP_GEMM_THREADS), nry, nbatch), \
+                     dim3(DDP_GEMM_THREADS), 0, s, x, ldx, nrows, O, w, k, ncols, out, ldo)
+  const bool wide = ((ncols | ldo) & 3) == 0 && ncols >= 4 * DDP_GEMM_THREADS && (reinterpret_cast<size_t>(out) & 15) == 0;
+#define DDP_GEMM_MFMA(KT)                                                                                        \
+  hipLaunchKernelGGL((ddp_stage_a_mfma_kernel<KT>), dim3((ncols + 128 * DDP_SA_CT - 1) / (128 * DDP_SA_CT), (nrows + DDP_GEMM_MROWS - 1) / DDP_GEMM_MROWS, nbatch), \
+                     dim3(DDP_GEMM_THREADS), 0, s, x, ldx, nrows, O, w, ncols, out, ldo)
+  static const bool no_mfma = getenv("DDP_STAGE_A_VALU") != nullptr;   // diagnostic: force the VALU form
+  if (ncols >= 512 && !no_mfma && (k == 60 || k == 64 || k == 32 || k == 24 || k == 16)) {
+    switch (k) {
+      case 60: DDP_GEMM_MFMA(60); break;
+      case 64: DDP_GEMM_MFMA(64); break;
+      case 32: DDP_GEMM_MFMA(32); break;
+      case 24: DDP_GEMM_MFMA(24); break;
+      default: DDP_GEMM_MFMA(16); break;
+    }
+  } else
+  switch (k) {
+    case 60: if (wide) DDP_GEMM_LAUNCH(60, 4); else DDP_GEMM_LAUNCH(60, 2); break;
+    case 32: DDP_GEMM_LAUNCH(32, 2); break;
+    case 24: DDP_GEMM_LAUNCH(24, 2); break;
+    case 16: DDP_GEMM_LAUNCH(16, 2); break;
+    default: DDP_GEMM_LAUNCH(0, 2); break;
+  }
+#undef DDP_GEMM_LAUNCH
+#undef DDP_GEMM_MFMA
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return ddp_fail_hip(err, "ddp_stage_a launch");
+  return 0;
+}

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DDP_ABI_VERSION 2
+#define DDP_ABI_VERSION 3
 #define DDP_EINVAL (-1)   /* bad argument (shape not supported, null pointer, ...) */
 #define DDP_ELIMIT (-2)   /* exceeds a compiled-in limit (see DDP_MAX_*) */
 
@@ -102,7 +102,8 @@ typedef struct {
   float* msg;           /* per-edge messages, CSR order                       [E, d_out] */
   /* factorised convs only (shape.g_cols != 0): edges are then listed in SOURCE-node order (so that a workgroup streams
    * each G[j] once) and `pos` gives the message row (= position in the receiver-CSR order) of every listed edge */
-  const float* g[2];    /* G[s]:  [n_src, hg/4, g_cols[s], 4], hg = hid rounded up to 4: G[j][k/4][c][k%4] (16-byte aligned) */
+  const float* g[2];    /* G[s]:  [n_src, DDP_G_LD(hid, g_cols[s])] floats per node, of which the first hg * g_cols[s] are
+                           [hg/4, g_cols[s], 4], hg = hid rounded up to 4: G[j][k/4][c][k%4]; 16-byte aligned */
   const float* gb[2];   /* Gb[s]: [n_src, g_cols[s]]      (fc.3 bias part) */
   const int32_t* pos;   /* [E] message row per listed edge; NULL = identity */
 } ddp_conv_task_t;
@@ -148,6 +149,20 @@ int ddp_edge_featurize(const float* pos_a, const int32_t* ia, const float* pos_b
  * Replaces all_atom_score_model.py:394-395,418-419 (o3.spherical_harmonics("2e") + o3.FullTensorProduct). */
 int ddp_torsion_sh(const float* sh_edge, const float* bond_vec, const int32_t* bond_of_edge, int n_edges, float* out,
                    void* stream);
+
+/* Stage A of the source-node factorisation (ddp_block_t::g_slot): the per-source-node tensors consumed through
+ * ddp_conv_task_t::g / ::gb, for all (conv, G slot) pairs that read one node-feature array x:
+ *   out[b][j * ldo + n] = sum_{u < k} x[j * ldx + offs[b] + u] * w[b][u, n],     b < nbatch, j < nrows, n < ncols
+ * (offs[b] = first scalar channel of the slot, host array; w = the fc.3 weight rows of the slot's scalar-input features
+ * regrouped per (k, column) by the host - models/score_model.py:100-105 and models/layers.py:41,42,52,53 contracted
+ * over the input channel u per NODE instead of per edge).  w is [nbatch][k][ncols] contiguous, out [nbatch][nrows][ldo]
+ * (ldo >= ncols; the columns [ncols, ldo) are not written); k even, <= 64; out 8-byte aligned.
+ * For G use ldo = DDP_G_LD(hid, g_cols): rows that start on a 128-byte boundary are written (and later fetched) at twice
+ * the rate of unaligned ones. */
+#define DDP_MAX_GEMM_BATCH 16
+#define DDP_G_LD(hid, gcols) (((((hid) + 3) / 4) * 4 * (gcols) + 31) / 32 * 32)   /* floats per node of a G array */
+int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* offs, int nbatch, const float* w, int k, int ncols,
+                float* out, int ldo, void* stream);
 
 int ddp_abi_version(void);
 const char* ddp_last_error(void);

@@ -144,3 +144,30 @@ def test_edge_featurize_and_torsion_sh():
     bv_d, boe_d = bv.to(dev).contiguous(), boe.int().to(dev)   # keep the device buffers alive across the launch
     L.check(L.load().ddp_torsion_sh(_ptr(sh), _ptr(bv_d), _ptr(boe_d), E, _ptr(got_t), _stream()), "ddp_torsion_sh")
     assert float((got_t.cpu()[:, 1:] - want_t).abs().max()) < 1e-5 and float(got_t[:, 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("k,ncols,nrows,ldx,offs", [(60, 12600, 300, 180, (120, 0)), (60, 70, 129, 180, (0,)),
+                                                    (16, 980, 77, 37, (5, 3, 0)), (10, 33, 5, 12, (2,)), (64, 513, 200, 64, (0,))])
+def test_stage_a_gemm(k, ncols, nrows, ldx, offs):
+    """ddp_stage_a (weight-stationary VALU GEMM of the source-node factorisation, strided batch over (conv, slot)) against
+    fp64 matmul; tolerance = fp32 rounding of a K-term sum."""
+    import ctypes as C
+    from diffdock_pocket_amd import _lib as L
+    from diffdock_pocket_amd.score_model import _stream
+    torch.manual_seed(k + ncols)
+    dev = _dev()
+    lib = L.load()
+    nb = len(offs)
+    x, w = torch.randn(nrows, ldx), torch.randn(nb, k, ncols)
+    xd, wd = x.to(dev), w.to(dev)
+    ldo = (ncols + 31) // 32 * 32 if ncols > 100 else ncols        # padded rows (the G layout) and dense rows (Gb)
+    od = torch.full((nb, nrows, ldo), float("nan"), device=dev)
+    L.check(lib.ddp_stage_a(xd.data_ptr(), ldx, nrows, (C.c_int32 * nb)(*offs), nb, wd.data_ptr(), k, ncols, od.data_ptr(),
+                            ldo, _stream()), "ddp_stage_a")
+    torch.cuda.synchronize()
+    assert torch.isnan(od[:, :, ncols:]).all()                     # the padding columns are not written
+    got = od[:, :, :ncols].cpu().double()
+    assert torch.isfinite(got).all()
+    for b in range(nb):
+        want = x[:, offs[b]:offs[b] + k].double() @ w[b].double()
+        assert float((got[b] - want).abs().max()) < 2e-5 * float(want.abs().max())

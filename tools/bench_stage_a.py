@@ -1,0 +1,47 @@
+"""Micro-benchmark of ddp_stage_a against torch.mm / torch.bmm on the stage-A shapes (diagnostic)."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from diffdock_pocket_amd import _lib as L  # noqa: E402
+
+
+def timeit(fn, n=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def main():
+    dev = torch.device("cuda:0")
+    lib = L.load()
+    st = torch.cuda.current_stream().cuda_stream
+    for name, N, nb, ncols in (("atom", 44440, 2, 12600), ("atom-pad32", 44440, 2, 12608), ("atom-pad512", 44440, 2, 12800),
+                               ("rec", 5560, 6, 12600), ("lig", 1480, 6, 12600)):
+        k, ldx = 60, 180
+        x = torch.randn(N, ldx, device=dev)
+        w = torch.randn(nb, k, ncols, device=dev)
+        ldo = (ncols + 31) // 32 * 32
+        out = torch.empty(nb, N, ldo, device=dev)
+        offs = (C.c_int32 * nb)(*[120 * (i % 2) for i in range(nb)])
+        t_mine = timeit(lambda: L.check(lib.ddp_stage_a(x.data_ptr(), ldx, N, offs, nb, w.data_ptr(), k, ncols, out.data_ptr(), ldo, st), "a"))
+        A = torch.stack([x[:, 120 * (i % 2):120 * (i % 2) + k] for i in range(nb)])
+        t_bmm = timeit(lambda: torch.bmm(A, w))
+        t_mm = timeit(lambda: [torch.mm(A[i], w[i]) for i in range(nb)])
+        gb = nb * N * ncols * 4 / 1e9
+        print(f"{name}: N={N} nb={nb}  {gb:.2f} GB out | ddp_stage_a {t_mine:.3f} ms ({gb / t_mine:.2f} TB/s)  bmm {t_bmm:.3f} ms ({gb / t_bmm:.2f})  "
+              f"mm x{nb} {t_mm:.3f} ms ({gb / t_mm:.2f})")
+
+
+if __name__ == "__main__":
+    main()
