@@ -202,7 +202,11 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, DDP_SA_WPE) void ddp_stage_a_mfma
 #else
           if (row0 + rr < R1 && c < ncols)
 #endif
+#ifdef DDP_SA_NT
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(&ob[(size_t)rr * ldo + c]));
+#else
             *reinterpret_cast<f32x4*>(&ob[(size_t)rr * ldo + c]) = v;
+#endif
         }
       } else {
         const int c = col0 + 32 * t + r;

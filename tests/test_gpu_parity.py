@@ -171,3 +171,34 @@ def test_stage_a_gemm(k, ncols, nrows, ldx, offs):
     for b in range(nb):
         want = x[:, offs[b]:offs[b] + k].double() @ w[b].double()
         assert float((got[b] - want).abs().max()) < 2e-5 * float(want.abs().max())
+
+
+def test_static_graph_cache_is_invalidated_by_in_place_updates():
+    """The receptor-side graph (atom kNN, CSR views) is kept across forward calls while its input tensors are unchanged
+    (score_model._cached).  Moving only the ligand must reuse it, moving atoms in place (side-chain updates) or handing
+    over a new batch must rebuild it: every call has to equal a fresh model's output bitwise."""
+    case, gold, batch, sd = case_inputs("cfg2_small")
+    dev = _dev()
+    cached, b = _model_for(case, sd), case.make_batch().to(dev)
+
+    def fresh(bb):
+        return [t.clone() for t in _model_for(case, sd)(bb)]
+
+    def same(x, y):
+        return all(torch.equal(p, q) for p, q in zip(x, y))
+
+    out0 = [t.clone() for t in cached(b)]
+    assert same(out0, fresh(b))
+    n_hit = len(cached._static_cache)
+    assert n_hit > 0
+    b["ligand"].pos = b["ligand"].pos + 0.3                       # ligand moves: the static entries are reused
+    keys_before = {k: id(v[3]) for k, v in cached._static_cache.items() if k in ("aa", "c_aa", "c_rr")}
+    out1 = [t.clone() for t in cached(b)]
+    assert {k: id(v[3]) for k, v in cached._static_cache.items() if k in keys_before} == keys_before
+    assert same(out1, fresh(b)) and not same(out1, out0)
+    b["atom"].pos.add_(torch.randn_like(b["atom"].pos) * 0.4)     # atoms move IN PLACE: version counter bumps -> rebuild
+    out2 = [t.clone() for t in cached(b)]
+    assert id(cached._static_cache["aa"][3]) != keys_before["aa"]
+    assert same(out2, fresh(b)) and not same(out2, out1)
+    b2 = case.make_batch().to(dev)                                # a different batch object
+    assert same([t.clone() for t in cached(b2)], out0)
