@@ -18,7 +18,7 @@ FS = 68  # feature-buffer row stride of ddp_conv.hip
 
 DDP_MAX_GEMM_BATCH = 16
 EXPORTS = ["ddp_conv_messages", "ddp_segment_reduce", "ddp_edge_featurize", "ddp_torsion_sh", "ddp_stage_a",
-           "ddp_abi_version", "ddp_last_error"]
+           "ddp_pose_update", "ddp_abi_version", "ddp_last_error"]
 
 
 class Seg(C.Structure):
@@ -91,6 +91,9 @@ def load():
     lib.ddp_stage_a.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_int, C.c_int,
                                 C.c_void_p, C.c_int, C.c_void_p]
     lib.ddp_stage_a.restype = C.c_int
+    lib.ddp_pose_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ddp_pose_update.restype = C.c_int
     if lib.ddp_abi_version() != 3:
         raise DdpError("libddp_hip.so ABI version mismatch")
     _lib = lib

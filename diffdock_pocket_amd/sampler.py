@@ -50,17 +50,23 @@ def kabsch(A: torch.Tensor, B: torch.Tensor):
     H = (A - ca).transpose(1, 2) @ (B - cb)
     U, S, Vt = torch.linalg.svd(H)
     R = Vt.transpose(1, 2) @ U.transpose(1, 2)
-    neg = torch.linalg.det(R) < 0
-    if bool(neg.any()):
-        D = torch.diag(torch.tensor([1.0, 1.0, -1.0], dtype=A.dtype, device=A.device))
-        R = torch.where(neg.reshape(-1, 1, 1), (Vt.transpose(1, 2) @ D) @ U.transpose(1, 2), R)
+    neg = torch.linalg.det(R) < 0          # reflection case (:232-236); applied without a host-side branch (no sync)
+    D = torch.ones(3, dtype=A.dtype, device=A.device)
+    D[2] = -1.0
+    R = torch.where(neg.reshape(-1, 1, 1), (Vt.transpose(1, 2) * D) @ U.transpose(1, 2), R)
     t = cb - ca @ R.transpose(1, 2)
     return R, t
 
 
-def apply_torsions(pos: torch.Tensor, bonds: torch.Tensor, mask_rotate: torch.Tensor, angles: torch.Tensor):
+def rotate_index_lists(mask_rotate: torch.Tensor):
+    """mask_rotate [T,n] bool -> per-bond index tensors of the atoms that move.  Built once: indexing with the boolean
+    mask itself costs a device-to-host synchronisation (nonzero) per bond and step."""
+    return [mask_rotate[j].nonzero(as_tuple=True)[0] for j in range(mask_rotate.shape[0])]
+
+
+def apply_torsions(pos: torch.Tensor, bonds: torch.Tensor, mask_rotate, angles: torch.Tensor):
     """Batched modify_conformer_torsion_angles (reference utils/torsion.py:68-94).
-    pos [N,n,3]; bonds [T,2] (u,v); mask_rotate [T,n] bool; angles [N,T]."""
+    pos [N,n,3]; bonds [T,2] (u,v); mask_rotate [T,n] bool or rotate_index_lists(mask_rotate); angles [N,T]."""
     pos = pos.clone()
     for j in range(bonds.shape[0]):
         u, v = int(bonds[j, 0]), int(bonds[j, 1])
@@ -84,6 +90,24 @@ def apply_sidechain_torsions(pos, edge_idx, subcomponents, mapping, angles):
         pv = pos[:, v:v + 1]
         pos[:, idx] = (pos[:, idx] - pv) @ rot.transpose(1, 2) + pv
     return pos
+
+
+def modify_conformer_hip(pos, tr, rot, tor, bonds_i32, mask_u8):
+    """modify_conformer for a device-resident batch in ONE launch (ddp_pose_update, csrc/ddp_pose.hip); same arguments
+    as modify_conformer with bonds as int32 [T,2] and mask_rotate as uint8 [T,n] device tensors."""
+    from . import _lib as L
+    lib = L.load()
+    pos = pos.contiguous()
+    out = torch.empty_like(pos)
+    tr, rot = tr.contiguous().float(), rot.contiguous().float()
+    has_tor = tor is not None and tor.shape[1] > 0
+    if has_tor:
+        tor = tor.contiguous().float()
+    L.check(lib.ddp_pose_update(pos.data_ptr(), pos.shape[0], pos.shape[1], tr.data_ptr(), rot.data_ptr(),
+                                tor.data_ptr() if has_tor else None, tor.shape[1] if has_tor else 0,
+                                bonds_i32.data_ptr() if has_tor else None, mask_u8.data_ptr() if has_tor else None,
+                                out.data_ptr(), torch.cuda.current_stream().cuda_stream), "ddp_pose_update")
+    return out
 
 
 def modify_conformer(pos, tr, rot, tor, bonds, mask_rotate):
@@ -129,7 +153,10 @@ class Sampler:
         self.bonds = g["ligand", "ligand"].edge_index.t()[em].clone()             # [T,2] (u,v)
         mr = g["ligand"].mask_rotate
         self.mask_rotate = torch.as_tensor(np.asarray(mr if isinstance(mr, np.ndarray) else mr[0])).bool().to(device)
+        self.rot_idx = rotate_index_lists(self.mask_rotate)
         self.T = int(self.bonds.shape[0])
+        self.bonds_i32 = self.bonds.to(torch.int32).contiguous().to(device)
+        self.mask_u8 = self.mask_rotate.to(torch.uint8).contiguous()
         self.has_flex = cfg.flexible_sidechains and ("flexResidues" in g) and len(g["flexResidues"]) > 0
         if self.has_flex:
             fr = g["flexResidues"]
@@ -147,7 +174,7 @@ class Sampler:
         cfg, N, sl = self.cfg, self.n_total, self.slice
         if not cfg.no_torsion and self.T > 0:
             ang = (torch.rand((N, self.T), generator=self.gen) * 2 - 1) * math.pi
-            self.lig_pos = apply_torsions(self.lig_pos, self.bonds, self.mask_rotate, ang[sl].to(self.device))
+            self.lig_pos = apply_torsions(self.lig_pos, self.bonds, self.rot_idx, ang[sl].to(self.device))
         if self.has_flex:
             ang = (torch.rand((N, self.S), generator=self.gen) * 2 - 1) * math.pi
             self.atom_pos = apply_sidechain_torsions(self.atom_pos, self.sc_edge_idx, self.sc_sub, self.sc_map,
@@ -176,17 +203,23 @@ class Sampler:
         tor_s = sg.tor_sigma_min ** (1 - t) * sg.tor_sigma_max ** t
         sc_s = sg.sidechain_tor_sigma_min ** (1 - t) * sg.sidechain_tor_sigma_max ** t
 
-        b = self.batch
-        b["ligand"].pos = self.lig_pos.reshape(-1, 3)
-        b["atom"].pos = self.atom_pos.reshape(-1, 3)
-        set_time(b, t, t, t, t, device=dev)
-        tr_score, rot_score, tor_score, sc_score = self.model(b)
-
         noise_off = cfg.no_random or (cfg.no_final_step_noise and t_idx == steps - 1)
 
         def z(shape):  # drawn for all samples of the job, sliced to this shard
             full = torch.zeros(shape) if noise_off else torch.randn(shape, generator=self.gen)
             return full[sl].to(dev)
+
+        # the step's noise does not depend on the scores: drawn (same generator order as the reference loop: tr, rot, tor,
+        # side chains) and uploaded before the model call, so that nothing between the model and the pose update waits
+        z_tr, z_rot = z((N, 3)), z((N, 3))
+        z_tor = z((N, self.T)) if (not cfg.no_torsion and self.T > 0) else None
+        z_sc = z((N, self.S)) if self.has_flex else None
+
+        b = self.batch
+        b["ligand"].pos = self.lig_pos.reshape(-1, 3)
+        b["atom"].pos = self.atom_pos.reshape(-1, 3)
+        set_time(b, t, t, t, t, device=dev)
+        tr_score, rot_score, tor_score, sc_score = self.model(b)
 
         def perturb(score, g, sigma, lo, hi, k, zz):
             if cfg.ode:
@@ -200,19 +233,21 @@ class Sampler:
 
         tr_g = tr_s * math.sqrt(2 * math.log(sg.tr_sigma_max / sg.tr_sigma_min))
         rot_g = 2 * rot_s * math.sqrt(math.log(sg.rot_sigma_max / sg.rot_sigma_min))
-        tr_p = perturb(tr_score, tr_g, tr_s, sg.tr_sigma_min, sg.tr_sigma_max, 0, z((N, 3)))
-        rot_p = perturb(rot_score, rot_g, rot_s, sg.rot_sigma_min, sg.rot_sigma_max, 1, z((N, 3)))
+        tr_p = perturb(tr_score, tr_g, tr_s, sg.tr_sigma_min, sg.tr_sigma_max, 0, z_tr)
+        rot_p = perturb(rot_score, rot_g, rot_s, sg.rot_sigma_min, sg.rot_sigma_max, 1, z_rot)
         tor_p = None
         if not cfg.no_torsion and self.T > 0:
             tor_g = tor_s * math.sqrt(2 * math.log(sg.tor_sigma_max / sg.tor_sigma_min))
-            tor_p = perturb(tor_score.reshape(self.n, self.T), tor_g, tor_s, sg.tor_sigma_min, sg.tor_sigma_max, 2,
-                            z((N, self.T)))
+            tor_p = perturb(tor_score.reshape(self.n, self.T), tor_g, tor_s, sg.tor_sigma_min, sg.tor_sigma_max, 2, z_tor)
         if self.has_flex:
             sc_g = sc_s * math.sqrt(2 * math.log(sg.sidechain_tor_sigma_max / sg.sidechain_tor_sigma_min))
             sc_p = perturb(sc_score.reshape(self.n, self.S), sc_g, sc_s, sg.sidechain_tor_sigma_min,
-                           sg.sidechain_tor_sigma_max, 3, z((N, self.S)))
+                           sg.sidechain_tor_sigma_max, 3, z_sc)
             self.atom_pos = apply_sidechain_torsions(self.atom_pos, self.sc_edge_idx, self.sc_sub, self.sc_map, sc_p)
-        self.lig_pos = modify_conformer(self.lig_pos, tr_p, rot_p, tor_p, self.bonds, self.mask_rotate)
+        if self.lig_pos.is_cuda:   # one HIP launch; the PyTorch form below is the same arithmetic (CPU tests)
+            self.lig_pos = modify_conformer_hip(self.lig_pos, tr_p, rot_p, tor_p, self.bonds_i32, self.mask_u8)
+        else:
+            self.lig_pos = modify_conformer(self.lig_pos, tr_p, rot_p, tor_p, self.bonds, self.rot_idx)
 
     # -- confidence pass + ranking (reference utils/sampling.py:263-283, inference.py:212-219) ------------------------
     def confidence(self, confidence_model):

@@ -164,6 +164,15 @@ int ddp_torsion_sh(const float* sh_edge, const float* bond_vec, const int32_t* b
 int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* offs, int nbatch, const float* w, int k, int ncols,
                 float* out, int ldo, void* stream);
 
+/* The pose update between two score-model calls, for all samples of a batch in one launch:
+ * modify_conformer(pos, tr_update, rot_update, torsion_updates) of utils/diffusion_utils.py:37-60 = rigid move about the
+ * centre (rot_update is an axis-angle vector, utils/geometry.py:72-86), torsions in bond order (utils/torsion.py:68-94:
+ * atoms with mask_rotate[j][i] != 0 turn by tor[s][j] about pos[bonds[j][0]] - pos[bonds[j][1]] through pos[bonds[j][1]]),
+ * Kabsch re-alignment onto the rigid conformer (utils/geometry.py:209-243).  pos_in / pos_out [n_samples][n_atoms][3]
+ * (may alias), tr / rot [n_samples][3], tor [n_samples][n_tor] or NULL (rigid move only). */
+int ddp_pose_update(const float* pos_in, int n_samples, int n_atoms, const float* tr, const float* rot, const float* tor,
+                    int n_tor, const int32_t* bonds, const uint8_t* mask_rotate, float* pos_out, void* stream);
+
 int ddp_abi_version(void);
 const char* ddp_last_error(void);
 

@@ -202,3 +202,31 @@ def test_static_graph_cache_is_invalidated_by_in_place_updates():
     assert same(out2, fresh(b)) and not same(out2, out1)
     b2 = case.make_batch().to(dev)                                # a different batch object
     assert same([t.clone() for t in cached(b2)], out0)
+
+
+def test_pose_update_kernel_matches_modify_conformer():
+    """ddp_pose_update (one launch: rigid move, torsions, Kabsch re-alignment via Horn's quaternion) against the batched
+    PyTorch modify_conformer, which tests/test_sampler_cpu.py pins to the reference's own functions."""
+    import numpy as np
+    from diffdock_pocket_amd import sampler as S
+    from diffdock_pocket_amd.synthetic import make_3dpf_complex
+    dev = _dev()
+    g = make_3dpf_complex(seed=0, flexible_sidechains=False)
+    em = g["ligand"].edge_mask.bool()
+    bonds = g["ligand", "ligand"].edge_index.t()[em].clone()
+    mr = g["ligand"].mask_rotate
+    mask = torch.as_tensor(np.asarray(mr if isinstance(mr, np.ndarray) else mr[0])).bool()
+    T, n = bonds.shape[0], g["ligand"].pos.shape[0]
+    torch.manual_seed(3)
+    N = 17
+    pos = g["ligand"].pos.unsqueeze(0).repeat(N, 1, 1) + torch.randn(N, 1, 3) * 3
+    tr, rot, tor = torch.randn(N, 3) * 0.5, torch.randn(N, 3) * 0.4, torch.randn(N, T) * 0.6
+    rot[0] = 0.0                                                   # zero rotation vector: small-angle branch
+    tor[1] = 0.0
+    want = S.modify_conformer(pos.double(), tr.double(), rot.double(), tor.double(), bonds, mask)
+    got = S.modify_conformer_hip(pos.to(dev), tr.to(dev), rot.to(dev), tor.to(dev), bonds.to(torch.int32).to(dev),
+                                 mask.to(torch.uint8).to(dev)).cpu().double()
+    assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
+    want_r = S.modify_conformer(pos.double(), tr.double(), rot.double(), None, bonds, mask)
+    got_r = S.modify_conformer_hip(pos.to(dev), tr.to(dev), rot.to(dev), None, None, None).cpu().double()
+    assert float((got_r - want_r).abs().max()) < 2e-5 * float(want_r.abs().max())
