@@ -42,7 +42,7 @@ class ConvTask(C.Structure):
                 ("eid", C.c_void_p), ("sh", C.c_void_p), ("seg_ptr", C.c_void_p * DDP_MAX_SEGS),
                 ("seg_idx", C.c_void_p * DDP_MAX_SEGS), ("seg_ld", C.c_int32 * DDP_MAX_SEGS),
                 ("seg_n", C.c_int32 * DDP_MAX_SEGS), ("w1p", C.c_void_p), ("b1p", C.c_void_p), ("w2p", C.c_void_p),
-                ("b2p", C.c_void_p), ("msg", C.c_void_p), ("g", C.c_void_p * 2), ("gb", C.c_void_p * 2),
+                ("b2p", C.c_void_p), ("msg", C.c_void_p), ("g", C.c_void_p * 2),
                 ("pos", C.c_void_p)]
 
 
@@ -53,7 +53,7 @@ class ReduceSrc(C.Structure):
 
 def g_ld(hid: int, gcols: int) -> int:
     """DDP_G_LD of include/ddp_hip.h: floats per node of a G array (rows start on 128-byte boundaries)."""
-    return ((hid + 3) // 4 * 4 * gcols + 31) // 32 * 32
+    return (((hid + 3) // 4 * 4 + 1) * gcols + 31) // 32 * 32
 
 
 class DdpError(RuntimeError):

@@ -219,7 +219,7 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
   constexpr int KC = 20, XK = 24, NW = ET / 8;   // NW waves per workgroup, at most 8 units per wave
   const int gc = S.g_cols[slot];
   const float* __restrict__ G = T.g[slot];
-  const float* __restrict__ Gb = T.gb[slot];
+  const float* __restrict__ Gb = G + 4 * (size_t)((S.hid + 3) >> 2) * gc;   // Gb[j] sits behind G[j] in the node's row
   const int nmain = min(gc, 64), nx = gc - nmain;
   const int xnb = nx <= 4 ? 1 : 2, xnsl = 16 / xnb;                       // K-slice layout of the extra columns
   const int xkper = (((S.hid + xnsl - 1) / xnsl) + 3) & ~3;
@@ -260,7 +260,7 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
       const f32x4* __restrict__ gp_ = G4 + (size_t)node_ * gstride + c0;                                      \
       _Pragma("unroll") for (int q4 = 0; q4 < KC / 4; ++q4)                                                   \
         BUF[q4] = DDP_ABL_G(gp_[(size_t)min(i_ch * (KC / 4) + q4, nq - 1) * gc], q4);                         \
-      if (i_ch == 0) BIAS = Gb[(size_t)node_ * gc + c0];                                                      \
+      if (i_ch == 0) BIAS = Gb[(size_t)node_ * (4 * gstride) + c0];                                           \
       if (++i_ch == nch) { i_ch = 0; ++i_ui; }                                                                \
     }
 
@@ -341,7 +341,7 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
       const int node_ = __builtin_amdgcn_readlane(my_node, (UI));                                             \
       const f32x4* __restrict__ gp_ = G4 + (size_t)node_ * gstride + cx;                                      \
       _Pragma("unroll") for (int q4 = 0; q4 < XK / 4; ++q4) DST[q4] = gp_[(size_t)min(qx0 + q4, nq - 1) * gc]; \
-      BDST = Gb[(size_t)node_ * gc + cx];                                                                     \
+      BDST = Gb[(size_t)node_ * (4 * gstride) + cx];                                                          \
     }
     DDP_GX_LOAD(0, gn, bn)
     for (int ui = 0; ui < nmine; ++ui) {
@@ -896,8 +896,8 @@ static int launch_conv(ConvLaunch& L, const ddp_conv_task_t* tasks, int ntasks, 
   for (int i = 0; i < ntasks; ++i) {
     if (tasks[i].n_edges <= 0) continue;  // an empty conv sends no message (models/score_model.py:109-111)
     for (int gs = 0; gs < 2; ++gs)
-      if (shape->g_cols[gs] > 0 && (!tasks[i].g[gs] || !tasks[i].gb[gs] || (reinterpret_cast<size_t>(tasks[i].g[gs]) & 15)))
-        return ddp_fail(DDP_EINVAL, "ddp_conv_messages: factorised shape but task.g / task.gb is null (or g not 16-byte aligned)");
+      if (shape->g_cols[gs] > 0 && (!tasks[i].g[gs] || (reinterpret_cast<size_t>(tasks[i].g[gs]) & 15)))
+        return ddp_fail(DDP_EINVAL, "ddp_conv_messages: factorised shape but task.g is null (or not 16-byte aligned)");
     L.tile_start[L.ntasks] = tiles;
     L.task[L.ntasks] = tasks[i];
     tiles += (tasks[i].n_edges + ET - 1) / ET;

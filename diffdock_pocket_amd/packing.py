@@ -179,8 +179,8 @@ def faster_tp_spec(in_mul: Sequence[int], out_mul: Sequence[int], n_edge_feature
 
 def factor_weights(spec: ConvSpec, weight: torch.Tensor, bias: torch.Tensor):
     """Right-hand sides of the per-source-node GEMMs of a factorised conv, per G slot s (0: 0e inputs, 1: 0o inputs):
-         Wg[s]  [n_in, hg * g_cols[s]]    G[j].reshape(hg/4, g_cols, 4) = x[j, in_off:in_off+n_in] @ Wg[s]
-         Bg[s]  [n_in, g_cols[s]]         Gb[j] = x[j, in_off:in_off+n_in] @ Bg[s]     (the fc.3 bias part)
+         Wg[s]  [n_in, DDP_G_LD]          row j of x[:, in_off:in_off+n_in] @ Wg[s] = [G[j] (hg/4, g_cols, 4) | Gb[j] (g_cols) | 0]
+         Bg[s]  [n_in, g_cols[s]]         Gb[j] = x[j, in_off:in_off+n_in] @ Bg[s]     (the fc.3 bias part; also inside Wg)
        hg = hid rounded up to 4 (zero rows); the k index of G is interleaved in quads, G[j][k/4][c][k%4], so that a lane
        of the kernel's G pass fetches 4 consecutive k of its column with one 16-byte load (include/ddp_hip.h),
        with the block scale 1/sqrt(U_orig) folded in.  Returns ([Wg0, Wg1], [Bg0, Bg1], [in_off0, in_off1]); entries
@@ -204,7 +204,12 @@ def factor_weights(spec: ConvSpec, weight: torch.Tensor, bias: torch.Tensor):
         Wq = torch.zeros(n_in, hg, spec.g_cols[slot])
         Wq[:, :spec.hid] = W
         Wq = Wq.reshape(n_in, hg // 4, 4, spec.g_cols[slot]).permute(0, 1, 3, 2)            # [u, k/4, c, k%4]
-        Wg[slot], Bg[slot], offs[slot] = Wq.reshape(n_in, -1).contiguous(), Bm.contiguous(), blks[0].g_in_off
+        # one right-hand side per slot: [G part | Gb part | zero padding to DDP_G_LD] - the bias columns ride in the same product
+        gld = ((hg + 1) * spec.g_cols[slot] + 31) // 32 * 32
+        Wfull = torch.zeros(n_in, gld)
+        Wfull[:, :hg * spec.g_cols[slot]] = Wq.reshape(n_in, -1)
+        Wfull[:, hg * spec.g_cols[slot]:(hg + 1) * spec.g_cols[slot]] = Bm
+        Wg[slot], Bg[slot], offs[slot] = Wfull.contiguous(), Bm.contiguous(), blks[0].g_in_off
     return Wg, Bg, offs
 
 

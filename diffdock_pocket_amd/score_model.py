@@ -163,21 +163,19 @@ class TensorProductConvLayer(nn.Module):
         return self._packed_g
 
     def node_tensors(self, pk: _PackedConv, x_src: torch.Tensor):
-        """Stage A of the factorised conv: per-source-node G = x_scalar @ Wg and its bias part Gb (ddp_stage_a)."""
+        """Stage A of the factorised conv: per-source-node rows [G | Gb | pad] = x_scalar @ Wg (ddp_stage_a)."""
         lib = L.load()
-        g, gb = [None, None], [None, None]
+        g = [None, None]
         N = x_src.shape[0]
         for slot in (0, 1):
             if pk.wg[slot] is None:
                 continue
-            n_in = pk.wg[slot].shape[0]
-            g[slot] = torch.empty((N, (pk.wg[slot].shape[1] + 31) // 32 * 32), device=x_src.device, dtype=torch.float32)
-            gb[slot] = torch.empty((N, pk.bg[slot].shape[1]), device=x_src.device, dtype=torch.float32)
+            w = pk.wg[slot]
+            g[slot] = torch.empty((N, w.shape[1]), device=x_src.device, dtype=torch.float32)
             offs = (C.c_int32 * 1)(pk.g_in_off[slot])
-            for w, out in ((pk.wg[slot], g[slot]), (pk.bg[slot], gb[slot])):
-                L.check(lib.ddp_stage_a(x_src.data_ptr(), x_src.shape[1], N, offs, 1, w.data_ptr(), n_in, w.shape[1],
-                                        out.data_ptr(), out.shape[1], _stream()), "ddp_stage_a")
-        return g, gb
+            L.check(lib.ddp_stage_a(x_src.data_ptr(), x_src.shape[1], N, offs, 1, w.data_ptr(), w.shape[0], w.shape[1],
+                                    g[slot].data_ptr(), w.shape[1], _stream()), "ddp_stage_a")
+        return g
 
     def packed(self, device) -> _PackedConv:
         if self._packed is None or self._packed.w1p.device != device:
@@ -215,8 +213,8 @@ class TensorProductConvLayer(nn.Module):
                 raise NotImplementedError("this conv has no factorised variant")
             pk = self.packed_g(dev)
             so = G.source_order(csr)
-            g, gb = self.node_tensors(pk, x)
-            task = _make_task(pk, x, x.shape[1], so, sh, [(ea, so.eid, ea.shape[1], ea.shape[1])], msg, g=g, gb=gb, pos=so.pos)
+            g = self.node_tensors(pk, x)
+            task = _make_task(pk, x, x.shape[1], so, sh, [(ea, so.eid, ea.shape[1], ea.shape[1])], msg, g=g, pos=so.pos)
             _launch_convs(self.spec_g, [task], flops_spec=self.spec)
         else:
             task = _make_task(self.packed(dev), x, x.shape[1], csr, sh, [(ea, csr.eid, ea.shape[1], ea.shape[1])], msg)
@@ -242,7 +240,7 @@ def _ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def _make_task(pk: _PackedConv, x_src, ldx_src, csr, sh, segs, msg, g=None, gb=None, pos=None) -> L.ConvTask:
+def _make_task(pk: _PackedConv, x_src, ldx_src, csr, sh, segs, msg, g=None, pos=None) -> L.ConvTask:
     """segs: [(tensor, idx_int32[E], ld, ncols)], concatenated into edge_attr_ in this order."""
     t = L.ConvTask()
     t.x_src, t.ldx_src, t.n_edges = x_src.data_ptr(), ldx_src, csr.n_edges
@@ -257,7 +255,6 @@ def _make_task(pk: _PackedConv, x_src, ldx_src, csr, sh, segs, msg, g=None, gb=N
     t.msg = msg.data_ptr()
     for k in range(2):
         t.g[k] = g[k].data_ptr() if (g is not None and g[k] is not None) else 0
-        t.gb[k] = gb[k].data_ptr() if (gb is not None and gb[k] is not None) else 0
     t.pos = pos.data_ptr() if pos is not None else 0
     return t
 
@@ -515,37 +512,31 @@ class TensorProductScoreModel(nn.Module):
         return out
 
     def _stage_a(self, l, convs, x_src):
-        """Stage A of the factorised convs of layer `l` that read the same source-node array: one ddp_stage_a launch
-        G[(conv, slot)] = x_src[:, scalars(slot)] @ Wg[(conv, slot)] for all of them (weight-stationary VALU kernel,
-        csrc/ddp_gemm.hip; the product is bound by the HBM write of G) and one for the bias parts Gb.
-        convs: [(k, TensorProductConvLayer)].  Returns {(k, slot): (G, Gb)}."""
+        """Stage A of the factorised convs of layer `l` that read the same source-node array: ONE ddp_stage_a launch
+        rows[(conv, slot)] = x_src[:, scalars(slot)] @ Wg[(conv, slot)] = [G | Gb | pad] for all of them (weight-stationary
+        fp32-MFMA kernel, csrc/ddp_gemm.hip; bound by the HBM write of G).  convs: [(k, TensorProductConvLayer)].
+        Returns {(k, slot): G rows}."""
         lib = L.load()
         key = (l, tuple(k for k, _ in convs))
         ent = self._stage_a_stacks.get(key)
         if ent is None or ent[0].device != x_src.device:
-            Ws, Bs, meta = [], [], []
+            Ws, meta = [], []
             for k, conv in convs:
                 pk = conv.packed_g(x_src.device)
                 for slot in (0, 1):
                     if pk.wg[slot] is not None:
                         Ws.append(pk.wg[slot])
-                        Bs.append(pk.bg[slot])
                         meta.append((k, slot, pk.g_in_off[slot]))
-            Wst = torch.stack(Ws)
-            gld = (Wst.shape[2] + 31) // 32 * 32      # = DDP_G_LD(hid, g_cols); zero weight columns make the padding
-            Wst = torch.nn.functional.pad(Wst, (0, gld - Wst.shape[2])).contiguous()   # part of the product itself
-            ent = (Wst, torch.stack(Bs).contiguous(), meta, (C.c_int32 * len(meta))(*[m[2] for m in meta]))
+            ent = (torch.stack(Ws).contiguous(), meta, (C.c_int32 * len(meta))(*[m[2] for m in meta]))
             self._stage_a_stacks[key] = ent
-        Wst, Bst, meta, offs = ent
+        Wst, meta, offs = ent
         nb, N, n_in = len(meta), x_src.shape[0], Wst.shape[1]
         if nb > L.DDP_MAX_GEMM_BATCH:
             raise L.DdpError("more (conv, slot) pairs per source array than DDP_MAX_GEMM_BATCH")
-        Gall = torch.empty((nb, N, Wst.shape[2]), device=x_src.device, dtype=torch.float32)   # 128-byte aligned G rows
-        Gball = torch.empty((nb, N, Bst.shape[2]), device=x_src.device, dtype=torch.float32)
-        for W, out in ((Wst, Gall), (Bst, Gball)):
-            L.check(lib.ddp_stage_a(x_src.data_ptr(), x_src.shape[1], N, offs, nb, W.data_ptr(), n_in, W.shape[2],
-                                    out.data_ptr(), out.shape[2], _stream()), "ddp_stage_a")
-        return {(k, slot): (Gall[i], Gball[i]) for i, (k, slot, _) in enumerate(meta)}
+        Gall = torch.empty((nb, N, Wst.shape[2]), device=x_src.device, dtype=torch.float32)   # 128-byte aligned rows
+        L.check(lib.ddp_stage_a(x_src.data_ptr(), x_src.shape[1], N, offs, nb, Wst.data_ptr(), n_in, Wst.shape[2],
+                                Gall.data_ptr(), Wst.shape[2], _stream()), "ddp_stage_a")
+        return {(k, slot): Gall[i] for i, (k, slot, _) in enumerate(meta)}
 
     def invalidate_packed(self):
         self._stage_a_stacks = {}
@@ -737,9 +728,8 @@ class TensorProductScoreModel(nn.Module):
                     if grp:
                         gmap.update(self._stage_a(l, grp, nodes[st][0]))
             if overlap:
-                for gt, gbt in gmap.values():
+                for gt in gmap.values():
                     gt.record_stream(main_stream)
-                    gbt.record_stream(main_stream)
             keep.append(gmap)
             for k, csr, x_recv, x_src, e_base, sh, rt in plan:
                 if not active[rt]:
@@ -752,10 +742,9 @@ class TensorProductScoreModel(nn.Module):
                     continue
                 if k in so_views:
                     so, pkg = so_views[k], conv.packed_g(dev)
-                    g = [gmap[(k, sl)][0] if (k, sl) in gmap else None for sl in (0, 1)]
-                    gb = [gmap[(k, sl)][1] if (k, sl) in gmap else None for sl in (0, 1)]
+                    g = [gmap.get((k, sl)) for sl in (0, 1)]
                     segs = [(e_base, so.eid, ns, ns), (x_recv, so.recv, ldx, ns), (x_src, so.src, ldx, ns)]
-                    tasks_g.append(_make_task(pkg, x_src, ldx, so, sh, segs, msg, g=g, gb=gb, pos=so.pos))
+                    tasks_g.append(_make_task(pkg, x_src, ldx, so, sh, segs, msg, g=g, pos=so.pos))
                 else:
                     segs = [(e_base, csr.eid, ns, ns), (x_recv, csr.recv, ldx, ns), (x_src, csr.src, ldx, ns)]
                     tasks.append(_make_task(pkc, x_src, ldx, csr, sh, segs, msg))

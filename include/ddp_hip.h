@@ -102,9 +102,9 @@ typedef struct {
   float* msg;           /* per-edge messages, CSR order                       [E, d_out] */
   /* factorised convs only (shape.g_cols != 0): edges are then listed in SOURCE-node order (so that a workgroup streams
    * each G[j] once) and `pos` gives the message row (= position in the receiver-CSR order) of every listed edge */
-  const float* g[2];    /* G[s]:  [n_src, DDP_G_LD(hid, g_cols[s])] floats per node, of which the first hg * g_cols[s] are
-                           [hg/4, g_cols[s], 4], hg = hid rounded up to 4: G[j][k/4][c][k%4]; 16-byte aligned */
-  const float* gb[2];   /* Gb[s]: [n_src, g_cols[s]]      (fc.3 bias part) */
+  const float* g[2];    /* G[s]: [n_src, DDP_G_LD(hid, g_cols[s])] floats per node: first [hg/4, g_cols[s], 4] (hg = hid rounded
+                           up to 4): G[j][k/4][c][k%4]; then the g_cols[s] values Gb[j][c] (the fc.3 bias part); then
+                           padding to a 128-byte multiple.  One ddp_stage_a product writes the whole row.  16-byte aligned */
   const int32_t* pos;   /* [E] message row per listed edge; NULL = identity */
 } ddp_conv_task_t;
 
@@ -151,7 +151,7 @@ int ddp_torsion_sh(const float* sh_edge, const float* bond_vec, const int32_t* b
                    void* stream);
 
 /* Stage A of the source-node factorisation (ddp_block_t::g_slot): the per-source-node tensors consumed through
- * ddp_conv_task_t::g / ::gb, for all (conv, G slot) pairs that read one node-feature array x:
+ * ddp_conv_task_t::g, for all (conv, G slot) pairs that read one node-feature array x:
  *   out[b][j * ldo + n] = sum_{u < k} x[j * ldx + offs[b] + u] * w[b][u, n],     b < nbatch, j < nrows, n < ncols
  * (offs[b] = first scalar channel of the slot, host array; w = the fc.3 weight rows of the slot's scalar-input features
  * regrouped per (k, column) by the host - models/score_model.py:100-105 and models/layers.py:41,42,52,53 contracted
@@ -160,7 +160,7 @@ int ddp_torsion_sh(const float* sh_edge, const float* bond_vec, const int32_t* b
  * For G use ldo = DDP_G_LD(hid, g_cols): rows that start on a 128-byte boundary are written (and later fetched) at twice
  * the rate of unaligned ones. */
 #define DDP_MAX_GEMM_BATCH 16
-#define DDP_G_LD(hid, gcols) (((((hid) + 3) / 4) * 4 * (gcols) + 31) / 32 * 32)   /* floats per node of a G array */
+#define DDP_G_LD(hid, gcols) ((((((hid) + 3) / 4) * 4 + 1) * (gcols) + 31) / 32 * 32)   /* floats per node of a G array */
 int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* offs, int nbatch, const float* w, int k, int ncols,
                 float* out, int ldo, void* stream);
 

@@ -51,9 +51,12 @@ def emulate_conv(spec, w1p, b1p, w2p, b2p, edge_attr, x_src_rows, sh, fact=None)
                 continue
             xs = x[:, offs[b.g_slot]:offs[b.g_slot] + Wg[b.g_slot].shape[0]]
             hg = (spec.hid + 3) // 4 * 4      # G[j][k/4][c][k%4] -> [E, hid, g_cols]
-            G = (xs @ Wg[b.g_slot].double()).reshape(E, hg // 4, spec.g_cols[b.g_slot], 4).permute(0, 1, 3, 2)
-            G = G.reshape(E, hg, spec.g_cols[b.g_slot])[:, :spec.hid]
-            Gb = xs @ Bg[b.g_slot].double()
+            gc_ = spec.g_cols[b.g_slot]
+            row = xs @ Wg[b.g_slot].double()                       # [G | Gb | padding] per node
+            G = row[:, :hg * gc_].reshape(E, hg // 4, gc_, 4).permute(0, 1, 3, 2)
+            G = G.reshape(E, hg, gc_)[:, :spec.hid]
+            Gb = row[:, hg * gc_:(hg + 1) * gc_]
+            assert torch.equal(Gb, xs @ Bg[b.g_slot].double()) and float(row[:, (hg + 1) * gc_:].abs().sum()) == 0
             tv = torch.einsum("ek,ekn->en", hp[:, :spec.hid], G) + Gb
             tv = tv[:, b.g_col0:b.g_col0 + b.n]
             for c in range(b.C):
