@@ -74,6 +74,23 @@ class AtomEncoder(nn.Module):
             emb = self.additional_features_embedder(torch.cat([emb, extra], dim=1))
         return emb
 
+    def forward_split(self, x_cat, static_extra, sigma_emb, cached):
+        """Same value as forward(x_cat, cat([static_extra, sigma_emb])) with the Linear split by input columns: the part
+        fed by the node's own features (embedding sums, ESM block: 1280 of the 1340+ input columns of the receptor
+        encoder) does not change between denoising steps and is kept through `cached` (score_model._cached); only the
+        sigma-embedding columns are multiplied per call."""
+        lin = self.additional_features_embedder
+        n_static = lin.in_features - sigma_emb.shape[1]
+
+        def static():
+            emb = 0
+            for i in range(self.num_categorical_features):
+                emb = emb + self.atom_embedding_list[i](x_cat[:, i].long())
+            feats = emb if static_extra is None else torch.cat([emb, static_extra.float()], dim=1)
+            return torch.nn.functional.linear(feats, lin.weight[:, :n_static], lin.bias)
+
+        return cached(static) + sigma_emb @ lin.weight[:, n_static:].t()
+
 
 class OldAtomEncoder(nn.Module):
     """reference models/score_model.py:17-52 (legacy slicing kept literally)."""
@@ -622,9 +639,18 @@ class TensorProductScoreModel(nn.Module):
         xr = torch.zeros((Nr, ldx), device=dev)
         xa = torch.zeros((Na, ldx), device=dev)
         ncat_r = len(REC_RESIDUE_FEATURE_DIMS)
-        xl[:, :ns] = self.lig_node_embedding(lig.x, lig.node_sigma_emb)
-        xr[:, :ns] = self.rec_node_embedding(rec.x[:, :ncat_r], torch.cat([rec.x[:, ncat_r:].float(), rec.node_sigma_emb], 1))
-        xa[:, :ns] = self.atom_node_embedding(atom.x, atom.node_sigma_emb)
+        if isinstance(self.rec_node_embedding, AtomEncoder) and self.rec_node_embedding.additional_features_dim > 0:
+            # node encoders (:249,254,259) with their step-independent part kept across calls
+            xl[:, :ns] = self.lig_node_embedding.forward_split(
+                lig.x, None, lig.node_sigma_emb, lambda f: self._cached("enc_l", (lig.x,), f))
+            xr[:, :ns] = self.rec_node_embedding.forward_split(
+                rec.x[:, :ncat_r], rec.x[:, ncat_r:], rec.node_sigma_emb, lambda f: self._cached("enc_r", (rec.x,), f))
+            xa[:, :ns] = self.atom_node_embedding.forward_split(
+                atom.x, None, atom.node_sigma_emb, lambda f: self._cached("enc_a", (atom.x,), f))
+        else:
+            xl[:, :ns] = self.lig_node_embedding(lig.x, lig.node_sigma_emb)
+            xr[:, :ns] = self.rec_node_embedding(rec.x[:, :ncat_r], torch.cat([rec.x[:, ncat_r:].float(), rec.node_sigma_emb], 1))
+            xa[:, :ns] = self.atom_node_embedding(atom.x, atom.node_sigma_emb)
 
         mark("node_embed")
         # ---- graphs (:444-583)
