@@ -88,7 +88,7 @@ extern "C" int ddp_debug_read_stamps(unsigned long long* host_dst, int n_wgs) {
 // Timing-only ablations for tools/ablate_conv.py (never defined in the product build): DDP_ABLATE=1 drops the weight
 // loads of the scalar-block main loop, =2 drops its LDS A-operand reads; results are then wrong by construction.
 #if defined(DDP_ABLATE) && DDP_ABLATE == 1
-#define DDP_ABL_B(x) (f32x4{1.f, 2.f, 3.f, 4.f} * (float)(mn + 1))
+#define DDP_ABL_B(x) (f32x4{1e-9f, 2e-9f, 3e-9f, 4e-9f} * (float)(mn + 1))
 #else
 #define DDP_ABL_B(x) (x)
 #endif
@@ -584,38 +584,68 @@ __device__ __forceinline__ void run_block_rows(const ddp_conv_shape_t& S, const 
 #pragma unroll
   for (int c = 0; c < C; ++c) out[c] = splat16(0.f);
 
-  // B-operand prefetch, flattened over (group, m)
-  f32x4 bnext = {0.f, 0.f, 0.f, 0.f};
-  if (wq < ngroups) bnext = w2p[((size_t)(B.tile0 + wq) * nm * 2 + hh) * 32 + r];
+  // The wave's (tile, k-group) steps are flattened into one sequence f = j * nm + m (tile g = wq + 4 j).  The 16-byte
+  // weight fragment of step f + 2 is requested before the 4 MFMAs of step f (two register buffers, loop unrolled by two;
+  // sched_barriers pin the requests: hipcc otherwise sinks them to their first use).  With a lone wave per SIMD in a
+  // tile loop one k-group (256 cycles) does not cover an L2 round trip: dropping the loads altogether made the layer
+  // launches 9 % faster with the unpinned one-step prefetch this replaces (tools/per_launch.py with -DDDP_ABLATE=1); this form
+  // recovers 2 % of it.
+  const int nmine = (ngroups > wq) ? (ngroups - wq + 3) >> 2 : 0;
+  const int F = nmine * nm;
+  // request pointer of the next fragment to fetch: fragments of one tile are 64 f32x4 apart, tiles of this wave
+  // 4 * nm * 64; kept incrementally (pm = k-group inside the tile), clamped at the last fragment
+  const f32x4* __restrict__ wp = w2p + ((size_t)(B.tile0 + wq) * nm * 2 + hh) * 32 + r;
+  int pm = 0, pleft = F;
+  auto wfrag = [&]() -> f32x4 {
+    const f32x4 v = DDP_ABL_B(*wp);
+    if (pleft > 1) {
+      --pleft;
+      if (++pm == nm) { pm = 0; wp += (size_t)(3 * nm + 1) * 64; } else wp += 64;
+    }
+    return v;
+  };
+  f32x16 acc = splat16(0.f);
   f32x4 anext = *reinterpret_cast<const f32x4*>(arow);
-  for (int g = wq; g < ngroups; g += 4) {
-    f32x16 acc = splat16(T.b2p[(B.tile0 + g) * 32 + r]);
-    for (int m = 0; m < nm; ++m) {
-      const f32x4 bcur = bnext;
-      {  // prefetch the next (group, m)
-        int gn = g, mn = m + 1;
-        if (mn == nm) { gn = g + 4; mn = 0; }
-        if (gn < ngroups) bnext = w2p[(((size_t)(B.tile0 + gn) * nm + mn) * 2 + hh) * 32 + r];
+  int sj = 0, sm = 0;                                  // (tile, k-group) of the step being computed
+  auto step = [&](const f32x4 bcur) {
+    if (sm == 0) acc = splat16(T.b2p[(B.tile0 + wq + 4 * sj) * 32 + r]);
+    const f32x4 a = anext;
+    anext = DDP_ABL_A(*reinterpret_cast<const f32x4*>(arow + 8 * ((sm + 1 == nm) ? 0 : sm + 1)), anext);  // h is tile independent: wrap
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[i], acc, 0, 0, 0);
+    if (++sm == nm) {
+      // contraction with the basis features, in the MFMA C/D layout: reg i <-> edge row (i&3) + 8*(i>>2) + 4*hh
+      int u, ncol, us;
+      bool valid;
+      tile_lane_map(B, wq + 4 * sj, r, u, ncol, us, valid);
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float* frow = &fbuf[(u * C + c) * FS + rt * 32 + 4 * hh];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const f32x4 f = *reinterpret_cast<const f32x4*>(frow + 8 * q4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) out[c][4 * q4 + q] += f[q] * acc[4 * q4 + q];
+        }
       }
-      const f32x4 a = anext;
-      anext = *reinterpret_cast<const f32x4*>(arow + 8 * ((m + 1 == nm) ? 0 : m + 1));  // h is tile independent: wrap
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[i], acc, 0, 0, 0);
+      sm = 0;
+      ++sj;
     }
-    // contraction with the basis features, in the MFMA C/D layout: reg i <-> edge row (i&3) + 8*(i>>2) + 4*hh
-    int u, ncol, us;
-    bool valid;
-    tile_lane_map(B, g, r, u, ncol, us, valid);
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const float* frow = &fbuf[(u * C + c) * FS + rt * 32 + 4 * hh];
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const f32x4 f = *reinterpret_cast<const f32x4*>(frow + 8 * q4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) out[c][4 * q4 + q] += f[q] * acc[4 * q4 + q];
-      }
+  };
+  if (F > 0) {
+    f32x4 b0 = wfrag(), b1 = wfrag();
+#define DDP_ROWS_STEP(BUF, OFF)                 \
+    if (f + (OFF) < F) {                         \
+      const f32x4 c_ = BUF;                      \
+      BUF = wfrag();                             \
+      __builtin_amdgcn_sched_barrier(0);         \
+      step(c_);                                  \
     }
+    for (int f = 0; f < F; f += 2) {   // (a four-deep ring measured the same within noise)
+      DDP_ROWS_STEP(b0, 0)
+      DDP_ROWS_STEP(b1, 1)
+    }
+#undef DDP_ROWS_STEP
   }
 
   // ---- phase 4: deterministic cross-wave / cross-lane reduction.  Every wave parks a 32-row partial tile in its own
