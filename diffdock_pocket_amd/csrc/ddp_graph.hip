@@ -1,0 +1,178 @@
+// ddp_graph.hip - neighbour search of the score-model forward on the device (include/ddp_hip.h: ddp_radius_count /
+// ddp_radius_fill / ddp_knn), the counterpart of the torch_cluster calls inside the reference forward
+// (models/all_atom_score_model.py:457,524,545-564,607,627; conventions restated in SURVEY Appendix B.3):
+//   radius(x, y, r, batch_x, batch_y, max_num_neighbors): for every query y all x of the SAME graph with |x - y|^2 < r^2
+//     (strict), query-major, ascending x; more matches than the cap -> the cap nearest (ties at the cut distance kept)
+//   knn_graph(x, k, batch): the k nearest other nodes of the same graph, nearest first
+// Graphs are contiguous node ranges (x_ptr[g] .. x_ptr[g+1]).  One thread per query scans its graph's points; the points
+// of a graph are a few kB and stay in L1/L2 (all threads of a wave mostly scan the same graph).  Distances are formed
+// exactly like the dense PyTorch formulation this replaces (differences, then (dx^2 + dy^2) + dz^2 with separate roundings:
+// no FMA contraction), so the strict comparisons select the same pairs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ddp_hip.h"
+#include "ddp_internal.h"
+
+#define DDP_KNN_MAX 32
+
+__device__ __forceinline__ float sqdist(const float* __restrict__ a, const float* __restrict__ b) {
+  // contraction off: with it hipcc fuses some instances of this expression into FMAs and not others, so the SAME pair
+  // evaluates to values one ulp apart in the counting and the selecting loop (seen as off-by-one cuts), and no instance
+  // matches the separately rounded products of the dense formulation
+#pragma clang fp contract(off)
+  const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+  const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+  return (xx + yy) + zz;
+}
+
+// cut distance of a capped query: the cap-th smallest squared distance among the matches (d2 < r2); matches with
+// d2 <= cut are kept.  cap <= DDP_CUT_LIST: one pass that keeps the cap smallest distances in a sorted register list
+// (the side-chain torsion head searches 1111-atom graphs with cap 32).  Larger caps (they only bind on graphs with more
+// than that many neighbours inside r, which the default 10000 never does): O(matches * n) counting.
+#define DDP_CUT_LIST 64
+__device__ float radius_cut(const float* __restrict__ x, int j0, int j1, const float* __restrict__ yq, float r2, int cap) {
+  if (cap <= DDP_CUT_LIST) {
+    float best[DDP_CUT_LIST];
+#pragma unroll
+    for (int i = 0; i < DDP_CUT_LIST; ++i) best[i] = __builtin_inff();
+    float worst = __builtin_inff();                 // = best[cap - 1]
+    for (int j = j0; j < j1; ++j) {
+      float d = sqdist(yq, x + 3 * (size_t)j);
+      if (!(d < r2) || !(d < worst)) continue;
+      bool shifting = false;
+#pragma unroll
+      for (int i = 0; i < DDP_CUT_LIST; ++i) {
+        if (i < cap && (shifting || d < best[i])) {
+          const float t = best[i];
+          best[i] = d;
+          d = t;
+          shifting = true;
+        }
+        if (i == cap - 1) worst = best[i];
+      }
+    }
+    return worst;
+  }
+  float cut = r2;
+  for (int i = j0; i < j1; ++i) {
+    const float di = sqdist(yq, x + 3 * (size_t)i);
+    if (!(di < r2) || !(di < cut)) continue;
+    int le = 0;
+    for (int j = j0; j < j1; ++j) {
+      const float dj = sqdist(yq, x + 3 * (size_t)j);
+      le += (dj < r2 && dj <= di) ? 1 : 0;
+    }
+    if (le >= cap) cut = di;   // smallest d with #(d2 <= d) >= cap
+  }
+  return cut;
+}
+
+template <bool FILL>
+__global__ void ddp_radius_kernel(const float* __restrict__ x, const int32_t* __restrict__ x_ptr, const float* __restrict__ y,
+                                  const int32_t* __restrict__ y_batch, int ny, float r2, int cap, int drop_self,
+                                  int32_t* __restrict__ counts, const int32_t* __restrict__ offsets,
+                                  int32_t* __restrict__ out_q, int32_t* __restrict__ out_x) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= ny) return;
+  const int g = y_batch[q];
+  const int j0 = x_ptr[g], j1 = x_ptr[g + 1];
+  const float yq[3] = {y[3 * (size_t)q], y[3 * (size_t)q + 1], y[3 * (size_t)q + 2]};
+  int n = 0;
+  for (int j = j0; j < j1; ++j) n += (sqdist(yq, x + 3 * (size_t)j) < r2) ? 1 : 0;
+  float lim = r2;           // keep d2 < r2 ...
+  bool capped = false;
+  if (n > cap) {            // ... or, capped, d2 <= cut
+    lim = radius_cut(x, j0, j1, yq, r2, cap);
+    capped = true;
+  }
+  int kept = 0;
+  int32_t* oq = FILL ? out_q + offsets[q] : nullptr;
+  int32_t* ox = FILL ? out_x + offsets[q] : nullptr;
+  for (int j = j0; j < j1; ++j) {
+    const float d = sqdist(yq, x + 3 * (size_t)j);
+    const bool ok = capped ? (d < r2 && d <= lim) : (d < r2);
+    if (ok && !(drop_self && j == q)) {
+      if (FILL) { oq[kept] = q; ox[kept] = j; }
+      ++kept;
+    }
+  }
+  if (!FILL) counts[q] = kept;
+}
+
+__global__ void ddp_knn_kernel(const float* __restrict__ x, const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ batch,
+                               int n, int k, int32_t* __restrict__ out_nb /*[n][k], -1 padded*/) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int g = batch[q];
+  const int j0 = x_ptr[g], j1 = x_ptr[g + 1];
+  const float yq[3] = {x[3 * (size_t)q], x[3 * (size_t)q + 1], x[3 * (size_t)q + 2]};
+  float bd[DDP_KNN_MAX];
+  int bi[DDP_KNN_MAX];
+#pragma unroll
+  for (int i = 0; i < DDP_KNN_MAX; ++i) { bd[i] = __builtin_inff(); bi[i] = -1; }
+  for (int j = j0; j < j1; ++j) {
+    if (j == q) continue;
+    float d = sqdist(yq, x + 3 * (size_t)j);
+    if (!(d == d)) d = __builtin_inff();            // NaN distances sort last, like the dense formulation
+    if (!(d < bd[k - 1]) && bi[k - 1] >= 0) continue;
+    // insertion into the ascending list (equal distances: lower index first)
+    int jj = j;
+    bool shifting = false;
+#pragma unroll
+    for (int i = 0; i < DDP_KNN_MAX; ++i) {
+      if (i < k && (shifting || bi[i] < 0 || d < bd[i])) {   // insert here, then push the rest of the list down
+        const float td = bd[i]; const int ti = bi[i];
+        bd[i] = d; bi[i] = jj;
+        d = td; jj = ti;
+        shifting = true;
+        if (jj < 0) break;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < DDP_KNN_MAX; ++i)
+    if (i < k) out_nb[(size_t)q * k + i] = (bi[i] >= 0 && bd[i] < __builtin_inff()) ? bi[i] : -1;
+}
+
+static int radius_args_ok(const float* x, const int32_t* x_ptr, const float* y, const int32_t* y_batch, int ny, float r, int cap) {
+  if (ny < 0 || cap < 1 || !(r > 0.f)) return ddp_fail(DDP_EINVAL, "ddp_radius: ny / max_neighbors / r");
+  if (ny > 0 && (!x || !x_ptr || !y || !y_batch)) return ddp_fail(DDP_EINVAL, "ddp_radius: null argument");
+  return 0;
+}
+
+extern "C" int ddp_radius_count(const float* x, const int32_t* x_ptr, const float* y, const int32_t* y_batch, int ny, float r,
+                                int max_neighbors, int drop_self, int32_t* counts, void* stream) {
+  if (int rc = radius_args_ok(x, x_ptr, y, y_batch, ny, r, max_neighbors)) return rc;
+  if (ny == 0) return 0;
+  if (!counts) return ddp_fail(DDP_EINVAL, "ddp_radius_count: null counts");
+  hipLaunchKernelGGL((ddp_radius_kernel<false>), dim3((ny + 127) / 128), dim3(128), 0, (hipStream_t)stream, x, x_ptr, y, y_batch,
+                     ny, r * r, max_neighbors, drop_self, counts, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return ddp_fail_hip(err, "ddp_radius_count launch");
+  return 0;
+}
+
+extern "C" int ddp_radius_fill(const float* x, const int32_t* x_ptr, const float* y, const int32_t* y_batch, int ny, float r,
+                               int max_neighbors, int drop_self, const int32_t* offsets, int32_t* out_query, int32_t* out_x,
+                               void* stream) {
+  if (int rc = radius_args_ok(x, x_ptr, y, y_batch, ny, r, max_neighbors)) return rc;
+  if (ny == 0) return 0;
+  if (!offsets || !out_query || !out_x) return ddp_fail(DDP_EINVAL, "ddp_radius_fill: null argument");
+  hipLaunchKernelGGL((ddp_radius_kernel<true>), dim3((ny + 127) / 128), dim3(128), 0, (hipStream_t)stream, x, x_ptr, y, y_batch,
+                     ny, r * r, max_neighbors, drop_self, (int32_t*)nullptr, offsets, out_query, out_x);
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return ddp_fail_hip(err, "ddp_radius_fill launch");
+  return 0;
+}
+
+extern "C" int ddp_knn(const float* x, const int32_t* x_ptr, const int32_t* batch, int n, int k, int32_t* out_neighbors,
+                       void* stream) {
+  if (n < 0 || k < 1 || k > DDP_KNN_MAX) return ddp_fail(DDP_ELIMIT, "ddp_knn: k must be in [1, 32]");
+  if (n == 0) return 0;
+  if (!x || !x_ptr || !batch || !out_neighbors) return ddp_fail(DDP_EINVAL, "ddp_knn: null argument");
+  hipLaunchKernelGGL(ddp_knn_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, x, x_ptr, batch, n, k, out_neighbors);
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return ddp_fail_hip(err, "ddp_knn launch");
+  return 0;
+}

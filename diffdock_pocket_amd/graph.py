@@ -63,9 +63,58 @@ def _sqdist(y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return (d * d).sum(-1)
 
 
+def _i32(t):
+    return t.to(torch.int32).contiguous()
+
+
+def _ptr(layout: "DenseLayout") -> torch.Tensor:
+    """int32 [B+1] node offsets of the graphs of a layout (cached on the layout)."""
+    p = getattr(layout, "_ptr32", None)
+    if p is None:
+        p = torch.zeros(layout.B + 1, dtype=torch.int32, device=layout.counts.device)
+        p[1:] = torch.cumsum(layout.counts, 0).to(torch.int32)
+        layout._ptr32 = p
+        layout._batch32 = None
+    return p
+
+
+def _radius_hip(x, y, r, lx, ly, ybatch32, max_num_neighbors, drop_self):
+    """radius() on the device (csrc/ddp_graph.hip): count pass, prefix sum, fill pass.  One host sync (the edge count)."""
+    from . import _lib as L
+    lib = L.load()
+    ny = y.shape[0]
+    st = torch.cuda.current_stream().cuda_stream
+    xc, yc = x.float().contiguous(), y.float().contiguous()
+    counts = torch.empty(ny, dtype=torch.int32, device=x.device)
+    L.check(lib.ddp_radius_count(xc.data_ptr(), _ptr(lx).data_ptr(), yc.data_ptr(), ybatch32.data_ptr(), ny, float(r),
+                                 int(max_num_neighbors), int(drop_self), counts.data_ptr(), st), "ddp_radius_count")
+    offs = torch.zeros(ny + 1, dtype=torch.int32, device=x.device)
+    offs[1:] = torch.cumsum(counts, 0)
+    E = int(offs[-1].item())
+    oq = torch.empty(E, dtype=torch.int32, device=x.device)
+    ox = torch.empty(E, dtype=torch.int32, device=x.device)
+    if E > 0:
+        L.check(lib.ddp_radius_fill(xc.data_ptr(), _ptr(lx).data_ptr(), yc.data_ptr(), ybatch32.data_ptr(), ny, float(r),
+                                    int(max_num_neighbors), int(drop_self), offs.data_ptr(), oq.data_ptr(), ox.data_ptr(), st),
+                "ddp_radius_fill")
+    return oq.long(), ox.long()
+
+
+def _batch32(layout: "DenseLayout", n: int) -> torch.Tensor:
+    """int32 [N] graph index per node, from the layout (cached)."""
+    _ptr(layout)
+    if layout._batch32 is None:
+        layout._batch32 = torch.repeat_interleave(torch.arange(layout.B, device=layout.counts.device, dtype=torch.int32),
+                                                  layout.counts, output_size=n)
+    return layout._batch32
+
+
 def radius(x, y, r, lx: DenseLayout, ly: DenseLayout, max_num_neighbors=32):
     """See module docstring.  `r` may be a python float or a [B] tensor is NOT supported (scale inputs instead,
     as the reference does for the dynamic cross cutoff)."""
+    if x.is_cuda:   # device search (no dense [B, ny, nx] blocks); the PyTorch form below is the CPU / test definition
+        q, n = _radius_hip(x, y, r, lx, ly, _batch32(ly, y.shape[0]), max_num_neighbors, False)
+        return torch.stack([q, n], 0)
     xd, yd = lx.dense(x, float("inf")), ly.dense(y, float("inf"))
     d2 = _sqdist(yd, xd)
     ok = d2 < (float(r) ** 2)
@@ -82,12 +131,31 @@ def radius(x, y, r, lx: DenseLayout, ly: DenseLayout, max_num_neighbors=32):
 
 
 def radius_graph(x, r, lx: DenseLayout, max_num_neighbors=32):
+    if x.is_cuda:
+        q, n = _radius_hip(x, x, r, lx, lx, _batch32(lx, x.shape[0]), max_num_neighbors + 1, True)
+        return torch.stack([n, q], 0)
     ei = radius(x, x, r, lx, lx, max_num_neighbors + 1)
     keep = ei[0] != ei[1]
     return torch.stack([ei[1][keep], ei[0][keep]], 0)
 
 
 def knn_graph(x, k, lx: DenseLayout):
+    if x.is_cuda:
+        from . import _lib as L
+        lib = L.load()
+        n = x.shape[0]
+        kk = min(k, max(lx.nmax - 1, 0))
+        if kk == 0 or n == 0:
+            return torch.zeros((2, 0), dtype=torch.long, device=x.device)
+        xc = x.float().contiguous()
+        nb = torch.empty((n, kk), dtype=torch.int32, device=x.device)
+        L.check(lib.ddp_knn(xc.data_ptr(), _ptr(lx).data_ptr(), _batch32(lx, n).data_ptr(), n, kk, nb.data_ptr(),
+                            torch.cuda.current_stream().cuda_stream), "ddp_knn")
+        q = torch.arange(n, device=x.device).unsqueeze(1).expand(n, kk)
+        if lx.uniform or int(lx.counts.min().item()) > kk:       # every node has kk neighbours: no compaction
+            return torch.stack([nb.reshape(-1).long(), q.reshape(-1)], 0)
+        keep = nb >= 0
+        return torch.stack([nb[keep].long(), q[keep]], 0)
     xd = lx.dense(x, float("inf"))
     d2 = _sqdist(xd, xd)
     if not lx.uniform:

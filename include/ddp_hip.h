@@ -173,6 +173,19 @@ int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* offs, int nba
 int ddp_pose_update(const float* pos_in, int n_samples, int n_atoms, const float* tr, const float* rot, const float* tor,
                     int n_tor, const int32_t* bonds, const uint8_t* mask_rotate, float* pos_out, void* stream);
 
+/* Neighbour search of the forward (torch_cluster radius / radius_graph / knn_graph, models/all_atom_score_model.py:457,
+ * 524,545-564,607,627).  Graphs are contiguous node ranges x_ptr[g] .. x_ptr[g+1]; y_batch[q] is the graph of query q.
+ *  radius: every x of the query's graph with |x - y|^2 < r^2 (strict); more than max_neighbors matches -> the nearest
+ *          max_neighbors (and ties at that distance); drop_self removes the pair (q, x == q) AFTER the cap (radius_graph:
+ *          call with max_neighbors + 1); two passes: counts[q], then (after an exclusive prefix sum into offsets) the
+ *          pairs (out_query[e], out_x[e]) query-major with ascending x.
+ *  knn:    out_neighbors[q][0..k) = the k nearest other nodes of q's graph, nearest first, -1 where the graph is smaller. */
+int ddp_radius_count(const float* x, const int32_t* x_ptr, const float* y, const int32_t* y_batch, int ny, float r,
+                     int max_neighbors, int drop_self, int32_t* counts, void* stream);
+int ddp_radius_fill(const float* x, const int32_t* x_ptr, const float* y, const int32_t* y_batch, int ny, float r,
+                    int max_neighbors, int drop_self, const int32_t* offsets, int32_t* out_query, int32_t* out_x, void* stream);
+int ddp_knn(const float* x, const int32_t* x_ptr, const int32_t* batch, int n, int k, int32_t* out_neighbors, void* stream);
+
 int ddp_abi_version(void);
 const char* ddp_last_error(void);
 

@@ -230,3 +230,43 @@ def test_pose_update_kernel_matches_modify_conformer():
     want_r = S.modify_conformer(pos.double(), tr.double(), rot.double(), None, bonds, mask)
     got_r = S.modify_conformer_hip(pos.to(dev), tr.to(dev), rot.to(dev), None, None, None).cpu().double()
     assert float((got_r - want_r).abs().max()) < 2e-5 * float(want_r.abs().max())
+
+
+def _ragged_points(sizes, scale, seed):
+    g = torch.Generator().manual_seed(seed)
+    pos = torch.cat([torch.randn(n, 3, generator=g) * scale + 3.0 * i for i, n in enumerate(sizes)])
+    batch = torch.cat([torch.full((n,), i, dtype=torch.long) for i, n in enumerate(sizes)])
+    return pos, batch
+
+
+@pytest.mark.parametrize("cap", [10000, 32, 5])
+def test_hip_radius_matches_dense_formulation(cap):
+    """ddp_radius_count / ddp_radius_fill (csrc/ddp_graph.hip) against the dense PyTorch formulation of graph.py, which
+    tests/test_host_logic.py pins to the oracle's torch_cluster restatement: identical pairs in identical order, ragged
+    graphs (one of them empty on the x side), cap binding and not binding, self-loop removal after the cap."""
+    from diffdock_pocket_amd import graph as G
+    dev = _dev()
+    x, bx = _ragged_points([40, 7, 0, 120, 33], 2.0, 1)
+    y, by = _ragged_points([9, 3, 5, 30, 1], 2.0, 2)
+    B = 5
+    lx_c, ly_c = G.DenseLayout.build(bx, B), G.DenseLayout.build(by, B)
+    lx_d, ly_d = G.DenseLayout.build(bx.to(dev), B), G.DenseLayout.build(by.to(dev), B)
+    for r in (1.5, 3.0):
+        want = G.radius(x, y, r, lx_c, ly_c, max_num_neighbors=cap)
+        got = G.radius(x.to(dev), y.to(dev), r, lx_d, ly_d, max_num_neighbors=cap).cpu()
+        assert want.shape == got.shape and torch.equal(want, got), (r, cap, want.shape, got.shape)
+        want_g = G.radius_graph(x, r, lx_c, max_num_neighbors=cap)
+        got_g = G.radius_graph(x.to(dev), r, lx_d, max_num_neighbors=cap).cpu()
+        assert torch.equal(want_g, got_g), (r, cap)
+
+
+@pytest.mark.parametrize("k", [1, 8, 32])
+def test_hip_knn_matches_dense_formulation(k):
+    from diffdock_pocket_amd import graph as G
+    dev = _dev()
+    for sizes in ([50, 50, 50], [40, 3, 1, 120, 9]):      # uniform and ragged (graphs smaller than k + 1)
+        x, bx = _ragged_points(sizes, 2.0, 3)
+        lc, ld = G.DenseLayout.build(bx, len(sizes)), G.DenseLayout.build(bx.to(dev), len(sizes))
+        want = G.knn_graph(x, k, lc)
+        got = G.knn_graph(x.to(dev), k, ld).cpu()
+        assert torch.equal(want, got), (k, sizes, want.shape, got.shape)
