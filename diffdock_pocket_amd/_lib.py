@@ -18,7 +18,7 @@ FS = 68  # feature-buffer row stride of ddp_conv.hip
 
 DDP_MAX_GEMM_BATCH = 16
 EXPORTS = ["ddp_conv_messages", "ddp_segment_reduce", "ddp_edge_featurize", "ddp_torsion_sh", "ddp_stage_a",
-           "ddp_pose_update", "ddp_radius_count", "ddp_radius_fill", "ddp_knn", "ddp_abi_version", "ddp_last_error"]
+           "ddp_pose_update", "ddp_sidechain_update", "ddp_radius_count", "ddp_radius_fill", "ddp_knn", "ddp_abi_version", "ddp_last_error"]
 
 
 class Seg(C.Structure):
@@ -94,6 +94,9 @@ def load():
     lib.ddp_pose_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ddp_pose_update.restype = C.c_int
+    lib.ddp_sidechain_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]
+    lib.ddp_sidechain_update.restype = C.c_int
     lib.ddp_radius_count.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int,
                                      C.c_void_p, C.c_void_p]
     lib.ddp_radius_count.restype = C.c_int

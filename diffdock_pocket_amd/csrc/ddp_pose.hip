@@ -212,3 +212,55 @@ extern "C" int ddp_pose_update(const float* pos_in, int n_samples, int n_atoms, 
   if (err != hipSuccess) return ddp_fail_hip(err, "ddp_pose_update launch");
   return 0;
 }
+
+// ---- side-chain torsion update (modify_sidechains, utils/diffusion_utils.py:63-70 / utils/torsion.py:251-278): for every
+// sample the flexible-residue bonds are applied one after the other; bond j turns the atoms subcomponents[map[j][0] ..
+// map[j][1]) by angles[s][j] about pos[u_j] - pos[v_j] through pos[v_j].  One workgroup per sample; the PyTorch form is
+// ~9 launches per bond.
+__global__ __launch_bounds__(64) void ddp_sidechain_update_kernel(const float* __restrict__ pos_in, int n_atoms,
+                                                                  const float* __restrict__ angles, int n_bonds,
+                                                                  const int32_t* __restrict__ edge_idx,
+                                                                  const int32_t* __restrict__ subcomponents,
+                                                                  const int32_t* __restrict__ mapping,
+                                                                  float* __restrict__ pos_out) {
+  __shared__ float M[12];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* __restrict__ pin = pos_in + (size_t)b * n_atoms * 3;
+  float* po = pos_out + (size_t)b * n_atoms * 3;
+  if (pin != po)
+    for (int i = tid; i < 3 * n_atoms; i += 64) po[i] = pin[i];
+  __syncthreads();
+  for (int j = 0; j < n_bonds; ++j) {
+    const int u = edge_idx[2 * j], v = edge_idx[2 * j + 1];
+    if (tid == 0) {
+      const float pvx = po[3 * v], pvy = po[3 * v + 1], pvz = po[3 * v + 2];
+      const float ax = po[3 * u] - pvx, ay = po[3 * u + 1] - pvy, az = po[3 * u + 2] - pvz;
+      const float k = angles[(size_t)b * n_bonds + j] / sqrtf(ax * ax + ay * ay + az * az);
+      rotvec_to_matrix(ax * k, ay * k, az * k, M);
+      M[9] = pvx; M[10] = pvy; M[11] = pvz;
+    }
+    __syncthreads();
+    const int m0 = mapping[2 * j], m1 = mapping[2 * j + 1];
+    for (int i = m0 + tid; i < m1; i += 64) {
+      const int a = subcomponents[i];
+      const float x = po[3 * a] - M[9], y = po[3 * a + 1] - M[10], z = po[3 * a + 2] - M[11];
+      po[3 * a] = M[0] * x + M[1] * y + M[2] * z + M[9];
+      po[3 * a + 1] = M[3] * x + M[4] * y + M[5] * z + M[10];
+      po[3 * a + 2] = M[6] * x + M[7] * y + M[8] * z + M[11];
+    }
+    __syncthreads();   // block-wide visibility of the moved atoms before the next bond reads its axis
+  }
+}
+
+extern "C" int ddp_sidechain_update(const float* pos_in, int n_samples, int n_atoms, const float* angles, int n_bonds,
+                                    const int32_t* edge_idx, const int32_t* subcomponents, const int32_t* mapping, float* pos_out,
+                                    void* stream) {
+  if (n_samples <= 0 || n_atoms <= 0) return 0;
+  if (!pos_in || !pos_out || (n_bonds > 0 && (!angles || !edge_idx || !subcomponents || !mapping)))
+    return ddp_fail(DDP_EINVAL, "ddp_sidechain_update: null argument");
+  hipLaunchKernelGGL(ddp_sidechain_update_kernel, dim3(n_samples), dim3(64), 0, (hipStream_t)stream, pos_in, n_atoms, angles,
+                     n_bonds, edge_idx, subcomponents, mapping, pos_out);
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return ddp_fail_hip(err, "ddp_sidechain_update launch");
+  return 0;
+}

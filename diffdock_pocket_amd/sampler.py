@@ -92,6 +92,20 @@ def apply_sidechain_torsions(pos, edge_idx, subcomponents, mapping, angles):
     return pos
 
 
+def apply_sidechain_torsions_hip(pos, edge_idx_i32, sub_i32, map_i32, angles):
+    """apply_sidechain_torsions for a device-resident batch in one launch (ddp_sidechain_update); returns a NEW tensor (the
+    score model's static-graph cache keys on tensor identity / version)."""
+    from . import _lib as L
+    lib = L.load()
+    pos = pos.contiguous()
+    out = torch.empty_like(pos)
+    angles = angles.contiguous().float()
+    L.check(lib.ddp_sidechain_update(pos.data_ptr(), pos.shape[0], pos.shape[1], angles.data_ptr(), angles.shape[1],
+                                     edge_idx_i32.data_ptr(), sub_i32.data_ptr(), map_i32.data_ptr(), out.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream), "ddp_sidechain_update")
+    return out
+
+
 def modify_conformer_hip(pos, tr, rot, tor, bonds_i32, mask_u8):
     """modify_conformer for a device-resident batch in ONE launch (ddp_pose_update, csrc/ddp_pose.hip); same arguments
     as modify_conformer with bonds as int32 [T,2] and mask_rotate as uint8 [T,n] device tensors."""
@@ -163,6 +177,9 @@ class Sampler:
             self.sc_edge_idx, self.sc_sub = fr.edge_idx.clone(), fr.subcomponents.clone().to(device)
             self.sc_map = fr.subcomponentsMapping.clone()
             self.S = int(self.sc_edge_idx.shape[0])
+            self.sc_edge_i32 = self.sc_edge_idx.to(torch.int32).contiguous().to(device)
+            self.sc_sub_i32 = self.sc_sub.to(torch.int32).contiguous()
+            self.sc_map_i32 = self.sc_map.to(torch.int32).contiguous().to(device)
         else:
             self.S = 0
         self.batch = collate([g] * self.n).to(device)
@@ -243,7 +260,10 @@ class Sampler:
             sc_g = sc_s * math.sqrt(2 * math.log(sg.sidechain_tor_sigma_max / sg.sidechain_tor_sigma_min))
             sc_p = perturb(sc_score.reshape(self.n, self.S), sc_g, sc_s, sg.sidechain_tor_sigma_min,
                            sg.sidechain_tor_sigma_max, 3, z_sc)
-            self.atom_pos = apply_sidechain_torsions(self.atom_pos, self.sc_edge_idx, self.sc_sub, self.sc_map, sc_p)
+            if self.atom_pos.is_cuda:
+                self.atom_pos = apply_sidechain_torsions_hip(self.atom_pos, self.sc_edge_i32, self.sc_sub_i32, self.sc_map_i32, sc_p)
+            else:
+                self.atom_pos = apply_sidechain_torsions(self.atom_pos, self.sc_edge_idx, self.sc_sub, self.sc_map, sc_p)
         if self.lig_pos.is_cuda:   # one HIP launch; the PyTorch form below is the same arithmetic (CPU tests)
             self.lig_pos = modify_conformer_hip(self.lig_pos, tr_p, rot_p, tor_p, self.bonds_i32, self.mask_u8)
         else:

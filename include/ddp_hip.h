@@ -173,6 +173,14 @@ int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* offs, int nba
 int ddp_pose_update(const float* pos_in, int n_samples, int n_atoms, const float* tr, const float* rot, const float* tor,
                     int n_tor, const int32_t* bonds, const uint8_t* mask_rotate, float* pos_out, void* stream);
 
+/* Side-chain torsion update of all samples in one launch: modify_sidechains (utils/diffusion_utils.py:63-70,
+ * utils/torsion.py:251-278): bond j (edge_idx[j] = (u, v)) turns the atoms subcomponents[mapping[j][0] .. mapping[j][1]) by
+ * angles[s][j] about pos[u] - pos[v] through pos[v]; bonds are applied in list order.  pos_in / pos_out
+ * [n_samples][n_atoms][3] (may alias). */
+int ddp_sidechain_update(const float* pos_in, int n_samples, int n_atoms, const float* angles, int n_bonds,
+                         const int32_t* edge_idx, const int32_t* subcomponents, const int32_t* mapping, float* pos_out,
+                         void* stream);
+
 /* Neighbour search of the forward (torch_cluster radius / radius_graph / knn_graph, models/all_atom_score_model.py:457,
  * 524,545-564,607,627).  Graphs are contiguous node ranges x_ptr[g] .. x_ptr[g+1]; y_batch[q] is the graph of query q.
  *  radius: every x of the query's graph with |x - y|^2 < r^2 (strict); more than max_neighbors matches -> the nearest

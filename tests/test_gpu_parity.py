@@ -270,3 +270,20 @@ def test_hip_knn_matches_dense_formulation(k):
         want = G.knn_graph(x, k, lc)
         got = G.knn_graph(x.to(dev), k, ld).cpu()
         assert torch.equal(want, got), (k, sizes, want.shape, got.shape)
+
+
+def test_sidechain_update_kernel_matches_pytorch_form():
+    from diffdock_pocket_amd import sampler as S
+    from diffdock_pocket_amd.synthetic import make_3dpf_complex
+    dev = _dev()
+    g = make_3dpf_complex(seed=0, flexible_sidechains=True)
+    fr = g["flexResidues"]
+    torch.manual_seed(5)
+    N = 6
+    pos = g["atom"].pos.unsqueeze(0).repeat(N, 1, 1) + torch.randn(N, 1, 3)
+    ang = torch.randn(N, fr.edge_idx.shape[0]) * 0.8
+    want = S.apply_sidechain_torsions(pos.double(), fr.edge_idx, fr.subcomponents, fr.subcomponentsMapping, ang.double())
+    got = S.apply_sidechain_torsions_hip(pos.to(dev), fr.edge_idx.to(torch.int32).to(dev), fr.subcomponents.to(torch.int32).to(dev),
+                                         fr.subcomponentsMapping.to(torch.int32).to(dev), ang.to(dev)).cpu().double()
+    assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
+    assert float((got - pos.double()).abs().max()) > 0.1          # something moved
