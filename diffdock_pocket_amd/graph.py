@@ -1,8 +1,10 @@
-"""Graph construction for the score-model forward: host-side PyTorch on the ROCm device.
+"""Graph construction for the score-model forward.
 
-North-star keeps graph construction in PyTorch (BASELINE.json); these are the MI355X-side counterparts of the
-torch_cluster calls inside the reference forward (models/all_atom_score_model.py:457,524,545-564,607,627) with
-the conventions restated in SURVEY Appendix B.3:
+The counterparts of the torch_cluster calls inside the reference forward (models/all_atom_score_model.py:457,524,
+545-564,607,627) with the conventions restated in SURVEY Appendix B.3.  For tensors on the ROCm device the searches run
+in csrc/ddp_graph.hip (ddp_radius_count / ddp_radius_fill / ddp_knn: one thread per query scanning its graph's points,
+no dense distance blocks); the dense PyTorch formulation below is their definition - it is what the CPU tests pin to
+the oracle's torch_cluster restatement, and what the HIP kernels are tested against bit for bit on the GPU.
 
   radius(x, y, r, batch_x, batch_y, max_num_neighbors) -> [2,E]: row0 = query (y) index, row1 = x index,
       strict '<', same graph only, at most max_num_neighbors per query (we keep the NEAREST when truncating),

@@ -464,8 +464,6 @@ class TensorProductScoreModel(nn.Module):
         # average at least `factorize_min_degree` edges per source node (then streaming one G[j] per node is cheaper
         # than the per-edge MFMA work it replaces).  0 disables it (every conv on the direct path).
         self.factorize_min_degree = 3.0
-        self.overlap_stage_a = bool(int(os.environ.get("DDP_OVERLAP_STAGE_A", "0")))   # GEMMs on a side stream
-        self._side_stream = None
         self._static_cache = {}        # see _cached()
         self._stage_a_stacks = {}      # (layer, conv ids) -> stacked stage-A right-hand sides, see _stage_a()
         self.section_timer = None      # optional SectionTimer (tools/time_sections.py): per-section GPU + host time
@@ -741,21 +739,11 @@ class TensorProductScoreModel(nn.Module):
             tasks, tasks_g, msgs, keep = [], [], {}, []
             # stage A of the factorised convs, one batched GEMM per source-node array
             gmap = {}
-            overlap = self.overlap_stage_a
-            main_stream = torch.cuda.current_stream()
-            if overlap:
-                if self._side_stream is None:
-                    self._side_stream = torch.cuda.Stream()
-                self._side_stream.wait_stream(main_stream)
-            with torch.cuda.stream(self._side_stream if overlap else main_stream):
-                for st in ("l", "r", "a"):
-                    grp = [(k, self.conv_layers[9 * l + k]) for k, csr, _, _, _, _, rt in plan
-                           if active[rt] and k in so_views and src_type[k] == st and csr.n_edges > 0]
-                    if grp:
-                        gmap.update(self._stage_a(l, grp, nodes[st][0]))
-            if overlap:
-                for gt in gmap.values():
-                    gt.record_stream(main_stream)
+            for st in ("l", "r", "a"):
+                grp = [(k, self.conv_layers[9 * l + k]) for k, csr, _, _, _, _, rt in plan
+                       if active[rt] and k in so_views and src_type[k] == st and csr.n_edges > 0]
+                if grp:
+                    gmap.update(self._stage_a(l, grp, nodes[st][0]))
             keep.append(gmap)
             for k, csr, x_recv, x_src, e_base, sh, rt in plan:
                 if not active[rt]:
@@ -775,13 +763,10 @@ class TensorProductScoreModel(nn.Module):
                     segs = [(e_base, csr.eid, ns, ns), (x_recv, csr.recv, ldx, ns), (x_src, csr.src, ldx, ns)]
                     tasks.append(_make_task(pkc, x_src, ldx, csr, sh, segs, msg))
             mark("conv_prep")
-            if overlap:   # direct convs beside the stage-A GEMMs, then the factorised convs that need their results
-                _launch_convs(spec, tasks)
-                main_stream.wait_stream(self._side_stream)
-                _launch_convs(spec_g, tasks_g, flops_spec=spec)
-            else:
-                _launch_convs(spec_g, tasks_g, flops_spec=spec)
-                _launch_convs(spec, tasks)
+            # (measured without gain on one MI355X: stage A on a second stream beside the direct convs, and the direct
+            # convs on a second stream beside the factorised ones - neither pair fits on a CU together)
+            _launch_convs(spec_g, tasks_g, flops_spec=spec)
+            _launch_convs(spec, tasks)
             mark("conv_launch")
             for rt in ("l", "a", "r"):
                 if active[rt]:
