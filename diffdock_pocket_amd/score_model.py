@@ -464,6 +464,7 @@ class TensorProductScoreModel(nn.Module):
         # average at least `factorize_min_degree` edges per source node (then streaming one G[j] per node is cheaper
         # than the per-edge MFMA work it replaces).  0 disables it (every conv on the direct path).
         self.factorize_min_degree = 3.0
+        self.share_layer0 = True       # layer-0 receptor-side convs once per batch of identical receptors (forward)
         self._static_cache = {}        # see _cached()
         self._stage_a_stacks = {}      # (layer, conv ids) -> stacked stage-A right-hand sides, see _stage_a()
         self.section_timer = None      # optional SectionTimer (tools/time_sections.py): per-section GPU + host time
@@ -552,6 +553,44 @@ class TensorProductScoreModel(nn.Module):
         L.check(lib.ddp_stage_a(x_src.data_ptr(), x_src.shape[1], N, offs, nb, Wst.data_ptr(), n_in, Wst.shape[2],
                                 Gall.data_ptr(), Wst.shape[2], _stream()), "ddp_stage_a")
         return {(k, slot): Gall[i] for i, (k, slot, _) in enumerate(meta)}
+
+    def _shared_receptor_side(self, B, rec, atom, rpos, apos, lay_r, lay_a, rr, ar, aa):
+        """Which receptor-side convs see the SAME problem in every graph of the batch (the usual sampling batch: N poses of
+        one complex): per conv k in (3 atom<-atom, 5 atom<-receptor, 6 receptor<-receptor, 8 receptor<-atom) either None
+        or (receiver nodes per graph, edges per graph, source nodes per graph).  Exact comparison of node features,
+        positions and per-graph edge lists; depends only on step-independent tensors, so it is evaluated once (`_cached`)."""
+        out = {3: None, 5: None, 6: None, 8: None}
+        if B < 2 or not (lay_r.uniform and lay_a.uniform):
+            return out
+        nr, na = lay_r.nmax, lay_a.nmax
+
+        def same_rows(t, n):
+            v = t.reshape(B, n, -1)
+            return bool((v == v[:1]).all())
+
+        def same_edges(ei, n0, n1):
+            E = ei.shape[1]
+            if E == 0 or E % B:
+                return 0
+            e = E // B
+            off = torch.arange(B, device=ei.device).unsqueeze(1)
+            a, b = ei[0].reshape(B, e) - off * n0, ei[1].reshape(B, e) - off * n1
+            ok = (a == a[:1]).all() & (b == b[:1]).all() & (a >= 0).all() & (a < n0).all() & (b >= 0).all() & (b < n1).all()
+            return e if bool(ok) else 0
+
+        rec_same = same_rows(rec.x, nr) and same_rows(rpos, nr)
+        atom_same = same_rows(atom.x, na) and same_rows(apos, na)
+        if rec_same:
+            e = same_edges(rr, nr, nr)
+            out[6] = (nr, e, nr) if e else None
+        if atom_same:
+            e = same_edges(aa, na, na)
+            out[3] = (na, e, na) if e else None
+        if rec_same and atom_same:
+            e = same_edges(ar, na, nr)
+            if e:
+                out[5], out[8] = (na, e, nr), (nr, e, na)
+        return out
 
     def invalidate_packed(self):
         self._stage_a_stacks = {}
@@ -730,32 +769,53 @@ class TensorProductScoreModel(nn.Module):
                 if csr.n_edges > 0 and csr.n_edges >= self.factorize_min_degree * n_src_nodes[src_type[k]]:
                     so_views[k] = self._cached(f"so_{k}", (csr.src, csr.eid), lambda: G.source_order(csr)) if k in (3, 5, 6, 8) \
                         else G.source_order(csr)
+        # Layer 0 of the receptor-side convs: before any message has been passed, receptor and atom features are the node
+        # encoders' outputs, so in a batch of N poses of ONE complex (same receptor, same diffusion time) the messages of
+        # atom<-atom, atom<-receptor, receptor<-receptor and receptor<-atom are the same in every graph.  They are then
+        # computed for graph 0 only (its edges are a prefix of the receiver- and of the source-ordered edge lists) and the
+        # resulting node update is added to every graph.  Checked exactly; any difference -> the general path.
+        shared0 = {}
+        if self.share_layer0 and B > 1:
+            t_nodes = torch.cat([rec.node_t["tr"], atom.node_t["tr"]])
+            if bool((t_nodes == t_nodes[0]).all()):
+                sh_ = self._cached("shared0", (rec.x, rpos, atom.x, apos, rr, ar, aa),
+                                   lambda: self._shared_receptor_side(B, rec, atom, rpos, apos, lay_r, lay_a, rr, ar, aa))
+                shared0 = {k: v for k, v in sh_.items() if v is not None}
         mark("csr")
         for l in range(L_):
             spec, spec_g = self._layer_specs[l], self._layer_specs_g[l]
             do_atom = self.flexible_sidechains or l != L_ - 1
             do_rec = do_atom and l != L_ - 1
             active = {"l": True, "a": do_atom, "r": do_rec}
+            shared = shared0 if l == 0 else {}
             tasks, tasks_g, msgs, keep = [], [], {}, []
-            # stage A of the factorised convs, one batched GEMM per source-node array
+            # stage A of the factorised convs, one batched GEMM per source-node array (graph 0's rows only for shared convs)
             gmap = {}
             for st in ("l", "r", "a"):
-                grp = [(k, self.conv_layers[9 * l + k]) for k, csr, _, _, _, _, rt in plan
-                       if active[rt] and k in so_views and src_type[k] == st and csr.n_edges > 0]
-                if grp:
-                    gmap.update(self._stage_a(l, grp, nodes[st][0]))
+                for part in (False, True):
+                    grp = [(k, self.conv_layers[9 * l + k]) for k, csr, _, _, _, _, rt in plan
+                           if active[rt] and k in so_views and src_type[k] == st and csr.n_edges > 0 and (k in shared) == part]
+                    if grp:
+                        xs_ = nodes[st][0][:shared[grp[0][0]][2]] if part else nodes[st][0]
+                        gmap.update(self._stage_a(l, grp, xs_))
             keep.append(gmap)
             for k, csr, x_recv, x_src, e_base, sh, rt in plan:
                 if not active[rt]:
                     continue
                 conv = self.conv_layers[9 * l + k]
                 pkc = conv.packed(dev)
+                so_k = so_views.get(k)
+                if k in shared:   # graph 0's edges = a prefix of both orderings
+                    n0, e0, _ = shared[k]
+                    csr = G.CSR(e0, csr.recv[:e0], csr.src[:e0], csr.eid[:e0], csr.rowptr[:n0 + 1])
+                    if so_k is not None:
+                        so_k = G.SourceOrder(e0, so_k.recv[:e0], so_k.src[:e0], so_k.eid[:e0], so_k.pos[:e0])
                 msg = torch.empty((csr.n_edges, spec.d_out), device=dev, dtype=torch.float32)
                 msgs[k] = (msg, csr, pkc)
                 if csr.n_edges == 0:
                     continue
-                if k in so_views:
-                    so, pkg = so_views[k], conv.packed_g(dev)
+                if so_k is not None:
+                    so, pkg = so_k, conv.packed_g(dev)
                     g = [gmap.get((k, sl)) for sl in (0, 1)]
                     segs = [(e_base, so.eid, ns, ns), (x_recv, so.recv, ldx, ns), (x_src, so.src, ldx, ns)]
                     tasks_g.append(_make_task(pkg, x_src, ldx, so, sh, segs, msg, g=g, pos=so.pos))
@@ -771,7 +831,15 @@ class TensorProductScoreModel(nn.Module):
             for rt in ("l", "a", "r"):
                 if active[rt]:
                     x, n = nodes[rt]
-                    _launch_reduce(x, ldx, n, spec.d_out, [msgs[k] for k in order[rt]], accumulate=True)
+                    own = [msgs[k] for k in order[rt] if k not in shared]
+                    if own:
+                        _launch_reduce(x, ldx, n, spec.d_out, own, accumulate=True)
+                    com = [msgs[k] for k in order[rt] if k in shared]
+                    if com:   # graph 0's update of the shared convs, added to every graph
+                        n0 = shared[[k for k in order[rt] if k in shared][0]][0]
+                        u0 = torch.empty((n0, spec.d_out), device=dev, dtype=torch.float32)
+                        _launch_reduce(u0, spec.d_out, n0, spec.d_out, com, accumulate=False)
+                        x.view(B, n0, ldx)[:, :, :spec.d_out] += u0
             mark("reduce")
 
         num_flex = 0

@@ -287,3 +287,43 @@ def test_sidechain_update_kernel_matches_pytorch_form():
                                          fr.subcomponentsMapping.to(torch.int32).to(dev), ang.to(dev)).cpu().double()
     assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
     assert float((got - pos.double()).abs().max()) > 0.1          # something moved
+
+
+def test_layer0_sharing_across_identical_receptors():
+    """A sampling batch = N poses of one complex at one diffusion time: the layer-0 receptor-side convs are computed for
+    graph 0 only (score_model.share_layer0).  Same result as the general path (up to the changed summation order of the
+    residual update) and as the CPU oracle; a batch with different times or moved atoms must not take the shortcut."""
+    from diffdock_pocket_amd.batch import collate, set_time
+    from diffdock_pocket_amd.synthetic import make_3dpf_complex
+    case, gold, batch, sd = case_inputs("cfg2_small")
+    dev = _dev()
+    model = _model_for(case, sd)
+    gs = []
+    g = torch.Generator().manual_seed(11)
+    for i in range(3):
+        c = make_3dpf_complex(seed=case.data_seed, flexible_sidechains=case.flexible_sidechains, n_rec=case.n_rec)
+        c["ligand"].pos = c["ligand"].pos + torch.randn(1, 3, generator=g) * 1.5
+        gs.append(c)
+    b = collate(gs)
+    set_time(b, 0.4, 0.4, 0.4, 0.4)
+    bd = b.to(dev)
+    model.share_layer0 = True
+    fast = [t.clone() for t in model(bd)]
+    assert {3, 5, 6, 8} <= {k for k, v in model._static_cache["shared0"][3].items() if v is not None}
+    model.share_layer0 = False
+    slow = [t.clone() for t in model(bd)]
+    want = OracleScoreModel(case.oracle_config(), sd)(b)
+    for f, s_, w in zip(fast, slow, want):
+        if w.numel():
+            assert rel_err(f.float().cpu(), s_.float().cpu()) < 2e-6
+            assert rel_err(f.float().cpu(), w) < TOL
+    # different times per graph: the general path is taken and gives the general result
+    model.share_layer0 = True
+    set_time(bd, 0.4, 0.4, 0.4, 0.4)
+    bd["receptor"].node_t["tr"][0] += 0.1
+    bd["atom"].node_t["tr"][-1] += 0.1
+    mixed = [t.clone() for t in model(bd)]
+    model.share_layer0 = False
+    mixed_ref = [t.clone() for t in model(bd)]
+    for x, y in zip(mixed, mixed_ref):
+        assert torch.equal(x, y)
