@@ -464,6 +464,7 @@ class TensorProductScoreModel(nn.Module):
         # average at least `factorize_min_degree` edges per source node (then streaming one G[j] per node is cheaper
         # than the per-edge MFMA work it replaces).  0 disables it (every conv on the direct path).
         self.factorize_min_degree = 3.0
+        self.prune_last_receptor_layer = True   # layer L-2 receptor-side convs only where the final layer reads them
         self.share_layer0 = True       # layer-0 receptor-side convs once per batch of identical receptors (forward)
         self._static_cache = {}        # see _cached()
         self._stage_a_stacks = {}      # (layer, conv ids) -> stacked stage-A right-hand sides, see _stage_a()
@@ -781,6 +782,25 @@ class TensorProductScoreModel(nn.Module):
                 sh_ = self._cached("shared0", (rec.x, rpos, atom.x, apos, rr, ar, aa),
                                    lambda: self._shared_receptor_side(B, rec, atom, rpos, apos, lay_r, lay_a, rr, ar, aa))
                 shared0 = {k: v for k, v in sh_.items() if v is not None}
+        # Last receptor-side layer (l = L-2 without flexible side chains): its atom / receptor outputs are read only by the
+        # final layer's ligand<-atom and ligand<-receptor convs, i.e. only at the atoms within the ligand cutoff and the
+        # residues within the cross cutoff.  The receptor-side convs of that layer are therefore restricted to the edges
+        # that END in such a node (exact: nothing else of their output is ever read; the other rows of x are left stale).
+        pruned = {}
+        if self.prune_last_receptor_layer and not self.flexible_sidechains and L_ >= 2 and not self.confidence_mode:
+            need = {"a": torch.zeros(Na, dtype=torch.bool, device=dev), "r": torch.zeros(Nr, dtype=torch.bool, device=dev)}
+            need["a"][la[1]] = True
+            need["r"][lr[1]] = True
+            cand = [(k, csr, rt) for k, csr, _, _, _, _, rt in plan if k in (3, 5, 6, 8) and csr.n_edges > 0]
+            keeps = [need[rt][csr.recv.long()] for _, csr, rt in cand]
+            counts = torch.stack([kp.sum() for kp in keeps]).tolist() if cand else []
+            for (k, csr, rt), kp, e_keep in zip(cand, keeps, counts):
+                if e_keep >= 0.9 * csr.n_edges:      # not worth the re-indexing
+                    continue
+                recv = csr.recv[kp]
+                rowptr = torch.zeros(csr.rowptr.shape[0], dtype=torch.int32, device=dev)
+                rowptr[1:] = torch.cumsum(torch.bincount(recv.long(), minlength=csr.rowptr.shape[0] - 1), 0).to(torch.int32)
+                pruned[k] = G.CSR(int(e_keep), recv.contiguous(), csr.src[kp].contiguous(), csr.eid[kp].contiguous(), rowptr)
         mark("csr")
         for l in range(L_):
             spec, spec_g = self._layer_specs[l], self._layer_specs_g[l]
@@ -788,6 +808,7 @@ class TensorProductScoreModel(nn.Module):
             do_rec = do_atom and l != L_ - 1
             active = {"l": True, "a": do_atom, "r": do_rec}
             shared = shared0 if l == 0 else {}
+            layer_csr = pruned if (l == L_ - 2 and l > 0) else {}
             tasks, tasks_g, msgs, keep = [], [], {}, []
             # stage A of the factorised convs, one batched GEMM per source-node array (graph 0's rows only for shared convs)
             gmap = {}
@@ -805,11 +826,16 @@ class TensorProductScoreModel(nn.Module):
                 conv = self.conv_layers[9 * l + k]
                 pkc = conv.packed(dev)
                 so_k = so_views.get(k)
+                if k in layer_csr:   # edges that end in a node the final layer reads
+                    csr = layer_csr[k]
+                    if so_k is not None:
+                        so_k = G.source_order(csr) if csr.n_edges > 0 else None
                 if k in shared:   # graph 0's edges = a prefix of both orderings
                     n0, e0, _ = shared[k]
                     csr = G.CSR(e0, csr.recv[:e0], csr.src[:e0], csr.eid[:e0], csr.rowptr[:n0 + 1])
                     if so_k is not None:
                         so_k = G.SourceOrder(e0, so_k.recv[:e0], so_k.src[:e0], so_k.eid[:e0], so_k.pos[:e0])
+                keep.append((csr, so_k))   # the launches below take raw pointers: per-layer views must outlive them
                 msg = torch.empty((csr.n_edges, spec.d_out), device=dev, dtype=torch.float32)
                 msgs[k] = (msg, csr, pkc)
                 if csr.n_edges == 0:

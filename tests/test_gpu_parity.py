@@ -327,3 +327,19 @@ def test_layer0_sharing_across_identical_receptors():
     mixed_ref = [t.clone() for t in model(bd)]
     for x, y in zip(mixed, mixed_ref):
         assert torch.equal(x, y)
+
+
+def test_last_receptor_layer_pruning_is_exact():
+    """Without flexible side chains the atom / receptor outputs of layer L-2 are read only by the final layer's
+    ligand<-atom / ligand<-receptor convs; restricting that layer's receptor-side convs to edges ending in such nodes
+    (score_model.prune_last_receptor_layer) must not change a bit of the result."""
+    case, gold, batch, sd = case_inputs("cfg2_noflex")
+    dev = _dev()
+    model = _model_for(case, sd)
+    b = case.make_batch().to(dev)
+    model.prune_last_receptor_layer = True
+    a = [t.clone() for t in model(b)]
+    model.prune_last_receptor_layer = False
+    c = [t.clone() for t in model(b)]
+    for x, y in zip(a, c):
+        assert torch.equal(x, y)
