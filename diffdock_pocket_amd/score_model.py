@@ -791,7 +791,9 @@ class TensorProductScoreModel(nn.Module):
             need = {"a": torch.zeros(Na, dtype=torch.bool, device=dev), "r": torch.zeros(Nr, dtype=torch.bool, device=dev)}
             need["a"][la[1]] = True
             need["r"][lr[1]] = True
-            cand = [(k, csr, rt) for k, csr, _, _, _, _, rt in plan if k in (3, 5, 6, 8) and csr.n_edges > 0]
+            frac = torch.stack([need["a"].float().mean(), need["r"].float().mean()]).tolist()
+            worth = {"a": frac[0] < 0.85, "r": frac[1] < 0.85}   # e.g. the cross cutoff usually reaches every pocket residue
+            cand = [(k, csr, rt) for k, csr, _, _, _, _, rt in plan if k in (3, 5, 6, 8) and csr.n_edges > 0 and worth[rt]]
             keeps = [need[rt][csr.recv.long()] for _, csr, rt in cand]
             counts = torch.stack([kp.sum() for kp in keeps]).tolist() if cand else []
             for (k, csr, rt), kp, e_keep in zip(cand, keeps, counts):
