@@ -4,8 +4,8 @@
 //   radius(x, y, r, batch_x, batch_y, max_num_neighbors): for every query y all x of the SAME graph with |x - y|^2 < r^2
 //     (strict), query-major, ascending x; more matches than the cap -> the cap nearest (ties at the cut distance kept)
 //   knn_graph(x, k, batch): the k nearest other nodes of the same graph, nearest first
-// Graphs are contiguous node ranges (x_ptr[g] .. x_ptr[g+1]).  One thread per query scans its graph's points; the points
-// of a graph are a few kB and stay in L1/L2 (all threads of a wave mostly scan the same graph).  Distances are formed
+// Graphs are contiguous node ranges (x_ptr[g] .. x_ptr[g+1]).  radius: one wave per query, kNN: one thread per query; the
+// points of a graph are a few kB and stay in L1/L2.  Distances are formed
 // exactly like the dense PyTorch formulation this replaces (differences, then (dx^2 + dy^2) + dz^2 with separate roundings:
 // no FMA contraction), so the strict comparisons select the same pairs.
 #include <hip/hip_runtime.h>
@@ -68,36 +68,50 @@ __device__ float radius_cut(const float* __restrict__ x, int j0, int j1, const f
   return cut;
 }
 
+// One WAVE per query (the ligand-side searches have ~1.5 k queries against ~1.1 k points each: one thread per query
+// leaves the chip empty and every thread in a 1111-iteration latency chain): lane l tests points j0 + l, + 64, ...;
+// a 64-point chunk's matches are placed with a ballot / prefix-popcount, which keeps the ascending-x order.
 template <bool FILL>
-__global__ void ddp_radius_kernel(const float* __restrict__ x, const int32_t* __restrict__ x_ptr, const float* __restrict__ y,
-                                  const int32_t* __restrict__ y_batch, int ny, float r2, int cap, int drop_self,
-                                  int32_t* __restrict__ counts, const int32_t* __restrict__ offsets,
-                                  int32_t* __restrict__ out_q, int32_t* __restrict__ out_x) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void ddp_radius_kernel(const float* __restrict__ x, const int32_t* __restrict__ x_ptr,
+                                                         const float* __restrict__ y, const int32_t* __restrict__ y_batch, int ny,
+                                                         float r2, int cap, int drop_self, int32_t* __restrict__ counts,
+                                                         const int32_t* __restrict__ offsets, int32_t* __restrict__ out_q,
+                                                         int32_t* __restrict__ out_x) {
+  const int q = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
   if (q >= ny) return;
   const int g = y_batch[q];
   const int j0 = x_ptr[g], j1 = x_ptr[g + 1];
   const float yq[3] = {y[3 * (size_t)q], y[3 * (size_t)q + 1], y[3 * (size_t)q + 2]};
   int n = 0;
-  for (int j = j0; j < j1; ++j) n += (sqdist(yq, x + 3 * (size_t)j) < r2) ? 1 : 0;
+  for (int j = j0 + lane; j < j1; j += 64) n += (sqdist(yq, x + 3 * (size_t)j) < r2) ? 1 : 0;
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) n += __shfl_xor(n, m);
   float lim = r2;           // keep d2 < r2 ...
   bool capped = false;
-  if (n > cap) {            // ... or, capped, d2 <= cut
-    lim = radius_cut(x, j0, j1, yq, r2, cap);
+  if (n > cap) {            // ... or, capped, d2 <= cut (rare: one lane selects, the wave takes its answer)
+    float c = 0.f;
+    if (lane == 0) c = radius_cut(x, j0, j1, yq, r2, cap);
+    lim = __shfl(c, 0);
     capped = true;
   }
   int kept = 0;
-  int32_t* oq = FILL ? out_q + offsets[q] : nullptr;
-  int32_t* ox = FILL ? out_x + offsets[q] : nullptr;
-  for (int j = j0; j < j1; ++j) {
-    const float d = sqdist(yq, x + 3 * (size_t)j);
-    const bool ok = capped ? (d < r2 && d <= lim) : (d < r2);
-    if (ok && !(drop_self && j == q)) {
-      if (FILL) { oq[kept] = q; ox[kept] = j; }
-      ++kept;
+  const int obase = FILL ? offsets[q] : 0;
+  for (int jb = j0; jb < j1; jb += 64) {
+    const int j = jb + lane;
+    bool ok = false;
+    if (j < j1) {
+      const float d = sqdist(yq, x + 3 * (size_t)j);
+      ok = (capped ? (d < r2 && d <= lim) : (d < r2)) && !(drop_self && j == q);
     }
+    const unsigned long long mk = __ballot(ok);
+    if (FILL && ok) {
+      const int o = obase + kept + __popcll(mk & ((1ull << lane) - 1ull));
+      out_q[o] = q;
+      out_x[o] = j;
+    }
+    kept += __popcll(mk);
   }
-  if (!FILL) counts[q] = kept;
+  if (!FILL && lane == 0) counts[q] = kept;
 }
 
 __global__ void ddp_knn_kernel(const float* __restrict__ x, const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ batch,
@@ -146,7 +160,7 @@ extern "C" int ddp_radius_count(const float* x, const int32_t* x_ptr, const floa
   if (int rc = radius_args_ok(x, x_ptr, y, y_batch, ny, r, max_neighbors)) return rc;
   if (ny == 0) return 0;
   if (!counts) return ddp_fail(DDP_EINVAL, "ddp_radius_count: null counts");
-  hipLaunchKernelGGL((ddp_radius_kernel<false>), dim3((ny + 127) / 128), dim3(128), 0, (hipStream_t)stream, x, x_ptr, y, y_batch,
+  hipLaunchKernelGGL((ddp_radius_kernel<false>), dim3((ny + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, x_ptr, y, y_batch,
                      ny, r * r, max_neighbors, drop_self, counts, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
   const hipError_t err = hipGetLastError();
   if (err != hipSuccess) return ddp_fail_hip(err, "ddp_radius_count launch");
@@ -159,7 +173,7 @@ extern "C" int ddp_radius_fill(const float* x, const int32_t* x_ptr, const float
   if (int rc = radius_args_ok(x, x_ptr, y, y_batch, ny, r, max_neighbors)) return rc;
   if (ny == 0) return 0;
   if (!offsets || !out_query || !out_x) return ddp_fail(DDP_EINVAL, "ddp_radius_fill: null argument");
-  hipLaunchKernelGGL((ddp_radius_kernel<true>), dim3((ny + 127) / 128), dim3(128), 0, (hipStream_t)stream, x, x_ptr, y, y_batch,
+  hipLaunchKernelGGL((ddp_radius_kernel<true>), dim3((ny + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, x_ptr, y, y_batch,
                      ny, r * r, max_neighbors, drop_self, (int32_t*)nullptr, offsets, out_query, out_x);
   const hipError_t err = hipGetLastError();
   if (err != hipSuccess) return ddp_fail_hip(err, "ddp_radius_fill launch");
