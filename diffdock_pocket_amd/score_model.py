@@ -619,7 +619,9 @@ class TensorProductScoreModel(nn.Module):
         lo, hi, n = math.log10(0.01), math.log10(2.0), 1000
         idx = (torch.log10(sigma.float()) - np.float32(lo)) / np.float32(hi - lo) * n
         idx = torch.clamp(torch.round(idx).long(), 0, n - 1)
-        return self._so3_table.to(sigma.device)[idx]
+        if self._so3_table.device != sigma.device:
+            self._so3_table = self._so3_table.to(sigma.device)
+        return self._so3_table[idx]
 
     def _torus_score_norm(self, sigma):
         """reference utils/torus.py:78-82."""
@@ -627,7 +629,9 @@ class TensorProductScoreModel(nn.Module):
         s = torch.log(sigma.float() / np.float32(np.pi))
         s = (s - np.float32(lo)) / np.float32(hi - lo) * n
         idx = torch.round(torch.clamp(s, 0, n)).long()
-        return self._torus_table.to(sigma.device)[idx]
+        if self._torus_table.device != sigma.device:
+            self._torus_table = self._torus_table.to(sigma.device)
+        return self._torus_table[idx]
 
     def _cached(self, name, inputs, fn):
         """Results that depend only on `inputs` (tensors) are kept across forward calls while those tensors are unchanged:
@@ -770,6 +774,30 @@ class TensorProductScoreModel(nn.Module):
                 if csr.n_edges > 0 and csr.n_edges >= self.factorize_min_degree * n_src_nodes[src_type[k]]:
                     so_views[k] = self._cached(f"so_{k}", (csr.src, csr.eid), lambda: G.source_order(csr)) if k in (3, 5, 6, 8) \
                         else G.source_order(csr)
+        # ---- graph parts of the heads, here because they synchronise with the host (edge counts): once the conv layers
+        # are queued the host must be able to queue the heads and the pose update without waiting for the device
+        num_flex = 0
+        if self.flexible_sidechains and ("flexResidues" in data) and len(data["flexResidues"]) > 0:
+            num_flex = int(data["flexResidues"].edge_idx.shape[0])
+        head_c = head_tor = head_sc = rot_bond_idx = None
+        if not self.confidence_mode:
+            ar_l = torch.arange(Nl, device=dev)
+            cnt = torch.bincount(lbatch, minlength=B).unsqueeze(1)
+            center = torch.zeros((B, 3), device=dev).index_add_(0, lbatch, lpos) / cnt
+            pk = self._edge_pack("center_edge_embedding", slice(0, dd), dev)
+            pre_c = torch.addmm(pk.b1, lig.node_sigma_emb, pk.W1[:, dd:dd + sd_].t())
+            e_c, sh_c = _edge_featurize(pk, self.center_distance_expansion, center, i32(lbatch), lpos, i32(ar_l), pre_c, i32(ar_l))
+            head_c = (e_c, sh_c, self._cached("c_c", (lbatch,), lambda: G.build_csr(lbatch, ar_l, B, presorted=True)))
+            if not self.no_torsion:
+                rot_bond_idx = self._cached("rot_bonds", (lig.edge_mask,), lambda: lig.edge_mask.bool().nonzero(as_tuple=True)[0])
+                if rot_bond_idx.shape[0] > 0:
+                    bonds = bond_ei[:, rot_bond_idx]
+                    head_tor = self._torsion_graph("final_edge_embedding", lpos, lay_l, bonds, lbatch[bonds[0]], B, dev)
+            if num_flex > 0:
+                fr = data["flexResidues"]
+                bonds = lay_a.starts[fr.batch.long()] + fr.edge_idx.t().long()     # get_sc_tor_bonds (:638-652)
+                head_sc = self._torsion_graph("sidechain_final_edge_embedding", apos, lay_a, bonds, fr.batch.long(), B, dev)
+        mark("head_graphs")
         # Layer 0 of the receptor-side convs: before any message has been passed, receptor and atom features are the node
         # encoders' outputs, so in a batch of N poses of ONE complex (same receptor, same diffusion time) the messages of
         # atom<-atom, atom<-receptor, receptor<-receptor and receptor<-atom are the same in every graph.  They are then
@@ -870,10 +898,6 @@ class TensorProductScoreModel(nn.Module):
                         x.view(B, n0, ldx)[:, :, :spec.d_out] += u0
             mark("reduce")
 
-        num_flex = 0
-        if self.flexible_sidechains and ("flexResidues" in data) and len(data["flexResidues"]) > 0:
-            num_flex = int(data["flexResidues"].edge_idx.shape[0])
-
         if self.confidence_mode:   # (:329-353) mean of the scalar channels per graph -> MLP
             def scalars(x):
                 return torch.cat([x[:, :ns], x[:, self._d_final - ns:self._d_final]], dim=1) if L_ >= 3 else x[:, :ns]
@@ -893,14 +917,8 @@ class TensorProductScoreModel(nn.Module):
                     conf_in = torch.cat([conf_in, torch.zeros_like(conf_in)], dim=1)
             return self.confidence_predictor(conf_in).squeeze(dim=-1)
 
-        # ---- translation / rotation head (:357-384)
-        ar_l = torch.arange(Nl, device=dev)
-        cnt = torch.bincount(lbatch, minlength=B).unsqueeze(1)
-        center = torch.zeros((B, 3), device=dev).index_add_(0, lbatch, lpos) / cnt
-        pk = self._edge_pack("center_edge_embedding", slice(0, dd), dev)
-        pre_c = torch.addmm(pk.b1, lig.node_sigma_emb, pk.W1[:, dd:dd + sd_].t())
-        e_c, sh_c = _edge_featurize(pk, self.center_distance_expansion, center, i32(lbatch), lpos, i32(ar_l), pre_c, i32(ar_l))
-        c_c = G.build_csr(lbatch, ar_l, B, presorted=True)
+        # ---- translation / rotation head (:357-384); its graph part (head_c) was prepared before the conv layers
+        e_c, sh_c, c_c = head_c
         fspec = self.final_conv.spec
         pkc = self.final_conv.packed(dev)
         msg = torch.empty((Nl, fspec.d_out), device=dev)
@@ -921,32 +939,27 @@ class TensorProductScoreModel(nn.Module):
 
         mark("center_head")
         # ---- torsion heads (:386-434)
-        edge_mask = lig.edge_mask.bool()
-        if self.no_torsion or int(edge_mask.sum()) == 0:
+        if head_tor is None:
             tor_pred = torch.empty(0, device=dev)
         else:
-            bonds = bond_ei[:, edge_mask]
-            tor_pred = self._torsion_head(self.tor_bond_conv, self.tor_final_layer, "final_edge_embedding", xl, lpos,
-                                          lay_l, bonds, lbatch[bonds[0]], B, dev)
+            tor_pred = self._torsion_apply(self.tor_bond_conv, self.tor_final_layer, head_tor, xl, dev)
             if self.scale_by_sigma:
-                edge_sigma = tor_sigma[lbatch][bond_ei[0]][edge_mask]
+                edge_sigma = tor_sigma[lbatch][bond_ei[0]][rot_bond_idx]
                 tor_pred = tor_pred * torch.sqrt(self._torus_score_norm(edge_sigma))
-        if num_flex == 0:
+        if head_sc is None:
             sc_pred = torch.empty(0, device=dev)
         else:
-            fr = data["flexResidues"]
-            bonds = lay_a.starts[fr.batch.long()] + fr.edge_idx.t().long()     # get_sc_tor_bonds (:638-652)
-            sc_pred = self._torsion_head(self.sc_tor_bond_conv, self.sc_tor_final_layer, "sidechain_final_edge_embedding",
-                                         xa, apos, lay_a, bonds, fr.batch.long(), B, dev)
+            sc_pred = self._torsion_apply(self.sc_tor_bond_conv, self.sc_tor_final_layer, head_sc, xa, dev)
             if self.scale_by_sigma:
-                sc_pred = sc_pred * torch.sqrt(self._torus_score_norm(sc_sigma[fr.batch.long()]))
+                sc_pred = sc_pred * torch.sqrt(self._torus_score_norm(sc_sigma[data["flexResidues"].batch.long()]))
         mark("tor_heads")
         return tr_pred, rot_pred, tor_pred, sc_pred
 
-    def _torsion_head(self, conv: TensorProductConvLayer, final_layer, edge_mlp_name, x, pos, lay, bonds, bond_batch, B, dev):
-        """build_bond_conv_graph / build_sidechain_conv_graph + FullTensorProduct + tor_bond_conv + final layer."""
+    def _torsion_graph(self, edge_mlp_name, pos, lay, bonds, bond_batch, B, dev):
+        """build_bond_conv_graph / build_sidechain_conv_graph (:586-636): everything of a torsion head that depends only on
+        positions - the bond-centre radius graph, its edge embedding and harmonics.  It contains the head's host
+        synchronisations (edge count), so forward() runs it BEFORE the conv layers: after them nothing waits for the host."""
         lib = L.load()
-        ns, ldx = self.ns, self._ldx
         T = bonds.shape[1]
         bond_pos = ((pos[bonds[0]] + pos[bonds[1]]) / 2).contiguous()
         lay_b = G.DenseLayout.build(bond_batch, B)
@@ -963,12 +976,18 @@ class TensorProductScoreModel(nn.Module):
         tor_sh = torch.empty((E, 4), device=dev)
         bond_of_edge = i32(ei[0])
         L.check(lib.ddp_torsion_sh(_ptr(sh_e), _ptr(bond_vec), _ptr(bond_of_edge), E, _ptr(tor_sh), _stream()), "ddp_torsion_sh")
-        bond_attr = (x[bonds[0], :ns] + x[bonds[1], :ns]).contiguous()
         csr = G.build_csr(ei[0], ei[1], T, presorted=True)
+        return {"bonds": bonds, "T": T, "E": E, "e_t": e_t, "tor_sh": tor_sh, "csr": csr}
+
+    def _torsion_apply(self, conv: TensorProductConvLayer, final_layer, tg, x, dev):
+        """FullTensorProduct + tor_bond_conv + final layer (:386-434) on the graph of _torsion_graph; no host sync."""
+        ns, ldx = self.ns, self._ldx
+        bonds, csr, T, E = tg["bonds"], tg["csr"], tg["T"], tg["E"]
+        bond_attr = (x[bonds[0], :ns] + x[bonds[1], :ns]).contiguous()
         spec, pkc = conv.spec, conv.packed(dev)
         msg = torch.empty((E, spec.d_out), device=dev)
-        segs = [(e_t, csr.eid, ns, ns), (x, csr.src, ldx, ns), (bond_attr, csr.recv, ns, ns)]
-        _launch_convs(spec, [_make_task(pkc, x, ldx, csr, tor_sh, segs, msg)])
+        segs = [(tg["e_t"], csr.eid, ns, ns), (x, csr.src, ldx, ns), (bond_attr, csr.recv, ns, ns)]
+        _launch_convs(spec, [_make_task(pkc, x, ldx, csr, tg["tor_sh"], segs, msg)])
         h = torch.zeros((T, spec.d_out), device=dev)
         _launch_reduce(h, spec.d_out, T, spec.d_out, [(msg, csr, pkc)], accumulate=False)
         return final_layer(h).squeeze(1)
