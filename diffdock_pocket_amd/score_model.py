@@ -713,6 +713,27 @@ class TensorProductScoreModel(nn.Module):
         self.last_stats = {"E_ll": ll.shape[1], "E_rr": rr.shape[1], "E_aa": aa.shape[1], "E_lr": lr.shape[1],
                            "E_la": la.shape[1], "E_ar": ar.shape[1], "N_l": Nl, "N_r": Nr, "N_a": Na, "B": B}
 
+        # Batches of N poses of ONE complex at one diffusion time (the sampling loop): receptor-side quantities that do not
+        # involve the ligand are the same in every graph.  Checked exactly (`_shared_receptor_side`, cached); used twice:
+        #  * the edge embeddings / harmonics of receptor<-receptor, atom<-atom, atom<->receptor edges are computed for graph 0
+        #    only and addressed through edge ids modulo the per-graph edge count;
+        #  * layer 0 of those convs (before any message has been passed, receptor and atom features are just the node
+        #    encoders' outputs) is computed for graph 0 only - its edges are a prefix of the receiver- and of the
+        #    source-ordered edge lists - and the resulting node update is added to every graph.
+        # Any difference between the graphs -> the general path.
+        shared0 = {}
+        if self.share_layer0 and B > 1:
+            t_nodes = torch.cat([rec.node_t["tr"], atom.node_t["tr"]])
+            if bool((t_nodes == t_nodes[0]).all()):
+                sh_ = self._cached("shared0", (rec.x, rpos, atom.x, apos, rr, ar, aa),
+                                   lambda: self._shared_receptor_side(B, rec, atom, rpos, apos, lay_r, lay_a, rr, ar, aa))
+                shared0 = {k: v for k, v in sh_.items() if v is not None}
+
+        def graph0(k, ei):   # canonical edges of graph 0 (a prefix: edge lists are graph-major) when conv k is shared
+            return ei[:, :shared0[k][1]] if k in shared0 else ei
+
+        rr_f, aa_f, ar_f = graph0(6, rr), graph0(3, aa), graph0(5, ar)
+
         mark("graphs")
         # ---- edge featurisation: per-node / per-edge `pre` tables hold the non-RBF part of the first Linear
         sd_, dd, cd = self.sigma_embed_dim, self.distance_embed_dim, self.cross_distance_embed_dim
@@ -729,11 +750,11 @@ class TensorProductScoreModel(nn.Module):
         e_ll, sh_ll = _edge_featurize(pk, self.lig_distance_expansion, lpos, i32(ll[0]), lpos, i32(ll[1]), pre_ll,
                                       torch.arange(ll.shape[1], device=dev, dtype=torch.int32))
         pk = self._edge_pack("rec_edge_embedding", slice(sd_, sd_ + dd), dev)
-        e_rr, sh_rr = _edge_featurize(pk, self.rec_distance_expansion, rpos, i32(rr[0]), rpos, i32(rr[1]),
-                                      sigma_pre(pk, rec.node_sigma_emb, slice(0, sd_)), i32(rr[0]))
+        e_rr, sh_rr = _edge_featurize(pk, self.rec_distance_expansion, rpos, i32(rr_f[0]), rpos, i32(rr_f[1]),
+                                      sigma_pre(pk, rec.node_sigma_emb, slice(0, sd_)), i32(rr_f[0]))
         pk = self._edge_pack("atom_edge_embedding", slice(sd_, sd_ + dd), dev)
-        e_aa, sh_aa = _edge_featurize(pk, self.lig_distance_expansion, apos, i32(aa[0]), apos, i32(aa[1]),
-                                      sigma_pre(pk, atom.node_sigma_emb, slice(0, sd_)), i32(aa[0]))
+        e_aa, sh_aa = _edge_featurize(pk, self.lig_distance_expansion, apos, i32(aa_f[0]), apos, i32(aa_f[1]),
+                                      sigma_pre(pk, atom.node_sigma_emb, slice(0, sd_)), i32(aa_f[0]))
         pk = self._edge_pack("lr_edge_embedding", slice(sd_, sd_ + cd), dev)
         e_lr, sh_lr = _edge_featurize(pk, self.cross_distance_expansion, lpos, i32(lr[0]), rpos, i32(lr[1]),
                                       sigma_pre(pk, lig.node_sigma_emb, slice(0, sd_)), i32(lr[0]))
@@ -741,20 +762,32 @@ class TensorProductScoreModel(nn.Module):
         e_la, sh_la = _edge_featurize(pk, self.cross_distance_expansion, lpos, i32(la[0]), apos, i32(la[1]),
                                       sigma_pre(pk, lig.node_sigma_emb, slice(0, sd_)), i32(la[0]))
         pk = self._edge_pack("ar_edge_embedding", slice(sd_, sd_ + dd), dev)
-        e_ar, sh_ar = _edge_featurize(pk, self.rec_distance_expansion, apos, i32(ar[0]), rpos, i32(ar[1]),
-                                      sigma_pre(pk, atom.node_sigma_emb, slice(0, sd_)), i32(ar[0]))
+        e_ar, sh_ar = _edge_featurize(pk, self.rec_distance_expansion, apos, i32(ar_f[0]), rpos, i32(ar_f[1]),
+                                      sigma_pre(pk, atom.node_sigma_emb, slice(0, sd_)), i32(ar_f[0]))
 
         mark("edge_featurize")
         # ---- CSR per conv direction (receiver = edge_index[0] of the conv call)
         c_ll = G.build_csr(ll[0], ll[1], Nl)
         c_lr = G.build_csr(lr[0], lr[1], Nl, presorted=True)
         c_la = G.build_csr(la[0], la[1], Nl, presorted=True)
-        c_aa = self._cached("c_aa", (aa,), lambda: G.build_csr(aa[0], aa[1], Na))
+        def static_csr(name, k, ei, recv, src, n):
+            """CSR view of a step-independent edge set, kept across calls; edge ids modulo the per-graph edge count when
+            the edge embeddings exist for graph 0 only."""
+            if k in shared0:
+                e0 = shared0[k][1]
+
+                def modded():
+                    c = G.build_csr(recv, src, n)
+                    return G.CSR(c.n_edges, c.recv, c.src, (c.eid % e0).contiguous(), c.rowptr)
+                return self._cached(f"{name}_mod{e0}", (ei,), modded)
+            return self._cached(name, (ei,), lambda: G.build_csr(recv, src, n))
+
+        c_aa = static_csr("c_aa", 3, aa, aa[0], aa[1], Na)
         c_al = G.build_csr(la[1], la[0], Na)
-        c_ar = self._cached("c_ar", (ar,), lambda: G.build_csr(ar[0], ar[1], Na))
-        c_rr = self._cached("c_rr", (rr,), lambda: G.build_csr(rr[0], rr[1], Nr))
+        c_ar = static_csr("c_ar", 5, ar, ar[0], ar[1], Na)
+        c_rr = static_csr("c_rr", 6, rr, rr[0], rr[1], Nr)
         c_rl = G.build_csr(lr[1], lr[0], Nr)
-        c_ra = self._cached("c_ra", (ar,), lambda: G.build_csr(ar[1], ar[0], Nr))
+        c_ra = static_csr("c_ra", 8, ar, ar[1], ar[0], Nr)
 
         # conv k of a layer: (csr, receiver x, source x, edge_base, sh, receiver type)
         plan = [
@@ -798,18 +831,6 @@ class TensorProductScoreModel(nn.Module):
                 bonds = lay_a.starts[fr.batch.long()] + fr.edge_idx.t().long()     # get_sc_tor_bonds (:638-652)
                 head_sc = self._torsion_graph("sidechain_final_edge_embedding", apos, lay_a, bonds, fr.batch.long(), B, dev)
         mark("head_graphs")
-        # Layer 0 of the receptor-side convs: before any message has been passed, receptor and atom features are the node
-        # encoders' outputs, so in a batch of N poses of ONE complex (same receptor, same diffusion time) the messages of
-        # atom<-atom, atom<-receptor, receptor<-receptor and receptor<-atom are the same in every graph.  They are then
-        # computed for graph 0 only (its edges are a prefix of the receiver- and of the source-ordered edge lists) and the
-        # resulting node update is added to every graph.  Checked exactly; any difference -> the general path.
-        shared0 = {}
-        if self.share_layer0 and B > 1:
-            t_nodes = torch.cat([rec.node_t["tr"], atom.node_t["tr"]])
-            if bool((t_nodes == t_nodes[0]).all()):
-                sh_ = self._cached("shared0", (rec.x, rpos, atom.x, apos, rr, ar, aa),
-                                   lambda: self._shared_receptor_side(B, rec, atom, rpos, apos, lay_r, lay_a, rr, ar, aa))
-                shared0 = {k: v for k, v in sh_.items() if v is not None}
         # Last receptor-side layer (l = L-2 without flexible side chains): its atom / receptor outputs are read only by the
         # final layer's ligand<-atom and ligand<-receptor convs, i.e. only at the atoms within the ligand cutoff and the
         # residues within the cross cutoff.  The receptor-side convs of that layer are therefore restricted to the edges
