@@ -197,7 +197,8 @@ def build_csr(recv: torch.Tensor, src: torch.Tensor, n_recv: int, presorted: boo
         r_sorted = recv
     else:
         r_sorted, perm = torch.sort(recv, stable=True)
-    counts = torch.bincount(r_sorted, minlength=n_recv)
+    # (torch.bincount synchronises with the host to size its output; the node count is known here)
+    counts = torch.zeros(n_recv, dtype=torch.int64, device=dev).index_add_(0, r_sorted, torch.ones_like(r_sorted))
     rowptr = torch.zeros(n_recv + 1, dtype=torch.int32, device=dev)
     rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
     return CSR(E, r_sorted.to(torch.int32), src[perm].to(torch.int32), perm.to(torch.int32), rowptr)

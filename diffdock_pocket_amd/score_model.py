@@ -815,17 +815,22 @@ class TensorProductScoreModel(nn.Module):
         head_c = head_tor = head_sc = rot_bond_idx = None
         if not self.confidence_mode:
             ar_l = torch.arange(Nl, device=dev)
-            cnt = torch.bincount(lbatch, minlength=B).unsqueeze(1)
+            cnt = lay_l.counts.unsqueeze(1)
             center = torch.zeros((B, 3), device=dev).index_add_(0, lbatch, lpos) / cnt
             pk = self._edge_pack("center_edge_embedding", slice(0, dd), dev)
             pre_c = torch.addmm(pk.b1, lig.node_sigma_emb, pk.W1[:, dd:dd + sd_].t())
             e_c, sh_c = _edge_featurize(pk, self.center_distance_expansion, center, i32(lbatch), lpos, i32(ar_l), pre_c, i32(ar_l))
             head_c = (e_c, sh_c, self._cached("c_c", (lbatch,), lambda: G.build_csr(lbatch, ar_l, B, presorted=True)))
             if not self.no_torsion:
-                rot_bond_idx = self._cached("rot_bonds", (lig.edge_mask,), lambda: lig.edge_mask.bool().nonzero(as_tuple=True)[0])
+                def tor_static():   # rotatable bonds, their graph index and dense layout: fixed for a batch
+                    idx = lig.edge_mask.bool().nonzero(as_tuple=True)[0]
+                    bnd = bond_ei[:, idx]
+                    bb = lbatch[bnd[0]]
+                    return idx, bnd, bb, (G.DenseLayout.build(bb, B) if idx.shape[0] > 0 else None)
+
+                rot_bond_idx, bonds, bond_batch, lay_b = self._cached("tor_static", (lig.edge_mask, bond_ei, lbatch), tor_static)
                 if rot_bond_idx.shape[0] > 0:
-                    bonds = bond_ei[:, rot_bond_idx]
-                    head_tor = self._torsion_graph("final_edge_embedding", lpos, lay_l, bonds, lbatch[bonds[0]], B, dev)
+                    head_tor = self._torsion_graph("final_edge_embedding", lpos, lay_l, bonds, bond_batch, B, dev, lay_b)
             if num_flex > 0:
                 fr = data["flexResidues"]
                 bonds = lay_a.starts[fr.batch.long()] + fr.edge_idx.t().long()     # get_sc_tor_bonds (:638-652)
@@ -976,14 +981,15 @@ class TensorProductScoreModel(nn.Module):
         mark("tor_heads")
         return tr_pred, rot_pred, tor_pred, sc_pred
 
-    def _torsion_graph(self, edge_mlp_name, pos, lay, bonds, bond_batch, B, dev):
+    def _torsion_graph(self, edge_mlp_name, pos, lay, bonds, bond_batch, B, dev, lay_b=None):
         """build_bond_conv_graph / build_sidechain_conv_graph (:586-636): everything of a torsion head that depends only on
         positions - the bond-centre radius graph, its edge embedding and harmonics.  It contains the head's host
         synchronisations (edge count), so forward() runs it BEFORE the conv layers: after them nothing waits for the host."""
         lib = L.load()
         T = bonds.shape[1]
         bond_pos = ((pos[bonds[0]] + pos[bonds[1]]) / 2).contiguous()
-        lay_b = G.DenseLayout.build(bond_batch, B)
+        if lay_b is None:
+            lay_b = G.DenseLayout.build(bond_batch, B)
         ei = G.radius(pos, bond_pos, self.lig_max_radius, lay, lay_b)          # [bond; atom], default cap 32
         E = ei.shape[1]
         if E == 0:
