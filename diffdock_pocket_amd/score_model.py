@@ -840,7 +840,7 @@ class TensorProductScoreModel(nn.Module):
         # final layer's ligand<-atom and ligand<-receptor convs, i.e. only at the atoms within the ligand cutoff and the
         # residues within the cross cutoff.  The receptor-side convs of that layer are therefore restricted to the edges
         # that END in such a node (exact: nothing else of their output is ever read; the other rows of x are left stale).
-        pruned = {}
+        pruned, pruned_so = {}, {}
         if self.prune_last_receptor_layer and not self.flexible_sidechains and L_ >= 2 and not self.confidence_mode:
             need = {"a": torch.zeros(Na, dtype=torch.bool, device=dev), "r": torch.zeros(Nr, dtype=torch.bool, device=dev)}
             need["a"][la[1]] = True
@@ -857,6 +857,15 @@ class TensorProductScoreModel(nn.Module):
                 rowptr = torch.zeros(csr.rowptr.shape[0], dtype=torch.int32, device=dev)
                 rowptr[1:] = torch.cumsum(torch.bincount(recv.long(), minlength=csr.rowptr.shape[0] - 1), 0).to(torch.int32)
                 pruned[k] = G.CSR(int(e_keep), recv.contiguous(), csr.src[kp].contiguous(), csr.eid[kp].contiguous(), rowptr)
+            # source-ordered views of the pruned factorised convs and, where few source nodes are left, their compact
+            # numbering for stage A - all of it independent of the features, so done here (it synchronises with the host)
+            for k, c in pruned.items():
+                if k in so_views and c.n_edges > 0:
+                    so_p, uniq = G.source_order(c), None
+                    if c.n_edges * 2 < plan[k][1].n_edges:
+                        uniq, inv = torch.unique_consecutive(so_p.src.long(), return_inverse=True)
+                        so_p = G.SourceOrder(so_p.n_edges, so_p.recv, inv.to(torch.int32), so_p.eid, so_p.pos)
+                    pruned_so[k] = (so_p, uniq)
         mark("csr")
         for l in range(L_):
             spec, spec_g = self._layer_specs[l], self._layer_specs_g[l]
@@ -866,32 +875,41 @@ class TensorProductScoreModel(nn.Module):
             shared = shared0 if l == 0 else {}
             layer_csr = pruned if (l == L_ - 2 and l > 0) else {}
             tasks, tasks_g, msgs, keep = [], [], {}, []
-            # stage A of the factorised convs, one batched GEMM per source-node array (graph 0's rows only for shared convs)
-            gmap = {}
-            for st in ("l", "r", "a"):
-                for part in (False, True):
-                    grp = [(k, self.conv_layers[9 * l + k]) for k, csr, _, _, _, _, rt in plan
-                           if active[rt] and k in so_views and src_type[k] == st and csr.n_edges > 0 and (k in shared) == part]
-                    if grp:
-                        xs_ = nodes[st][0][:shared[grp[0][0]][2]] if part else nodes[st][0]
-                        gmap.update(self._stage_a(l, grp, xs_))
+            # per conv of this layer: (csr, source-ordered view or None, source-node array) after the layer-specific
+            # restrictions (pruned last receptor layer, graph-0 prefix of shared layer-0 convs)
+            per = {}
+            for k, csr, x_recv, x_src, e_base, sh, rt in plan:
+                if not active[rt]:
+                    continue
+                so_k, xs_k = so_views.get(k), x_src
+                if k in layer_csr:   # edges that end in a node the final layer reads
+                    csr = layer_csr[k]
+                    if so_k is not None:
+                        so_k, uniq = pruned_so.get(k, (None, None))
+                        if uniq is not None:   # stage A on the remaining source rows only (compact copy of x, renumbered src)
+                            xs_k = x_src.index_select(0, uniq)
+                if k in shared:   # graph 0's edges = a prefix of both orderings
+                    n0, e0, _ = shared[k]
+                    csr = G.CSR(e0, csr.recv[:e0], csr.src[:e0], csr.eid[:e0], csr.rowptr[:n0 + 1])
+                    if so_k is not None:
+                        so_k = G.SourceOrder(e0, so_k.recv[:e0], so_k.src[:e0], so_k.eid[:e0], so_k.pos[:e0])
+                    xs_k = x_src[:shared[k][2]]
+                per[k] = (csr, so_k, xs_k)
+            keep.append(per)   # the launches below take raw pointers: per-layer views must outlive them
+            # stage A of the factorised convs: one batched product per source-node array
+            gmap, groups = {}, {}
+            for k, (csr_k, so_k, xs_k) in per.items():
+                if so_k is not None and csr_k.n_edges > 0:
+                    groups.setdefault((xs_k.data_ptr(), xs_k.shape[0]), (xs_k, []))[1].append((k, self.conv_layers[9 * l + k]))
+            for xs_k, grp in groups.values():
+                gmap.update(self._stage_a(l, grp, xs_k))
             keep.append(gmap)
             for k, csr, x_recv, x_src, e_base, sh, rt in plan:
                 if not active[rt]:
                     continue
                 conv = self.conv_layers[9 * l + k]
                 pkc = conv.packed(dev)
-                so_k = so_views.get(k)
-                if k in layer_csr:   # edges that end in a node the final layer reads
-                    csr = layer_csr[k]
-                    if so_k is not None:
-                        so_k = G.source_order(csr) if csr.n_edges > 0 else None
-                if k in shared:   # graph 0's edges = a prefix of both orderings
-                    n0, e0, _ = shared[k]
-                    csr = G.CSR(e0, csr.recv[:e0], csr.src[:e0], csr.eid[:e0], csr.rowptr[:n0 + 1])
-                    if so_k is not None:
-                        so_k = G.SourceOrder(e0, so_k.recv[:e0], so_k.src[:e0], so_k.eid[:e0], so_k.pos[:e0])
-                keep.append((csr, so_k))   # the launches below take raw pointers: per-layer views must outlive them
+                csr, so_k, xs_k = per[k]
                 msg = torch.empty((csr.n_edges, spec.d_out), device=dev, dtype=torch.float32)
                 msgs[k] = (msg, csr, pkc)
                 if csr.n_edges == 0:
@@ -899,8 +917,8 @@ class TensorProductScoreModel(nn.Module):
                 if so_k is not None:
                     so, pkg = so_k, conv.packed_g(dev)
                     g = [gmap.get((k, sl)) for sl in (0, 1)]
-                    segs = [(e_base, so.eid, ns, ns), (x_recv, so.recv, ldx, ns), (x_src, so.src, ldx, ns)]
-                    tasks_g.append(_make_task(pkg, x_src, ldx, so, sh, segs, msg, g=g, pos=so.pos))
+                    segs = [(e_base, so.eid, ns, ns), (x_recv, so.recv, ldx, ns), (xs_k, so.src, ldx, ns)]
+                    tasks_g.append(_make_task(pkg, xs_k, ldx, so, sh, segs, msg, g=g, pos=so.pos))
                 else:
                     segs = [(e_base, csr.eid, ns, ns), (x_recv, csr.recv, ldx, ns), (x_src, csr.src, ldx, ns)]
                     tasks.append(_make_task(pkc, x_src, ldx, csr, sh, segs, msg))
