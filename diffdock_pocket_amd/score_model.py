@@ -801,12 +801,20 @@ class TensorProductScoreModel(nn.Module):
         # source-ordered views for the factorised convs (built once per forward, reused by every layer)
         n_src_nodes = {"l": Nl, "a": Na, "r": Nr}
         src_type = {0: "l", 1: "r", 2: "a", 3: "a", 4: "l", 5: "r", 6: "r", 7: "l", 8: "a"}
-        so_views = {}
+        so_views, compact_src = {}, {}
         if self.factorize_min_degree > 0:
             for k, csr, *_ in plan:
                 if csr.n_edges > 0 and csr.n_edges >= self.factorize_min_degree * n_src_nodes[src_type[k]]:
                     so_views[k] = self._cached(f"so_{k}", (csr.src, csr.eid), lambda: G.source_order(csr)) if k in (3, 5, 6, 8) \
                         else G.source_order(csr)
+                elif k == 2 and csr.n_edges > 0:
+                    # ligand<-atom: few edges per atom over ALL atoms, but the edges leave only the atoms around the ligand.
+                    # Degree over the atoms that occur: factorise with stage A on those rows only (compact copy of x per layer)
+                    so_c = G.source_order(csr)
+                    uniq, inv = torch.unique_consecutive(so_c.src.long(), return_inverse=True)
+                    if csr.n_edges >= self.factorize_min_degree * uniq.shape[0]:
+                        so_views[k] = G.SourceOrder(so_c.n_edges, so_c.recv, inv.to(torch.int32), so_c.eid, so_c.pos)
+                        compact_src[k] = uniq
         # ---- graph parts of the heads, here because they synchronise with the host (edge counts): once the conv layers
         # are queued the host must be able to queue the heads and the pose update without waiting for the device
         num_flex = 0
@@ -882,6 +890,8 @@ class TensorProductScoreModel(nn.Module):
                 if not active[rt]:
                     continue
                 so_k, xs_k = so_views.get(k), x_src
+                if k in compact_src:
+                    xs_k = x_src.index_select(0, compact_src[k])
                 if k in layer_csr:   # edges that end in a node the final layer reads
                     csr = layer_csr[k]
                     if so_k is not None:
