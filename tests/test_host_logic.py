@@ -240,3 +240,43 @@ def test_c_abi_exports_every_declared_symbol():
     lib.ddp_abi_version.restype = ctypes.c_int
     assert lib.ddp_abi_version() == 3
     assert ctypes.sizeof(L.ConvShape) == 11 * 4 + 4 * (11 * 4 + 3 * 12)
+
+
+def test_shared_receptor_side_detection():
+    """score_model._shared_receptor_side (pure host logic): N copies of one complex -> every receptor-side conv is marked
+    shared with the per-graph node / edge counts; any difference between the graphs un-marks exactly the convs it touches."""
+    from diffdock_pocket_amd.synthetic import make_3dpf_complex
+    case = CASES["cfg1_edge"]
+    kw = dict(case.model_kwargs())
+    kw.update(case.ctor_extras())
+    model = TensorProductScoreModel(**kw)
+    B = 3
+    gs = [make_3dpf_complex(seed=1, flexible_sidechains=True, n_rec=12) for _ in range(B)]
+    b = collate(gs)
+    rec, atom = b["receptor"], b["atom"]
+    nr, na = rec.pos.shape[0] // B, atom.pos.shape[0] // B
+    lay_r, lay_a = G.DenseLayout.build(rec.batch.long(), B), G.DenseLayout.build(atom.batch.long(), B)
+    rr, ar = b["receptor", "receptor"].edge_index.long(), b["atom", "receptor"].edge_index.long()
+
+    def detect():
+        aa = G.knn_graph(atom.pos.float(), 8, lay_a)
+        return model._shared_receptor_side(B, rec, atom, rec.pos.float(), atom.pos.float(), lay_r, lay_a, rr, ar, aa), aa
+
+    out, aa = detect()
+    assert out[6] == (nr, rr.shape[1] // B, nr)
+    assert out[3] == (na, aa.shape[1] // B, na)
+    assert out[5] == (na, ar.shape[1] // B, nr) and out[8] == (nr, ar.shape[1] // B, na)
+    atom.pos[na + 5] += 0.25                         # one atom of graph 1 moves: atom-side convs lose the shortcut
+    out, _ = detect()
+    assert out[6] is not None and out[3] is None and out[5] is None and out[8] is None
+    atom.pos[na + 5] -= 0.25
+    rec.x[2 * nr + 1, 0] += 1                        # one residue type of graph 2 differs
+    out, _ = detect()
+    assert out[6] is None and out[5] is None and out[8] is None and out[3] is not None
+    rec.x[2 * nr + 1, 0] -= 1
+    rr2 = rr.clone()
+    rr2[1, -1] = rr2[1, -2]                          # one edge of the last graph differs
+    out = model._shared_receptor_side(B, rec, atom, rec.pos.float(), atom.pos.float(), lay_r, lay_a, rr2, ar, aa)
+    assert out[6] is None and out[3] is not None and out[5] is not None
+    assert model._shared_receptor_side(1, rec, atom, rec.pos.float(), atom.pos.float(), lay_r, lay_a, rr, ar, aa) \
+        == {3: None, 5: None, 6: None, 8: None}
