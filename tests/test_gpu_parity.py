@@ -343,3 +343,43 @@ def test_last_receptor_layer_pruning_is_exact():
     c = [t.clone() for t in model(b)]
     for x, y in zip(a, c):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("flex", [False, True])
+def test_sampler_end_to_end_on_device(flex):
+    """The reverse-diffusion loop on the device: a few denoising steps of a small batch through the HIP score model and
+    the HIP pose / side-chain updates, then the confidence pass; the same seeds on a second sampler reproduce the poses
+    bitwise (deterministic kernels), and a sampler holding only the second half of the samples (a rank's shard) gets
+    the poses of that half after one step (to fp32 rounding: a few batch-level PyTorch reductions depend on the batch
+    composition; with random-init weights the score is not smooth, so later steps amplify that rounding and are not
+    compared - the exact shard-invariance check is the 2-rank CPU test in tests/test_sampler_cpu.py)."""
+    from diffdock_pocket_amd.diffusion import get_t_schedule
+    from diffdock_pocket_amd.sampler import Sampler, SamplerConfig
+    from diffdock_pocket_amd.synthetic import make_3dpf_complex
+    dev = _dev()
+    case = CASES["cfg1_full"] if flex else CASES["cfg2_noflex"]
+    _, _, _, sd = case_inputs(case.name)
+    model = _model_for(case, sd)
+    conf_case = CASES["conf_ns24_l5"] if flex else CASES["conf_noflex"]
+    conf_model = _model_for(conf_case, case_inputs(conf_case.name)[3])
+    g = make_3dpf_complex(seed=0, flexible_sidechains=flex, n_rec=16)
+    sched = get_t_schedule(4)
+
+    def run(n_total, sl=None, steps=4):
+        s = Sampler(model, g, n_total, dev, SamplerConfig(inference_steps=4, flexible_sidechains=flex), seed=3, sample_slice=sl)
+        s.randomize()
+        for i in range(steps):
+            s.step(i, sched)
+        return s, s.lig_pos.clone(), s.atom_pos.clone()
+
+    s_all, lig_all, atoms_all = run(4)
+    assert torch.isfinite(lig_all).all() and torch.isfinite(atoms_all).all()
+    _, lig_again, atoms_again = run(4)
+    assert torch.equal(lig_all, lig_again) and torch.equal(atoms_all, atoms_again)
+    _, lig_one, _ = run(4, steps=1)
+    _, lig_half, _ = run(4, slice(2, 4), steps=1)
+    assert torch.allclose(lig_half, lig_one[2:4], atol=5e-4, rtol=0)    # same noise stream; batch composition differs
+    conf, order = s_all.confidence(conf_model)
+    assert conf.shape[0] == 4 and sorted(order.tolist()) == [0, 1, 2, 3] and torch.isfinite(conf).all()
+    if flex:
+        assert float((atoms_all - g["atom"].pos.to(dev)).abs().max()) > 1e-3      # side chains moved
