@@ -844,36 +844,70 @@ class TensorProductScoreModel(nn.Module):
                 bonds = lay_a.starts[fr.batch.long()] + fr.edge_idx.t().long()     # get_sc_tor_bonds (:638-652)
                 head_sc = self._torsion_graph("sidechain_final_edge_embedding", apos, lay_a, bonds, fr.batch.long(), B, dev)
         mark("head_graphs")
-        # Last receptor-side layer (l = L-2 without flexible side chains): its atom / receptor outputs are read only by the
-        # final layer's ligand<-atom and ligand<-receptor convs, i.e. only at the atoms within the ligand cutoff and the
-        # residues within the cross cutoff.  The receptor-side convs of that layer are therefore restricted to the edges
-        # that END in such a node (exact: nothing else of their output is ever read; the other rows of x are left stale).
+        # Dead-output elimination over the last layers.  What is read after the last layer: all ligand features (heads),
+        # with flexible side chains the atom features around the flexible bonds (side-chain torsion head), nothing of the
+        # receptor.  Walking backwards, a layer's receptor-side convs only have to produce the rows that are still read
+        # (by the residual of a needed node or as source / receiver of a kept edge of the next layer), so their edge lists
+        # are restricted to the edges that END in a needed node - exact, the other rows of x are simply left stale.
+        # Without flexible side chains this prunes layer L-2 (its atom outputs feed only the final ligand<-atom conv), with
+        # them layers L-1 and L-2.  The walk stops as soon as (almost) everything is needed; layer 0 is never touched.
         pruned, pruned_so = {}, {}
-        if self.prune_last_receptor_layer and not self.flexible_sidechains and L_ >= 2 and not self.confidence_mode:
-            need = {"a": torch.zeros(Na, dtype=torch.bool, device=dev), "r": torch.zeros(Nr, dtype=torch.bool, device=dev)}
-            need["a"][la[1]] = True
-            need["r"][lr[1]] = True
-            frac = torch.stack([need["a"].float().mean(), need["r"].float().mean()]).tolist()
-            worth = {"a": frac[0] < 0.85, "r": frac[1] < 0.85}   # e.g. the cross cutoff usually reaches every pocket residue
-            cand = [(k, csr, rt) for k, csr, _, _, _, _, rt in plan if k in (3, 5, 6, 8) and csr.n_edges > 0 and worth[rt]]
-            keeps = [need[rt][csr.recv.long()] for _, csr, rt in cand]
-            counts = torch.stack([kp.sum() for kp in keeps]).tolist() if cand else []
-            for (k, csr, rt), kp, e_keep in zip(cand, keeps, counts):
-                if e_keep >= 0.9 * csr.n_edges:      # not worth the re-indexing
-                    continue
-                recv = csr.recv[kp]
-                rowptr = torch.zeros(csr.rowptr.shape[0], dtype=torch.int32, device=dev)
-                rowptr[1:] = torch.cumsum(torch.bincount(recv.long(), minlength=csr.rowptr.shape[0] - 1), 0).to(torch.int32)
-                pruned[k] = G.CSR(int(e_keep), recv.contiguous(), csr.src[kp].contiguous(), csr.eid[kp].contiguous(), rowptr)
+        if self.prune_last_receptor_layer and L_ >= 2 and not self.confidence_mode:
+            ALL = None
+            need = {"l": ALL, "a": torch.zeros(Na, dtype=torch.bool, device=dev), "r": torch.zeros(Nr, dtype=torch.bool, device=dev)}
+            if head_sc is not None:
+                need["a"][head_sc["bonds"].reshape(-1)] = True
+                need["a"][head_sc["csr"].src.long()] = True
+            elif self.flexible_sidechains:
+                need["a"] = ALL      # (flexible model without flexible residues in the batch: keep the general path)
+            recv_of = {"a": (3, 4, 5), "r": (6, 7, 8)}
+            for l in range(L_ - 1, 0, -1):
+                act = {"l": True, "a": self.flexible_sidechains or l != L_ - 1}
+                act["r"] = act["a"] and l != L_ - 1
+                todo = [rt for rt in ("a", "r") if act[rt] and need[rt] is not ALL]
+                if todo:
+                    fr = torch.stack([need[rt].float().mean() for rt in todo]).tolist()
+                    for rt, f in zip(todo, fr):
+                        if f >= 0.85:        # e.g. the cross cutoff usually reaches every pocket residue
+                            need[rt] = ALL
+                cand = [(k, plan[k][1], rt) for rt in ("a", "r") if act[rt] and need[rt] is not ALL
+                        for k in recv_of[rt] if plan[k][1].n_edges > 0]
+                keeps = [need[rt][csr.recv.long()] for _, csr, rt in cand]
+                counts = torch.stack([kp.sum() for kp in keeps]).tolist() if cand else []
+                for (k, csr, rt), kp, e_keep in zip(cand, keeps, counts):
+                    if e_keep >= 0.9 * csr.n_edges:      # not worth the re-indexing
+                        continue
+                    recv = csr.recv[kp]
+                    n_rows = csr.rowptr.shape[0] - 1
+                    cnts = torch.zeros(n_rows, dtype=torch.int64, device=dev).index_add_(0, recv.long(), torch.ones_like(recv, dtype=torch.int64))
+                    rowptr = torch.zeros(n_rows + 1, dtype=torch.int32, device=dev)
+                    rowptr[1:] = torch.cumsum(cnts, 0).to(torch.int32)
+                    pruned.setdefault(l, {})[k] = G.CSR(int(e_keep), recv.contiguous(), csr.src[kp].contiguous(),
+                                                        csr.eid[kp].contiguous(), rowptr)
+                # rows of x(l) that layer l reads: the needed rows themselves (residual) and the sources of its kept edges
+                nxt = {}
+                for t in ("l", "a", "r"):
+                    if need[t] is ALL:
+                        nxt[t] = ALL
+                        continue
+                    m = need[t].clone()
+                    for k, csr, _, _, _, _, rt in plan:
+                        if act[rt] and src_type[k] == t and csr.n_edges > 0:
+                            m[(pruned.get(l, {}).get(k, csr)).src.long()] = True
+                    nxt[t] = m
+                need = nxt
+                if all(v is ALL for v in need.values()):
+                    break
             # source-ordered views of the pruned factorised convs and, where few source nodes are left, their compact
             # numbering for stage A - all of it independent of the features, so done here (it synchronises with the host)
-            for k, c in pruned.items():
-                if k in so_views and c.n_edges > 0:
-                    so_p, uniq = G.source_order(c), None
-                    if c.n_edges * 2 < plan[k][1].n_edges:
-                        uniq, inv = torch.unique_consecutive(so_p.src.long(), return_inverse=True)
-                        so_p = G.SourceOrder(so_p.n_edges, so_p.recv, inv.to(torch.int32), so_p.eid, so_p.pos)
-                    pruned_so[k] = (so_p, uniq)
+            for l, pl in pruned.items():
+                for k, c in pl.items():
+                    if k in so_views and c.n_edges > 0:
+                        so_p, uniq = G.source_order(c), None
+                        if c.n_edges * 2 < plan[k][1].n_edges:
+                            uniq, inv = torch.unique_consecutive(so_p.src.long(), return_inverse=True)
+                            so_p = G.SourceOrder(so_p.n_edges, so_p.recv, inv.to(torch.int32), so_p.eid, so_p.pos)
+                        pruned_so.setdefault(l, {})[k] = (so_p, uniq)
         mark("csr")
         for l in range(L_):
             spec, spec_g = self._layer_specs[l], self._layer_specs_g[l]
@@ -881,7 +915,7 @@ class TensorProductScoreModel(nn.Module):
             do_rec = do_atom and l != L_ - 1
             active = {"l": True, "a": do_atom, "r": do_rec}
             shared = shared0 if l == 0 else {}
-            layer_csr = pruned if (l == L_ - 2 and l > 0) else {}
+            layer_csr, layer_so = pruned.get(l, {}), pruned_so.get(l, {})
             tasks, tasks_g, msgs, keep = [], [], {}, []
             # per conv of this layer: (csr, source-ordered view or None, source-node array) after the layer-specific
             # restrictions (pruned last receptor layer, graph-0 prefix of shared layer-0 convs)
@@ -895,7 +929,7 @@ class TensorProductScoreModel(nn.Module):
                 if k in layer_csr:   # edges that end in a node the final layer reads
                     csr = layer_csr[k]
                     if so_k is not None:
-                        so_k, uniq = pruned_so.get(k, (None, None))
+                        so_k, uniq = layer_so.get(k, (None, None))
                         if uniq is not None:   # stage A on the remaining source rows only (compact copy of x, renumbered src)
                             xs_k = x_src.index_select(0, uniq)
                 if k in shared:   # graph 0's edges = a prefix of both orderings

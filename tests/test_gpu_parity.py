@@ -329,11 +329,13 @@ def test_layer0_sharing_across_identical_receptors():
         assert torch.equal(x, y)
 
 
-def test_last_receptor_layer_pruning_is_exact():
-    """Without flexible side chains the atom / receptor outputs of layer L-2 are read only by the final layer's
-    ligand<-atom / ligand<-receptor convs; restricting that layer's receptor-side convs to edges ending in such nodes
-    (score_model.prune_last_receptor_layer) must not change a bit of the result."""
-    case, gold, batch, sd = case_inputs("cfg2_noflex")
+@pytest.mark.parametrize("name", ["cfg2_noflex", "cfg2_small", "cfg1_full", "ns24_l3"])
+def test_last_receptor_layer_pruning_is_exact(name):
+    """Dead-output elimination over the last layers (score_model.prune_last_receptor_layer): the receptor-side convs of
+    the last layers keep only the edges that end in a node whose features are still read (without flexible side chains:
+    layer L-2, read by the final ligand<-atom / ligand<-receptor convs; with them: layers L-1 and L-2, read by the
+    side-chain torsion head).  Must not change a bit of the result."""
+    case, gold, batch, sd = case_inputs(name)
     dev = _dev()
     model = _model_for(case, sd)
     b = case.make_batch().to(dev)
