@@ -118,8 +118,8 @@ def main():
     ap.add_argument("--cfg", default="cfg2", choices=["cfg1", "cfg2"])
     ap.add_argument("--flex", action="store_true", help="flexible side chains (BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-samples", type=int, default=1)
-    ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--cpu-samples", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=32)
     args = ap.parse_args()
 
