@@ -32,6 +32,11 @@ class Case:
     fixed_center_conv: bool = True
     use_old_atom_encoder: bool = False
     no_torsion: bool = False
+    dynamic_max_cross: bool = True
+    cross_max_distance: float = 80.0
+    scale_by_sigma: bool = True
+    batch_norm: bool = True
+    atom_max_neighbors: int = 8
     confidence_mode: bool = False
     num_confidence_outputs: int = 1
     n_graphs: int = 2
@@ -48,9 +53,10 @@ class Case:
         """kwargs for TensorProductScoreModel (reference ctor signature, README.md:72 settings)."""
         return dict(sh_lmax=1, ns=self.ns, nv=self.nv, num_conv_layers=self.num_conv_layers,
                     sigma_embed_dim=self.embed, distance_embed_dim=self.embed, cross_distance_embed_dim=self.embed,
-                    lig_max_radius=5.0, cross_max_distance=80.0, dynamic_max_cross=True, scale_by_sigma=True,
-                    batch_norm=True, dropout=0.0, lm_embedding_type="esm", fixed_center_conv=self.fixed_center_conv,
-                    atom_max_neighbors=8, flexible_sidechains=self.flexible_sidechains, no_torsion=self.no_torsion,
+                    lig_max_radius=5.0, cross_max_distance=self.cross_max_distance, dynamic_max_cross=self.dynamic_max_cross,
+                    scale_by_sigma=self.scale_by_sigma, batch_norm=self.batch_norm, dropout=0.0, lm_embedding_type="esm",
+                    fixed_center_conv=self.fixed_center_conv, atom_max_neighbors=self.atom_max_neighbors,
+                    flexible_sidechains=self.flexible_sidechains, no_torsion=self.no_torsion,
                     use_old_atom_encoder=self.use_old_atom_encoder, confidence_mode=self.confidence_mode,
                     num_confidence_outputs=self.num_confidence_outputs)
 
@@ -59,6 +65,9 @@ class Case:
                             distance_embed_dim=self.embed, cross_distance_embed_dim=self.embed,
                             flexible_sidechains=self.flexible_sidechains, fixed_center_conv=self.fixed_center_conv,
                             use_old_atom_encoder=self.use_old_atom_encoder, no_torsion=self.no_torsion,
+                            dynamic_max_cross=self.dynamic_max_cross, cross_max_distance=self.cross_max_distance,
+                            scale_by_sigma=self.scale_by_sigma, batch_norm=self.batch_norm,
+                            atom_max_neighbors=self.atom_max_neighbors,
                             confidence_mode=self.confidence_mode, embedding_scale=1000.0)
 
     def ctor_extras(self):
@@ -114,6 +123,11 @@ CASES: Dict[str, Case] = {c.name: c for c in [
     # reference utils/sampling.py:269-281, two classification outputs
     Case("conf_ns24_l5", ns=24, nv=6, num_conv_layers=5, embed=32, n_graphs=3, n_rec=24, t=[0.0, 0.0, 0.0],
          confidence_mode=True, num_confidence_outputs=2, weight_seed=7, data_seed=2),
+    # the other branches of the constructor switches: fixed cross cutoff, no sigma scaling, no BatchNorm, no torsion head,
+    # another atom-graph degree
+    Case("opts_alt", ns=16, nv=4, num_conv_layers=3, embed=32, n_graphs=2, n_rec=20, t=[0.8, 0.3], no_torsion=True,
+         dynamic_max_cross=False, cross_max_distance=14.0, scale_by_sigma=False, batch_norm=False, atom_max_neighbors=5,
+         weight_seed=9, data_seed=4),
     Case("conf_noflex", ns=16, nv=4, num_conv_layers=2, embed=32, n_graphs=2, n_rec=20, t=[0.0, 0.0],
          confidence_mode=True, flexible_sidechains=False, weight_seed=8),
 ]}
