@@ -113,11 +113,12 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, DDP_SA_WPE) void ddp_stage_a_mfma
                                                                                 const GemmOffs offs, const float* __restrict__ w,
                                                                                 int ncols, float* __restrict__ out, int ldo) {
   constexpr int KH = KT / 2, CT = DDP_SA_CT;
+  constexpr bool LAG = (4 + 3 * (KH / 4) <= KH - 1);   // room for the lagged stores between a block's MFMAs
   constexpr int XS = KT + 1;                                    // odd LDS row stride: conflict-free ds_read_b32 down a column
   constexpr int NV = (32 * KT / 4 + DDP_GEMM_THREADS - 1) / DDP_GEMM_THREADS;   // 16-byte pieces of an x tile per thread
   constexpr int TS = 36;                                        // LDS row stride of the per-wave store tile
   __shared__ float xt[2][32 * XS];
-  __shared__ __attribute__((aligned(16))) float st[4][32 * TS];
+  __shared__ __attribute__((aligned(16))) float st[4][2][32 * TS];
   const bool wide = ((ncols & 3) == 0) && ((ldo & 3) == 0) && ((reinterpret_cast<size_t>(out) & 15) == 0);
   const int z = (int)blockIdx.z, tid = (int)threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
@@ -162,6 +163,19 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, DDP_SA_WPE) void ddp_stage_a_mfma
       }
     }
   };
+  // pending block of this wave (parked in LDS, not yet written out)
+  float* pend_ob = nullptr;
+  int pend_c0 = 0, pend_rows = 0, pend_buf = 0, pbuf = 0;
+  f32x4 dv = {0.f, 0.f, 0.f, 0.f};
+  auto drain_read = [&](int p) {
+    if (pend_ob) dv = *reinterpret_cast<const f32x4*>(&st[wave][pend_buf][(8 * p + (lane >> 3)) * TS + 4 * (lane & 7)]);
+  };
+  auto drain_store = [&](int p) {
+    if (pend_ob) {
+      const int rr = 8 * p + (lane >> 3), c = pend_c0 + 4 * (lane & 7);
+      if (rr < pend_rows && c < ncols) *reinterpret_cast<f32x4*>(&pend_ob[(size_t)rr * ldo + c]) = dv;
+    }
+  };
   fetch(R0);
   park(0);
   __syncthreads();
@@ -188,28 +202,33 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, DDP_SA_WPE) void ddp_stage_a_mfma
 #if defined(DDP_SA_ABL) && DDP_SA_ABL == 3
       for (int s2 = 0; s2 < 1; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], wr[t][s2], acc, 0, 0, 0);
 #else
-      for (int s2 = 0; s2 < KH; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], wr[t][s2], acc, 0, 0, 0);
+      for (int s2 = 0; s2 < KH; ++s2) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], wr[t][s2], acc, 0, 0, 0);
+        if (wide && LAG) {   // quarter p of the pending block: LDS read at MFMA 2 + p*KH/4, store two MFMAs later
+          if ((s2 - 2) % (KH / 4) == 0 && (s2 - 2) / (KH / 4) < 4 && s2 >= 2) drain_read((s2 - 2) / (KH / 4));
+          if ((s2 - 4) % (KH / 4) == 0 && (s2 - 4) / (KH / 4) < 4 && s2 >= 4) drain_store((s2 - 4) / (KH / 4));
+        }
+      }
 #endif
       if (wide) {
-        // through a per-wave LDS tile: a lane then writes 16 bytes, an instruction 8 rows x 128 bytes (4 store
-        // instructions per 32 x 32 block instead of 16)
-        float* tl = st[wave];
+        // park the block in this wave's LDS tile (double buffered); its four 16-byte-per-lane stores (8 rows x 128
+        // bytes each) are issued one at a time between the MFMAs of the NEXT block (drain() calls in the loop above), so
+        // the writes leave the CU as a steady stream instead of a 16-KiB burst per workgroup after every block
+        float* tl = st[wave][pbuf];
 #pragma unroll
         for (int i = 0; i < 16; ++i) tl[((i & 3) + 8 * (i >> 2) + 4 * hh) * TS + r] = acc[i];
+        pend_ob = ob;
+        pend_c0 = col0 + 32 * t;
+        pend_rows = R1 - row0;
+        pend_buf = pbuf;
+        pbuf ^= 1;
+        if (!LAG) {   // (short K: no room between the MFMAs, write the block out right away)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const int rr = 8 * p + (lane >> 3), q = lane & 7, c = col0 + 32 * t + 4 * q;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(&tl[rr * TS + 4 * q]);
-#if defined(DDP_SA_ABL) && DDP_SA_ABL == 1
-          if (row0 + rr < R1 && c < ncols && v[0] == 1.2345e30f)
-#else
-          if (row0 + rr < R1 && c < ncols)
-#endif
-#ifdef DDP_SA_NT
-            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(&ob[(size_t)rr * ldo + c]));
-#else
-            *reinterpret_cast<f32x4*>(&ob[(size_t)rr * ldo + c]) = v;
-#endif
+          for (int p = 0; p < 4; ++p) {
+            drain_read(p);
+            drain_store(p);
+          }
+          pend_ob = nullptr;
         }
       } else {
         const int c = col0 + 32 * t + r;
@@ -224,6 +243,13 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, DDP_SA_WPE) void ddp_stage_a_mfma
     }
     if (more) park(buf ^ 1);
     __syncthreads();
+  }
+  if (wide && LAG) {   // the last block
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      drain_read(p);
+      drain_store(p);
+    }
   }
 }
 
