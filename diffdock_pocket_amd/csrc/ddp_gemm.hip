@@ -101,7 +101,7 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_kernel(const 
 // 512 rows per workgroup, and a producer / consumer split (4 MFMA waves handing blocks through LDS to 4 store waves).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef DDP_GEMM_MROWS
-#define DDP_GEMM_MROWS 256
+#define DDP_GEMM_MROWS 512
 #endif //  // rows per workgroup of the MFMA form
 
 #ifndef DDP_SA_CT
