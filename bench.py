@@ -135,6 +135,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
+    sync = (lambda: dist.barrier(device_ids=[local_rank])) if world > 1 else (lambda: None)
 
     from diffdock_pocket_amd.sampler import Sampler, SamplerConfig
     from diffdock_pocket_amd.diffusion import get_t_schedule
@@ -164,8 +165,7 @@ def main():
     prof = sm.ConvProfiler()
     sm.set_conv_profiler(prof)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    sync()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -174,8 +174,7 @@ def main():
         out = [torch.empty_like(sampler.lig_pos) for _ in range(world)]
         dist.all_gather(out, sampler.lig_pos.contiguous())
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     sm.set_conv_profiler(None)
@@ -222,7 +221,7 @@ def main():
                                        f"flexible_sidechains={args.flex}", "samples_per_gpu": args.samples,
                            "edges_last_step": model.last_stats},
                 "roofline": roof}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (the other ranks must not wait for it)
             line["cpu_baseline"] = cpu_baseline(args, model, kw, complex_graph)
         print(json.dumps(line), flush=True)
     if dist is not None:
