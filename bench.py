@@ -117,6 +117,10 @@ def main():
     ap.add_argument("--samples", type=int, default=40)
     ap.add_argument("--cfg", default="cfg2", choices=["cfg1", "cfg2"])
     ap.add_argument("--flex", action="store_true", help="flexible side chains (BASELINE configs[2])")
+    ap.add_argument("--ways", type=int, default=1,
+                    help="resident sample groups per GPU (sampler.PipelinedSampler: groups stepped alternately, a group's front on a "
+                         "high-priority stream beside the other group's conv layers).  Measured slower than one batch on MI355X "
+                         "(DESIGN.md section 4.5), hence 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -137,7 +141,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
     sync = (lambda: dist.barrier(device_ids=[local_rank])) if world > 1 else (lambda: None)
 
-    from diffdock_pocket_amd.sampler import Sampler, SamplerConfig
+    from diffdock_pocket_amd.sampler import PipelinedSampler, Sampler, SamplerConfig
     from diffdock_pocket_amd.diffusion import get_t_schedule
     from diffdock_pocket_amd.synthetic import make_3dpf_complex
     from diffdock_pocket_amd import score_model as sm
@@ -147,8 +151,13 @@ def main():
     scfg = SamplerConfig(inference_steps=20, flexible_sidechains=args.flex)
     # weak scaling: every rank owns `samples` samples of the job of world*samples samples
     n_total = args.samples * world
-    sampler = Sampler(model, complex_graph, n_total, device, scfg, seed=0,
-                      sample_slice=slice(rank * args.samples, (rank + 1) * args.samples))
+    def make_sampler():
+        sl = slice(rank * args.samples, (rank + 1) * args.samples)
+        if args.ways > 1:
+            return PipelinedSampler(model, complex_graph, n_total, device, scfg, seed=0, sample_slice=sl, ways=args.ways)
+        return Sampler(model, complex_graph, n_total, device, scfg, seed=0, sample_slice=sl)
+
+    sampler = make_sampler()
     sampler.randomize()
     schedule = get_t_schedule(20)
 
@@ -158,8 +167,7 @@ def main():
     for i in range(args.warmup):
         one_step(i)
     # restart from fresh poses so that the timed steps see the schedule's own edge counts
-    sampler = Sampler(model, complex_graph, n_total, device, scfg, seed=0,
-                      sample_slice=slice(rank * args.samples, (rank + 1) * args.samples))
+    sampler = make_sampler()
     sampler.randomize()
 
     prof = sm.ConvProfiler()
@@ -170,9 +178,10 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(i)
+    final_pos = sampler.lig_pos.contiguous()
     if dist is not None:   # gather final ligand poses of all shards (RCCL over xGMI)
-        out = [torch.empty_like(sampler.lig_pos) for _ in range(world)]
-        dist.all_gather(out, sampler.lig_pos.contiguous())
+        out = [torch.empty_like(final_pos) for _ in range(world)]
+        dist.all_gather(out, final_pos)
     torch.cuda.synchronize()
     sync()
     torch.cuda.synchronize()
@@ -182,7 +191,7 @@ def main():
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    assert torch.isfinite(sampler.lig_pos).all(), "non-finite poses"
+    assert torch.isfinite(final_pos).all(), "non-finite poses"
 
     if rank == 0:
         global TRAFFIC_BYTES_PER_LAUNCH
@@ -219,7 +228,8 @@ def main():
                                        f"{args.samples} samples/GPU x 20-step schedule, score model {args.cfg} "
                                        f"(ns={kw['ns']} nv={kw['nv']} L={kw['num_conv_layers']}), "
                                        f"flexible_sidechains={args.flex}", "samples_per_gpu": args.samples,
-                           "edges_last_step": model.last_stats},
+                           "ways": args.ways,
+                           "edges_last_step": getattr(sampler, "last_stats", None) or model.last_stats},
                 "roofline": roof}
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (the other ranks must not wait for it)
             line["cpu_baseline"] = cpu_baseline(args, model, kw, complex_graph)

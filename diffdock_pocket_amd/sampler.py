@@ -287,3 +287,100 @@ class Sampler:
         for i in range(len(schedule)):
             self.step(i, schedule)
         return self.lig_pos, self.atom_pos
+
+
+class PipelinedSampler:
+    """The same job as `Sampler`, with the local samples split into `ways` contiguous groups that are stepped one after
+    the other on their own HIP streams.
+
+    Why: the front of a forward (neighbour searches, CSR views, head graphs) is a chain of small launches with a few
+    host synchronisations - the host, not the device, sets its pace - while the conv layers that follow keep the device
+    busy for tens of milliseconds with the host far ahead.  With two resident groups the host prepares and queues group
+    B's front while the device still runs group A's conv layers (and the other way round), so the device does not wait
+    for the host between steps.  Every group is a `Sampler` over its own `sample_slice` of the same seeded job (noise is
+    drawn for the whole job and sliced): the poses are bit for bit those of the groups run on their own
+    (`tests/test_gpu_parity.py::test_sampler_end_to_end_on_device`), i.e. those of the single-batch `Sampler` up to the
+    fp32 rounding of a few batch-level reductions, exactly like sharding over GPUs.
+    Each group keeps its own slot of the model's static-graph cache (`model.cache_slot`)."""
+
+    def __init__(self, model, complex_graph: HeteroBatch, n_total: int, device, cfg: SamplerConfig, seed: int = 0,
+                 sample_slice: Optional[slice] = None, ways: int = 2):
+        self.model, self.device = model, device
+        lo, hi, _ = (sample_slice or slice(0, n_total)).indices(n_total)
+        ways = max(1, min(ways, hi - lo))
+        cuts = [lo + (hi - lo) * w // ways for w in range(ways + 1)]
+        self.streams = [torch.cuda.Stream(device=device, priority=-1) for _ in range(ways)]       # fronts: high priority
+        self.layer_streams = [torch.cuda.Stream(device=device, priority=0) for _ in range(ways)]
+        self._part_done = [None] * ways
+        self.parts: List[Sampler] = []
+        torch.cuda.synchronize(device)
+        for st, a, b in zip(self.streams, cuts[:-1], cuts[1:]):
+            with torch.cuda.stream(st):
+                self.parts.append(Sampler(model, complex_graph, n_total, device, cfg, seed=seed, sample_slice=slice(a, b)))
+        torch.cuda.synchronize(device)
+        self.n = hi - lo
+        self.n_l, self.n_a = self.parts[0].n_l, self.parts[0].n_a
+        self.last_stats: dict = {}
+        self._warm = False
+        self._done = None          # event after the most recent group step
+
+    def _each(self, fn):
+        stats = []
+        for slot, part in enumerate(self.parts):
+            F, Ls = self.streams[slot], self.layer_streams[slot]
+            self.model.cache_slot = slot
+
+            def to_layers(F=F, Ls=Ls):
+                # front -> layers handoff: the layers go to the group's normal-priority stream, after this group's front
+                # and after the previous group's step.  The conv layers of the groups run one after the other - two
+                # saturating kernel sequences sharing the CUs would both finish late and the host could not start either
+                # group's next front early; only a group's front (high-priority stream, small kernels) overlaps them.
+                ev = torch.cuda.Event()
+                ev.record(F)
+                Ls.wait_event(ev)
+                if self._done is not None:
+                    Ls.wait_event(self._done)
+                torch.cuda.set_stream(Ls)
+
+            self.model.before_layers = to_layers
+            try:
+                with torch.cuda.stream(F):
+                    if self._part_done[slot] is not None:    # the front reads what the group's last step left on Ls
+                        F.wait_event(self._part_done[slot])
+                    fn(part)
+                    done = torch.cuda.Event()
+                    done.record(torch.cuda.current_stream())
+                    self._done = self._part_done[slot] = done
+            finally:
+                self.model.before_layers = None
+            stats.append(dict(self.model.last_stats))
+            if not self._warm:   # weights are packed on first use: finished before another stream reads them
+                torch.cuda.synchronize(self.device)
+        self.model.cache_slot = 0
+        self._warm = True
+        return stats
+
+    def randomize(self):
+        self._each(lambda p: p.randomize())
+
+    def step(self, t_idx: int, schedule: np.ndarray):
+        stats = self._each(lambda p: p.step(t_idx, schedule))
+        self.last_stats = {k: sum(s.get(k, 0) for s in stats) for k in stats[0]}   # edge / node / graph counts of the step
+
+    def _gather(self, name):
+        torch.cuda.synchronize(self.device)
+        return torch.cat([getattr(p, name) for p in self.parts], 0)
+
+    @property
+    def lig_pos(self):
+        return self._gather("lig_pos")
+
+    @property
+    def atom_pos(self):
+        return self._gather("atom_pos")
+
+    def run(self, schedule: Optional[np.ndarray] = None):
+        schedule = get_t_schedule(self.parts[0].cfg.inference_steps) if schedule is None else schedule
+        for i in range(len(schedule)):
+            self.step(i, schedule)
+        return self.lig_pos, self.atom_pos

@@ -467,6 +467,11 @@ class TensorProductScoreModel(nn.Module):
         self.prune_last_receptor_layer = True   # layer L-2 receptor-side convs only where the final layer reads them
         self.share_layer0 = True       # layer-0 receptor-side convs once per batch of identical receptors (forward)
         self._static_cache = {}        # see _cached()
+        self.before_layers = None      # optional callable, run once per forward between the front (graphs, edge embeddings,
+                                       # CSR views) and the conv layers: sampler.PipelinedSampler orders the layers of its
+                                       # resident groups with it (an event wait on the current stream)
+        self.cache_slot = 0            # callers that alternate between several resident batches (sampler.PipelinedSampler)
+                                       # give each its own slot so that they do not evict each other's entries
         self._stage_a_stacks = {}      # (layer, conv ids) -> stacked stage-A right-hand sides, see _stage_a()
         self.section_timer = None      # optional SectionTimer (tools/time_sections.py): per-section GPU + host time
         for i in range(num_conv_layers):
@@ -606,6 +611,15 @@ class TensorProductScoreModel(nn.Module):
         out = super()._apply(fn, *a, **kw)
         self.invalidate_packed()
         return out
+
+    @property
+    def _static_cache(self):
+        """The `_cached` entries of the current `cache_slot`."""
+        return self.__dict__.setdefault("_static_caches", {}).setdefault(self.__dict__.get("cache_slot", 0), {})
+
+    @_static_cache.setter
+    def _static_cache(self, value):   # assigning {} drops the entries of every slot
+        self.__dict__["_static_caches"] = {self.__dict__.get("cache_slot", 0): value} if value else {}
 
     # ---- small host-side pieces ---------------------------------------------------------------
     def _edge_pack(self, name, rbf_slice, dev) -> _EdgeMLPPack:
@@ -909,6 +923,8 @@ class TensorProductScoreModel(nn.Module):
                             so_p = G.SourceOrder(so_p.n_edges, so_p.recv, inv.to(torch.int32), so_p.eid, so_p.pos)
                         pruned_so.setdefault(l, {})[k] = (so_p, uniq)
         mark("csr")
+        if self.before_layers is not None:
+            self.before_layers()
         for l in range(L_):
             spec, spec_g = self._layer_specs[l], self._layer_specs_g[l]
             do_atom = self.flexible_sidechains or l != L_ - 1

@@ -383,5 +383,46 @@ def test_sampler_end_to_end_on_device(flex):
     assert torch.allclose(lig_half, lig_one[2:4], atol=5e-4, rtol=0)    # same noise stream; batch composition differs
     conf, order = s_all.confidence(conf_model)
     assert conf.shape[0] == 4 and sorted(order.tolist()) == [0, 1, 2, 3] and torch.isfinite(conf).all()
+    # two resident groups stepped alternately on their own streams = the two shards run on their own, bit for bit
+    from diffdock_pocket_amd.sampler import PipelinedSampler
+    pipe = PipelinedSampler(model, g, 4, dev, SamplerConfig(inference_steps=4, flexible_sidechains=flex), seed=3, ways=2)
+    pipe.randomize()
+    for i in range(4):
+        pipe.step(i, sched)
+    lig_pipe, atoms_pipe = pipe.lig_pos.clone(), pipe.atom_pos.clone()
+    _, lig_a, atoms_a = run(4, slice(0, 2))
+    _, lig_b, atoms_b = run(4, slice(2, 4))
+    assert torch.equal(lig_pipe, torch.cat([lig_a, lig_b])) and torch.equal(atoms_pipe, torch.cat([atoms_a, atoms_b]))
+    assert model.cache_slot == 0
     if flex:
         assert float((atoms_all - g["atom"].pos.to(dev)).abs().max()) > 1e-3      # side chains moved
+
+
+def test_forward_on_graph_from_the_input_pipeline():
+    """a complex graph built from PDB / SDF text (inputs.build_complex_graph, the reference's example
+    complex with the README's flexible residues) goes through the HIP forward and matches the oracle on the same batch."""
+    import os
+    from diffdock_pocket_amd import inputs as I
+    from diffdock_pocket_amd.batch import collate, set_time
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = I.build_complex_graph(open(os.path.join(gdir, "3dpf_protein.pdb")).read(), open(os.path.join(gdir, "3dpf_ligand.sdf")).read(),
+                              flexible_sidechains="A:160-A:193-A:197-A:198-A:222-A:224-A:227")
+    gen = torch.Generator().manual_seed(11)
+    g["receptor"].x = torch.cat([g["receptor"].x, torch.randn(g["receptor"].x.shape[0], 1280, generator=gen)], 1)
+    graphs = []
+    for shift in (0.0, 1.5):
+        c = g.clone()
+        c["ligand"].pos = c["ligand"].pos + shift * torch.randn(1, 3, generator=gen)
+        graphs.append(c)
+
+    def batch():
+        b = collate(graphs)
+        set_time(b, 0.7, 0.7, 0.7, 0.7)
+        return b
+
+    case, _, _, sd = case_inputs("cfg1_full")
+    want = OracleScoreModel(case.oracle_config(), sd)(batch())
+    got = _model_for(case, sd)(batch().to(_dev()))
+    for a, w, k in zip(got, want, ("tr", "rot", "tor", "sc_tor")):
+        assert a.shape == w.shape and w.numel() > 0, k
+        assert rel_err(a.float().cpu(), w) < TOL, (k, rel_err(a.float().cpu(), w))

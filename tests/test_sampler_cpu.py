@@ -90,7 +90,10 @@ def test_two_rank_sharding_is_shard_invariant():
     full, _ = _run(n_total, slice(0, n_total))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+    with socket.socket() as sk:          # a port that is free right now (a fixed one may still be in TIME_WAIT)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_worker, args=(r, 2, n_total, port, q)) for r in range(2)]
     for p in procs:
         p.start()
