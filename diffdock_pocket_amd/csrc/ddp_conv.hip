@@ -254,14 +254,22 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
     int i_ui = 0, i_ch = 0, c_ui = 0, c_ch = 0;   // (unit, chunk) of the next step to request / to compute
 
+    // A request step is ALWAYS the same straight-line sequence (KC/4 row loads + the bias word), also beyond the wave's
+    // last step, where it re-requests the last step's lines (cache hits, results unused): hipcc's waitcnt insertion only
+    // keeps exact vmcnt distances across the ring when no load sits under a condition - with `if (step < nsteps)` /
+    // `if (chunk == 0)` around them it fell back to vmcnt(4) .. vmcnt(0) inside every compute step (the ISA now shows
+    // vmcnt(12): two steps in flight).  Measured neutral on the 3dpf launches (4.18 ms either way): the pass is bound
+    // by the rate at which the memory system delivers G under the launch's other phases, not by exposed latency.
 #define DDP_G_ISSUE(STEP, BUF, BIAS)                                                                          \
-    if ((STEP) < nsteps) {                                                                                    \
+    {                                                                                                         \
       const int node_ = __builtin_amdgcn_readlane(my_node, i_ui);                                             \
       const f32x4* __restrict__ gp_ = G4 + (size_t)node_ * gstride + c0;                                      \
       _Pragma("unroll") for (int q4 = 0; q4 < KC / 4; ++q4)                                                   \
         BUF[q4] = DDP_ABL_G(gp_[(size_t)min(i_ch * (KC / 4) + q4, nq - 1) * gc], q4);                         \
-      if (i_ch == 0) BIAS = Gb[(size_t)node_ * (4 * gstride) + c0];                                           \
-      if (++i_ch == nch) { i_ch = 0; ++i_ui; }                                                                \
+      BIAS = Gb[(size_t)node_ * (4 * gstride) + c0];                                                          \
+      if ((STEP) + 1 < nsteps) {                                                                              \
+        if (++i_ch == nch) { i_ch = 0; ++i_ui; }                                                              \
+      }                                                                                                       \
     }
 
 #define DDP_G_COMPUTE(STEP, BUF, BIAS)                                                                        \
