@@ -132,14 +132,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU product path)")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1) if os.environ.get("DDP_BENCH_BACKEND") else local_rank
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    sync = (lambda: dist.barrier(device_ids=[local_rank])) if world > 1 else (lambda: None)
+        # RCCL ("nccl") is the backend of every real run; DDP_BENCH_BACKEND=gloo only exists to exercise the multi-rank code
+        # path with several ranks on ONE device (tests on a 1-GPU box), where RCCL refuses duplicate devices
+        backend = os.environ.get("DDP_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    if world > 1:
+        sync = (lambda: dist.barrier(device_ids=[local_rank])) if backend == "nccl" else dist.barrier
+    else:
+        sync = lambda: None   # noqa: E731
 
     from diffdock_pocket_amd.sampler import PipelinedSampler, Sampler, SamplerConfig
     from diffdock_pocket_amd.diffusion import get_t_schedule
@@ -195,7 +202,9 @@ def main():
 
     if rank == 0:
         global TRAFFIC_BYTES_PER_LAUNCH
-        TRAFFIC_BYTES_PER_LAUNCH = _load_traffic()
+        # the PMC passes were taken on the default workload only (40 samples, cfg2, rigid receptor, one batch)
+        default_workload = args.samples == 40 and args.cfg == "cfg2" and not args.flex and args.ways == 1
+        TRAFFIC_BYTES_PER_LAUNCH = _load_traffic() if default_workload else None
         poses = n_total * args.steps / 20.0
         # the dominant kernel = the instantiation with the larger share of the timed region
         kinds = sorted({k for k in prof.kernel}, key=lambda k: -prof.summary(k)[2])
