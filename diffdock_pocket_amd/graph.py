@@ -80,26 +80,53 @@ def _ptr(layout: "DenseLayout") -> torch.Tensor:
     return p
 
 
-def _radius_hip(x, y, r, lx, ly, ybatch32, max_num_neighbors, drop_self):
-    """radius() on the device (csrc/ddp_graph.hip): count pass, prefix sum, fill pass.  One host sync (the edge count)."""
-    from . import _lib as L
-    lib = L.load()
-    ny = y.shape[0]
-    st = torch.cuda.current_stream().cuda_stream
-    xc, yc = x.float().contiguous(), y.float().contiguous()
-    counts = torch.empty(ny, dtype=torch.int32, device=x.device)
-    L.check(lib.ddp_radius_count(xc.data_ptr(), _ptr(lx).data_ptr(), yc.data_ptr(), ybatch32.data_ptr(), ny, float(r),
-                                 int(max_num_neighbors), int(drop_self), counts.data_ptr(), st), "ddp_radius_count")
-    offs = torch.zeros(ny + 1, dtype=torch.int32, device=x.device)
-    offs[1:] = torch.cumsum(counts, 0)
-    E = int(offs[-1].item())
-    oq = torch.empty(E, dtype=torch.int32, device=x.device)
-    ox = torch.empty(E, dtype=torch.int32, device=x.device)
-    if E > 0:
-        L.check(lib.ddp_radius_fill(xc.data_ptr(), _ptr(lx).data_ptr(), yc.data_ptr(), ybatch32.data_ptr(), ny, float(r),
-                                    int(max_num_neighbors), int(drop_self), offs.data_ptr(), oq.data_ptr(), ox.data_ptr(), st),
-                "ddp_radius_fill")
-    return oq.long(), ox.long()
+class RadiusSearch:
+    """radius() / radius_graph() on the device (csrc/ddp_graph.hip) in two halves - count pass + prefix sum, then fill pass -
+    so that several searches of a forward share ONE host synchronisation (`resolve`) and a search whose edges are only
+    needed late (the heads' bond-centre graphs) can be counted early and filled after the conv layers are queued.
+
+        s = RadiusSearch(x, y, r, lx, ly, cap)          # edges [query (y); x], as radius()
+        s = RadiusSearch.graph(x, r, lx, cap)           # edges [neighbour; query], self loops dropped, as radius_graph()
+        (E,) = resolve([s]);  edge_index = s.fill(E)
+    """
+
+    def __init__(self, x, y, r, lx, ly, max_num_neighbors=32, drop_self=False, flip=False):
+        from . import _lib as L
+        lib = L.load()
+        self.args = (x.float().contiguous(), y.float().contiguous(), float(r), _ptr(lx), _batch32(ly, y.shape[0]),
+                     int(max_num_neighbors), int(drop_self))
+        self.flip = flip
+        xc, yc, r, xptr, ybatch, cap, ds = self.args
+        ny = yc.shape[0]
+        counts = torch.empty(ny, dtype=torch.int32, device=xc.device)
+        if ny > 0:
+            L.check(lib.ddp_radius_count(xc.data_ptr(), xptr.data_ptr(), yc.data_ptr(), ybatch.data_ptr(), ny, r, cap, ds,
+                                         counts.data_ptr(), torch.cuda.current_stream().cuda_stream), "ddp_radius_count")
+        self.offs = torch.zeros(ny + 1, dtype=torch.int32, device=xc.device)
+        self.offs[1:] = torch.cumsum(counts, 0)
+
+    @classmethod
+    def graph(cls, x, r, lx, max_num_neighbors=32):
+        return cls(x, x, r, lx, lx, max_num_neighbors + 1, drop_self=True, flip=True)
+
+    def fill(self, E: int) -> torch.Tensor:
+        from . import _lib as L
+        lib = L.load()
+        xc, yc, r, xptr, ybatch, cap, ds = self.args
+        oq = torch.empty(E, dtype=torch.int32, device=xc.device)
+        ox = torch.empty(E, dtype=torch.int32, device=xc.device)
+        if E > 0:
+            L.check(lib.ddp_radius_fill(xc.data_ptr(), xptr.data_ptr(), yc.data_ptr(), ybatch.data_ptr(), yc.shape[0], r, cap, ds,
+                                        self.offs.data_ptr(), oq.data_ptr(), ox.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream), "ddp_radius_fill")
+        return torch.stack([ox.long(), oq.long()] if self.flip else [oq.long(), ox.long()], 0)
+
+
+def resolve(searches):
+    """Edge counts of several RadiusSearch objects with one device-to-host copy (the only host synchronisation of them)."""
+    if not searches:
+        return []
+    return [int(v) for v in torch.stack([s.offs[-1] for s in searches]).tolist()]
 
 
 def _batch32(layout: "DenseLayout", n: int) -> torch.Tensor:
@@ -115,8 +142,8 @@ def radius(x, y, r, lx: DenseLayout, ly: DenseLayout, max_num_neighbors=32):
     """See module docstring.  `r` may be a python float or a [B] tensor is NOT supported (scale inputs instead,
     as the reference does for the dynamic cross cutoff)."""
     if x.is_cuda:   # device search (no dense [B, ny, nx] blocks); the PyTorch form below is the CPU / test definition
-        q, n = _radius_hip(x, y, r, lx, ly, _batch32(ly, y.shape[0]), max_num_neighbors, False)
-        return torch.stack([q, n], 0)
+        s = RadiusSearch(x, y, r, lx, ly, max_num_neighbors)
+        return s.fill(resolve([s])[0])
     xd, yd = lx.dense(x, float("inf")), ly.dense(y, float("inf"))
     d2 = _sqdist(yd, xd)
     ok = d2 < (float(r) ** 2)
@@ -134,8 +161,8 @@ def radius(x, y, r, lx: DenseLayout, ly: DenseLayout, max_num_neighbors=32):
 
 def radius_graph(x, r, lx: DenseLayout, max_num_neighbors=32):
     if x.is_cuda:
-        q, n = _radius_hip(x, x, r, lx, lx, _batch32(lx, x.shape[0]), max_num_neighbors + 1, True)
-        return torch.stack([n, q], 0)
+        s = RadiusSearch.graph(x, r, lx, max_num_neighbors)
+        return s.fill(resolve([s])[0])
     ei = radius(x, x, r, lx, lx, max_num_neighbors + 1)
     keep = ei[0] != ei[1]
     return torch.stack([ei[1][keep], ei[0][keep]], 0)

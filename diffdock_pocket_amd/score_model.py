@@ -467,6 +467,8 @@ class TensorProductScoreModel(nn.Module):
         self.prune_last_receptor_layer = True   # layer L-2 receptor-side convs only where the final layer reads them
         self.share_layer0 = True       # layer-0 receptor-side convs once per batch of identical receptors (forward)
         self._static_cache = {}        # see _cached()
+        self.prune_async = True        # dead-output walk on a side stream behind the first layers (forward)
+        self._side = None
         self.before_layers = None      # optional callable, run once per forward between the front (graphs, edge embeddings,
                                        # CSR views) and the conv layers: sampler.PipelinedSampler orders the layers of its
                                        # resident groups with it (an event wait on the current stream)
@@ -612,6 +614,11 @@ class TensorProductScoreModel(nn.Module):
         self.invalidate_packed()
         return out
 
+    def _side_stream(self, dev):
+        if self._side is None or self._side.device != torch.device(dev):
+            self._side = torch.cuda.Stream(device=dev, priority=-1)
+        return self._side
+
     @property
     def _static_cache(self):
         """The `_cached` entries of the current `cache_slot`."""
@@ -712,17 +719,45 @@ class TensorProductScoreModel(nn.Module):
         # ---- graphs (:444-583)
         i32 = lambda t: t.to(torch.int32).contiguous()
         bond_ei = data["ligand", "ligand"].edge_index.long()
-        rad = G.radius_graph(lpos, self.lig_max_radius, lay_l)
-        ll = torch.cat([bond_ei, rad], 1)
+        # The neighbour searches that depend on the pose - ligand radius graph, ligand<-receptor, ligand<-atom and the heads'
+        # bond-centre graphs - are COUNTED first and share one host synchronisation (G.resolve); the heads' graphs are
+        # filled only after the conv layers are queued (nothing before the layers needs them unless side chains are flexible)
+        s_ll = G.RadiusSearch.graph(lpos, self.lig_max_radius, lay_l)
         rr = data["receptor", "receptor"].edge_index.long()
         aa = self._cached("aa", (apos, abatch), lambda: G.knn_graph(apos, self.atom_max_neighbors if self.atom_max_neighbors else 32, lay_a))
         data["atom", "atom"].edge_index = aa
         if self.dynamic_max_cross:
             cut = (tr_sigma * 3 + 20).unsqueeze(1)
-            lr = G.radius(rpos / cut[rbatch], lpos / cut[lbatch], 1.0, lay_r, lay_l, max_num_neighbors=10000)
+            s_lr = G.RadiusSearch(rpos / cut[rbatch], lpos / cut[lbatch], 1.0, lay_r, lay_l, max_num_neighbors=10000)
         else:
-            lr = G.radius(rpos, lpos, self.cross_max_distance, lay_r, lay_l, max_num_neighbors=10000)
-        la = G.radius(apos, lpos, self.lig_max_radius, lay_a, lay_l, max_num_neighbors=10000)
+            s_lr = G.RadiusSearch(rpos, lpos, self.cross_max_distance, lay_r, lay_l, max_num_neighbors=10000)
+        s_la = G.RadiusSearch(apos, lpos, self.lig_max_radius, lay_a, lay_l, max_num_neighbors=10000)
+        num_flex = 0
+        if self.flexible_sidechains and ("flexResidues" in data) and len(data["flexResidues"]) > 0:
+            num_flex = int(data["flexResidues"].edge_idx.shape[0])
+        pend_tor = pend_sc = rot_bond_idx = None
+        if not self.confidence_mode:
+            if not self.no_torsion:
+                def tor_static():   # rotatable bonds, their graph index and dense layout: fixed for a batch
+                    idx = lig.edge_mask.bool().nonzero(as_tuple=True)[0]
+                    bnd = bond_ei[:, idx]
+                    bb = lbatch[bnd[0]]
+                    return idx, bnd, bb, (G.DenseLayout.build(bb, B) if idx.shape[0] > 0 else None)
+
+                rot_bond_idx, bonds_t, bond_batch, lay_b = self._cached("tor_static", (lig.edge_mask, bond_ei, lbatch), tor_static)
+                if rot_bond_idx.shape[0] > 0:
+                    pend_tor = self._torsion_search("final_edge_embedding", lpos, lay_l, bonds_t, bond_batch, B, lay_b)
+            if num_flex > 0:
+                fr = data["flexResidues"]
+                bonds_s = lay_a.starts[fr.batch.long()] + fr.edge_idx.t().long()     # get_sc_tor_bonds (:638-652)
+                pend_sc = self._torsion_search("sidechain_final_edge_embedding", apos, lay_a, bonds_s, fr.batch.long(), B)
+        pending = [p for p in (pend_tor, pend_sc) if p is not None]
+        counts = G.resolve([s_ll, s_lr, s_la] + [p["search"] for p in pending])
+        for p, e in zip(pending, counts[3:]):
+            p["E"] = e
+        ll = torch.cat([bond_ei, s_ll.fill(counts[0])], 1)
+        lr = s_lr.fill(counts[1])
+        la = s_la.fill(counts[2])
         ar = data["atom", "receptor"].edge_index.long()
         self.last_stats = {"E_ll": ll.shape[1], "E_rr": rr.shape[1], "E_aa": aa.shape[1], "E_lr": lr.shape[1],
                            "E_la": la.shape[1], "E_ar": ar.shape[1], "N_l": Nl, "N_r": Nr, "N_a": Na, "B": B}
@@ -829,35 +864,12 @@ class TensorProductScoreModel(nn.Module):
                     if csr.n_edges >= self.factorize_min_degree * uniq.shape[0]:
                         so_views[k] = G.SourceOrder(so_c.n_edges, so_c.recv, inv.to(torch.int32), so_c.eid, so_c.pos)
                         compact_src[k] = uniq
-        # ---- graph parts of the heads, here because they synchronise with the host (edge counts): once the conv layers
-        # are queued the host must be able to queue the heads and the pose update without waiting for the device
-        num_flex = 0
-        if self.flexible_sidechains and ("flexResidues" in data) and len(data["flexResidues"]) > 0:
-            num_flex = int(data["flexResidues"].edge_idx.shape[0])
-        head_c = head_tor = head_sc = rot_bond_idx = None
-        if not self.confidence_mode:
-            ar_l = torch.arange(Nl, device=dev)
-            cnt = lay_l.counts.unsqueeze(1)
-            center = torch.zeros((B, 3), device=dev).index_add_(0, lbatch, lpos) / cnt
-            pk = self._edge_pack("center_edge_embedding", slice(0, dd), dev)
-            pre_c = torch.addmm(pk.b1, lig.node_sigma_emb, pk.W1[:, dd:dd + sd_].t())
-            e_c, sh_c = _edge_featurize(pk, self.center_distance_expansion, center, i32(lbatch), lpos, i32(ar_l), pre_c, i32(ar_l))
-            head_c = (e_c, sh_c, self._cached("c_c", (lbatch,), lambda: G.build_csr(lbatch, ar_l, B, presorted=True)))
-            if not self.no_torsion:
-                def tor_static():   # rotatable bonds, their graph index and dense layout: fixed for a batch
-                    idx = lig.edge_mask.bool().nonzero(as_tuple=True)[0]
-                    bnd = bond_ei[:, idx]
-                    bb = lbatch[bnd[0]]
-                    return idx, bnd, bb, (G.DenseLayout.build(bb, B) if idx.shape[0] > 0 else None)
-
-                rot_bond_idx, bonds, bond_batch, lay_b = self._cached("tor_static", (lig.edge_mask, bond_ei, lbatch), tor_static)
-                if rot_bond_idx.shape[0] > 0:
-                    head_tor = self._torsion_graph("final_edge_embedding", lpos, lay_l, bonds, bond_batch, B, dev, lay_b)
-            if num_flex > 0:
-                fr = data["flexResidues"]
-                bonds = lay_a.starts[fr.batch.long()] + fr.edge_idx.t().long()     # get_sc_tor_bonds (:638-652)
-                head_sc = self._torsion_graph("sidechain_final_edge_embedding", apos, lay_a, bonds, fr.batch.long(), B, dev)
-        mark("head_graphs")
+        # ---- graph parts of the heads.  Their only host synchronisation (the edge counts) happened above; with flexible
+        # side chains the side-chain graph is completed here because the dead-output walk below reads it, everything else
+        # (centre graph, ligand torsion graph) is queued after the conv layers, behind which it costs no wall time
+        head_tor = None
+        head_sc = self._torsion_finish(pend_sc, dev) if pend_sc is not None else None
+        mark("head_sc_graph")
         # Dead-output elimination over the last layers.  What is read after the last layer: all ligand features (heads),
         # with flexible side chains the atom features around the flexible bonds (side-chain torsion head), nothing of the
         # receptor.  Walking backwards, a layer's receptor-side convs only have to produce the rows that are still read
@@ -865,8 +877,8 @@ class TensorProductScoreModel(nn.Module):
         # are restricted to the edges that END in a needed node - exact, the other rows of x are simply left stale.
         # Without flexible side chains this prunes layer L-2 (its atom outputs feed only the final ligand<-atom conv), with
         # them layers L-1 and L-2.  The walk stops as soon as (almost) everything is needed; layer 0 is never touched.
-        pruned, pruned_so = {}, {}
-        if self.prune_last_receptor_layer and L_ >= 2 and not self.confidence_mode:
+        def prune_plan():
+            pruned, pruned_so = {}, {}
             ALL = None
             need = {"l": ALL, "a": torch.zeros(Na, dtype=torch.bool, device=dev), "r": torch.zeros(Nr, dtype=torch.bool, device=dev)}
             if head_sc is not None:
@@ -922,6 +934,21 @@ class TensorProductScoreModel(nn.Module):
                             uniq, inv = torch.unique_consecutive(so_p.src.long(), return_inverse=True)
                             so_p = G.SourceOrder(so_p.n_edges, so_p.recv, inv.to(torch.int32), so_p.eid, so_p.pos)
                         pruned_so.setdefault(l, {})[k] = (so_p, uniq)
+            return pruned, pruned_so
+
+        # The walk costs ~1.7 ms of small launches with host synchronisations (data-dependent sizes) and only the last layers
+        # need its result: with `prune_async` it runs on a side stream AFTER layers 0 .. L-4 are queued - its inputs are graph
+        # structure only, not features - so that it hides behind those layers instead of delaying the first one.  A layer
+        # that is already queued when the plan arrives simply runs unpruned (always exact).
+        pruned, pruned_so = {}, {}
+        prune_on = self.prune_last_receptor_layer and L_ >= 2 and not self.confidence_mode
+        prune_after = (L_ - 4) if (prune_on and self.prune_async and L_ >= 4 and self.before_layers is None) else None
+        if prune_on and prune_after is None:
+            pruned, pruned_so = prune_plan()
+        inputs_ready = None
+        if prune_after is not None:
+            inputs_ready = torch.cuda.Event()
+            inputs_ready.record()
         mark("csr")
         if self.before_layers is not None:
             self.before_layers()
@@ -931,6 +958,17 @@ class TensorProductScoreModel(nn.Module):
             do_rec = do_atom and l != L_ - 1
             active = {"l": True, "a": do_atom, "r": do_rec}
             shared = shared0 if l == 0 else {}
+            if prune_after is not None and l == prune_after + 1:
+                side = self._side_stream(dev)
+                side.wait_event(inputs_ready)
+                with torch.cuda.stream(side):
+                    pruned, pruned_so = prune_plan()
+                    plan_ready = torch.cuda.Event()
+                    plan_ready.record()
+                torch.cuda.current_stream().wait_event(plan_ready)
+                pruned = {ll_: v for ll_, v in pruned.items() if ll_ > prune_after}
+                pruned_so = {ll_: v for ll_, v in pruned_so.items() if ll_ > prune_after}
+                mark("prune_plan")
             layer_csr, layer_so = pruned.get(l, {}), pruned_so.get(l, {})
             tasks, tasks_g, msgs, keep = [], [], {}, []
             # per conv of this layer: (csr, source-ordered view or None, source-node array) after the layer-specific
@@ -1021,8 +1059,18 @@ class TensorProductScoreModel(nn.Module):
                     conf_in = torch.cat([conf_in, torch.zeros_like(conf_in)], dim=1)
             return self.confidence_predictor(conf_in).squeeze(dim=-1)
 
-        # ---- translation / rotation head (:357-384); its graph part (head_c) was prepared before the conv layers
-        e_c, sh_c, c_c = head_c
+        # ---- graph parts of the remaining heads (sync-free, see above)
+        ar_l = torch.arange(Nl, device=dev)
+        cnt = lay_l.counts.unsqueeze(1)
+        center = torch.zeros((B, 3), device=dev).index_add_(0, lbatch, lpos) / cnt
+        pk = self._edge_pack("center_edge_embedding", slice(0, dd), dev)
+        pre_c = torch.addmm(pk.b1, lig.node_sigma_emb, pk.W1[:, dd:dd + sd_].t())
+        e_c, sh_c = _edge_featurize(pk, self.center_distance_expansion, center, i32(lbatch), lpos, i32(ar_l), pre_c, i32(ar_l))
+        c_c = self._cached("c_c", (lbatch,), lambda: G.build_csr(lbatch, ar_l, B, presorted=True))
+        if pend_tor is not None:
+            head_tor = self._torsion_finish(pend_tor, dev)
+        mark("head_graphs")
+        # ---- translation / rotation head (:357-384)
         fspec = self.final_conv.spec
         pkc = self.final_conv.packed(dev)
         msg = torch.empty((Nl, fspec.d_out), device=dev)
@@ -1059,21 +1107,26 @@ class TensorProductScoreModel(nn.Module):
         mark("tor_heads")
         return tr_pred, rot_pred, tor_pred, sc_pred
 
-    def _torsion_graph(self, edge_mlp_name, pos, lay, bonds, bond_batch, B, dev, lay_b=None):
-        """build_bond_conv_graph / build_sidechain_conv_graph (:586-636): everything of a torsion head that depends only on
-        positions - the bond-centre radius graph, its edge embedding and harmonics.  It contains the head's host
-        synchronisations (edge count), so forward() runs it BEFORE the conv layers: after them nothing waits for the host."""
-        lib = L.load()
-        T = bonds.shape[1]
+    def _torsion_search(self, edge_mlp_name, pos, lay, bonds, bond_batch, B, lay_b=None):
+        """First half of build_bond_conv_graph / build_sidechain_conv_graph (:586-636): the bond-centre radius search is
+        counted (its edge count is read by forward() together with the other searches' - one host synchronisation)."""
         bond_pos = ((pos[bonds[0]] + pos[bonds[1]]) / 2).contiguous()
         if lay_b is None:
             lay_b = G.DenseLayout.build(bond_batch, B)
-        ei = G.radius(pos, bond_pos, self.lig_max_radius, lay, lay_b)          # [bond; atom], default cap 32
-        E = ei.shape[1]
+        return {"name": edge_mlp_name, "pos": pos, "bonds": bonds, "bond_pos": bond_pos,
+                "search": G.RadiusSearch(pos, bond_pos, self.lig_max_radius, lay, lay_b)}   # [bond; atom], default cap 32
+
+    def _torsion_finish(self, tg, dev):
+        """Second half: everything of a torsion head that depends only on positions - the edges of the bond-centre graph,
+        their embedding and harmonics, the CSR view.  No host synchronisation: forward() queues it after the conv layers."""
+        lib = L.load()
+        pos, bonds, bond_pos, E = tg["pos"], tg["bonds"], tg["bond_pos"], tg["E"]
+        T = bonds.shape[1]
         if E == 0:
             raise RuntimeError("torsion head has no edges (the reference fails here as well)")
+        ei = tg["search"].fill(E)
         i32 = lambda t: t.to(torch.int32).contiguous()
-        pk = self._edge_pack(edge_mlp_name, slice(0, self.distance_embed_dim), dev)
+        pk = self._edge_pack(tg["name"], slice(0, self.distance_embed_dim), dev)
         pre = pk.b1.reshape(1, -1).contiguous()
         e_t, sh_e = _edge_featurize(pk, self.lig_distance_expansion, bond_pos, i32(ei[0]), pos, i32(ei[1]), pre,
                                     torch.zeros(E, device=dev, dtype=torch.int32))
