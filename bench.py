@@ -32,6 +32,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+HBM_PEAK_GBS = 8000.0           # same guide: HBM3E ~8 TB/s
 
 
 def _load_traffic():
@@ -194,6 +195,16 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     sm.set_conv_profiler(None)
+    # the HBM-bound kernels (stage A, segment reduce) are timed in two extra steps AFTER the timed region: ~45 more event
+    # pairs per step would otherwise sit inside it (measured: +4 % on ms_per_step)
+    prof_hbm = sm.ConvProfiler()
+    prof_hbm.hbm_on = True
+    if rank == 0:
+        sm.set_conv_profiler(prof_hbm)
+        for i in range(2):
+            one_step((args.steps + i) % 20)
+        torch.cuda.synchronize()
+        sm.set_conv_profiler(None)
     if dist is not None:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -214,7 +225,8 @@ def main():
                 n_, fl_, ms_ = prof.summary(kname)
                 ach_ = fl_ / n_ / (ms_ / n_ * 1e-3) / 1e12
                 exe_ = prof.executed_flops(kname) / n_ / (ms_ / n_ * 1e-3) / 1e12
-                return {"kernel": kname, "launches": n_, "avg_launch_ms": ms_ / n_, "achieved": ach_,
+                return {"kernel": kname, "bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TFLOPS,
+                        "frac": ach_ / FP32_MFMA_PEAK_TFLOPS, "launches": n_, "avg_launch_ms": ms_ / n_, "achieved": ach_,
                         "algorithmic_gflop_per_launch": fl_ / n_ / 1e9, "executed_tflops": exe_,
                         "executed_frac": exe_ / FP32_MFMA_PEAK_TFLOPS, "share_of_wall": ms_ * 1e-3 / elapsed,
                         "traffic": (TRAFFIC_BYTES_PER_LAUNCH or {}).get(kname)}
@@ -230,6 +242,16 @@ def main():
                             "executed_tflops of fp32 MFMA work are issued (executed_frac = share of the fp32 MFMA peak)",
                     "conv_share_of_wall": sum(prof.summary(k)[2] for k in kinds) * 1e-3 / elapsed,
                     "other_kernels": [entry(k) for k in kinds[1:]]}
+
+            def hbm_entry(kname):   # HBM-bound kernels of the path: algorithmic bytes / HIP-event time against ~8 TB/s
+                n_, by_, ms_ = prof_hbm.hbm_summary(kname)
+                if n_ == 0:
+                    return None
+                gbs = by_ / (ms_ * 1e-3) / 1e9
+                return {"kernel": kname, "bound": "hbm", "launches": n_, "avg_launch_ms": ms_ / n_, "achieved": gbs, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_mb_per_launch": by_ / n_ / 1e6,
+                        "ms_per_step": ms_ / 2.0, "measured": "2 extra steps after the timed region", "traffic": None}
+            roof["other_kernels"] += [e for e in (hbm_entry("ddp_stage_a_mfma_kernel"), hbm_entry("ddp_segment_reduce_kernel")) if e]
         line = {"metric": "ligand poses/sec (40 samples x 20 steps) on 3dpf", "value": poses / elapsed, "unit": "poses/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -282,6 +282,13 @@ class ConvProfiler:
 
     def __init__(self):
         self.events, self.flops, self.executed, self.kernel = [], [], [], []
+        self.hbm = {}   # HBM-bound kernels: name -> [(event0, event1, algorithmic bytes of the launch)]
+        self.hbm_on = False   # their ~45 extra event pairs per step cost wall time: bench.py times them in extra steps
+
+    def hbm_summary(self, name):
+        """(launches, algorithmic bytes, ms) of an HBM-bound kernel (ddp_stage_a_mfma_kernel, ddp_segment_reduce_kernel)."""
+        rec = self.hbm.get(name, [])
+        return len(rec), float(sum(r[2] for r in rec)), float(sum(r[0].elapsed_time(r[1]) for r in rec))
 
     def summary(self, kernel=None):
         """(launches, algorithmic FLOPs, ms) over all launches or over those of one kernel instantiation
@@ -354,8 +361,17 @@ def _launch_reduce(x, ldx, n_nodes, d_out, sources, accumulate=True):
     for i, (msg, csr, pk) in enumerate(sources):
         arr[i].msg, arr[i].rowptr = msg.data_ptr(), csr.rowptr.data_ptr()
         arr[i].bn_scale, arr[i].bn_shift, arr[i].n_edges = pk.bn_scale.data_ptr(), pk.bn_shift.data_ptr(), csr.n_edges
+    prof = _PROFILER if (_PROFILER is not None and _PROFILER.hbm_on) else None
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     L.check(lib.ddp_segment_reduce(_ptr(x), ldx, n_nodes, d_out, arr, len(sources), 1 if accumulate else 0, _stream()),
             "ddp_segment_reduce")
+    if prof is not None:
+        e1.record()
+        # algorithmic bytes: every message row read once, every node row read and written once
+        ne = sum(csr.n_edges for _, csr, _ in sources)
+        prof.hbm.setdefault("ddp_segment_reduce_kernel", []).append((e0, e1, 4.0 * d_out * (ne + 2 * n_nodes)))
 
 
 class _EdgeMLPPack:
@@ -558,8 +574,17 @@ class TensorProductScoreModel(nn.Module):
         if nb > L.DDP_MAX_GEMM_BATCH:
             raise L.DdpError("more (conv, slot) pairs per source array than DDP_MAX_GEMM_BATCH")
         Gall = torch.empty((nb, N, Wst.shape[2]), device=x_src.device, dtype=torch.float32)   # 128-byte aligned rows
+        prof = _PROFILER if (_PROFILER is not None and _PROFILER.hbm_on) else None
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         L.check(lib.ddp_stage_a(x_src.data_ptr(), x_src.shape[1], N, offs, nb, Wst.data_ptr(), n_in, Wst.shape[2],
                                 Gall.data_ptr(), Wst.shape[2], _stream()), "ddp_stage_a")
+        if prof is not None:
+            e1.record()
+            # algorithmic bytes: the G rows written once + the scalar columns of x read once per product + the weights
+            prof.hbm.setdefault("ddp_stage_a_mfma_kernel", []).append(
+                (e0, e1, 4.0 * (Gall.numel() + nb * N * n_in + Wst.numel())))
         return {(k, slot): Gall[i] for i, (k, slot, _) in enumerate(meta)}
 
     def _shared_receptor_side(self, B, rec, atom, rpos, apos, lay_r, lay_a, rr, ar, aa):
