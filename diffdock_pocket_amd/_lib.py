@@ -18,7 +18,7 @@ FS = 68  # feature-buffer row stride of ddp_conv.hip
 
 DDP_MAX_GEMM_BATCH = 16
 EXPORTS = ["ddp_conv_messages", "ddp_segment_reduce", "ddp_edge_featurize", "ddp_torsion_sh", "ddp_stage_a",
-           "ddp_pose_update", "ddp_sidechain_update", "ddp_radius_count", "ddp_radius_fill", "ddp_knn", "ddp_abi_version", "ddp_last_error"]
+           "ddp_pose_update", "ddp_sidechain_update", "ddp_radius_count", "ddp_radius_fill", "ddp_knn", "ddp_group_by_key", "ddp_abi_version", "ddp_last_error"]
 
 
 class Seg(C.Structure):
@@ -105,7 +105,9 @@ def load():
     lib.ddp_radius_fill.restype = C.c_int
     lib.ddp_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.ddp_knn.restype = C.c_int
-    if lib.ddp_abi_version() != 3:
+    lib.ddp_group_by_key.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 11
+    lib.ddp_group_by_key.restype = C.c_int
+    if lib.ddp_abi_version() != 4:
         raise DdpError("libddp_hip.so ABI version mismatch")
     _lib = lib
     return lib

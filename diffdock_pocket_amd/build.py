@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SOURCES = ["ddp_conv.hip", "ddp_misc.hip", "ddp_gemm.hip", "ddp_pose.hip", "ddp_graph.hip", "ddp_capi.hip"]
+SOURCES = ["ddp_conv.hip", "ddp_misc.hip", "ddp_gemm.hip", "ddp_pose.hip", "ddp_graph.hip", "ddp_views.hip", "ddp_capi.hip"]
 OUT = os.path.join(HERE, "libddp_hip.so")
 
 

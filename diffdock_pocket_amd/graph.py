@@ -119,6 +119,7 @@ class RadiusSearch:
             L.check(lib.ddp_radius_fill(xc.data_ptr(), xptr.data_ptr(), yc.data_ptr(), ybatch.data_ptr(), yc.shape[0], r, cap, ds,
                                         self.offs.data_ptr(), oq.data_ptr(), ox.data_ptr(),
                                         torch.cuda.current_stream().cuda_stream), "ddp_radius_fill")
+        self.row32 = (ox, oq) if self.flip else (oq, ox)     # int32 rows of the returned edge_index
         return torch.stack([ox.long(), oq.long()] if self.flip else [oq.long(), ox.long()], 0)
 
 
@@ -213,19 +214,52 @@ class CSR:
     rowptr: torch.Tensor   # int32 [n_recv + 1]
 
 
+def _group_by_key(key32, n_keys, pays, want_key=True, want_perm=True):
+    """csrc/ddp_views.hip (ddp_group_by_key): stable grouping of int32 items on the device, see include/ddp_hip.h."""
+    from . import _lib as L
+    lib = L.load()
+    E, dev = int(key32.shape[0]), key32.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    rowptr = torch.empty(n_keys + 1, **i32)
+    scratch = torch.empty(n_keys + E, **i32)
+    perm = torch.empty(E, **i32) if want_perm else None
+    out_key = torch.empty(E, **i32) if (want_perm and want_key) else None
+    outs = [torch.empty(E, **i32) if want_perm else None for _ in pays]
+    ptr = lambda t: t.data_ptr() if t is not None else None          # noqa: E731
+    pp = [ptr(p) for p in pays] + [None] * (3 - len(pays))
+    oo = [ptr(o) for o in outs] + [None] * (3 - len(outs))
+    L.check(lib.ddp_group_by_key(key32.data_ptr(), E, n_keys, pp[0], pp[1], pp[2], rowptr.data_ptr(), ptr(perm), ptr(out_key),
+                                 oo[0], oo[1], oo[2], scratch.data_ptr(), torch.cuda.current_stream().cuda_stream),
+            "ddp_group_by_key")
+    return rowptr, perm, out_key, outs
+
+
+def _as_i32(t):
+    return t if t.dtype == torch.int32 else t.to(torch.int32)
+
+
 def build_csr(recv: torch.Tensor, src: torch.Tensor, n_recv: int, presorted: bool = False) -> CSR:
+    """recv / src: int64 or int32 [E].  On the device this is ONE ddp_group_by_key call (5 launches); the PyTorch form below
+    is its definition (CPU tests; tests/test_gpu_parity.py compares the two bit for bit)."""
     E = int(recv.shape[0])
     dev = recv.device
     if E == 0:
         z = torch.zeros(0, dtype=torch.int32, device=dev)
         return CSR(0, z, z, z, torch.zeros(n_recv + 1, dtype=torch.int32, device=dev))
+    if recv.is_cuda:
+        r32, s32 = _as_i32(recv).contiguous(), _as_i32(src).contiguous()
+        if presorted:
+            rowptr, _, _, _ = _group_by_key(r32, n_recv, [], want_perm=False)
+            return CSR(E, r32, s32, torch.arange(E, dtype=torch.int32, device=dev), rowptr)
+        rowptr, perm, r_sorted, (s_sorted,) = _group_by_key(r32, n_recv, [s32])
+        return CSR(E, r_sorted, s_sorted, perm, rowptr)
     if presorted:
         perm = torch.arange(E, device=dev)
         r_sorted = recv
     else:
         r_sorted, perm = torch.sort(recv, stable=True)
     # (torch.bincount synchronises with the host to size its output; the node count is known here)
-    counts = torch.zeros(n_recv, dtype=torch.int64, device=dev).index_add_(0, r_sorted, torch.ones_like(r_sorted))
+    counts = torch.zeros(n_recv, dtype=torch.int64, device=dev).index_add_(0, r_sorted.long(), torch.ones_like(r_sorted, dtype=torch.int64))
     rowptr = torch.zeros(n_recv + 1, dtype=torch.int32, device=dev)
     rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
     return CSR(E, r_sorted.to(torch.int32), src[perm].to(torch.int32), perm.to(torch.int32), rowptr)
@@ -242,9 +276,14 @@ class SourceOrder:
     pos: torch.Tensor
 
 
-def source_order(csr: CSR) -> SourceOrder:
+def source_order(csr: CSR, n_src: Optional[int] = None) -> SourceOrder:
+    """n_src (number of source nodes, an upper bound of csr.src + 1) selects the device grouping kernel; without it the
+    PyTorch stable sort is used (same result)."""
     if csr.n_edges == 0:
         return SourceOrder(0, csr.recv, csr.src, csr.eid, csr.eid)
+    if csr.src.is_cuda and n_src is not None:
+        _, pos, src_sorted, (recv_s, eid_s) = _group_by_key(csr.src.contiguous(), int(n_src), [csr.recv.contiguous(), csr.eid.contiguous()])
+        return SourceOrder(csr.n_edges, recv_s, src_sorted, eid_s, pos)
     _, order = torch.sort(csr.src.long(), stable=True)
     return SourceOrder(csr.n_edges, csr.recv[order].contiguous(), csr.src[order].contiguous(),
                        csr.eid[order].contiguous(), order.to(torch.int32).contiguous())

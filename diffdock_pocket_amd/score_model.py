@@ -229,7 +229,7 @@ class TensorProductConvLayer(nn.Module):
             if self.spec_g is None:
                 raise NotImplementedError("this conv has no factorised variant")
             pk = self.packed_g(dev)
-            so = G.source_order(csr)
+            so = G.source_order(csr, x.shape[0])
             g = self.node_tensors(pk, x)
             task = _make_task(pk, x, x.shape[1], so, sh, [(ea, so.eid, ea.shape[1], ea.shape[1])], msg, g=g, pos=so.pos)
             _launch_convs(self.spec_g, [task], flops_spec=self.spec)
@@ -783,6 +783,7 @@ class TensorProductScoreModel(nn.Module):
         ll = torch.cat([bond_ei, s_ll.fill(counts[0])], 1)
         lr = s_lr.fill(counts[1])
         la = s_la.fill(counts[2])
+        ll32, lr32, la32 = (i32(ll[0]), i32(ll[1])), s_lr.row32, s_la.row32    # int32 rows for the kernels
         ar = data["atom", "receptor"].edge_index.long()
         self.last_stats = {"E_ll": ll.shape[1], "E_rr": rr.shape[1], "E_aa": aa.shape[1], "E_lr": lr.shape[1],
                            "E_la": la.shape[1], "E_ar": ar.shape[1], "N_l": Nl, "N_r": Nr, "N_a": Na, "B": B}
@@ -821,7 +822,7 @@ class TensorProductScoreModel(nn.Module):
         pre_ll = pre_node[ll[0]]
         nb = bond_ei.shape[1]
         pre_ll[:nb] += data["ligand", "ligand"].edge_attr.float() @ pk.W1[:, :nf].t()
-        e_ll, sh_ll = _edge_featurize(pk, self.lig_distance_expansion, lpos, i32(ll[0]), lpos, i32(ll[1]), pre_ll,
+        e_ll, sh_ll = _edge_featurize(pk, self.lig_distance_expansion, lpos, ll32[0], lpos, ll32[1], pre_ll,
                                       torch.arange(ll.shape[1], device=dev, dtype=torch.int32))
         pk = self._edge_pack("rec_edge_embedding", slice(sd_, sd_ + dd), dev)
         e_rr, sh_rr = _edge_featurize(pk, self.rec_distance_expansion, rpos, i32(rr_f[0]), rpos, i32(rr_f[1]),
@@ -830,20 +831,20 @@ class TensorProductScoreModel(nn.Module):
         e_aa, sh_aa = _edge_featurize(pk, self.lig_distance_expansion, apos, i32(aa_f[0]), apos, i32(aa_f[1]),
                                       sigma_pre(pk, atom.node_sigma_emb, slice(0, sd_)), i32(aa_f[0]))
         pk = self._edge_pack("lr_edge_embedding", slice(sd_, sd_ + cd), dev)
-        e_lr, sh_lr = _edge_featurize(pk, self.cross_distance_expansion, lpos, i32(lr[0]), rpos, i32(lr[1]),
-                                      sigma_pre(pk, lig.node_sigma_emb, slice(0, sd_)), i32(lr[0]))
+        e_lr, sh_lr = _edge_featurize(pk, self.cross_distance_expansion, lpos, lr32[0], rpos, lr32[1],
+                                      sigma_pre(pk, lig.node_sigma_emb, slice(0, sd_)), lr32[0])
         pk = self._edge_pack("la_edge_embedding", slice(sd_, sd_ + cd), dev)
-        e_la, sh_la = _edge_featurize(pk, self.cross_distance_expansion, lpos, i32(la[0]), apos, i32(la[1]),
-                                      sigma_pre(pk, lig.node_sigma_emb, slice(0, sd_)), i32(la[0]))
+        e_la, sh_la = _edge_featurize(pk, self.cross_distance_expansion, lpos, la32[0], apos, la32[1],
+                                      sigma_pre(pk, lig.node_sigma_emb, slice(0, sd_)), la32[0])
         pk = self._edge_pack("ar_edge_embedding", slice(sd_, sd_ + dd), dev)
         e_ar, sh_ar = _edge_featurize(pk, self.rec_distance_expansion, apos, i32(ar_f[0]), rpos, i32(ar_f[1]),
                                       sigma_pre(pk, atom.node_sigma_emb, slice(0, sd_)), i32(ar_f[0]))
 
         mark("edge_featurize")
         # ---- CSR per conv direction (receiver = edge_index[0] of the conv call)
-        c_ll = G.build_csr(ll[0], ll[1], Nl)
-        c_lr = G.build_csr(lr[0], lr[1], Nl, presorted=True)
-        c_la = G.build_csr(la[0], la[1], Nl, presorted=True)
+        c_ll = G.build_csr(ll32[0], ll32[1], Nl)
+        c_lr = G.build_csr(lr32[0], lr32[1], Nl, presorted=True)
+        c_la = G.build_csr(la32[0], la32[1], Nl, presorted=True)
         def static_csr(name, k, ei, recv, src, n):
             """CSR view of a step-independent edge set, kept across calls; edge ids modulo the per-graph edge count when
             the edge embeddings exist for graph 0 only."""
@@ -857,10 +858,10 @@ class TensorProductScoreModel(nn.Module):
             return self._cached(name, (ei,), lambda: G.build_csr(recv, src, n))
 
         c_aa = static_csr("c_aa", 3, aa, aa[0], aa[1], Na)
-        c_al = G.build_csr(la[1], la[0], Na)
+        c_al = G.build_csr(la32[1], la32[0], Na)
         c_ar = static_csr("c_ar", 5, ar, ar[0], ar[1], Na)
         c_rr = static_csr("c_rr", 6, rr, rr[0], rr[1], Nr)
-        c_rl = G.build_csr(lr[1], lr[0], Nr)
+        c_rl = G.build_csr(lr32[1], lr32[0], Nr)
         c_ra = static_csr("c_ra", 8, ar, ar[1], ar[0], Nr)
 
         # conv k of a layer: (csr, receiver x, source x, edge_base, sh, receiver type)
@@ -879,12 +880,12 @@ class TensorProductScoreModel(nn.Module):
         if self.factorize_min_degree > 0:
             for k, csr, *_ in plan:
                 if csr.n_edges > 0 and csr.n_edges >= self.factorize_min_degree * n_src_nodes[src_type[k]]:
-                    so_views[k] = self._cached(f"so_{k}", (csr.src, csr.eid), lambda: G.source_order(csr)) if k in (3, 5, 6, 8) \
-                        else G.source_order(csr)
+                    so_views[k] = self._cached(f"so_{k}", (csr.src, csr.eid), lambda: G.source_order(csr, n_src_nodes[src_type[k]])) if k in (3, 5, 6, 8) \
+                        else G.source_order(csr, n_src_nodes[src_type[k]])
                 elif k == 2 and csr.n_edges > 0:
                     # ligand<-atom: few edges per atom over ALL atoms, but the edges leave only the atoms around the ligand.
                     # Degree over the atoms that occur: factorise with stage A on those rows only (compact copy of x per layer)
-                    so_c = G.source_order(csr)
+                    so_c = G.source_order(csr, Na)
                     uniq, inv = torch.unique_consecutive(so_c.src.long(), return_inverse=True)
                     if csr.n_edges >= self.factorize_min_degree * uniq.shape[0]:
                         so_views[k] = G.SourceOrder(so_c.n_edges, so_c.recv, inv.to(torch.int32), so_c.eid, so_c.pos)
@@ -954,7 +955,7 @@ class TensorProductScoreModel(nn.Module):
             for l, pl in pruned.items():
                 for k, c in pl.items():
                     if k in so_views and c.n_edges > 0:
-                        so_p, uniq = G.source_order(c), None
+                        so_p, uniq = G.source_order(c, n_src_nodes[src_type[k]]), None
                         if c.n_edges * 2 < plan[k][1].n_edges:
                             uniq, inv = torch.unique_consecutive(so_p.src.long(), return_inverse=True)
                             so_p = G.SourceOrder(so_p.n_edges, so_p.recv, inv.to(torch.int32), so_p.eid, so_p.pos)
@@ -1149,17 +1150,17 @@ class TensorProductScoreModel(nn.Module):
         T = bonds.shape[1]
         if E == 0:
             raise RuntimeError("torsion head has no edges (the reference fails here as well)")
-        ei = tg["search"].fill(E)
-        i32 = lambda t: t.to(torch.int32).contiguous()
+        tg["search"].fill(E)
+        r32 = tg["search"].row32            # [bond; atom] int32
         pk = self._edge_pack(tg["name"], slice(0, self.distance_embed_dim), dev)
         pre = pk.b1.reshape(1, -1).contiguous()
-        e_t, sh_e = _edge_featurize(pk, self.lig_distance_expansion, bond_pos, i32(ei[0]), pos, i32(ei[1]), pre,
+        e_t, sh_e = _edge_featurize(pk, self.lig_distance_expansion, bond_pos, r32[0], pos, r32[1], pre,
                                     torch.zeros(E, device=dev, dtype=torch.int32))
         bond_vec = (pos[bonds[1]] - pos[bonds[0]]).contiguous()
         tor_sh = torch.empty((E, 4), device=dev)
-        bond_of_edge = i32(ei[0])
+        bond_of_edge = r32[0]
         L.check(lib.ddp_torsion_sh(_ptr(sh_e), _ptr(bond_vec), _ptr(bond_of_edge), E, _ptr(tor_sh), _stream()), "ddp_torsion_sh")
-        csr = G.build_csr(ei[0], ei[1], T, presorted=True)
+        csr = G.build_csr(r32[0], r32[1], T, presorted=True)
         return {"bonds": bonds, "T": T, "E": E, "e_t": e_t, "tor_sh": tor_sh, "csr": csr}
 
     def _torsion_apply(self, conv: TensorProductConvLayer, final_layer, tg, x, dev):

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DDP_ABI_VERSION 3
+#define DDP_ABI_VERSION 4
 #define DDP_EINVAL (-1)   /* bad argument (shape not supported, null pointer, ...) */
 #define DDP_ELIMIT (-2)   /* exceeds a compiled-in limit (see DDP_MAX_*) */
 
@@ -193,6 +193,20 @@ int ddp_radius_count(const float* x, const int32_t* x_ptr, const float* y, const
 int ddp_radius_fill(const float* x, const int32_t* x_ptr, const float* y, const int32_t* y_batch, int ny, float r,
                     int max_neighbors, int drop_self, const int32_t* offsets, int32_t* out_query, int32_t* out_x, void* stream);
 int ddp_knn(const float* x, const int32_t* x_ptr, const int32_t* batch, int n, int k, int32_t* out_neighbors, void* stream);
+
+/* ---- CSR / source-order views of an edge list (csrc/ddp_views.hip).  Replaces, per view, the torch.sort(stable) + index_add +
+ * cumsum + gathers of the host-side graph code that stands for the reference's per-conv `edge_index` handling
+ * (models/score_model.py:115-117: messages are gathered by edge_index[1] and mean-reduced over edge_index[0]).
+ * Stable grouping of n_items items by key[i] in [0, n_keys):
+ *   rowptr[n_keys + 1]   items of key k occupy positions rowptr[k] .. rowptr[k+1] of the outputs
+ *   perm[n_items]        original index of the item at each position (ascending inside a key = stable sort)
+ *   out_key / out0..2    key / payload pay0..2 of the item at each position (each optional: NULL skips it)
+ *   scratch              n_keys + n_items int32 of workspace
+ * perm == NULL: only rowptr is produced (the items are already grouped).
+ * Results do not depend on the order in which the atomics inside land (bitwise deterministic). */
+int ddp_group_by_key(const int32_t* key, int n_items, int n_keys, const int32_t* pay0, const int32_t* pay1, const int32_t* pay2,
+                     int32_t* rowptr, int32_t* perm, int32_t* out_key, int32_t* out0, int32_t* out1, int32_t* out2,
+                     int32_t* scratch, void* stream);
 
 int ddp_abi_version(void);
 const char* ddp_last_error(void);

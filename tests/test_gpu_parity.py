@@ -426,3 +426,32 @@ def test_forward_on_graph_from_the_input_pipeline():
     for a, w, k in zip(got, want, ("tr", "rot", "tor", "sc_tor")):
         assert a.shape == w.shape and w.numel() > 0, k
         assert rel_err(a.float().cpu(), w) < TOL, (k, rel_err(a.float().cpu(), w))
+
+
+@pytest.mark.parametrize("E,n_recv,n_src", [(0, 7, 5), (1, 1, 1), (5000, 300, 40), (40000, 45000, 1500), (93000, 5600, 1480)])
+def test_group_by_key_views_match_the_pytorch_definition(E, n_recv, n_src):
+    """ddp_group_by_key (CSR and source-order views on the device) against graph.py's PyTorch stable-sort definition, bit
+    for bit: ragged rows, empty rows, long rows (every item on one key), presorted input, empty edge set."""
+    from diffdock_pocket_amd import graph as G
+    dev = _dev()
+    gen = torch.Generator().manual_seed(E + n_recv)
+    recv = torch.randint(0, n_recv, (E,), generator=gen)
+    src = torch.randint(0, n_src, (E,), generator=gen)
+    if E >= 5000:
+        recv[: E // 50] = n_recv // 2          # one long row (its items must come out in edge order)
+    for presorted in (False, True):
+        r = torch.sort(recv).values if presorted else recv
+        want = G.build_csr(r, src, n_recv, presorted=presorted)
+        got = G.build_csr(r.to(dev), src.to(dev), n_recv, presorted=presorted)
+        got32 = G.build_csr(r.to(dev).to(torch.int32), src.to(dev).to(torch.int32), n_recv, presorted=presorted)
+        for g in (got, got32):
+            assert g.n_edges == want.n_edges
+            for f in ("recv", "src", "eid", "rowptr"):
+                a, b = getattr(g, f), getattr(want, f)
+                assert a.dtype == torch.int32 and torch.equal(a.cpu(), b), (f, presorted)
+        so_want = G.source_order(want)
+        so_got = G.source_order(got, n_src)
+        for f in ("recv", "src", "eid", "pos"):
+            assert torch.equal(getattr(so_got, f).cpu(), getattr(so_want, f)), (f, presorted)
+    again = G.source_order(G.build_csr(recv.to(dev), src.to(dev), n_recv), n_src)
+    assert torch.equal(again.pos, G.source_order(G.build_csr(recv.to(dev), src.to(dev), n_recv), n_src).pos)

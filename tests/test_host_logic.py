@@ -238,7 +238,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.ddp_abi_version.restype = ctypes.c_int
-    assert lib.ddp_abi_version() == 3
+    assert lib.ddp_abi_version() == 4
     assert ctypes.sizeof(L.ConvShape) == 11 * 4 + 4 * (11 * 4 + 3 * 12)
 
 
