@@ -165,6 +165,110 @@ __global__ __launch_bounds__(256) void ddp_edge_featurize_kernel(
   }
 }
 
+// MFMA form of the same op for k_rbf in {8, 16, .., 64}: a wave owns 32 edges; both Linears run on v_mfma_f32_32x32x2_f32
+// (exact fp32 FMA chains) with the packed weights in LDS:  lane (r = lane & 31, hh = lane >> 5) feeds A[r][8m + 4hh + i] -
+// for the first layer the Gaussian of edge r evaluated on the fly (each half-wave evaluates half of the k's of an edge, no
+// exp is computed twice) - and B[8m + 4hh + i][32 ct + r]; C/D register i <-> edge row (i&3) + 8(i>>2) + 4hh, column r.
+// The first layer's accumulators start from the `pre` rows (sigma / bond-type part of the Linear + bias), relu(hidden)
+// goes through LDS once to turn the C/D layout into the A layout of the second layer.
+typedef float ef_f32x16 __attribute__((ext_vector_type(16)));
+#define EF_HS 68   // LDS row stride of the hidden tile
+__global__ __launch_bounds__(256) void ddp_edge_featurize_mfma_kernel(
+    const float* __restrict__ pos_a, const int* __restrict__ ia, const float* __restrict__ pos_b,
+    const int* __restrict__ ib, int n_edges, const float* __restrict__ offset, int k_rbf, float coeff,
+    const float* __restrict__ pre, const int* __restrict__ pre_idx, int ld_pre, const float* __restrict__ w1d,
+    const float* __restrict__ w2, const float* __restrict__ b2, int ns, float* __restrict__ out,
+    float* __restrict__ sh) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_w1 = smem;                         // packed [k_rbf/8][2 hh][64 cols][4]
+  float* s_w2 = s_w1 + k_rbf * EF_NS;         // packed [8][2][64][4]
+  float* s_b2 = s_w2 + EF_NS * EF_NS;         // [64]
+  float* s_off = s_b2 + EF_NS;                // [k_rbf]
+  float* s_h = s_off + 64;                    // [4 waves][32][EF_HS]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < k_rbf * EF_NS; i += 256) {
+    const int k = i / EF_NS, c = i - k * EF_NS;
+    s_w1[(((k >> 3) * 2 + ((k >> 2) & 1)) * EF_NS + c) * 4 + (k & 3)] = w1d[i];
+  }
+  for (int i = tid; i < EF_NS * EF_NS; i += 256) {
+    const int k = i / EF_NS, c = i - k * EF_NS;
+    s_w2[(((k >> 3) * 2 + ((k >> 2) & 1)) * EF_NS + c) * 4 + (k & 3)] = w2[i];
+  }
+  if (tid < EF_NS) s_b2[tid] = b2[tid];
+  for (int i = tid; i < k_rbf; i += 256) s_off[i] = offset[i];
+  __syncthreads();
+
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  float* my_h = s_h + wave * 32 * EF_HS;
+  const f32x4* w1q = reinterpret_cast<const f32x4*>(s_w1);
+  const f32x4* w2q = reinterpret_cast<const f32x4*>(s_w2);
+  const int nm1 = k_rbf >> 3;
+  for (int base = (blockIdx.x * 4 + wave) * 32; base < n_edges; base += gridDim.x * 128) {
+    const int e = base + r;
+    const int ec = min(e, n_edges - 1);
+    const int a = ia[ec], b = ib[ec];
+    const float vx = pos_b[3 * b] - pos_a[3 * a], vy = pos_b[3 * b + 1] - pos_a[3 * a + 1],
+                vz = pos_b[3 * b + 2] - pos_a[3 * a + 2];
+    const float d = sqrtf(vx * vx + vy * vy + vz * vz);
+    if (hh == 0 && e < n_edges) {
+      const float inv = 1.7320508075688772f / fmaxf(d, 1e-12f);  // sqrt(3) / max(|v|, eps)  (F.normalize eps)
+      reinterpret_cast<f32x4*>(sh)[e] = f32x4{1.0f, vx * inv, vy * inv, vz * inv};
+    }
+    // first layer: accumulators start from the pre rows of the 16 edge rows this lane holds in the C/D layout
+    ef_f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+      const float* prow = pre + (size_t)pre_idx[min(base + row, n_edges - 1)] * ld_pre;
+      acc0[i] = (r < ns) ? prow[r] : 0.f;
+      acc1[i] = (32 + r < ns) ? prow[32 + r] : 0.f;
+    }
+    for (int m = 0; m < nm1; ++m) {
+      const f32x4 b0 = w1q[(m * 2 + hh) * EF_NS + r], b1 = w1q[(m * 2 + hh) * EF_NS + 32 + r];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float t = d - s_off[8 * m + 4 * hh + i];
+        const float rb = expf(coeff * (t * t));
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(rb, b0[i], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(rb, b1[i], acc1, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+      my_h[row * EF_HS + r] = fmaxf(acc0[i], 0.f);
+      my_h[row * EF_HS + 32 + r] = fmaxf(acc1[i], 0.f);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the tile is complete before it is read back in the A layout
+    {
+      const float bb0 = s_b2[r], bb1 = s_b2[32 + r];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { acc0[i] = bb0; acc1[i] = bb1; }
+    }
+    const float* hrow = my_h + r * EF_HS + 4 * hh;
+#pragma unroll
+    for (int m = 0; m < EF_NS / 8; ++m) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(hrow + 8 * m);
+      const f32x4 b0 = w2q[(m * 2 + hh) * EF_NS + r], b1 = w2q[(m * 2 + hh) * EF_NS + 32 + r];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b0[i], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b1[i], acc1, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+      if (base + row < n_edges) {
+        if (r < ns) out[(size_t)(base + row) * ns + r] = acc0[i];
+        if (32 + r < ns) out[(size_t)(base + row) * ns + 32 + r] = acc1[i];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // my_h is rewritten by the next tile
+  }
+}
+
 extern "C" int ddp_edge_featurize(const float* pos_a, const int32_t* ia, const float* pos_b, const int32_t* ib,
                                   int n_edges, const float* offset, int k_rbf, float coeff, const float* pre,
                                   const int32_t* pre_idx, int ld_pre, const float* w1d, const float* w2, const float* b2,
@@ -174,6 +278,19 @@ extern "C" int ddp_edge_featurize(const float* pos_a, const int32_t* ia, const f
     return ddp_fail(DDP_EINVAL, "ddp_edge_featurize: null argument");
   if (ns < 1 || ns > EF_NS) return ddp_fail(DDP_ELIMIT, "ddp_edge_featurize: ns > 64");
   if (k_rbf < 2 || k_rbf > 256) return ddp_fail(DDP_ELIMIT, "ddp_edge_featurize: k_rbf");
+  if ((k_rbf & 7) == 0 && k_rbf <= 64) {   // both Linears on the matrix cores
+    const size_t lds_m = (size_t)(k_rbf * EF_NS + EF_NS * EF_NS + EF_NS + 64 + 4 * 32 * EF_HS) * sizeof(float);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(ddp_edge_featurize_mfma_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+    if (e2 != hipSuccess) return ddp_fail_hip(e2, "hipFuncSetAttribute(edge_featurize_mfma)");
+    int blocks_m = (n_edges + 127) / 128;
+    if (blocks_m > 1024) blocks_m = 1024;
+    hipLaunchKernelGGL(ddp_edge_featurize_mfma_kernel, dim3(blocks_m), dim3(256), lds_m, (hipStream_t)stream, pos_a, ia, pos_b,
+                       ib, n_edges, offset, k_rbf, coeff, pre, pre_idx, ld_pre, w1d, w2, b2, ns, out, sh);
+    e2 = hipGetLastError();
+    if (e2 != hipSuccess) return ddp_fail_hip(e2, "ddp_edge_featurize (mfma) launch");
+    return 0;
+  }
   const size_t lds = (size_t)(k_rbf * EF_NS + EF_NS * EF_NS + EF_NS + ((k_rbf + 3) & ~3) + 4 * 64 * 65) * sizeof(float);
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(ddp_edge_featurize_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

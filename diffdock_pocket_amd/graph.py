@@ -123,11 +123,14 @@ class RadiusSearch:
         return torch.stack([ox.long(), oq.long()] if self.flip else [oq.long(), ox.long()], 0)
 
 
-def resolve(searches):
-    """Edge counts of several RadiusSearch objects with one device-to-host copy (the only host synchronisation of them)."""
-    if not searches:
+def resolve(searches, extra=()):
+    """Edge counts of several RadiusSearch objects - and the values of `extra` 0-dim device tensors the caller wants on the
+    host at the same time - with ONE device-to-host copy (the only host synchronisation of the searches).
+    Returns the counts as ints followed by the extra values as ints."""
+    items = [s.offs[-1] for s in searches] + [e.to(torch.int32) for e in extra]
+    if not items:
         return []
-    return [int(v) for v in torch.stack([s.offs[-1] for s in searches]).tolist()]
+    return [int(v) for v in torch.stack(items).tolist()]
 
 
 def _batch32(layout: "DenseLayout", n: int) -> torch.Tensor:

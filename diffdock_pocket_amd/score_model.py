@@ -777,9 +777,15 @@ class TensorProductScoreModel(nn.Module):
                 bonds_s = lay_a.starts[fr.batch.long()] + fr.edge_idx.t().long()     # get_sc_tor_bonds (:638-652)
                 pend_sc = self._torsion_search("sidechain_final_edge_embedding", apos, lay_a, bonds_s, fr.batch.long(), B)
         pending = [p for p in (pend_tor, pend_sc) if p is not None]
-        counts = G.resolve([s_ll, s_lr, s_la] + [p["search"] for p in pending])
+        # (the "all receptor-side nodes at one diffusion time" flag of the layer-0 sharing below rides in the same copy)
+        flags = []
+        if self.share_layer0 and B > 1:
+            t_nodes = torch.cat([rec.node_t["tr"], atom.node_t["tr"]])
+            flags.append((t_nodes == t_nodes[0]).all())
+        counts = G.resolve([s_ll, s_lr, s_la] + [p["search"] for p in pending], extra=flags)
         for p, e in zip(pending, counts[3:]):
             p["E"] = e
+        one_time = bool(flags) and bool(counts[-1])
         ll = torch.cat([bond_ei, s_ll.fill(counts[0])], 1)
         lr = s_lr.fill(counts[1])
         la = s_la.fill(counts[2])
@@ -797,17 +803,22 @@ class TensorProductScoreModel(nn.Module):
         #    source-ordered edge lists - and the resulting node update is added to every graph.
         # Any difference between the graphs -> the general path.
         shared0 = {}
-        if self.share_layer0 and B > 1:
-            t_nodes = torch.cat([rec.node_t["tr"], atom.node_t["tr"]])
-            if bool((t_nodes == t_nodes[0]).all()):
-                sh_ = self._cached("shared0", (rec.x, rpos, atom.x, apos, rr, ar, aa),
-                                   lambda: self._shared_receptor_side(B, rec, atom, rpos, apos, lay_r, lay_a, rr, ar, aa))
-                shared0 = {k: v for k, v in sh_.items() if v is not None}
+        if one_time:
+            sh_ = self._cached("shared0", (rec.x, rpos, atom.x, apos, rr, ar, aa),
+                               lambda: self._shared_receptor_side(B, rec, atom, rpos, apos, lay_r, lay_a, rr, ar, aa))
+            shared0 = {k: v for k, v in sh_.items() if v is not None}
 
         def graph0(k, ei):   # canonical edges of graph 0 (a prefix: edge lists are graph-major) when conv k is shared
             return ei[:, :shared0[k][1]] if k in shared0 else ei
 
         rr_f, aa_f, ar_f = graph0(6, rr), graph0(3, aa), graph0(5, ar)
+
+        def rows32(name, ei, ei_f):   # int32 rows of a step-independent edge set (kept across calls), cut like ei_f
+            r0, r1 = self._cached(name, (ei,), lambda: (i32(ei[0]), i32(ei[1])))
+            n = ei_f.shape[1]
+            return r0[:n], r1[:n]
+
+        rr32, aa32, ar32 = rows32("rr32", rr, rr_f), rows32("aa32", aa, aa_f), rows32("ar32", ar, ar_f)
 
         mark("graphs")
         # ---- edge featurisation: per-node / per-edge `pre` tables hold the non-RBF part of the first Linear
@@ -825,11 +836,11 @@ class TensorProductScoreModel(nn.Module):
         e_ll, sh_ll = _edge_featurize(pk, self.lig_distance_expansion, lpos, ll32[0], lpos, ll32[1], pre_ll,
                                       torch.arange(ll.shape[1], device=dev, dtype=torch.int32))
         pk = self._edge_pack("rec_edge_embedding", slice(sd_, sd_ + dd), dev)
-        e_rr, sh_rr = _edge_featurize(pk, self.rec_distance_expansion, rpos, i32(rr_f[0]), rpos, i32(rr_f[1]),
-                                      sigma_pre(pk, rec.node_sigma_emb, slice(0, sd_)), i32(rr_f[0]))
+        e_rr, sh_rr = _edge_featurize(pk, self.rec_distance_expansion, rpos, rr32[0], rpos, rr32[1],
+                                      sigma_pre(pk, rec.node_sigma_emb, slice(0, sd_)), rr32[0])
         pk = self._edge_pack("atom_edge_embedding", slice(sd_, sd_ + dd), dev)
-        e_aa, sh_aa = _edge_featurize(pk, self.lig_distance_expansion, apos, i32(aa_f[0]), apos, i32(aa_f[1]),
-                                      sigma_pre(pk, atom.node_sigma_emb, slice(0, sd_)), i32(aa_f[0]))
+        e_aa, sh_aa = _edge_featurize(pk, self.lig_distance_expansion, apos, aa32[0], apos, aa32[1],
+                                      sigma_pre(pk, atom.node_sigma_emb, slice(0, sd_)), aa32[0])
         pk = self._edge_pack("lr_edge_embedding", slice(sd_, sd_ + cd), dev)
         e_lr, sh_lr = _edge_featurize(pk, self.cross_distance_expansion, lpos, lr32[0], rpos, lr32[1],
                                       sigma_pre(pk, lig.node_sigma_emb, slice(0, sd_)), lr32[0])
@@ -837,8 +848,8 @@ class TensorProductScoreModel(nn.Module):
         e_la, sh_la = _edge_featurize(pk, self.cross_distance_expansion, lpos, la32[0], apos, la32[1],
                                       sigma_pre(pk, lig.node_sigma_emb, slice(0, sd_)), la32[0])
         pk = self._edge_pack("ar_edge_embedding", slice(sd_, sd_ + dd), dev)
-        e_ar, sh_ar = _edge_featurize(pk, self.rec_distance_expansion, apos, i32(ar_f[0]), rpos, i32(ar_f[1]),
-                                      sigma_pre(pk, atom.node_sigma_emb, slice(0, sd_)), i32(ar_f[0]))
+        e_ar, sh_ar = _edge_featurize(pk, self.rec_distance_expansion, apos, ar32[0], rpos, ar32[1],
+                                      sigma_pre(pk, atom.node_sigma_emb, slice(0, sd_)), ar32[0])
 
         mark("edge_featurize")
         # ---- CSR per conv direction (receiver = edge_index[0] of the conv call)
