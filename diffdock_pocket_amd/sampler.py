@@ -224,7 +224,13 @@ class Sampler:
 
         def z(shape):  # drawn for all samples of the job, sliced to this shard
             full = torch.zeros(shape) if noise_off else torch.randn(shape, generator=self.gen)
-            return full[sl].to(dev)
+            part = full[sl]
+            if torch.device(dev).type == "cuda":
+                # pinned staging + asynchronous copy: a copy from pageable memory makes the host wait until the stream has
+                # drained, i.e. for the previous step's conv layers - and everything the host could have queued behind them
+                # (time tensors, node encoders, the neighbour-search count passes) would start late
+                return part.contiguous().pin_memory().to(dev, non_blocking=True)
+            return part.to(dev)
 
         # the step's noise does not depend on the scores: drawn (same generator order as the reference loop: tr, rot, tor,
         # side chains) and uploaded before the model call, so that nothing between the model and the pose update waits
