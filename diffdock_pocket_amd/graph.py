@@ -237,6 +237,17 @@ def _group_by_key(key32, n_keys, pays, want_key=True, want_perm=True):
     return rowptr, perm, out_key, outs
 
 
+_IOTA = {}
+
+
+def iota32(n: int, dev) -> torch.Tensor:
+    """int32 [0, n) on `dev` as a view of a cached, growing arange (read-only by convention; no launch per call)."""
+    buf = _IOTA.get(dev)
+    if buf is None or buf.shape[0] < n:
+        buf = _IOTA[dev] = torch.arange(max(2 * n, 1 << 16), dtype=torch.int32, device=dev)
+    return buf[:n]
+
+
 def _as_i32(t):
     return t if t.dtype == torch.int32 else t.to(torch.int32)
 
@@ -253,7 +264,7 @@ def build_csr(recv: torch.Tensor, src: torch.Tensor, n_recv: int, presorted: boo
         r32, s32 = _as_i32(recv).contiguous(), _as_i32(src).contiguous()
         if presorted:
             rowptr, _, _, _ = _group_by_key(r32, n_recv, [], want_perm=False)
-            return CSR(E, r32, s32, torch.arange(E, dtype=torch.int32, device=dev), rowptr)
+            return CSR(E, r32, s32, iota32(E, dev), rowptr)
         rowptr, perm, r_sorted, (s_sorted,) = _group_by_key(r32, n_recv, [s32])
         return CSR(E, r_sorted, s_sorted, perm, rowptr)
     if presorted:

@@ -744,6 +744,24 @@ class TensorProductScoreModel(nn.Module):
         # ---- graphs (:444-583)
         i32 = lambda t: t.to(torch.int32).contiguous()
         bond_ei = data["ligand", "ligand"].edge_index.long()
+        # Per-node `pre` tables of the edge-embedding MLPs (the non-RBF part of their first Linear: W1[:, sigma cols] @ emb + b1,
+        # [N, ns]).  They depend on the diffusion time only, so they are queued here, ahead of the searches' host
+        # synchronisation: whatever is queued before it runs behind the previous step's tail instead of in the host-paced
+        # window between the synchronisation and the first conv layer.
+        sd_, dd, cd = self.sigma_embed_dim, self.distance_embed_dim, self.cross_distance_embed_dim
+        nf = self.in_lig_edge_features
+        epk, pre = {}, {}
+        for key, name, rbf0, rbf_n, emb, sig0 in (
+                ("ll", "lig_edge_embedding", nf + sd_, dd, lig.node_sigma_emb, nf),
+                ("rr", "rec_edge_embedding", sd_, dd, rec.node_sigma_emb, 0),
+                ("aa", "atom_edge_embedding", sd_, dd, atom.node_sigma_emb, 0),
+                ("lr", "lr_edge_embedding", sd_, cd, lig.node_sigma_emb, 0),
+                ("la", "la_edge_embedding", sd_, cd, lig.node_sigma_emb, 0),
+                ("ar", "ar_edge_embedding", sd_, dd, atom.node_sigma_emb, 0)):
+            epk[key] = pk = self._edge_pack(name, slice(rbf0, rbf0 + rbf_n), dev)
+            pre[key] = torch.addmm(pk.b1, emb, pk.W1[:, sig0:sig0 + sd_].t())
+        bond_pre = data["ligand", "ligand"].edge_attr.float() @ epk["ll"].W1[:, :nf].t()     # bond-type columns, [E_bond, ns]
+
         # The neighbour searches that depend on the pose - ligand radius graph, ligand<-receptor, ligand<-atom and the heads'
         # bond-centre graphs - are COUNTED first and share one host synchronisation (G.resolve); the heads' graphs are
         # filled only after the conv layers are queued (nothing before the layers needs them unless side chains are flexible)
@@ -821,35 +839,17 @@ class TensorProductScoreModel(nn.Module):
         rr32, aa32, ar32 = rows32("rr32", rr, rr_f), rows32("aa32", aa, aa_f), rows32("ar32", ar, ar_f)
 
         mark("graphs")
-        # ---- edge featurisation: per-node / per-edge `pre` tables hold the non-RBF part of the first Linear
-        sd_, dd, cd = self.sigma_embed_dim, self.distance_embed_dim, self.cross_distance_embed_dim
-        nf = self.in_lig_edge_features
-
-        def sigma_pre(pack, emb, sl):  # W1[:, sigma cols] @ emb + b1   [N, ns]
-            return torch.addmm(pack.b1, emb, pack.W1[:, sl].t())
-
-        pk = self._edge_pack("lig_edge_embedding", slice(nf + sd_, nf + sd_ + dd), dev)
-        pre_node = sigma_pre(pk, lig.node_sigma_emb, slice(nf, nf + sd_))
-        pre_ll = pre_node[ll[0]]
-        nb = bond_ei.shape[1]
-        pre_ll[:nb] += data["ligand", "ligand"].edge_attr.float() @ pk.W1[:, :nf].t()
+        # ---- edge featurisation (the per-node `pre` tables were prepared ahead of the searches, see above)
+        pk = epk["ll"]
+        pre_ll = pre["ll"][ll[0]]
+        pre_ll[:bond_ei.shape[1]] += bond_pre
         e_ll, sh_ll = _edge_featurize(pk, self.lig_distance_expansion, lpos, ll32[0], lpos, ll32[1], pre_ll,
-                                      torch.arange(ll.shape[1], device=dev, dtype=torch.int32))
-        pk = self._edge_pack("rec_edge_embedding", slice(sd_, sd_ + dd), dev)
-        e_rr, sh_rr = _edge_featurize(pk, self.rec_distance_expansion, rpos, rr32[0], rpos, rr32[1],
-                                      sigma_pre(pk, rec.node_sigma_emb, slice(0, sd_)), rr32[0])
-        pk = self._edge_pack("atom_edge_embedding", slice(sd_, sd_ + dd), dev)
-        e_aa, sh_aa = _edge_featurize(pk, self.lig_distance_expansion, apos, aa32[0], apos, aa32[1],
-                                      sigma_pre(pk, atom.node_sigma_emb, slice(0, sd_)), aa32[0])
-        pk = self._edge_pack("lr_edge_embedding", slice(sd_, sd_ + cd), dev)
-        e_lr, sh_lr = _edge_featurize(pk, self.cross_distance_expansion, lpos, lr32[0], rpos, lr32[1],
-                                      sigma_pre(pk, lig.node_sigma_emb, slice(0, sd_)), lr32[0])
-        pk = self._edge_pack("la_edge_embedding", slice(sd_, sd_ + cd), dev)
-        e_la, sh_la = _edge_featurize(pk, self.cross_distance_expansion, lpos, la32[0], apos, la32[1],
-                                      sigma_pre(pk, lig.node_sigma_emb, slice(0, sd_)), la32[0])
-        pk = self._edge_pack("ar_edge_embedding", slice(sd_, sd_ + dd), dev)
-        e_ar, sh_ar = _edge_featurize(pk, self.rec_distance_expansion, apos, ar32[0], rpos, ar32[1],
-                                      sigma_pre(pk, atom.node_sigma_emb, slice(0, sd_)), ar32[0])
+                                      G.iota32(ll.shape[1], dev))
+        e_rr, sh_rr = _edge_featurize(epk["rr"], self.rec_distance_expansion, rpos, rr32[0], rpos, rr32[1], pre["rr"], rr32[0])
+        e_aa, sh_aa = _edge_featurize(epk["aa"], self.lig_distance_expansion, apos, aa32[0], apos, aa32[1], pre["aa"], aa32[0])
+        e_lr, sh_lr = _edge_featurize(epk["lr"], self.cross_distance_expansion, lpos, lr32[0], rpos, lr32[1], pre["lr"], lr32[0])
+        e_la, sh_la = _edge_featurize(epk["la"], self.cross_distance_expansion, lpos, la32[0], apos, la32[1], pre["la"], la32[0])
+        e_ar, sh_ar = _edge_featurize(epk["ar"], self.rec_distance_expansion, apos, ar32[0], rpos, ar32[1], pre["ar"], ar32[0])
 
         mark("edge_featurize")
         # ---- CSR per conv direction (receiver = edge_index[0] of the conv call)
