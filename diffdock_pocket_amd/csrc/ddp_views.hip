@@ -20,30 +20,42 @@ __global__ void ddp_hist_kernel(const int32_t* __restrict__ key, int E, int32_t*
   if (i < E) atomicAdd(&counts[key[i]], 1);
 }
 
-// exclusive prefix sum of counts[0..n) into rowptr[0..n], one workgroup of 1024 threads; cursor[k] = rowptr[k] on exit
+// exclusive prefix sum of counts[0..n) into rowptr[0..n], one workgroup of 1024 threads = 16 waves; cursor[k] = rowptr[k]
+// on exit.  Wave w owns the contiguous segment [w S, (w+1) S): it walks it 64 items at a time (coalesced), scanning each
+// group with shuffles and carrying the running total; the 16 segment totals are combined through LDS and added in a
+// second coalesced pass.
 __global__ __launch_bounds__(1024) void ddp_scan_kernel(int32_t* __restrict__ counts_cursor, int n, int32_t* __restrict__ rowptr) {
-  __shared__ int part[1024];
-  const int t = threadIdx.x;
-  const int per = (n + 1023) / 1024;
-  const int lo = min(t * per, n), hi = min(lo + per, n);
-  int s = 0;
-  for (int i = lo; i < hi; ++i) s += counts_cursor[i];
-  part[t] = s;
+  __shared__ int seg_total[16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int S = (((n + 15) / 16) + 63) & ~63;
+  const int lo = min(wave * S, n), hi = min(lo + S, n);
+  int run = 0;
+  for (int base = lo; base < hi; base += 64) {
+    const int i = base + lane;
+    const int c = (i < hi) ? counts_cursor[i] : 0;
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off);
+      if (lane >= off) incl += v;
+    }
+    if (i < hi) rowptr[i] = run + incl - c;      // exclusive inside the segment
+    run += __shfl(incl, 63);
+  }
+  if (lane == 0) seg_total[wave] = run;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {     // inclusive scan of the 1024 partial sums
-    const int v = (t >= off) ? part[t - off] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
+  int offset = 0;
+  for (int w = 0; w < wave; ++w) offset += seg_total[w];
+  for (int i = lo + lane; i < hi; i += 64) {
+    const int v = rowptr[i] + offset;
+    rowptr[i] = v;
+    counts_cursor[i] = v;
   }
-  int run = part[t] - s;
-  for (int i = lo; i < hi; ++i) {
-    const int c = counts_cursor[i];
-    rowptr[i] = run;
-    counts_cursor[i] = run;
-    run += c;
+  if (threadIdx.x == 0) {
+    int total = 0;
+    for (int w = 0; w < 16; ++w) total += seg_total[w];
+    rowptr[n] = total;
   }
-  if (t == 1023) rowptr[n] = part[1023];
 }
 
 __global__ void ddp_slot_kernel(const int32_t* __restrict__ key, int E, int32_t* __restrict__ cursor, int32_t* __restrict__ tmp) {
