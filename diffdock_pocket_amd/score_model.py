@@ -1085,7 +1085,7 @@ class TensorProductScoreModel(nn.Module):
                 out = torch.zeros((B, v.shape[1]), device=dev).index_add_(0, b, v)
                 return out / torch.bincount(b, minlength=B).clamp(min=1).unsqueeze(1)
 
-            conf_in = graph_mean(scalars(xl), lbatch)
+            conf_in = lay_l.dense(scalars(xl), 0.0).sum(1) / lay_l.counts.clamp(min=1).unsqueeze(1)   # (deterministic order)
             if self.flexible_sidechains:
                 if num_flex > 0:
                     fr = data["flexResidues"]
@@ -1099,7 +1099,9 @@ class TensorProductScoreModel(nn.Module):
         # ---- graph parts of the remaining heads (sync-free, see above)
         ar_l = torch.arange(Nl, device=dev)
         cnt = lay_l.counts.unsqueeze(1)
-        center = torch.zeros((B, 3), device=dev).index_add_(0, lbatch, lpos) / cnt
+        # (a dense sum, not index_add_: float atomics land in an order that depends on what else the device is doing, and
+        # one ulp in the centre is one ulp in tr / rot - seen as run-to-run differences at the full size)
+        center = lay_l.dense(lpos, 0.0).sum(1) / cnt
         pk = self._edge_pack("center_edge_embedding", slice(0, dd), dev)
         pre_c = torch.addmm(pk.b1, lig.node_sigma_emb, pk.W1[:, dd:dd + sd_].t())
         e_c, sh_c = _edge_featurize(pk, self.center_distance_expansion, center, i32(lbatch), lpos, i32(ar_l), pre_c, i32(ar_l))

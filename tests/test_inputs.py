@@ -133,3 +133,35 @@ def test_graph_feeds_collate_and_schema(graph):
     assert b.num_graphs == 2 and b["ligand"].x.shape[0] == 74 and b["atom", "receptor"].edge_index.shape[1] == 2 * graph["atom"].x.shape[0]
     assert int(b["atom", "receptor"].edge_index[1].max()) == 2 * graph["receptor"].x.shape[0] - 1
     assert b["flexResidues"].edge_idx.shape == (16, 2)
+
+
+def test_receptor_filters_chains_waters_and_incomplete_residues():
+    """extract_receptor (reference datasets/process_mols.py:291-432): waters and residues without N / CA / C are dropped,
+    a chain far from the ligand is dropped, modified residues in HETATM records with a backbone are kept, insertion codes
+    make distinct residues."""
+    def atom(i, name, res, chain, seq, x, rec="ATOM  ", icode=" ", el=None):
+        return f"{rec}{i:5d} {name:<4s} {res:>3s} {chain}{seq:4d}{icode}   {x:8.3f}{0.0:8.3f}{0.0:8.3f}  1.00  0.00          {el or name[0]:>2s}"
+
+    lines, i = [], 1
+    def residue(res, chain, seq, x0, rec="ATOM  ", icode=" ", names=("N", "CA", "C", "O", "CB")):
+        nonlocal i
+        for k, n in enumerate(names):
+            lines.append(atom(i, n, res, chain, seq, x0 + 0.5 * k, rec, icode))
+            i += 1
+    residue("ALA", "A", 1, 0.0)
+    residue("SER", "A", 1, 3.0, icode="A")                       # insertion code: its own residue
+    residue("MSE", "A", 2, 6.0, rec="HETATM")                    # modified residue with a backbone: kept
+    residue("GLY", "A", 3, 9.0, names=("N", "CA"))               # no C: dropped
+    lines.append(atom(i, "O", "HOH", "A", 100, 1.0, "HETATM")); i += 1
+    residue("LEU", "B", 1, 200.0)                                # chain B is 200 A away
+    residue("VAL", "B", 2, 203.0)
+    res = I.parse_pdb("\n".join(lines))
+    lig = np.array([[1.0, 1.0, 0.0], [2.0, 1.0, 0.0]])
+    rec = I.extract_receptor(res, lig, cutoff=10.0)
+    assert [(r.chain, r.resseq, r.icode, r.resname) for r in rec.residues] == [("A", 1, " ", "ALA"), ("A", 1, "A", "SER"), ("A", 2, " ", "MSE")]
+    assert rec.ca.shape == (3, 3) and I.rec_residue_features(rec)[:, 0].tolist() == [0.0, 15.0, 37.0]    # MSE -> 'misc'
+    rr, ax, apos, ares, heavy = I.receptor_graph(rec, cutoff=15.0, max_neighbors=24)
+    assert ax.shape == (15, 4) and ares.tolist() == [0] * 5 + [1] * 5 + [2] * 5 and sorted(set(rr[0].tolist())) == [0, 1, 2]
+    # nothing within the chain cutoff: the closest chain is kept (process_mols.py:388-389)
+    far = I.extract_receptor(res, lig + 1000.0, cutoff=10.0)
+    assert {r.chain for r in far.residues} == {"B"}
