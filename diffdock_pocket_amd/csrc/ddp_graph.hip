@@ -4,7 +4,7 @@
 //   radius(x, y, r, batch_x, batch_y, max_num_neighbors): for every query y all x of the SAME graph with |x - y|^2 < r^2
 //     (strict), query-major, ascending x; more matches than the cap -> the cap nearest (ties at the cut distance kept)
 //   knn_graph(x, k, batch): the k nearest other nodes of the same graph, nearest first
-// Graphs are contiguous node ranges (x_ptr[g] .. x_ptr[g+1]).  radius: one wave per query, kNN: one thread per query; the
+// Graphs are contiguous node ranges (x_ptr[g] .. x_ptr[g+1]).  radius and kNN: one wave per query; the
 // points of a graph are a few kB and stay in L1/L2.  Distances are formed
 // exactly like the dense PyTorch formulation this replaces (differences, then (dx^2 + dy^2) + dz^2 with separate roundings:
 // no FMA contraction), so the strict comparisons select the same pairs.
@@ -114,39 +114,46 @@ __global__ __launch_bounds__(256) void ddp_radius_kernel(const float* __restrict
   if (!FILL && lane == 0) counts[q] = kept;
 }
 
-__global__ void ddp_knn_kernel(const float* __restrict__ x, const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ batch,
-                               int n, int k, int32_t* __restrict__ out_nb /*[n][k], -1 padded*/) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+// kNN: one wave per query.  Round t selects the t-th nearest: every lane scans its share of the graph's points for the
+// smallest (distance, index) pair that comes strictly after the previous selection in that lexicographic order, a
+// shuffle butterfly takes the wave-wide minimum.  Equal distances: lower index first (the order of a stable sort by
+// distance, i.e. of the dense top-k formulation); NaN / infinite distances are never selected (-1 in the output).
+// Distances are re-evaluated per round from L1 (k * n / 64 evaluations per lane, 144 for the 1111-atom pocket at k = 8).
+__global__ __launch_bounds__(256) void ddp_knn_kernel(const float* __restrict__ x, const int32_t* __restrict__ x_ptr,
+                                                      const int32_t* __restrict__ batch, int n, int k,
+                                                      int32_t* __restrict__ out_nb /*[n][k], -1 padded*/) {
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (q >= n) return;
   const int g = batch[q];
   const int j0 = x_ptr[g], j1 = x_ptr[g + 1];
   const float yq[3] = {x[3 * (size_t)q], x[3 * (size_t)q + 1], x[3 * (size_t)q + 2]};
-  float bd[DDP_KNN_MAX];
-  int bi[DDP_KNN_MAX];
-#pragma unroll
-  for (int i = 0; i < DDP_KNN_MAX; ++i) { bd[i] = __builtin_inff(); bi[i] = -1; }
-  for (int j = j0; j < j1; ++j) {
-    if (j == q) continue;
-    float d = sqdist(yq, x + 3 * (size_t)j);
-    if (!(d == d)) d = __builtin_inff();            // NaN distances sort last, like the dense formulation
-    if (!(d < bd[k - 1]) && bi[k - 1] >= 0) continue;
-    // insertion into the ascending list (equal distances: lower index first)
-    int jj = j;
-    bool shifting = false;
-#pragma unroll
-    for (int i = 0; i < DDP_KNN_MAX; ++i) {
-      if (i < k && (shifting || bi[i] < 0 || d < bd[i])) {   // insert here, then push the rest of the list down
-        const float td = bd[i]; const int ti = bi[i];
-        bd[i] = d; bi[i] = jj;
-        d = td; jj = ti;
-        shifting = true;
-        if (jj < 0) break;
-      }
+  const int none = 0x7fffffff;
+  float pd = -1.f;   // previous selection (squared distances are >= 0)
+  int pj = -1;
+  for (int t = 0; t < k; ++t) {
+    float bd = __builtin_inff();
+    int bj = none;
+    for (int j = j0 + lane; j < j1; j += 64) {
+      if (j == q) continue;
+      const float d = sqdist(yq, x + 3 * (size_t)j);
+      if (!(d < __builtin_inff())) continue;                       // NaN or inf
+      const bool after = (d > pd) || (d == pd && j > pj);
+      if (after && (d < bd || (d == bd && j < bj))) { bd = d; bj = j; }
     }
-  }
 #pragma unroll
-  for (int i = 0; i < DDP_KNN_MAX; ++i)
-    if (i < k) out_nb[(size_t)q * k + i] = (bi[i] >= 0 && bd[i] < __builtin_inff()) ? bi[i] : -1;
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float od = __shfl_xor(bd, off);
+      const int oj = __shfl_xor(bj, off);
+      if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
+    }
+    if (bj == none) {                                              // fewer than k candidates: pad the rest
+      for (int u = t + lane; u < k; u += 64) out_nb[(size_t)q * k + u] = -1;
+      return;
+    }
+    if (lane == 0) out_nb[(size_t)q * k + t] = bj;
+    pd = bd;
+    pj = bj;
+  }
 }
 
 static int radius_args_ok(const float* x, const int32_t* x_ptr, const float* y, const int32_t* y_batch, int ny, float r, int cap) {
@@ -185,7 +192,7 @@ extern "C" int ddp_knn(const float* x, const int32_t* x_ptr, const int32_t* batc
   if (n < 0 || k < 1 || k > DDP_KNN_MAX) return ddp_fail(DDP_ELIMIT, "ddp_knn: k must be in [1, 32]");
   if (n == 0) return 0;
   if (!x || !x_ptr || !batch || !out_neighbors) return ddp_fail(DDP_EINVAL, "ddp_knn: null argument");
-  hipLaunchKernelGGL(ddp_knn_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, x, x_ptr, batch, n, k, out_neighbors);
+  hipLaunchKernelGGL(ddp_knn_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, x_ptr, batch, n, k, out_neighbors);
   const hipError_t err = hipGetLastError();
   if (err != hipSuccess) return ddp_fail_hip(err, "ddp_knn launch");
   return 0;

@@ -793,7 +793,9 @@ class TensorProductScoreModel(nn.Module):
             if num_flex > 0:
                 fr = data["flexResidues"]
                 bonds_s = lay_a.starts[fr.batch.long()] + fr.edge_idx.t().long()     # get_sc_tor_bonds (:638-652)
-                pend_sc = self._torsion_search("sidechain_final_edge_embedding", apos, lay_a, bonds_s, fr.batch.long(), B)
+                sc_batch = fr.batch.long()
+                lay_sc = self._cached("lay_sc", (fr.batch,), lambda: G.DenseLayout.build(sc_batch, B))   # (its build syncs)
+                pend_sc = self._torsion_search("sidechain_final_edge_embedding", apos, lay_a, bonds_s, sc_batch, B, lay_sc)
         pending = [p for p in (pend_tor, pend_sc) if p is not None]
         # (the "all receptor-side nodes at one diffusion time" flag of the layer-0 sharing below rides in the same copy)
         flags = []
