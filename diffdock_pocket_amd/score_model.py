@@ -587,11 +587,13 @@ class TensorProductScoreModel(nn.Module):
                 (e0, e1, 4.0 * (Gall.numel() + nb * N * n_in + Wst.numel())))
         return {(k, slot): Gall[i] for i, (k, slot, _) in enumerate(meta)}
 
-    def _shared_receptor_side(self, B, rec, atom, rpos, apos, lay_r, lay_a, rr, ar, aa):
+    def _shared_receptor_side(self, B, rec, atom, rpos, apos, lay_r, lay_a, rr, ar, aa, atoms=True):
         """Which receptor-side convs see the SAME problem in every graph of the batch (the usual sampling batch: N poses of
         one complex): per conv k in (3 atom<-atom, 5 atom<-receptor, 6 receptor<-receptor, 8 receptor<-atom) either None
         or (receiver nodes per graph, edges per graph, source nodes per graph).  Exact comparison of node features,
-        positions and per-graph edge lists; depends only on step-independent tensors, so it is evaluated once (`_cached`)."""
+        positions and per-graph edge lists; depends only on step-independent tensors, so it is evaluated once (`_cached`).
+        atoms=False: the atom side is not examined (flexible side chains move per sample and per step: its comparison
+        would fail anyway, after a handful of host synchronisations on every call)."""
         out = {3: None, 5: None, 6: None, 8: None}
         if B < 2 or not (lay_r.uniform and lay_a.uniform):
             return out
@@ -612,7 +614,7 @@ class TensorProductScoreModel(nn.Module):
             return e if bool(ok) else 0
 
         rec_same = same_rows(rec.x, nr) and same_rows(rpos, nr)
-        atom_same = same_rows(atom.x, na) and same_rows(apos, na)
+        atom_same = atoms and same_rows(atom.x, na) and same_rows(apos, na)
         if rec_same:
             e = same_edges(rr, nr, nr)
             out[6] = (nr, e, nr) if e else None
@@ -802,10 +804,14 @@ class TensorProductScoreModel(nn.Module):
         if self.share_layer0 and B > 1:
             t_nodes = torch.cat([rec.node_t["tr"], atom.node_t["tr"]])
             flags.append((t_nodes == t_nodes[0]).all())
+            if num_flex > 0 and lay_a.uniform:   # side chains usually differ between the samples: asked in the same copy
+                av = apos.reshape(B, lay_a.nmax, 3)
+                flags.append((av == av[:1]).all())
         counts = G.resolve([s_ll, s_lr, s_la] + [p["search"] for p in pending], extra=flags)
         for p, e in zip(pending, counts[3:]):
             p["E"] = e
-        one_time = bool(flags) and bool(counts[-1])
+        one_time = bool(flags) and bool(counts[-len(flags)])
+        atoms_alike = len(flags) < 2 or bool(counts[-1])
         ll = torch.cat([bond_ei, s_ll.fill(counts[0])], 1)
         lr = s_lr.fill(counts[1])
         la = s_la.fill(counts[2])
@@ -823,7 +829,11 @@ class TensorProductScoreModel(nn.Module):
         #    source-ordered edge lists - and the resulting node update is added to every graph.
         # Any difference between the graphs -> the general path.
         shared0 = {}
-        if one_time:
+        if one_time and not atoms_alike:
+            sh_ = self._cached("shared0_rec", (rec.x, rpos, rr),
+                               lambda: self._shared_receptor_side(B, rec, atom, rpos, apos, lay_r, lay_a, rr, ar, aa, atoms=False))
+            shared0 = {k: v for k, v in sh_.items() if v is not None}
+        elif one_time:
             sh_ = self._cached("shared0", (rec.x, rpos, atom.x, apos, rr, ar, aa),
                                lambda: self._shared_receptor_side(B, rec, atom, rpos, apos, lay_r, lay_a, rr, ar, aa))
             shared0 = {k: v for k, v in sh_.items() if v is not None}
