@@ -49,6 +49,16 @@ def _load_traffic():
 TRAFFIC_BYTES_PER_LAUNCH = None
 
 
+def _load_mfma_busy():
+    """Matrix-pipe busy fraction per kernel from the rocprofv3 PMC pass (profiles/r01_mfma_pmc.json, tools/pmc_mfma.py:
+    SQ_VALU_MFMA_BUSY_CYCLES against GRBM_GUI_ACTIVE x SIMDs); {} if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_mfma_pmc.json")) as f:
+            return {k: v.get("mfma_busy_frac") for k, v in json.load(f).get("kernels", {}).items()}
+    except OSError:
+        return {}
+
+
 def model_kwargs(cfg, flex):
     if cfg == "cfg2":
         ns, nv, L, emb = 60, 10, 6, 64
@@ -219,6 +229,7 @@ def main():
         # the PMC passes were taken on the default workload only (40 samples, cfg2, rigid receptor, one batch)
         default_workload = args.samples == 40 and args.cfg == "cfg2" and not args.flex and args.ways == 1
         TRAFFIC_BYTES_PER_LAUNCH = _load_traffic() if default_workload else None
+        mfma_busy = _load_mfma_busy() if default_workload else {}
         poses = n_total * args.steps / 20.0
         # the dominant kernel = the instantiation with the larger share of the timed region
         kinds = sorted({k for k in prof.kernel}, key=lambda k: -prof.summary(k)[2])
@@ -232,11 +243,11 @@ def main():
                         "frac": ach_ / FP32_MFMA_PEAK_TFLOPS, "launches": n_, "avg_launch_ms": ms_ / n_, "achieved": ach_,
                         "algorithmic_gflop_per_launch": fl_ / n_ / 1e9, "executed_tflops": exe_,
                         "executed_frac": exe_ / FP32_MFMA_PEAK_TFLOPS, "share_of_wall": ms_ * 1e-3 / elapsed,
-                        "traffic": (TRAFFIC_BYTES_PER_LAUNCH or {}).get(kname)}
+                        "traffic": (TRAFFIC_BYTES_PER_LAUNCH or {}).get(kname), "mfma_busy_pmc": mfma_busy.get(kname)}
             dom = entry(kinds[0])
             roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": dom["achieved"] / FP32_MFMA_PEAK_TFLOPS, "traffic": dom["traffic"],
-                    "launches": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"],
+                    "launches": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"], "mfma_busy_pmc": dom["mfma_busy_pmc"],
                     "algorithmic_gflop_per_launch": dom["algorithmic_gflop_per_launch"],
                     "executed_tflops": dom["executed_tflops"], "executed_frac": dom["executed_frac"],
                     "note": "achieved = ALGORITHMIC FLOPs of the reference formulation (BASELINE.md section 3: 2FH + 2HW + 2C per edge) / "
@@ -253,7 +264,8 @@ def main():
                 gbs = by_ / (ms_ * 1e-3) / 1e9
                 return {"kernel": kname, "bound": "hbm", "launches": n_, "avg_launch_ms": ms_ / n_, "achieved": gbs, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_mb_per_launch": by_ / n_ / 1e6,
-                        "ms_per_step": ms_ / 2.0, "measured": "2 extra steps after the timed region", "traffic": None}
+                        "ms_per_step": ms_ / 2.0, "measured": "2 extra steps after the timed region", "traffic": None,
+                        "mfma_busy_pmc": mfma_busy.get(kname)}
             roof["other_kernels"] += [e for e in (hbm_entry("ddp_stage_a_mfma_kernel"), hbm_entry("ddp_segment_reduce_kernel")) if e]
         line = {"metric": "ligand poses/sec (40 samples x 20 steps) on 3dpf", "value": poses / elapsed, "unit": "poses/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
