@@ -18,7 +18,7 @@ FS = 68  # feature-buffer row stride of ddp_conv.hip
 
 DDP_MAX_GEMM_BATCH = 16
 EXPORTS = ["ddp_conv_messages", "ddp_segment_reduce", "ddp_edge_featurize", "ddp_torsion_sh", "ddp_stage_a",
-           "ddp_pose_update", "ddp_sidechain_update", "ddp_radius_count", "ddp_radius_fill", "ddp_knn", "ddp_group_by_key", "ddp_abi_version", "ddp_last_error"]
+           "ddp_pose_update", "ddp_sidechain_update", "ddp_radius_count", "ddp_radius_fill", "ddp_knn", "ddp_group_by_key", "ddp_abi_version", "ddp_last_error", "ddp_source_hash"]
 
 
 class Seg(C.Structure):
@@ -109,6 +109,13 @@ def load():
     lib.ddp_group_by_key.restype = C.c_int
     if lib.ddp_abi_version() != 4:
         raise DdpError("libddp_hip.so ABI version mismatch")
+    lib.ddp_source_hash.restype = C.c_char_p
+    if "DDP_HIP_LIB" not in os.environ:   # (diagnostic builds loaded through DDP_HIP_LIB carry extra -D flags, same sources)
+        from .build import source_hash
+        have, want = lib.ddp_source_hash().decode(), source_hash()
+        if have != want:
+            raise DdpError(f"{LIB_PATH} was built from other sources (library {have}, tree {want}): rebuild it with "
+                           f"`python -m diffdock_pocket_amd.build`")
     _lib = lib
     return lib
 

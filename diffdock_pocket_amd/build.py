@@ -10,13 +10,42 @@ SOURCES = ["ddp_conv.hip", "ddp_misc.hip", "ddp_gemm.hip", "ddp_pose.hip", "ddp_
 OUT = os.path.join(HERE, "libddp_hip.so")
 
 
-def needs_build():
-    if not os.path.exists(OUT):
-        return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(HERE, "csrc", s) for s in SOURCES] + [os.path.join(HERE, "csrc", "ddp_internal.h"),
+def _deps():
+    return [os.path.join(HERE, "csrc", s) for s in SOURCES] + [os.path.join(HERE, "csrc", "ddp_internal.h"),
                                                                os.path.join(ROOT, "include", "ddp_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def source_hash():
+    """16 hex digits of the SHA-256 over every source the library is compiled from, in a fixed order.  Compiled into the
+    library (-DDDP_SRC_SHA16, exported as ddp_source_hash()) and checked by _lib.load(): the binary that runs is provably
+    the one built from the sources in the tree."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in _deps():
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def built_hash(path=None):
+    """ddp_source_hash() of an existing library (None if it is missing or predates the export)."""
+    import ctypes
+    path = path or OUT
+    if not os.path.exists(path):
+        return None
+    try:
+        lib = ctypes.CDLL(path)
+        lib.ddp_source_hash.restype = ctypes.c_char_p
+        return lib.ddp_source_hash().decode()
+    except (OSError, AttributeError):
+        return None
+
+
+def needs_build():
+    """The library is rebuilt unless it carries the hash of the present sources (mtimes are not trusted: the .so travels to
+    the GPU box with the snapshot)."""
+    return built_hash() != source_hash()
 
 
 def build(force=False, verbose=True, stamps=False, ablate=0, defs=(), tag=""):
@@ -40,7 +69,7 @@ def build(force=False, verbose=True, stamps=False, ablate=0, defs=(), tag=""):
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", f'-DDDP_SRC_SHA16="{source_hash()}"',
            "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), "-o", OUT]
     cmd += [os.path.join(HERE, "csrc", s) for s in SOURCES]
     if verbose:

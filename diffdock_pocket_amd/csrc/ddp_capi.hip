@@ -19,3 +19,10 @@ int ddp_fail_hip(hipError_t err, const char* where) {
 
 extern "C" int ddp_abi_version(void) { return DDP_ABI_VERSION; }
 extern "C" const char* ddp_last_error(void) { return g_err; }
+
+// 16 hex digits of the SHA-256 over the kernel sources this library was compiled from (diffdock_pocket_amd/build.py passes
+// -DDDP_SRC_SHA16); _lib.load() compares it with the sources in the tree, so a stale binary cannot be loaded silently.
+#ifndef DDP_SRC_SHA16
+#define DDP_SRC_SHA16 "unknown"
+#endif
+extern "C" const char* ddp_source_hash(void) { return DDP_SRC_SHA16; }

@@ -121,7 +121,17 @@ class ConvSpec:
         return 2 * self.f_in * self.hid + 2 * self.hid * self.weight_numel + 2 * c
 
     def mfma_flops_per_edge_executed(self):
+        """fp32 MFMA FLOPs per edge the tile loops issue (K and columns padded to the 32-column / 8-k tiles)."""
         return 2 * self.kp1 * self.nct1 * 32 + 2 * self.hp * self.ntiles * 32
+
+    def useful_flops_per_edge(self):
+        """USEFUL fp32 FLOPs per edge of the formulation the kernel executes, without any padding: fc1, the fc2 columns of
+        the features that stay on the per-edge path (all of them on the direct path, the vector-input ones on the
+        factorised path), their contraction with the basis features, and the per-edge G contraction h @ G[src] of the
+        factorised features (2 * hid * g_cols).  This is what roofline.frac in bench.py counts."""
+        cols = sum(b.U * b.n for b in self.blocks)
+        contr = sum(b.U * b.n * b.C for b in self.blocks)
+        return 2 * self.f_in * self.hid + 2 * self.hid * cols + 2 * contr + 2 * self.hid * sum(self.g_cols)
 
 
 def irreps_muls(ns, nv, i):

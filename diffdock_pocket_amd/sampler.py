@@ -171,7 +171,7 @@ class Sampler:
         self.T = int(self.bonds.shape[0])
         self.bonds_i32 = self.bonds.to(torch.int32).contiguous().to(device)
         self.mask_u8 = self.mask_rotate.to(torch.uint8).contiguous()
-        self.has_flex = cfg.flexible_sidechains and ("flexResidues" in g) and len(g["flexResidues"]) > 0
+        self.has_flex = cfg.flexible_sidechains and len(g["flexResidues"]) > 0
         if self.has_flex:
             fr = g["flexResidues"]
             self.sc_edge_idx, self.sc_sub = fr.edge_idx.clone(), fr.subcomponents.clone().to(device)

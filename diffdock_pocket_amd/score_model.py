@@ -282,6 +282,7 @@ class ConvProfiler:
 
     def __init__(self):
         self.events, self.flops, self.executed, self.kernel = [], [], [], []
+        self.useful, self.edges, self.boundary = [], [], []   # per launch: useful FLOPs, edges, algorithmic boundary bytes
         self.hbm = {}   # HBM-bound kernels: name -> [(event0, event1, algorithmic bytes of the launch)]
         self.hbm_on = False   # their ~45 extra event pairs per step cost wall time: bench.py times them in extra steps
 
@@ -298,8 +299,17 @@ class ConvProfiler:
         return len(sel), float(sum(self.flops[i] for i in sel)), float(ms)
 
     def executed_flops(self, kernel=None):
-        """FLOPs the kernel actually issued (padded MFMA tiles + the G pass of factorised convs)."""
+        """FLOPs of the padded MFMA tiles + the G pass of factorised convs (a model of what is issued; the PMC pass counts it)."""
         return float(sum(e for e, k in zip(self.executed, self.kernel) if kernel is None or k == kernel))
+
+    def useful_flops(self, kernel=None):
+        """Useful fp32 FLOPs of the executed formulation without padding (packing.ConvSpec.useful_flops_per_edge)."""
+        return float(sum(e for e, k in zip(self.useful, self.kernel) if kernel is None or k == kernel))
+
+    def boundary_bytes(self):
+        """Algorithmic bytes at the module boundary of the recorded conv calls (SURVEY section 8(d):
+        4 (N_in D_in + E F + 4 E + N_out D_out) + 16 E per TensorProductConvLayer.forward call)."""
+        return float(sum(self.boundary))
 
 
 _PROFILER: Optional[ConvProfiler] = None
@@ -334,7 +344,8 @@ def set_conv_profiler(p: Optional[ConvProfiler]):
     _PROFILER = p
 
 
-def _launch_convs(spec: P.ConvSpec, tasks: List[L.ConvTask], flops_spec: Optional[P.ConvSpec] = None):
+def _launch_convs(spec: P.ConvSpec, tasks: List[L.ConvTask], flops_spec: Optional[P.ConvSpec] = None, node_bytes: float = 0.0):
+    """node_bytes: 4 (N_in D_in + N_out D_out) summed over the launch's conv calls (only used by the profiler)."""
     lib = L.load()
     if not tasks:
         return
@@ -351,6 +362,9 @@ def _launch_convs(spec: P.ConvSpec, tasks: List[L.ConvTask], flops_spec: Optiona
         ne = sum(t.n_edges for t in tasks)
         prof.flops.append((flops_spec or spec).flops_per_edge() * ne)
         prof.executed.append((spec.mfma_flops_per_edge_executed() + 2 * spec.hid * sum(spec.g_cols)) * ne)
+        prof.useful.append(spec.useful_flops_per_edge() * ne)
+        prof.edges.append(ne)
+        prof.boundary.append(ne * (4.0 * (flops_spec or spec).f_in + 32.0) + node_bytes)
         prof.kernel.append("ddp_conv_messages_kernel<32>" if spec.factorized else "ddp_conv_messages_kernel<64>")
 
 
@@ -778,7 +792,8 @@ class TensorProductScoreModel(nn.Module):
             s_lr = G.RadiusSearch(rpos, lpos, self.cross_max_distance, lay_r, lay_l, max_num_neighbors=10000)
         s_la = G.RadiusSearch(apos, lpos, self.lig_max_radius, lay_a, lay_l, max_num_neighbors=10000)
         num_flex = 0
-        if self.flexible_sidechains and ("flexResidues" in data) and len(data["flexResidues"]) > 0:
+        # (:327, literally: a PyG HeteroData answers `in` by attribute names, not node types, and creates the store on access)
+        if self.flexible_sidechains and len(data["flexResidues"]) > 0:
             num_flex = int(data["flexResidues"].edge_idx.shape[0])
         pend_tor = pend_sc = rot_bond_idx = None
         if not self.confidence_mode:
@@ -1069,11 +1084,21 @@ class TensorProductScoreModel(nn.Module):
                 else:
                     segs = [(e_base, csr.eid, ns, ns), (x_recv, csr.recv, ldx, ns), (x_src, csr.src, ldx, ns)]
                     tasks.append(_make_task(pkc, x_src, ldx, csr, sh, segs, msg))
+            nb_g = nb_d = 0.0
+            if _PROFILER is not None:   # algorithmic node bytes of the conv calls of this layer (profiler only)
+                d_in = P.irreps_dim(P.irreps_muls(ns, self.nv, l))
+                for k, (csr_k, so_k, xs_k) in per.items():
+                    if csr_k.n_edges > 0:
+                        b_ = 4.0 * (nodes[src_type[k]][1] * d_in + nodes[plan[k][6]][1] * spec.d_out)
+                        if so_k is not None:
+                            nb_g += b_
+                        else:
+                            nb_d += b_
             mark("conv_prep")
             # (measured without gain on one MI355X: stage A on a second stream beside the direct convs, and the direct
             # convs on a second stream beside the factorised ones - neither pair fits on a CU together)
-            _launch_convs(spec_g, tasks_g, flops_spec=spec)
-            _launch_convs(spec, tasks)
+            _launch_convs(spec_g, tasks_g, flops_spec=spec, node_bytes=nb_g)
+            _launch_convs(spec, tasks, node_bytes=nb_d)
             mark("conv_launch")
             for rt in ("l", "a", "r"):
                 if active[rt]:

@@ -210,6 +210,8 @@ int ddp_group_by_key(const int32_t* key, int n_items, int n_keys, const int32_t*
 
 int ddp_abi_version(void);
 const char* ddp_last_error(void);
+/* 16 hex digits of the SHA-256 over the sources (csrc/*.hip, csrc/ddp_internal.h, include/ddp_hip.h) the library was built from */
+const char* ddp_source_hash(void);
 
 #ifdef __cplusplus
 }

@@ -130,6 +130,13 @@ CASES: Dict[str, Case] = {c.name: c for c in [
          weight_seed=9, data_seed=4),
     Case("conf_noflex", ns=16, nv=4, num_conv_layers=2, embed=32, n_graphs=2, n_rec=20, t=[0.0, 0.0],
          confidence_mode=True, flexible_sidechains=False, weight_seed=8),
+    # BASELINE configs[1] / configs[2] AT FULL SIZE: ns=60 nv=10 L=6 on the complete 139-residue 3dpf pocket, two graphs at
+    # two different times; rigid receptor (the last layer skips the atom / receptor convs, all_atom_score_model.py:288,:301)
+    # and flexible side chains (last layer keeps the atom convs, side-chain torsion head on)
+    Case("cfg2_full_noflex", ns=60, nv=10, num_conv_layers=6, embed=64, flexible_sidechains=False, n_graphs=2,
+         t=[0.85, 0.3], weight_seed=11, data_seed=5),
+    Case("cfg2_full_flex", ns=60, nv=10, num_conv_layers=6, embed=64, flexible_sidechains=True, n_graphs=2,
+         t=[0.6, 0.15], weight_seed=12, data_seed=6),
 ]}
 
 

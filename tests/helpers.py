@@ -35,3 +35,104 @@ def rel_err(a, b):
         return 0.0
     assert a.shape == b.shape, (a.shape, b.shape)
     return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+def elementwise_excess(a, b, rtol=1e-4, atol_frac=1e-6):
+    """Element-wise parity metric for per-bond score arrays (tor / sc_tor), where one large bond score must not hide
+    errors on the small ones: max over elements of |a-b| / (rtol*|b| + atol_frac*max|b|); <= 1 passes."""
+    if a.numel() == 0 and b.numel() == 0:
+        return 0.0
+    assert a.shape == b.shape, (a.shape, b.shape)
+    a, b = a.double(), b.double()
+    bound = rtol * b.abs() + atol_frac * b.abs().max().clamp_min(1e-30)
+    return float(((a - b).abs() / bound).max())
+
+
+class PyGLikeStore:
+    """Storage of PyGLikeBatch: attributes live in a mapping; `len` = number of attributes, `in` by attribute name."""
+
+    def __init__(self):
+        object.__setattr__(self, "_mapping", {})
+
+    def __getattr__(self, k):
+        try:
+            return object.__getattribute__(self, "_mapping")[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self._mapping[k] = v
+
+    def __getitem__(self, k):
+        return self._mapping[k]
+
+    def __setitem__(self, k, v):
+        self._mapping[k] = v
+
+    def __contains__(self, k):
+        return k in self._mapping
+
+    def __len__(self):
+        return len(self._mapping)
+
+
+class PyGLikeBatch:
+    """An object with the ACCESS SEMANTICS of torch_geometric 2.4's HeteroData batch (restated from its documented behaviour;
+    torch_geometric itself is not installed): node stores under str keys, edge stores under canonical 3-tuples
+    (src, rel, dst) that also answer to (src, dst); a store is created on first access; `key in data` looks at ATTRIBUTE names
+    (BaseData.__contains__), not at node types; global attributes (complex_t, num_graphs) by attribute access.  Shares no
+    code with diffdock_pocket_amd.batch.HeteroBatch: the drop-in must only rely on what a PyG batch offers."""
+
+    def __init__(self):
+        object.__setattr__(self, "_node", {})
+        object.__setattr__(self, "_edge", {})
+        object.__setattr__(self, "_glob", PyGLikeStore())
+
+    def _edge_key(self, key):
+        if len(key) == 3:
+            return tuple(key)
+        hits = [k for k in self._edge if k[0] == key[0] and k[2] == key[1]]
+        return hits[0] if hits else (key[0], "to", key[1])
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple):
+            return self._edge.setdefault(self._edge_key(key), PyGLikeStore())
+        return self._node.setdefault(key, PyGLikeStore())
+
+    def __delitem__(self, key):
+        if isinstance(key, tuple):
+            del self._edge[self._edge_key(key)]
+        else:
+            del self._node[key]
+
+    def __contains__(self, key):      # attribute names over all stores, as PyG does
+        return any(key in st for st in [self._glob, *self._node.values(), *self._edge.values()])
+
+    def __getattr__(self, k):
+        return getattr(object.__getattribute__(self, "_glob"), k)
+
+    def __setattr__(self, k, v):
+        setattr(self._glob, k, v)
+
+    @classmethod
+    def from_hetero_batch(cls, b, device, rel=None):
+        """Copy of a collated diffdock_pocket_amd HeteroBatch (test inputs are generated as such) with tensors on `device`."""
+        import torch
+        rel = rel or {("ligand", "ligand"): "lig_bond", ("receptor", "receptor"): "rec_contact", ("atom", "atom"): "atom_contact",
+                      ("atom", "receptor"): "atom_rec_contact"}
+
+        def mv(v):
+            if torch.is_tensor(v):
+                return v.to(device)
+            if isinstance(v, dict):
+                return {k: mv(x) for k, x in v.items()}
+            return v
+
+        out = cls()
+        for key, st in b._stores.items():
+            dst = out[(key[0], rel.get(key, "to"), key[1])] if isinstance(key, tuple) else out[key]
+            for a, v in st.items():
+                setattr(dst, a, mv(v))
+        for a, v in b._globals.items():
+            setattr(out, a, mv(v))
+        return out

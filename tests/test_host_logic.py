@@ -280,3 +280,59 @@ def test_shared_receptor_side_detection():
     assert out[6] is None and out[3] is not None and out[5] is not None
     assert model._shared_receptor_side(1, rec, atom, rec.pos.float(), atom.pos.float(), lay_r, lay_a, rr, ar, aa) \
         == {3: None, 5: None, 6: None, 8: None}
+
+
+@pytest.mark.parametrize("key", ["score_README_72", "confidence_README_88", "confidence_two_cutoffs", "score_old_yml"])
+def test_get_model_passes_the_reference_kwargs(key, monkeypatch):
+    """factory.get_model against the kwargs the reference's OWN get_model (utils/utils.py:59-113) passes for namespaces made
+    by the reference's own parsers from the README command lines (tests/golden/factory_kwargs.json, captured by
+    oracle/make_golden_factory.py): every kwarg equal, incl. num_confidence_outputs = len(cutoffs) + 1 and the `in`-guard
+    defaults of old yml files; the time embedding is compared through its values on a probe."""
+    import argparse
+    import json
+    from diffdock_pocket_amd import factory
+    with open(os.path.join(ROOT, "tests", "golden", "factory_kwargs.json")) as f:
+        gold = json.load(f)[key]
+    seen = {}
+
+    class Rec:
+        def __init__(self, **kw):
+            seen.update(kw)
+
+        def to(self, device):
+            return self
+
+    monkeypatch.setattr(factory, "TensorProductScoreModel", Rec)
+    args = argparse.Namespace(**gold["args"])
+    conf = gold["kwargs"]["confidence_mode"]
+    factory.get_model(args, torch.device("cpu"), "T2S", no_parallel=True, confidence_mode=conf)
+    assert seen.pop("t_to_sigma") == "T2S" and seen.pop("device") == torch.device("cpu")
+    emb = seen.pop("timestep_emb_func")
+    probe = gold["timestep_emb_probe"]
+    assert torch.allclose(emb(torch.tensor(probe["t"])), torch.tensor(probe["values"]), atol=1e-6)
+    assert set(seen) == set(gold["kwargs"]), set(seen) ^ set(gold["kwargs"])
+    for k, v in gold["kwargs"].items():
+        assert seen[k] == v, (k, seen[k], v)
+
+
+def test_get_model_guards():
+    import argparse
+    import json
+    from diffdock_pocket_amd import factory
+    with open(os.path.join(ROOT, "tests", "golden", "factory_kwargs.json")) as f:
+        a = json.load(f)["score_README_72"]["args"]
+    with pytest.raises(NotImplementedError):       # coarse-grained model: out of scope, refused loudly
+        factory.get_model(argparse.Namespace(**dict(a, all_atoms=False)), torch.device("cpu"), None, no_parallel=True)
+    with pytest.raises(NotImplementedError):       # the reference would wrap in PyG DataParallel here (utils/utils.py:110)
+        factory.get_model(argparse.Namespace(**a), torch.device("cuda:0"), None, no_parallel=False)
+    m = factory.get_model(argparse.Namespace(**a), torch.device("cpu"), None, no_parallel=True)
+    assert isinstance(m, TensorProductScoreModel) and m.ns == 60 and m.num_conv_layers == 6 and m.flexible_sidechains
+
+
+def test_library_carries_the_hash_of_the_sources_in_the_tree():
+    """build.py compiles the SHA-256 of the kernel sources into the library; _lib.load() refuses a library built from other
+    sources, so the binary the GPU tests run is provably the one of the checked-out tree."""
+    from diffdock_pocket_amd import build as B
+    lib = L.load()
+    assert lib.ddp_source_hash().decode() == B.source_hash() and len(B.source_hash()) == 16
+    assert not B.needs_build()

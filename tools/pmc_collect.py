@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Consolidate the rocprofv3 PMC passes of one build into profiles/r02_pmc.json (read by bench.py).
+
+Run on the GPU box, every pass in its own process with --kernel-trace only (gpurun refuses --pmc with other trace domains),
+each on the same deterministic workload:
+
+  B="python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-hbm-pass --no-other-workloads"
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- $B --launch-log gpurun_out/pmc_fetch/launches.json
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- $B --launch-log gpurun_out/pmc_write/launches.json
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv \\
+            -d gpurun_out/pmc_mfma -- $B --launch-log gpurun_out/pmc_mfma/launches.json
+  python3 tools/pmc_collect.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma profiles/r02_pmc.json
+
+Corrections (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE are in units of 1024 bytes; on gfx950
+FETCH_SIZE counts a 128-byte request as 64 bytes, so it is doubled; WRITE_SIZE is exact for 16-byte-per-lane streaming stores.
+One MOP of SQ_INSTS_VALU_MFMA_MOPS_F32 = 512 FLOP.  mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x
+1024 SIMDs).
+
+Launch matching: bench.py --launch-log lists the conv launches of the TIMED steps in order (kernel instantiation, edges,
+useful FLOPs); with --no-hbm-pass / --no-other-workloads these are the last conv dispatches of the process, so the last
+len(log) dispatches of each instantiation are the logged ones.  padding_frac = 1 - sum(useful) / sum(issued) over exactly
+those launches.  Per step: HBM bytes of ALL dispatches between the first and the last logged conv dispatch / timed steps."""
+import glob
+import json
+import os
+import sys
+
+import pandas as pd
+
+CONV = ["ddp_conv_messages_kernel<32>", "ddp_conv_messages_kernel<64>"]
+OTHER = ["ddp_stage_a_mfma_kernel", "ddp_segment_reduce_kernel", "ddp_edge_featurize", "ddp_radius", "ddp_knn", "ddp_pose_update"]
+
+
+def load(d):
+    f = max(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+    c = pd.read_csv(f)
+    with open(os.path.join(d, "launches.json")) as fh:
+        log = json.load(fh)
+    return c, log
+
+
+def timed_window(c, log):
+    """Dispatch ids of the logged (timed) conv launches per instantiation + the [first, last] dispatch-id window."""
+    ids = {}
+    for k in CONV:
+        n = sum(1 for l in log["launches"] if l["kernel"] == k)
+        d = sorted(c[c.Kernel_Name.str.contains(k, regex=False)].Dispatch_Id.unique())
+        if n and len(d) >= n:
+            ids[k] = d[-n:]
+    lo = min(v[0] for v in ids.values())
+    hi = max(v[-1] for v in ids.values())
+    return ids, lo, hi
+
+
+def counter_sum(c, name, disp_ids=None, lo=None, hi=None, kernel=None):
+    s = c[c.Counter_Name == name]
+    if kernel is not None:
+        s = s[s.Kernel_Name.str.contains(kernel, regex=False)]
+    if disp_ids is not None:
+        s = s[s.Dispatch_Id.isin(disp_ids)]
+    if lo is not None:
+        s = s[(s.Dispatch_Id >= lo) & (s.Dispatch_Id <= hi)]
+    return float(s.Counter_Value.sum()), int(s.Dispatch_Id.nunique())
+
+
+def main():
+    fetch_dir, write_dir, mfma_dir, out = sys.argv[1:5]
+    (cf, lf), (cw, lw), (cm, lm) = load(fetch_dir), load(write_dir), load(mfma_dir)
+    assert lf["src_sha16"] == lw["src_sha16"] == lm["src_sha16"] and lf["workload"] == lw["workload"] == lm["workload"]
+    steps = None
+    res = {"src_sha16": lf["src_sha16"], "workload": lf["workload"],
+           "corrections": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B), WRITE_SIZE x1, units of 1024 B; 1 MFMA MOP = 512 FLOP",
+           "commands": __doc__.split("Corrections")[0].strip().splitlines()[3:],
+           "kernels": {}}
+    idf, lof, hif = timed_window(cf, lf)
+    idw, low, hiw = timed_window(cw, lw)
+    idm, lom, him = timed_window(cm, lm)
+    for k in CONV:
+        if k not in idf:
+            continue
+        n = len(idf[k])
+        fe, _ = counter_sum(cf, "FETCH_SIZE", idf[k])
+        wr, _ = counter_sum(cw, "WRITE_SIZE", idw[k])
+        mops, _ = counter_sum(cm, "SQ_INSTS_VALU_MFMA_MOPS_F32", idm[k])
+        busy, _ = counter_sum(cm, "SQ_VALU_MFMA_BUSY_CYCLES", idm[k])
+        gui, _ = counter_sum(cm, "GRBM_GUI_ACTIVE", idm[k])
+        useful = sum(l["useful_flops"] for l in lm["launches"] if l["kernel"] == k)
+        issued = mops * 512.0
+        res["kernels"][k] = {"launches_sampled": n, "hbm_bytes_per_launch": (2.0 * fe + wr) * 1024.0 / n,
+                             "fetch_bytes_per_launch": 2.0 * fe * 1024.0 / n, "write_bytes_per_launch": wr * 1024.0 / n,
+                             "issued_mfma_gflop_per_launch": issued / n / 1e9, "useful_gflop_per_launch_same_launches": useful / n / 1e9,
+                             "padding_frac": 1.0 - useful / issued if issued > 0 else None,
+                             "mfma_busy_frac": busy / (gui / 8.0 * 1024.0) if gui > 0 else None}
+    # the other kernels inside the timed window, per launch
+    for k in OTHER:
+        fe, n1 = counter_sum(cf, "FETCH_SIZE", lo=lof, hi=hif, kernel=k)
+        wr, n2 = counter_sum(cw, "WRITE_SIZE", lo=low, hi=hiw, kernel=k)
+        if n1 == 0 or n2 == 0:
+            continue
+        busy, _ = counter_sum(cm, "SQ_VALU_MFMA_BUSY_CYCLES", lo=lom, hi=him, kernel=k)
+        gui, _ = counter_sum(cm, "GRBM_GUI_ACTIVE", lo=lom, hi=him, kernel=k)
+        res["kernels"][k] = {"launches_sampled": n1, "hbm_bytes_per_launch": 2.0 * fe * 1024.0 / n1 + wr * 1024.0 / n2,
+                             "fetch_bytes_per_launch": 2.0 * fe * 1024.0 / n1, "write_bytes_per_launch": wr * 1024.0 / n2,
+                             "mfma_busy_frac": busy / (gui / 8.0 * 1024.0) if gui > 0 else None}
+    # whole step
+    dom = max(idf, key=lambda k: len(idf[k]))
+    per_step_launches = {}
+    for k in idf:
+        per_step_launches[k] = len(idf[k])
+    fe_all, _ = counter_sum(cf, "FETCH_SIZE", lo=lof, hi=hif)
+    wr_all, _ = counter_sum(cw, "WRITE_SIZE", lo=low, hi=hiw)
+    # timed steps = logged launches of the dominant instantiation / its launches per step (bench.py logs `steps` in the workload run)
+    steps = int(lf.get("steps", 0)) or None
+    if steps is None:   # infer: ddp_pose_update runs once per step
+        pose = cf[cf.Kernel_Name.str.contains("ddp_pose_update", regex=False) & (cf.Dispatch_Id >= lof) & (cf.Dispatch_Id <= hif)]
+        steps = max(int(pose.Dispatch_Id.nunique()), 1)
+    res["_per_step"] = {"timed_steps": steps, "hbm_bytes_per_step": (2.0 * fe_all + wr_all) * 1024.0 / steps,
+                        "fetch_bytes_per_step": 2.0 * fe_all * 1024.0 / steps, "write_bytes_per_step": wr_all * 1024.0 / steps,
+                        "window": "all dispatches from the first to the last logged conv launch (the last step's pose update falls outside)"}
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
