@@ -107,7 +107,7 @@ def load():
     lib.ddp_knn.restype = C.c_int
     lib.ddp_group_by_key.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 11
     lib.ddp_group_by_key.restype = C.c_int
-    if lib.ddp_abi_version() != 4:
+    if lib.ddp_abi_version() != 5:
         raise DdpError("libddp_hip.so ABI version mismatch")
     lib.ddp_source_hash.restype = C.c_char_p
     if "DDP_HIP_LIB" not in os.environ:   # (diagnostic builds loaded through DDP_HIP_LIB carry extra -D flags, same sources)

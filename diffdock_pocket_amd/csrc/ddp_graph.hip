@@ -2,7 +2,9 @@
 // ddp_radius_fill / ddp_knn), the counterpart of the torch_cluster calls inside the reference forward
 // (models/all_atom_score_model.py:457,524,545-564,607,627; conventions restated in SURVEY Appendix B.3):
 //   radius(x, y, r, batch_x, batch_y, max_num_neighbors): for every query y all x of the SAME graph with |x - y|^2 < r^2
-//     (strict), query-major, ascending x; more matches than the cap -> the cap nearest (ties at the cut distance kept)
+//     (strict), query-major, ascending x; more matches than the cap -> the FIRST cap matches in ascending x index (what
+//     torch_cluster's CUDA kernel, the one the reference runs on a GPU, keeps), or with DDP_RADIUS_NEAREST the cap nearest
+//     (ties at the cut distance kept)
 //   knn_graph(x, k, batch): the k nearest other nodes of the same graph, nearest first
 // Graphs are contiguous node ranges (x_ptr[g] .. x_ptr[g+1]).  radius and kNN: one wave per query; the
 // points of a graph are a few kB and stay in L1/L2.  Distances are formed
@@ -74,7 +76,7 @@ __device__ float radius_cut(const float* __restrict__ x, int j0, int j1, const f
 template <bool FILL>
 __global__ __launch_bounds__(256) void ddp_radius_kernel(const float* __restrict__ x, const int32_t* __restrict__ x_ptr,
                                                          const float* __restrict__ y, const int32_t* __restrict__ y_batch, int ny,
-                                                         float r2, int cap, int drop_self, int32_t* __restrict__ counts,
+                                                         float r2, int cap, int flags, int32_t* __restrict__ counts,
                                                          const int32_t* __restrict__ offsets, int32_t* __restrict__ out_q,
                                                          int32_t* __restrict__ out_x) {
   const int q = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
@@ -86,23 +88,28 @@ __global__ __launch_bounds__(256) void ddp_radius_kernel(const float* __restrict
   for (int j = j0 + lane; j < j1; j += 64) n += (sqdist(yq, x + 3 * (size_t)j) < r2) ? 1 : 0;
 #pragma unroll
   for (int m = 32; m > 0; m >>= 1) n += __shfl_xor(n, m);
+  const bool drop_self = (flags & DDP_RADIUS_DROP_SELF) != 0, nearest = (flags & DDP_RADIUS_NEAREST) != 0;
   float lim = r2;           // keep d2 < r2 ...
   bool capped = false;
-  if (n > cap) {            // ... or, capped, d2 <= cut (rare: one lane selects, the wave takes its answer)
+  if (n > cap && nearest) { // ... or, capped to the nearest, d2 <= cut (rare: one lane selects, the wave takes its answer)
     float c = 0.f;
     if (lane == 0) c = radius_cut(x, j0, j1, yq, r2, cap);
     lim = __shfl(c, 0);
     capped = true;
   }
-  int kept = 0;
+  int kept = 0, seen = 0;   // pairs emitted / matches met so far (the self pair counts towards the cap, then is dropped)
   const int obase = FILL ? offsets[q] : 0;
   for (int jb = j0; jb < j1; jb += 64) {
     const int j = jb + lane;
-    bool ok = false;
+    bool match = false;
     if (j < j1) {
       const float d = sqdist(yq, x + 3 * (size_t)j);
-      ok = (capped ? (d < r2 && d <= lim) : (d < r2)) && !(drop_self && j == q);
+      match = capped ? (d < r2 && d <= lim) : (d < r2);
     }
+    const unsigned long long mm = __ballot(match);
+    if (!nearest) match = match && (seen + __popcll(mm & ((1ull << lane) - 1ull)) < cap);   // first `cap` in index order
+    seen += __popcll(mm);
+    const bool ok = match && !(drop_self && j == q);
     const unsigned long long mk = __ballot(ok);
     if (FILL && ok) {
       const int o = obase + kept + __popcll(mk & ((1ull << lane) - 1ull));
@@ -110,6 +117,7 @@ __global__ __launch_bounds__(256) void ddp_radius_kernel(const float* __restrict
       out_x[o] = j;
     }
     kept += __popcll(mk);
+    if (!nearest && seen >= cap) break;   // (wave-uniform)
   }
   if (!FILL && lane == 0) counts[q] = kept;
 }
@@ -163,25 +171,25 @@ static int radius_args_ok(const float* x, const int32_t* x_ptr, const float* y, 
 }
 
 extern "C" int ddp_radius_count(const float* x, const int32_t* x_ptr, const float* y, const int32_t* y_batch, int ny, float r,
-                                int max_neighbors, int drop_self, int32_t* counts, void* stream) {
+                                int max_neighbors, int flags, int32_t* counts, void* stream) {
   if (int rc = radius_args_ok(x, x_ptr, y, y_batch, ny, r, max_neighbors)) return rc;
   if (ny == 0) return 0;
   if (!counts) return ddp_fail(DDP_EINVAL, "ddp_radius_count: null counts");
   hipLaunchKernelGGL((ddp_radius_kernel<false>), dim3((ny + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, x_ptr, y, y_batch,
-                     ny, r * r, max_neighbors, drop_self, counts, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+                     ny, r * r, max_neighbors, flags, counts, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
   const hipError_t err = hipGetLastError();
   if (err != hipSuccess) return ddp_fail_hip(err, "ddp_radius_count launch");
   return 0;
 }
 
 extern "C" int ddp_radius_fill(const float* x, const int32_t* x_ptr, const float* y, const int32_t* y_batch, int ny, float r,
-                               int max_neighbors, int drop_self, const int32_t* offsets, int32_t* out_query, int32_t* out_x,
+                               int max_neighbors, int flags, const int32_t* offsets, int32_t* out_query, int32_t* out_x,
                                void* stream) {
   if (int rc = radius_args_ok(x, x_ptr, y, y_batch, ny, r, max_neighbors)) return rc;
   if (ny == 0) return 0;
   if (!offsets || !out_query || !out_x) return ddp_fail(DDP_EINVAL, "ddp_radius_fill: null argument");
   hipLaunchKernelGGL((ddp_radius_kernel<true>), dim3((ny + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, x_ptr, y, y_batch,
-                     ny, r * r, max_neighbors, drop_self, (int32_t*)nullptr, offsets, out_query, out_x);
+                     ny, r * r, max_neighbors, flags, (int32_t*)nullptr, offsets, out_query, out_x);
   const hipError_t err = hipGetLastError();
   if (err != hipSuccess) return ddp_fail_hip(err, "ddp_radius_fill launch");
   return 0;

@@ -7,8 +7,10 @@ no dense distance blocks); the dense PyTorch formulation below is their definiti
 the oracle's torch_cluster restatement, and what the HIP kernels are tested against bit for bit on the GPU.
 
   radius(x, y, r, batch_x, batch_y, max_num_neighbors) -> [2,E]: row0 = query (y) index, row1 = x index,
-      strict '<', same graph only, at most max_num_neighbors per query (we keep the NEAREST when truncating),
-      emitted query-major with ascending x index.
+      strict '<', same graph only, at most max_num_neighbors per query, emitted query-major with ascending x index.
+      Truncation rule (`TRUNCATION`, or the `truncation=` argument): "first_index" (default) keeps the first
+      max_num_neighbors matches in ascending x index - what torch_cluster's CUDA kernel, i.e. the reference on a GPU,
+      does; "nearest" keeps the nearest ones (and ties).  torch_cluster's CPU path (nanoflann, unsorted) is neither.
   radius_graph(x, r, batch)      -> [neighbour; query], self loops dropped, cap 32 (+1 internally).
   knn_graph(x, k, batch)         -> [neighbour; query], k nearest by distance, self excluded.
 
@@ -23,6 +25,17 @@ from dataclasses import dataclass
 from typing import Optional
 
 import torch
+
+
+TRUNCATION = "first_index"     # rule of radius() / radius_graph() when a query has more matches than its cap
+_FLAG_DROP_SELF, _FLAG_NEAREST = 1, 2   # DDP_RADIUS_* of include/ddp_hip.h
+
+
+def _rule(truncation):
+    t = TRUNCATION if truncation is None else truncation
+    if t not in ("first_index", "nearest"):
+        raise ValueError(f"unknown radius truncation rule {t!r}")
+    return t
 
 
 @dataclass
@@ -90,11 +103,12 @@ class RadiusSearch:
         (E,) = resolve([s]);  edge_index = s.fill(E)
     """
 
-    def __init__(self, x, y, r, lx, ly, max_num_neighbors=32, drop_self=False, flip=False):
+    def __init__(self, x, y, r, lx, ly, max_num_neighbors=32, drop_self=False, flip=False, truncation=None):
         from . import _lib as L
         lib = L.load()
+        flags = (_FLAG_DROP_SELF if drop_self else 0) | (_FLAG_NEAREST if _rule(truncation) == "nearest" else 0)
         self.args = (x.float().contiguous(), y.float().contiguous(), float(r), _ptr(lx), _batch32(ly, y.shape[0]),
-                     int(max_num_neighbors), int(drop_self))
+                     int(max_num_neighbors), flags)
         self.flip = flip
         xc, yc, r, xptr, ybatch, cap, ds = self.args
         ny = yc.shape[0]
@@ -106,8 +120,8 @@ class RadiusSearch:
         self.offs[1:] = torch.cumsum(counts, 0)
 
     @classmethod
-    def graph(cls, x, r, lx, max_num_neighbors=32):
-        return cls(x, x, r, lx, lx, max_num_neighbors + 1, drop_self=True, flip=True)
+    def graph(cls, x, r, lx, max_num_neighbors=32, truncation=None):
+        return cls(x, x, r, lx, lx, max_num_neighbors + 1, drop_self=True, flip=True, truncation=truncation)
 
     def fill(self, E: int) -> torch.Tensor:
         from . import _lib as L
@@ -142,11 +156,11 @@ def _batch32(layout: "DenseLayout", n: int) -> torch.Tensor:
     return layout._batch32
 
 
-def radius(x, y, r, lx: DenseLayout, ly: DenseLayout, max_num_neighbors=32):
+def radius(x, y, r, lx: DenseLayout, ly: DenseLayout, max_num_neighbors=32, truncation=None):
     """See module docstring.  `r` may be a python float or a [B] tensor is NOT supported (scale inputs instead,
     as the reference does for the dynamic cross cutoff)."""
     if x.is_cuda:   # device search (no dense [B, ny, nx] blocks); the PyTorch form below is the CPU / test definition
-        s = RadiusSearch(x, y, r, lx, ly, max_num_neighbors)
+        s = RadiusSearch(x, y, r, lx, ly, max_num_neighbors, truncation=truncation)
         return s.fill(resolve([s])[0])
     xd, yd = lx.dense(x, float("inf")), ly.dense(y, float("inf"))
     d2 = _sqdist(yd, xd)
@@ -155,19 +169,21 @@ def radius(x, y, r, lx: DenseLayout, ly: DenseLayout, max_num_neighbors=32):
         ok = ok & (ly.index >= 0).unsqueeze(2) & (lx.index >= 0).unsqueeze(1)
     if lx.nmax > max_num_neighbors:
         cnt_max = int(ok.sum(-1).max().item()) if ok.numel() else 0
-        if cnt_max > max_num_neighbors:
+        if cnt_max > max_num_neighbors and _rule(truncation) == "nearest":
             d2m = torch.where(ok, d2, torch.full_like(d2, float("inf")))
             kth = torch.topk(d2m, max_num_neighbors, dim=-1, largest=False).values[..., -1:]
             ok = ok & (d2m <= kth)
+        elif cnt_max > max_num_neighbors:      # the first max_num_neighbors matches in ascending x index
+            ok = ok & (torch.cumsum(ok.to(torch.int32), dim=-1) <= max_num_neighbors)
     b, q, n = ok.nonzero(as_tuple=True)
     return torch.stack([ly.index[b, q], lx.index[b, n]], 0)
 
 
-def radius_graph(x, r, lx: DenseLayout, max_num_neighbors=32):
+def radius_graph(x, r, lx: DenseLayout, max_num_neighbors=32, truncation=None):
     if x.is_cuda:
-        s = RadiusSearch.graph(x, r, lx, max_num_neighbors)
+        s = RadiusSearch.graph(x, r, lx, max_num_neighbors, truncation=truncation)
         return s.fill(resolve([s])[0])
-    ei = radius(x, x, r, lx, lx, max_num_neighbors + 1)
+    ei = radius(x, x, r, lx, lx, max_num_neighbors + 1, truncation=truncation)
     keep = ei[0] != ei[1]
     return torch.stack([ei[1][keep], ei[0][keep]], 0)
 

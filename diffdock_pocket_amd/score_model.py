@@ -641,7 +641,13 @@ class TensorProductScoreModel(nn.Module):
                 out[5], out[8] = (na, e, nr), (nr, e, na)
         return out
 
+    def _weights_version(self):
+        """Sum of the autograd version counters of every parameter and buffer: any in-place update (optimizer step,
+        `ema.copy_to(model.parameters())`, `param.data.copy_`, BatchNorm buffer edits) bumps it."""
+        return sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers())
+
     def invalidate_packed(self):
+        self._weights_seen = None
         self._stage_a_stacks = {}
         for m in self.modules():
             if isinstance(m, TensorProductConvLayer):
@@ -717,6 +723,12 @@ class TensorProductScoreModel(nn.Module):
         lig, rec, atom = data["ligand"], data["receptor"], data["atom"]
         _require_hip(lig.pos)
         dev = lig.pos.device
+        # packed weights, edge-MLP packs, stage-A stacks and the cached encoder parts bake the weights in: dropped when any
+        # parameter / buffer was updated in place since they were built
+        wv = self._weights_version()
+        if self.__dict__.get("_weights_seen") != wv:
+            self.invalidate_packed()
+            self._weights_seen = wv
         ns, L_ = self.ns, self.num_conv_layers
         B = int(data.num_graphs)
         mark = self.section_timer.mark if self.section_timer is not None else (lambda name: None)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DDP_ABI_VERSION 4
+#define DDP_ABI_VERSION 5
 #define DDP_EINVAL (-1)   /* bad argument (shape not supported, null pointer, ...) */
 #define DDP_ELIMIT (-2)   /* exceeds a compiled-in limit (see DDP_MAX_*) */
 
@@ -183,15 +183,19 @@ int ddp_sidechain_update(const float* pos_in, int n_samples, int n_atoms, const 
 
 /* Neighbour search of the forward (torch_cluster radius / radius_graph / knn_graph, models/all_atom_score_model.py:457,
  * 524,545-564,607,627).  Graphs are contiguous node ranges x_ptr[g] .. x_ptr[g+1]; y_batch[q] is the graph of query q.
- *  radius: every x of the query's graph with |x - y|^2 < r^2 (strict); more than max_neighbors matches -> the nearest
- *          max_neighbors (and ties at that distance); drop_self removes the pair (q, x == q) AFTER the cap (radius_graph:
- *          call with max_neighbors + 1); two passes: counts[q], then (after an exclusive prefix sum into offsets) the
- *          pairs (out_query[e], out_x[e]) query-major with ascending x.
+ *  radius: every x of the query's graph with |x - y|^2 < r^2 (strict).  More than max_neighbors matches: by default the
+ *          FIRST max_neighbors in ascending x index are kept - what torch_cluster's CUDA kernel, the one the reference runs
+ *          on a GPU, does (it scans x in index order and stops at the cap); with DDP_RADIUS_NEAREST in `flags` the nearest
+ *          max_neighbors (and ties at that distance) instead.  DDP_RADIUS_DROP_SELF removes the pair (q, x == q) AFTER
+ *          the cap (radius_graph: call with max_neighbors + 1); two passes: counts[q], then (after an exclusive prefix sum
+ *          into offsets) the pairs (out_query[e], out_x[e]) query-major with ascending x.
  *  knn:    out_neighbors[q][0..k) = the k nearest other nodes of q's graph, nearest first, -1 where the graph is smaller. */
+#define DDP_RADIUS_DROP_SELF 1
+#define DDP_RADIUS_NEAREST 2
 int ddp_radius_count(const float* x, const int32_t* x_ptr, const float* y, const int32_t* y_batch, int ny, float r,
-                     int max_neighbors, int drop_self, int32_t* counts, void* stream);
+                     int max_neighbors, int flags, int32_t* counts, void* stream);
 int ddp_radius_fill(const float* x, const int32_t* x_ptr, const float* y, const int32_t* y_batch, int ny, float r,
-                    int max_neighbors, int drop_self, const int32_t* offsets, int32_t* out_query, int32_t* out_x, void* stream);
+                    int max_neighbors, int flags, const int32_t* offsets, int32_t* out_query, int32_t* out_x, void* stream);
 int ddp_knn(const float* x, const int32_t* x_ptr, const int32_t* batch, int n, int k, int32_t* out_neighbors, void* stream);
 
 /* ---- CSR / source-order views of an edge list (csrc/ddp_views.hip).  Replaces, per view, the torch.sort(stable) + index_add +

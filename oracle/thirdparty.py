@@ -305,10 +305,18 @@ def _graph_spans(batch, n):
     return list(zip(ids.tolist(), starts, stops))
 
 
-def radius(x, y, r, batch_x=None, batch_y=None, max_num_neighbors=32):
+TRUNCATION = "first_index"
+
+
+def radius(x, y, r, batch_x=None, batch_y=None, max_num_neighbors=32, truncation=None):
     """[recalled] torch_cluster.radius (SURVEY Appendix B.3): row0 indexes y (query), row1 indexes x;
-    strict '<' on float32 squared distances; per query the `max_num_neighbors` NEAREST are kept (build rule),
-    emitted in ascending (query, x) index order.  Evaluated graph by graph (memory-safe for 40 x 1111 atoms)."""
+    strict '<' on float32 squared distances; emitted in ascending (query, x) index order.  A query with more than
+    `max_num_neighbors` matches keeps, by default ("first_index"), the FIRST max_num_neighbors in ascending x index: the
+    CUDA kernel of torch_cluster 1.6.1 - what the reference executes on a GPU - scans x in index order and stops at the cap
+    (its CPU path, nanoflann with unsorted results, keeps an implementation-defined subset).  "nearest" keeps the nearest
+    ones and ties.  Evaluated graph by graph (memory-safe for 40 x 1111 atoms)."""
+    rule = TRUNCATION if truncation is None else truncation
+    assert rule in ("first_index", "nearest")
     sx = {g: (a, b) for g, a, b in _graph_spans(batch_x, x.shape[0])}
     qs, ns = [], []
     r2 = torch.as_tensor(r, dtype=x.dtype) ** 2
@@ -320,9 +328,12 @@ def radius(x, y, r, batch_x=None, batch_y=None, max_num_neighbors=32):
         d2 = (diff * diff).sum(-1)
         ok = d2 < r2
         if ok.shape[1] > max_num_neighbors and int(ok.sum(1).max()) > max_num_neighbors:
-            d2m = torch.where(ok, d2, torch.full_like(d2, float("inf")))
-            kth = torch.topk(d2m, max_num_neighbors, dim=1, largest=False).values[:, -1:]
-            ok = ok & (d2m <= kth)
+            if rule == "nearest":
+                d2m = torch.where(ok, d2, torch.full_like(d2, float("inf")))
+                kth = torch.topk(d2m, max_num_neighbors, dim=1, largest=False).values[:, -1:]
+                ok = ok & (d2m <= kth)
+            else:
+                ok = ok & (torch.cumsum(ok.long(), dim=1) <= max_num_neighbors)
         q, n = ok.nonzero(as_tuple=True)
         qs.append(q + ya)
         ns.append(n + xa)
@@ -331,11 +342,11 @@ def radius(x, y, r, batch_x=None, batch_y=None, max_num_neighbors=32):
     return torch.stack([torch.cat(qs), torch.cat(ns)], 0)
 
 
-def radius_graph(x, r, batch=None, loop=False, max_num_neighbors=32, flow="source_to_target"):
+def radius_graph(x, r, batch=None, loop=False, max_num_neighbors=32, flow="source_to_target", truncation=None):
     """[recalled] torch_cluster.radius_graph: radius(x, x, r, max+1 if not loop) -> rows swapped to
     [neighbour; query], self loops dropped."""
     assert flow == "source_to_target"
-    ei = radius(x, x, r, batch, batch, max_num_neighbors if loop else max_num_neighbors + 1)
+    ei = radius(x, x, r, batch, batch, max_num_neighbors if loop else max_num_neighbors + 1, truncation=truncation)
     q, n = ei[0], ei[1]
     if not loop:
         keep = q != n

@@ -320,8 +320,9 @@ def _ragged_points(sizes, scale, seed):
     return pos, batch
 
 
+@pytest.mark.parametrize("rule", ["first_index", "nearest"])
 @pytest.mark.parametrize("cap", [10000, 32, 5])
-def test_hip_radius_matches_dense_formulation(cap):
+def test_hip_radius_matches_dense_formulation(cap, rule):
     """ddp_radius_count / ddp_radius_fill (csrc/ddp_graph.hip) against the dense PyTorch formulation of graph.py, which
     tests/test_host_logic.py pins to the oracle's torch_cluster restatement: identical pairs in identical order, ragged
     graphs (one of them empty on the x side), cap binding and not binding, self-loop removal after the cap."""
@@ -333,11 +334,11 @@ def test_hip_radius_matches_dense_formulation(cap):
     lx_c, ly_c = G.DenseLayout.build(bx, B), G.DenseLayout.build(by, B)
     lx_d, ly_d = G.DenseLayout.build(bx.to(dev), B), G.DenseLayout.build(by.to(dev), B)
     for r in (1.5, 3.0):
-        want = G.radius(x, y, r, lx_c, ly_c, max_num_neighbors=cap)
-        got = G.radius(x.to(dev), y.to(dev), r, lx_d, ly_d, max_num_neighbors=cap).cpu()
+        want = G.radius(x, y, r, lx_c, ly_c, max_num_neighbors=cap, truncation=rule)
+        got = G.radius(x.to(dev), y.to(dev), r, lx_d, ly_d, max_num_neighbors=cap, truncation=rule).cpu()
         assert want.shape == got.shape and torch.equal(want, got), (r, cap, want.shape, got.shape)
-        want_g = G.radius_graph(x, r, lx_c, max_num_neighbors=cap)
-        got_g = G.radius_graph(x.to(dev), r, lx_d, max_num_neighbors=cap).cpu()
+        want_g = G.radius_graph(x, r, lx_c, max_num_neighbors=cap, truncation=rule)
+        got_g = G.radius_graph(x.to(dev), r, lx_d, max_num_neighbors=cap, truncation=rule).cpu()
         assert torch.equal(want_g, got_g), (r, cap)
 
 
@@ -477,6 +478,38 @@ def test_sampler_end_to_end_on_device(flex):
     assert model.cache_slot == 0
     if flex:
         assert float((atoms_all - g["atom"].pos.to(dev)).abs().max()) > 1e-3      # side chains moved
+
+
+def test_three_step_trajectory_matches_the_cpu_oracle_trajectory():
+    """A multi-step trajectory on the device (HIP score model + HIP pose / side-chain update kernels) against the same
+    trajectory on the CPU with the ORACLE as score function and the PyTorch pose update (which tests/test_sampler_cpu.py pins
+    to the reference's own loop): same seeded start, same noise stream.  cfg1 on the full complex, 3 of a 20-step schedule's
+    first steps.  The synthetic weights are scaled down (x 0.5 on every conv fc layer) so that the random-init network is
+    smooth enough for per-step fp32 rounding (~1e-6 relative per forward) not to be amplified beyond the tolerance."""
+    from diffdock_pocket_amd.diffusion import get_t_schedule
+    from diffdock_pocket_amd.sampler import Sampler, SamplerConfig
+    from diffdock_pocket_amd.synthetic import make_3dpf_complex
+    dev = _dev()
+    case = CASES["cfg1_full"]
+    _, _, _, sd = case_inputs(case.name)
+    sd = {k: (v * 0.5 if (".fc." in k and k.endswith("weight")) else v) for k, v in sd.items()}
+    model = _model_for(case, sd)
+    oracle = OracleScoreModel(case.oracle_config(), sd)
+    g = make_3dpf_complex(seed=0, flexible_sidechains=True)
+    sched = get_t_schedule(20)
+    cfg = SamplerConfig(inference_steps=20, flexible_sidechains=True)
+    s_gpu = Sampler(model, g, 4, dev, cfg, seed=9)
+    s_cpu = Sampler(lambda b: oracle(b), g, 4, torch.device("cpu"), cfg, seed=9)
+    s_gpu.randomize()
+    s_cpu.randomize()
+    assert float((s_gpu.lig_pos.cpu() - s_cpu.lig_pos).abs().max()) < 1e-4
+    for i in range(3):
+        s_gpu.step(i, sched)
+        s_cpu.step(i, sched)
+        dl = float((s_gpu.lig_pos.cpu() - s_cpu.lig_pos).abs().max())
+        da = float((s_gpu.atom_pos.cpu() - s_cpu.atom_pos).abs().max())
+        assert dl < 2e-3 and da < 2e-3, (i, dl, da)       # angstrom; the ligand has moved by several angstrom by then
+    assert float((s_cpu.lig_pos - g["ligand"].pos).abs().max()) > 1.0
 
 
 def test_forward_on_graph_from_the_input_pipeline():

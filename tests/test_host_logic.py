@@ -173,10 +173,14 @@ def test_graph_builders_match_oracle_semantics(uniform):
     by = torch.repeat_interleave(torch.arange(3), torch.tensor(sizes_y))
     lx, ly = G.DenseLayout.build(bx, 3), G.DenseLayout.build(by, 3)
     for cap in (10000, 5):
-        a = G.radius(x, y, 3.0, lx, ly, max_num_neighbors=cap)
-        b = tp.radius(x, y, 3.0, bx, by, max_num_neighbors=cap)
-        assert torch.equal(a, b)
+        for rule in (None, "first_index", "nearest"):
+            a = G.radius(x, y, 3.0, lx, ly, max_num_neighbors=cap, truncation=rule)
+            b = tp.radius(x, y, 3.0, bx, by, max_num_neighbors=cap, truncation=rule)
+            assert torch.equal(a, b)
     assert torch.equal(G.radius_graph(x, 3.0, lx), tp.radius_graph(x, 3.0, bx))
+    for rule in ("first_index", "nearest"):
+        assert torch.equal(G.radius_graph(x, 3.0, lx, max_num_neighbors=4, truncation=rule),
+                           tp.radius_graph(x, 3.0, bx, max_num_neighbors=4, truncation=rule))
     a, b = G.knn_graph(x, 8, lx), tp.knn_graph(x, 8, bx)
     assert torch.equal(a, b)
     csr = G.build_csr(a[0], a[1], x.shape[0])
@@ -238,7 +242,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.ddp_abi_version.restype = ctypes.c_int
-    assert lib.ddp_abi_version() == 4
+    assert lib.ddp_abi_version() == 5
     assert ctypes.sizeof(L.ConvShape) == 11 * 4 + 4 * (11 * 4 + 3 * 12)
 
 
@@ -336,3 +340,33 @@ def test_library_carries_the_hash_of_the_sources_in_the_tree():
     lib = L.load()
     assert lib.ddp_source_hash().decode() == B.source_hash() and len(B.source_hash()) == 16
     assert not B.needs_build()
+
+
+def test_radius_cap_keeps_the_first_matches_by_index_like_torch_cluster_on_a_gpu():
+    """The side-chain torsion head searches the pocket atoms around a bond centre with the default cap of 32, and bonds do
+    see that many atoms within 5 A (3dpf's flexible bonds: 10 .. 32, SURVEY Appendix B.3: up to ~40 on other complexes).
+    The reference runs torch_cluster's CUDA kernel there, which scans the atoms in index order and stops at the cap: the
+    default rule here.  Pinned on the 3dpf pocket with the cap lowered to 16 so that it binds: a bond centre with more
+    candidates gets exactly the 16 lowest-index ones, in index order; the 'nearest' rule gives another set."""
+    from diffdock_pocket_amd.synthetic import make_3dpf_complex
+    g = make_3dpf_complex(seed=0, flexible_sidechains=True)
+    pos = g["atom"].pos
+    fr = g["flexResidues"]
+    mid = (pos[fr.edge_idx[:, 0]] + pos[fr.edge_idx[:, 1]]) / 2
+    la = G.DenseLayout.build(torch.zeros(pos.shape[0], dtype=torch.long), 1)
+    lb = G.DenseLayout.build(torch.zeros(mid.shape[0], dtype=torch.long), 1)
+    assert G.TRUNCATION == "first_index" and tp.TRUNCATION == "first_index"
+    full = G.radius(pos, mid, 5.0, la, lb, max_num_neighbors=10000)
+    n_within = torch.bincount(full[0], minlength=mid.shape[0])
+    cap = 16
+    assert int(n_within.max()) >= 32 and int((n_within > cap).sum()) >= 10
+    capped = G.radius(pos, mid, 5.0, la, lb, max_num_neighbors=cap)                       # default rule
+    assert torch.equal(capped, tp.radius(pos, mid, 5.0, max_num_neighbors=cap))
+    near = G.radius(pos, mid, 5.0, la, lb, max_num_neighbors=cap, truncation="nearest")
+    assert torch.equal(near, tp.radius(pos, mid, 5.0, max_num_neighbors=cap, truncation="nearest"))
+    differs = 0
+    for q in range(mid.shape[0]):
+        want = full[1][full[0] == q][:cap]                          # ascending index, first `cap`
+        assert torch.equal(capped[1][capped[0] == q], want)
+        differs += int(not torch.equal(near[1][near[0] == q], want))
+    assert differs > 0

@@ -105,19 +105,26 @@ def test_two_rank_sharding_is_shard_invariant():
     assert torch.equal(gathered, full)
 
 
-def test_perturbation_formula_low_temperature():
-    """reference utils/sampling.py:129-195 for one component, written out literally."""
-    cfg = S.SamplerConfig()
-    sg = cfg.sigma
-    t, dt = 0.55, 0.05
-    tr_sigma = sg.tr_sigma_min ** (1 - t) * sg.tr_sigma_max ** t
-    tr_g = tr_sigma * torch.sqrt(torch.tensor(2 * np.log(sg.tr_sigma_max / sg.tr_sigma_min)))
-    score, z = torch.tensor([[0.3, -0.2, 0.1]]), torch.tensor([[0.5, 0.1, -1.0]])
-    sd = np.exp(cfg.temp_sigma_data * np.log(sg.tr_sigma_max) + (1 - cfg.temp_sigma_data) * np.log(sg.tr_sigma_min))
-    lam = (sd + tr_sigma) / (sd + tr_sigma / cfg.temp_sampling[0])
-    want = tr_g ** 2 * dt * (lam + cfg.temp_sampling[0] * cfg.temp_psi[0] / 2) * score + tr_g * np.sqrt(dt * (1 + cfg.temp_psi[0])) * z
-    g = tr_sigma * math.sqrt(2 * math.log(sg.tr_sigma_max / sg.tr_sigma_min))
-    sigma_data = math.exp(cfg.temp_sigma_data * math.log(sg.tr_sigma_max) + (1 - cfg.temp_sigma_data) * math.log(sg.tr_sigma_min))
-    lam2 = (sigma_data + tr_sigma) / (sigma_data + tr_sigma / cfg.temp_sampling[0])
-    got = g ** 2 * dt * (lam2 + cfg.temp_sampling[0] * cfg.temp_psi[0] / 2) * score + g * math.sqrt(dt * (1 + cfg.temp_psi[0])) * z
-    assert torch.allclose(got, want.float(), rtol=1e-6)
+def test_sampler_steps_match_the_reference_loop():
+    """Sampler.step (scores -> SDE perturbation with the low-temperature branch -> side-chain and ligand pose update) against
+    the reference's OWN loop utils/sampling.py:93-251, run unmodified for three steps on three poses with a stub score function
+    of the positions and a seeded global RNG (tests/golden/sampler_loop.pt, oracle/make_golden_sampler.py).  The same seed on
+    the Sampler's generator gives the same normal draws in the same order (tr, rot, tor, side chains), so the trajectories
+    agree to the fp32 rounding of the pose update (the reference rotates in float64 numpy / scipy)."""
+    from oracle.make_golden_sampler import LOOP_N, loop_inputs, stub_scores
+    gold = torch.load(os.path.join(os.path.dirname(GOLD), "sampler_loop.pt"), weights_only=True)
+    base, graphs = loop_inputs()
+    assert torch.equal(torch.stack([d["ligand"].pos for d in graphs]), gold["lig_start"])
+    T, S_ = int(base["ligand"].edge_mask.sum()), int(base["flexResidues"].edge_idx.shape[0])
+    steps = gold["steps"]
+    smp = S.Sampler(lambda b: stub_scores(b, T, S_), base, LOOP_N, torch.device("cpu"), S.SamplerConfig(inference_steps=steps),
+                    seed=gold["seed"])
+    smp.lig_pos, smp.atom_pos = gold["lig_start"].clone(), gold["atom_start"].clone()
+    sched = get_t_schedule(steps)
+    for i in range(steps):
+        assert float((smp.lig_pos - gold["lig_traj"][i]).abs().max()) < 5e-4, i      # poses at the start of step i
+        smp.step(i, sched)
+    assert float((smp.lig_pos - gold["lig_out"]).abs().max()) < 5e-4
+    assert float((smp.atom_pos - gold["atom_out"]).abs().max()) < 5e-4
+    assert float((gold["lig_out"] - gold["lig_start"]).abs().max()) > 1.0            # the ligands moved by angstroms
+    assert float((gold["atom_out"] - gold["atom_start"]).abs().max()) > 0.1          # and side chains turned

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Diagnostic: time the layer-3 conv launch (all four blocks / scalar block only) with the product library and with the
-timing-only ablation builds (1: no weight loads in the scalar main loop, 2: no LDS A reads).  One process per variant."""
+"""Diagnostic: time the layer-3 conv launch of the DIRECT path (model.factorize_min_degree = 0: all nine convs in one
+64-edge launch; all four blocks / scalar block only) with the product library and with the timing-only ablation builds
+(1: no weight loads in the scalar main loop, 2: no LDS A reads).  One process per variant."""
 import os
 import subprocess
 import sys
@@ -18,15 +19,16 @@ from diffdock_pocket_amd.sampler import Sampler, SamplerConfig
 from diffdock_pocket_amd.synthetic import make_3dpf_complex
 dev = torch.device("cuda:0")
 model, kw = bench.build_model("cfg2", False, dev)
+model.factorize_min_degree = 0      # every conv on the direct path: the launch this tool dissects
 g = make_3dpf_complex(seed=0, flexible_sidechains=False)
 smp = Sampler(model, g, 40, dev, SamplerConfig(flexible_sidechains=False), seed=0)
 smp.randomize()
 orig = sm._launch_convs
 saved = {}
-def hooked(spec, tasks):
-    if len(spec.blocks) == 4 and len(tasks) == 9 and spec.blocks[3].ntiles == 140 and "t" not in saved:
+def hooked(spec, tasks, **kw):
+    if (not spec.factorized) and len(spec.blocks) == 4 and len(tasks) == 9 and spec.blocks[3].ntiles == 140 and "t" not in saved:
         saved["t"] = (spec, list(tasks))
-    orig(spec, tasks)
+    orig(spec, tasks, **kw)
 sm._launch_convs = hooked
 smp.step(0, get_t_schedule(20))
 torch.cuda.synchronize()
