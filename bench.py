@@ -23,7 +23,7 @@ Synthetic data: real 3dpf geometry + random categorical features / ESM block, ra
 checkpoints).  Inputs are resident in HBM before the timed region.
 
 The JSON line also carries
-  roofline      the dominant kernel (ddp_conv_messages_kernel<32>, fp32-MFMA bound).  `achieved` = USEFUL fp32 MFMA FLOPs the
+  roofline      the dominant kernel (ddp_conv32_kernel, fp32-MFMA bound).  `achieved` = USEFUL fp32 MFMA FLOPs the
                 kernel's own formulation needs per launch (no tile padding; packing.ConvSpec.useful_flops_per_edge x the
                 launch's edge count) / mean launch time from HIP events on the launch stream inside the timed region;
                 `frac` = achieved / 157.3 TFLOP/s <= 1.  The reference formulation's FLOPs, most of

@@ -31,10 +31,18 @@ class Block(C.Structure):
                 ("seg", Seg * DDP_MAX_SEGS), ("g_slot", C.c_int32), ("g_col0", C.c_int32)]
 
 
+class RoleSeg(C.Structure):
+    _fields_ = [("block", C.c_int32), ("tile0", C.c_int32), ("tstride", C.c_int32), ("count", C.c_int32), ("round", C.c_int32)]
+
+
+DDP_CONV32_WAVES, DDP_MAX_ROLE_SEGS = 4, 2
+
+
 class ConvShape(C.Structure):
     _fields_ = [("f_in", C.c_int32), ("hid", C.c_int32), ("kp1", C.c_int32), ("hp", C.c_int32), ("hs", C.c_int32),
                 ("nct1", C.c_int32), ("d_out", C.c_int32), ("nblocks", C.c_int32), ("fbuf_floats", C.c_int32),
-                ("g_cols", C.c_int32 * 2), ("blk", Block * DDP_MAX_BLOCKS)]
+                ("g_cols", C.c_int32 * 2), ("blk", Block * DDP_MAX_BLOCKS), ("nrounds", C.c_int32),
+                ("nrole", C.c_int32 * DDP_CONV32_WAVES), ("role", (RoleSeg * DDP_MAX_ROLE_SEGS) * DDP_CONV32_WAVES)]
 
 
 class ConvTask(C.Structure):

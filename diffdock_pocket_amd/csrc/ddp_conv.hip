@@ -110,7 +110,7 @@ extern "C" int ddp_debug_read_stamps(unsigned long long* host_dst, int n_wgs) {
 
 struct ConvLaunch {
   ddp_conv_shape_t shape;
-  int tv_off;   // offset (floats) of the tv[ET][g_cols] region of the factorised part inside fbuf
+  int tv_off;   // 32-edge kernel: row stride (floats) of the LDS message tile; unused by the 64-edge kernel
   int ntasks;
   int tile_start[DDP_MAX_TASKS + 1];
   ddp_conv_task_t task[DDP_MAX_TASKS];
@@ -199,9 +199,22 @@ struct TileAux {
   int segi[DDP_MAX_SEGS][ET];   // row of every edge in each edge_attr_ segment
 };
 
+// tv[e, c] of a factorised feature column c, times the edge's harmonic, added to the workgroup's LDS message tile:
+// gm = out column | (C << 16) of G column c (C = 1: scalar block, factor s0; C = 3: vector block, factors s1[0..2])
+__device__ __forceinline__ void g_add_out(float* outb, int os, const float (*sh)[4], int e, int gm, float v) {
+  float* o = outb + e * os + (gm & 0xffff);
+  if ((gm >> 16) == 1) {
+    o[0] += sh[e][0] * v;
+  } else {
+    o[0] += sh[e][1] * v;
+    o[1] += sh[e][2] * v;
+    o[2] += sh[e][3] * v;
+  }
+}
+
 template <int ET>
 __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, const ddp_conv_task_t& T, const float* hbuf,
-                                        float* tvbuf, const TileAux<ET>& aux, int wave, int lane) {
+                                        float* outb, int os, const int* gmap, const TileAux<ET>& aux, int wave, int lane) {
   // One pass per G slot; a wave takes units wave, wave + NW, ...  For a unit (<= 8 edges of one source node)
   //   tv[i, c] = Gb[c] + sum_k h[e0 + i, k] * G[k, c]
   // is a [8 x hid] x [hid x gc] product with the 8 rows in LDS and the G rows streamed from memory exactly once.
@@ -302,9 +315,10 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
           acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q4][3], BUF[q4][3], acc3, 0, 0, 0);                    \
         }                                                                                                     \
       if (c_ch == nch - 1 && act0) {   /* rows >= len of the two 4-edge groups are never stored */            \
+        const int gm_ = gmap[cb + lane];                                                                      \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
-          if (i < len) tvbuf[(e0 + i) * gc + cb + lane] = acc0[i] + acc2[i];                                  \
-          if (4 + i < len) tvbuf[(e0 + 4 + i) * gc + cb + lane] = acc1[i] + acc3[i];                          \
+          if (i < len) g_add_out(outb, os, aux.sh, e0 + i, gm_, acc0[i] + acc2[i]);                           \
+          if (4 + i < len) g_add_out(outb, os, aux.sh, e0 + 4 + i, gm_, acc1[i] + acc3[i]);                   \
         }                                                                                                     \
       }                                                                                                       \
       if (++c_ch == nch) { c_ch = 0; ++c_ui; }                                                                \
@@ -388,10 +402,11 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
         }
       }
       if (lane < nx) {
+        const int gm = gmap[64 + lane];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          if (i < len) tvbuf[(e0 + i) * gc + 64 + lane] = bx + x0[i];
-          if (4 + i < len) tvbuf[(e0 + 4 + i) * gc + 64 + lane] = bx + x1[i];
+          if (i < len) g_add_out(outb, os, aux.sh, e0 + i, gm, bx + x0[i]);
+          if (4 + i < len) g_add_out(outb, os, aux.sh, e0 + 4 + i, gm, bx + x1[i]);
         }
       }
     }
@@ -411,7 +426,7 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
 //                  the vector blocks whose three (x,y,z) output accumulators would not fit next to a 2-row-tile acc)
 template <int C>
 __device__ __forceinline__ void run_block_full(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
-                                          const float* hbuf, float* fbuf, const float* tvbuf, int tid,
+                                          const float* hbuf, float* fbuf, int tid,
                                           const TileAux<64>& aux, int nvalid, int sbase) {
   constexpr int CT = (C == 1) ? 2 : 1;
   constexpr int FS = FS64;
@@ -566,7 +581,6 @@ __device__ __forceinline__ void run_block_full(const ddp_conv_shape_t& S, const 
       if (half == 0) {
         carry[idx] = sum;
       } else if (e < nvalid) {
-        if (B.g_slot >= 0) sum += aux.sh[e][0] * tvbuf[e * S.g_cols[B.g_slot] + B.g_col0 + ncol];   // factorised features
         T.msg[(size_t)aux.pos[e] * S.d_out + B.out_off + ncol] = sum;
       }
     }
@@ -577,7 +591,7 @@ __device__ __forceinline__ void run_block_full(const ddp_conv_shape_t& S, const 
 
 template <int ET, int C>
 __device__ __forceinline__ void run_block_rows(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
-                                          const float* hbuf, float* fbuf, const float* tvbuf, int tid,
+                                          const float* hbuf, float* fbuf, int tid,
                                           const TileAux<ET>& aux, int nvalid, int sbase) {
   constexpr int FS = ET + 4, NT = ET * 8;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps tile/loop indices in SGPRs
@@ -666,7 +680,6 @@ __device__ __forceinline__ void run_block_rows(const ddp_conv_shape_t& S, const 
   STAMP_SYNC();
   STAMP(sbase + 1);    // all waves done
   float* part = fbuf;
-  const int gcs = (B.g_slot >= 0) ? S.g_cols[B.g_slot] : 0;
   if constexpr (ET == 64) {
     constexpr int NP = (C == 1) ? 1 : 2;            // passes
     constexpr int RW = 32 * C;                      // floats per edge row in a wave region: [c][r]
@@ -703,74 +716,31 @@ __device__ __forceinline__ void run_block_rows(const ddp_conv_shape_t& S, const 
           }
         }
         if (e < nvalid) {
-          if (B.g_slot >= 0) sum += ((C == 1) ? aux.sh[e][0] : aux.sh[e][1 + c]) * tvbuf[e * gcs + B.g_col0 + ncol];
           T.msg[(size_t)aux.pos[e] * S.d_out + B.out_off + cc] = sum;
         }
       }
     }
   } else {
-    constexpr int REGION = 32 * 32;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      __syncthreads();  // F (or the previous component's partials) no longer needed
-      float* mine = part + wave * REGION;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-        mine[row * 32 + r] = out[c][i];
-      }
-      __syncthreads();
-      for (int idx = tid; idx < 32 * B.n; idx += NT) {
-        const int e = idx / B.n, ncol = idx - e * B.n;
-        float sum = 0.f;
-        for (int w = 0; w < 4; ++w) {
-          const float* reg = part + w * REGION + e * 32;
-          if (B.nsub > 1) {
-            if ((w & 1) == (ncol >> 5)) sum += reg[ncol & 31];
-          } else {
-            for (int k = 0; k < B.ups; ++k) sum += reg[k * B.n + ncol];
-          }
-        }
-        if (e < nvalid) {
-          if (B.g_slot >= 0) sum += ((C == 1) ? aux.sh[e][0] : aux.sh[e][1 + c]) * tvbuf[e * gcs + B.g_col0 + ncol];
-          T.msg[(size_t)aux.pos[e] * S.d_out + B.out_off + ncol * C + c] = sum;
-        }
-      }
-    }
+    static_assert(ET == 64, "run_block_rows is the 64-edge form; 32-edge workgroups run ddp_conv32_kernel");
   }
   __syncthreads();  // fbuf is rewritten by the next block's features
   STAMP(sbase + 2);
 }
 
-// ------------------------------------------------------------------------------------------------ kernel
-template <int ET>
-__global__ __launch_bounds__(ET * 8, (ET == 64) ? 2 : 3) void ddp_conv_messages_kernel(const ConvLaunch L) {
-  constexpr int NT = ET * 8, NW = ET / 8, RT = ET / 32;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ TileAux<ET> aux;
-  const ddp_conv_shape_t& S = L.shape;
-  const int tid = threadIdx.x;
-  // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), so id -> tile is
-  // remapped to give every XCD one contiguous range of tiles: neighbouring tiles share source nodes (G rows, x rows)
-  // and all tiles of a conv share its packed weights.
-  int tile;
-  {
-    const int ntl = (int)gridDim.x, q = ntl >> 3, rem = ntl & 7, x = (int)blockIdx.x & 7;
-    tile = ((x < rem) ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + ((int)blockIdx.x >> 3);
-  }
-  int t = 0;
-  while (t + 1 < L.ntasks && tile >= L.tile_start[t + 1]) ++t;
-  const ddp_conv_task_t& T = L.task[t];
-  const int p0 = (tile - L.tile_start[t]) * ET;
-  const int nvalid = min(ET, T.n_edges - p0);
-  float* hbuf = lds;
-  float* fbuf = lds + ET * S.hs;
-  float* xa = fbuf;  // edge_attr_ staging aliases the feature buffer
-  float* tvbuf = fbuf + L.tv_off;
+// ------------------------------------------------------------------------------------------------ phases 0 + 1
+// workgroup id -> tile.  XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), so
+// id -> tile is remapped to give every XCD one contiguous range of tiles: neighbouring tiles share source nodes (G rows,
+// x rows) and all tiles of a conv share its packed weights.
+__device__ __forceinline__ int xcd_tile() {
+  const int ntl = (int)gridDim.x, q = ntl >> 3, rem = ntl & 7, x = (int)blockIdx.x & 7;
+  return ((x < rem) ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + ((int)blockIdx.x >> 3);
+}
 
-  STAMP(0);
-  STAMP(22);  // s_memrealtime (100 MHz) at entry
-  // ---- phase 0: indices + edge_attr_ rows
+// phase 0: per-edge indices, harmonics, the units of the G pass, then the three row gathers of edge_attr_ into xa
+template <int ET>
+__device__ __forceinline__ void stage_edge_attr(const ddp_conv_shape_t& S, const ddp_conv_task_t& T, TileAux<ET>& aux, float* xa,
+                                                int p0, int nvalid, int tid) {
+  constexpr int NT = ET * 8;
   if (tid < 64) {   // wave 0, lane = edge
     const bool valid = tid < nvalid;
     const int p = p0 + min(tid, nvalid - 1);
@@ -839,79 +809,90 @@ __global__ __launch_bounds__(ET * 8, (ET == 64) ? 2 : 3) void ddp_conv_messages_
     }
   }
   __syncthreads();
-  STAMP(1);
+}
 
-  // ---- phase 1: h = relu(edge_attr_ @ W1 + b1)
-  {
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps tile/loop indices in SGPRs
-    const int lane = tid & 63, r = lane & 31, hh = lane >> 5;
-    const int nm1 = S.kp1 >> 3;
-    const f32x4* __restrict__ w1p = reinterpret_cast<const f32x4*>(T.w1p);
-    // RT * nct1 (row tile, column tile) pairs over the waves: pair t -> wave t % NW, i.e. SIMD t % 4, so the four matrix
-    // pipes get the same number of tiles (ET = 64: 12 tiles at hid = 180, 3 per SIMD)
-    for (int t1 = wave; t1 < RT * S.nct1; t1 += NW) {
-      const int rt = t1 % RT, ct = t1 / RT;
-      f32x16 acc = splat16(T.b1p[ct * 32 + r]);
-      const f32x4* __restrict__ wp = w1p + ((size_t)ct * nm1 * 2 + hh) * 32 + r;
-      // the whole K panel of this column tile is 23 KiB per wave: request 4 k-groups ahead (the loop is short and
-      // latency bound otherwise: 4 MFMAs = 256 cycles per k-group)
-      f32x4 q0 = wp[0], q1 = wp[64 * min(1, nm1 - 1)], q2 = wp[64 * min(2, nm1 - 1)], q3 = wp[64 * min(3, nm1 - 1)];
-      for (int m = 0; m < nm1; m += 4) {
+// phase 1: h = relu(edge_attr_ @ W1 + b1)
+template <int ET>
+__device__ __forceinline__ void fc1_to_lds(const ddp_conv_shape_t& S, const ddp_conv_task_t& T, const float* xa, float* hbuf, int tid) {
+  constexpr int NW = ET / 8, RT = ET / 32;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps tile/loop indices in SGPRs
+  const int lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int nm1 = S.kp1 >> 3;
+  const f32x4* __restrict__ w1p = reinterpret_cast<const f32x4*>(T.w1p);
+  // RT * nct1 (row tile, column tile) pairs over the waves: pair t -> wave t % NW, i.e. SIMD t % 4, so the four matrix
+  // pipes get the same number of tiles (ET = 64: 12 tiles at hid = 180, 3 per SIMD)
+  for (int t1 = wave; t1 < RT * S.nct1; t1 += NW) {
+    const int rt = t1 % RT, ct = t1 / RT;
+    f32x16 acc = splat16(T.b1p[ct * 32 + r]);
+    const f32x4* __restrict__ wp = w1p + ((size_t)ct * nm1 * 2 + hh) * 32 + r;
+    // the whole K panel of this column tile is 23 KiB per wave: request 4 k-groups ahead (the loop is short and
+    // latency bound otherwise: 4 MFMAs = 256 cycles per k-group)
+    f32x4 q0 = wp[0], q1 = wp[64 * min(1, nm1 - 1)], q2 = wp[64 * min(2, nm1 - 1)], q3 = wp[64 * min(3, nm1 - 1)];
+    for (int m = 0; m < nm1; m += 4) {
 #define DDP_FC1_STEP(Q, K)                                                                                   \
-        if (m + K < nm1) {                                                                                   \
-          const f32x4 b = Q;                                                                                 \
-          Q = wp[64 * min(m + K + 4, nm1 - 1)];                                                              \
-          const f32x4 a = *reinterpret_cast<const f32x4*>(&xa[(rt * 32 + r) * S.hs + 8 * (m + K) + 4 * hh]); \
-          _Pragma("unroll") for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0); \
-        }
-        DDP_FC1_STEP(q0, 0)
-        DDP_FC1_STEP(q1, 1)
-        DDP_FC1_STEP(q2, 2)
-        DDP_FC1_STEP(q3, 3)
-#undef DDP_FC1_STEP
+      if (m + K < nm1) {                                                                                   \
+        const f32x4 b = Q;                                                                                 \
+        Q = wp[64 * min(m + K + 4, nm1 - 1)];                                                              \
+        const f32x4 a = *reinterpret_cast<const f32x4*>(&xa[(rt * 32 + r) * S.hs + 8 * (m + K) + 4 * hh]); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0); \
       }
-      const int col = ct * 32 + r;
-      if (col < S.hp) {
+      DDP_FC1_STEP(q0, 0)
+      DDP_FC1_STEP(q1, 1)
+      DDP_FC1_STEP(q2, 2)
+      DDP_FC1_STEP(q3, 3)
+#undef DDP_FC1_STEP
+    }
+    const int col = ct * 32 + r;
+    if (col < S.hp) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          hbuf[row * S.hs + col] = fmaxf(acc[i], 0.f);
-        }
+      for (int i = 0; i < 16; ++i) {
+        const int row = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        hbuf[row * S.hs + col] = fmaxf(acc[i], 0.f);
       }
     }
   }
   __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------ kernel, 64-edge form
+// (direct shapes: every block's features on the per-edge MFMA path)
+__global__ __launch_bounds__(512, 2) void ddp_conv_messages_kernel(const ConvLaunch L) {
+  constexpr int ET = 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ TileAux<ET> aux;
+  const ddp_conv_shape_t& S = L.shape;
+  const int tid = threadIdx.x;
+  const int tile = xcd_tile();
+  int t = 0;
+  while (t + 1 < L.ntasks && tile >= L.tile_start[t + 1]) ++t;
+  const ddp_conv_task_t& T = L.task[t];
+  const int p0 = (tile - L.tile_start[t]) * ET;
+  const int nvalid = min(ET, T.n_edges - p0);
+  float* hbuf = lds;
+  float* fbuf = lds + ET * S.hs;
+  float* xa = fbuf;  // edge_attr_ staging aliases the feature buffer
+
+  STAMP(0);
+  STAMP(22);  // s_memrealtime (100 MHz) at entry
+  stage_edge_attr<ET>(S, T, aux, xa, p0, nvalid, tid);
+  STAMP(1);
+  fc1_to_lds<ET>(S, T, xa, hbuf, tid);
   STAMP(2);
 
   // ---- per weight block
   for (int bi = 0; bi < S.nblocks; ++bi) {
     const ddp_block_t& B = S.blk[bi];
     build_features<ET>(B, T, aux.src, aux.sh, fbuf, tid);
-    if (bi == 0) STAMP(35);
-    if (bi == 2) STAMP(32);
-    if constexpr (ET == 32) {   // (factorised shapes are always launched with 32-edge workgroups)
-      if (B.g_slot >= 0 && (bi == 0 || S.blk[bi - 1].g_slot != B.g_slot))   // one pass per G slot, shared by its blocks
-        g_stage<ET>(S, B.g_slot, T, hbuf, tvbuf, aux, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
-    }
-    if (bi == 0) STAMP(33);
-    if (bi == 2) STAMP(34);
     __syncthreads();
     STAMP(3 + 4 * bi);
-    // ET = 64, scalar blocks with many tiles (direct path: 140): 2x2 full-row blocking, 8-way tile split; otherwise
-    // single tiles over (4 column groups x RT row tiles)
-    if constexpr (ET == 64) {
-      if (B.C == 1 && B.ntiles >= 64)
-        run_block_full<1>(S, B, T, hbuf, fbuf, tvbuf, tid, aux, nvalid, 4 + 4 * bi);
-      else if (B.C == 1)
-        run_block_rows<ET, 1>(S, B, T, hbuf, fbuf, tvbuf, tid, aux, nvalid, 4 + 4 * bi);
-      else
-        run_block_rows<ET, 3>(S, B, T, hbuf, fbuf, tvbuf, tid, aux, nvalid, 4 + 4 * bi);
-    } else {
-      if (B.C == 1)
-        run_block_rows<ET, 1>(S, B, T, hbuf, fbuf, tvbuf, tid, aux, nvalid, 4 + 4 * bi);
-      else
-        run_block_rows<ET, 3>(S, B, T, hbuf, fbuf, tvbuf, tid, aux, nvalid, 4 + 4 * bi);
-    }
+    // scalar blocks with many tiles (140 at ns = 60): 2x2 full-row blocking, 8-way tile split; otherwise single tiles over
+    // (4 column groups x 2 row tiles)
+    if (B.C == 1 && B.ntiles >= 64)
+      run_block_full<1>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
+    else if (B.C == 1)
+      run_block_rows<ET, 1>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
+    else
+      run_block_rows<ET, 3>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
   }
   STAMP(23);  // s_memrealtime at exit
 #ifdef DDP_STAMPS
@@ -925,9 +906,255 @@ __global__ __launch_bounds__(ET * 8, (ET == 64) ? 2 : 3) void ddp_conv_messages_
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------ kernel, 32-edge form
+// Factorised shapes (include/ddp_hip.h, ddp_block_t::g_slot).  256 threads = 4 waves (one per SIMD), ~50 KiB of LDS, THREE
+// workgroups per CU whose phases interleave on the matrix pipes.  LDS: h[32][hs] | region B[>= 32][hs], where region B is,
+// in turn, the edge_attr_ staging tile (phases 0-1), the basis features F of ALL blocks (phases 2-3) and the workgroup's
+// message tile out[32][os] (phases 4-6).
+//   phase 2  F[u][c][e] of every block at once (one barrier instead of one per block)
+//   phase 3  NO barriers: wave w runs its role segments (shape.role[w], packing.conv32_roles): a segment = the tiles of one
+//            block that cover one set of output columns, so its contraction  out[e, n(,c)] += F[e,u(,c)] * acc[e,(u,n)]  is
+//            accumulated over all its tiles in the wave's own registers - no cross-wave reduction per block
+//   phase 4  the message tile is zeroed (it aliases F: one barrier after the tile loops) and the segments are added to it in
+//            `round` order (a block cut in two for load balance is summed in a fixed order; 1-2 rounds, a barrier each)
+//   phase 5  the G pass (g_stage) adds  s(e) * (h[e] . G[src(e)] + Gb[src(e)])  for the factorised features straight into the
+//            message tile; every (edge, column) has exactly one writer, the additions of an element happen in program order
+//   phase 6  the tile leaves as whole message rows (16-byte coalesced stores)
+// Summation order of a message element: tiles of a segment in tile order, segments in round order, then the factorised part:
+// fixed, so results are bitwise reproducible.
+template <int C>
+__device__ __forceinline__ void seg_tiles(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
+                                          const float* hbuf, const float* fblk, const ddp_role_seg_t& R, int lane, f32x16* out) {
+  constexpr int FS = 36;
+  const int r = lane & 31, hh = lane >> 5;
+  const int nm = S.hp >> 3;
+  const int t0 = R.tile0, ts = R.tstride, count = R.count;
+  const f32x4* __restrict__ w2p = reinterpret_cast<const f32x4*>(T.w2p);
+  const float* arow = &hbuf[r * S.hs + 4 * hh];
+#pragma unroll
+  for (int c = 0; c < C; ++c) out[c] = splat16(0.f);
+  // The segment's (tile, k-group) steps are flattened into one sequence; the 16-byte weight fragment of step f + 4 is requested
+  // before the 4 MFMAs of step f (register ring of four, sched_barriers pin the requests: hipcc otherwise sinks them to
+  // their first use).  Fragments of one tile are 64 f32x4 apart, tiles of the segment ts * nm * 64.
+  const int F = count * nm;
+  const f32x4* __restrict__ wp = w2p + ((size_t)(B.tile0 + t0) * nm * 2 + hh) * 32 + r;
+  const size_t tile_jump = (size_t)ts * nm * 64 - (size_t)(nm - 1) * 64;
+  int pm = 0, pleft = F;
+  auto wfrag = [&]() -> f32x4 {
+    const f32x4 v = DDP_ABL_B(*wp);
+    if (pleft > 1) {
+      --pleft;
+      if (++pm == nm) { pm = 0; wp += tile_jump; } else wp += 64;
+    }
+    return v;
+  };
+  f32x16 acc = splat16(0.f);
+  f32x4 anext = *reinterpret_cast<const f32x4*>(arow);
+  float bias_next = (count > 0) ? T.b2p[(B.tile0 + t0) * 32 + r] : 0.f;
+  int sj = 0, sm = 0;                                  // (tile, k-group) of the step being computed
+  auto step = [&](const f32x4 bcur) {
+    if (sm == 0) {
+      acc = splat16(bias_next);
+      bias_next = T.b2p[(B.tile0 + t0 + min(sj + 1, count - 1) * ts) * 32 + r];   // next tile's bias, a whole tile ahead
+    }
+    const f32x4 a = anext;
+    anext = DDP_ABL_A(*reinterpret_cast<const f32x4*>(arow + 8 * ((sm + 1 == nm) ? 0 : sm + 1)), anext);  // h is tile independent: wrap
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[i], acc, 0, 0, 0);
+    if (++sm == nm) {
+      // contraction with the basis features, in the MFMA C/D layout: reg i <-> edge row (i&3) + 8*(i>>2) + 4*hh
+      int u, ncol, us;
+      bool valid;
+      tile_lane_map(B, t0 + sj * ts, r, u, ncol, us, valid);
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float* frow = &fblk[(u * C + c) * FS + 4 * hh];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const f32x4 f = *reinterpret_cast<const f32x4*>(frow + 8 * q4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) out[c][4 * q4 + q] += f[q] * acc[4 * q4 + q];
+        }
+      }
+      sm = 0;
+      ++sj;
+    }
+  };
+  if (F > 0) {
+    f32x4 b0 = wfrag(), b1 = wfrag(), b2 = wfrag(), b3 = wfrag();
+#define DDP_SEG_STEP(BUF, OFF)                  \
+    if (f + (OFF) < F) {                         \
+      const f32x4 c_ = BUF;                      \
+      BUF = wfrag();                             \
+      __builtin_amdgcn_sched_barrier(0);         \
+      step(c_);                                  \
+    }
+    for (int f = 0; f < F; f += 4) {
+      DDP_SEG_STEP(b0, 0)
+      DDP_SEG_STEP(b1, 1)
+      DDP_SEG_STEP(b2, 2)
+      DDP_SEG_STEP(b3, 3)
+    }
+#undef DDP_SEG_STEP
+  }
+}
+
+// adds a segment's register tile to the LDS message tile.  Lane (r, hh) of the C/D layout holds column r of the 32-column
+// tile for the 16 edge rows (i&3) + 8*(i>>2) + 4*hh; a block with n <= 32 packs `ups` features per tile, whose lane groups
+// add one after the other (the wave's LDS operations execute in program order).
+template <int C>
+__device__ __forceinline__ void seg_park(const ddp_block_t& B, const ddp_role_seg_t& R, float* outb, int os, int lane,
+                                         const f32x16* res) {
+  const int r = lane & 31, hh = lane >> 5;
+  // output channel / feature group of this lane: the same in every tile of a segment (tile_lane_map)
+  int ncol, us;
+  bool valid;
+  if (B.nsub > 1) {
+    ncol = (R.tile0 % B.nsub) * 32 + r;
+    us = 0;
+    valid = ncol < B.n;
+  } else {
+    us = r / B.n;
+    ncol = r - us * B.n;
+    valid = us < B.ups;
+  }
+  if (!valid) ncol = 0;
+  float* o = outb + B.out_off + ncol * C + 4 * hh * os;
+  for (int s = 0; s < B.ups; ++s) {
+    if (valid && us == s) {
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[((i & 3) + 8 * (i >> 2)) * os + c] += res[c][i];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 3) void ddp_conv32_kernel(const ConvLaunch L) {
+  constexpr int ET = 32, NT = 256, FS = 36;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ TileAux<ET> aux;
+  __shared__ int gmap[2][128];   // G column -> message column | (C << 16)
+  const ddp_conv_shape_t& S = L.shape;
+  const int tid = threadIdx.x;
+  const int tile = xcd_tile();
+  int t = 0;
+  while (t + 1 < L.ntasks && tile >= L.tile_start[t + 1]) ++t;
+  const ddp_conv_task_t& T = L.task[t];
+  const int p0 = (tile - L.tile_start[t]) * ET;
+  const int nvalid = min(ET, T.n_edges - p0);
+  const int os = L.tv_off;       // row stride of the message tile
+  float* hbuf = lds;
+  float* rb = lds + ET * S.hs;   // region B: staging tile -> features -> message tile
+
+  STAMP(0);
+  STAMP(22);  // s_memrealtime (100 MHz) at entry
+  {
+    const int slot = tid >> 7, c = tid & 127;
+    int gm = 0;
+    if (c < S.g_cols[slot])
+      for (int bi = 0; bi < S.nblocks; ++bi) {
+        const ddp_block_t& B = S.blk[bi];
+        if (B.g_slot == slot && c >= B.g_col0 && c < B.g_col0 + B.n) gm = (B.out_off + (c - B.g_col0) * B.C) | (B.C << 16);
+      }
+    gmap[slot][c] = gm;
+  }
+  stage_edge_attr<ET>(S, T, aux, rb, p0, nvalid, tid);
+  STAMP(1);
+  fc1_to_lds<ET>(S, T, rb, hbuf, tid);
+  STAMP(2);
+
+  // ---- phase 2: basis features of every block
+  {
+    int frow = 0;
+    for (int bi = 0; bi < S.nblocks; ++bi) {
+      const ddp_block_t& B = S.blk[bi];
+      if (B.ntiles > 0) build_features<ET>(B, T, aux.src, aux.sh, rb + frow * FS, tid);
+      frow += B.U * B.C;
+    }
+  }
+  __syncthreads();
+  STAMP(3);
+
+  // ---- phase 3: role segments, results in registers (res[0]: a first scalar segment; res[1..3]: a vector segment or a second
+  // scalar one - static register indices in every combination the host assigns: (1), (3), (1,1), (1,3))
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int nseg = S.nrole[wave];
+  f32x16 res[4];
+  int c0 = 0, c1 = 0, f0 = 0, f1 = 0;   // components and first feature row of the wave's segments
+  if (nseg > 0) {
+    const ddp_role_seg_t& R0 = S.role[wave][0];
+    c0 = S.blk[R0.block].C;
+    for (int bi = 0; bi < R0.block; ++bi) f0 += S.blk[bi].U * S.blk[bi].C;
+    if (c0 == 1) seg_tiles<1>(S, S.blk[R0.block], T, hbuf, rb + f0 * FS, R0, lane, res);
+    else seg_tiles<3>(S, S.blk[R0.block], T, hbuf, rb + f0 * FS, R0, lane, res + 1);
+  }
+  if (nseg > 1) {
+    const ddp_role_seg_t& R1 = S.role[wave][1];
+    c1 = S.blk[R1.block].C;
+    for (int bi = 0; bi < R1.block; ++bi) f1 += S.blk[bi].U * S.blk[bi].C;
+    if (c1 == 1) seg_tiles<1>(S, S.blk[R1.block], T, hbuf, rb + f1 * FS, R1, lane, res + 1);
+    else seg_tiles<3>(S, S.blk[R1.block], T, hbuf, rb + f1 * FS, R1, lane, res + 1);
+  }
+  STAMP(4);
+  __syncthreads();   // every wave is done with F: region B becomes the message tile
+  STAMP(5);
+
+  // ---- phase 4: zero, then the segments round by round
+  for (int i = tid; i < (ET * os) >> 2; i += NT) reinterpret_cast<f32x4*>(rb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  for (int rnd = 0; rnd < S.nrounds; ++rnd) {
+    if (nseg > 0 && S.role[wave][0].round == rnd) {
+      const ddp_role_seg_t& R0 = S.role[wave][0];
+      if (c0 == 1) seg_park<1>(S.blk[R0.block], R0, rb, os, lane, res);
+      else seg_park<3>(S.blk[R0.block], R0, rb, os, lane, res + 1);
+    }
+    if (nseg > 1 && S.role[wave][1].round == rnd) {
+      const ddp_role_seg_t& R1 = S.role[wave][1];
+      if (c1 == 1) seg_park<1>(S.blk[R1.block], R1, rb, os, lane, res + 1);
+      else seg_park<3>(S.blk[R1.block], R1, rb, os, lane, res + 1);
+    }
+    __syncthreads();
+  }
+  STAMP(6);
+
+  // ---- phase 5: factorised features (one pass per G slot)
+  for (int slot = 0; slot < 2; ++slot)
+    if (S.g_cols[slot] > 0) g_stage<ET>(S, slot, T, hbuf, rb, os, gmap[slot], aux, wave, lane);
+  STAMP(7);
+  __syncthreads();
+  STAMP(8);
+
+  // ---- phase 6: whole message rows
+  if ((S.d_out & 3) == 0) {
+    const int n4 = S.d_out >> 2;
+    for (int i = tid; i < nvalid * n4; i += NT) {
+      const int e = i / n4, c4 = i - e * n4;
+      *reinterpret_cast<f32x4*>(&T.msg[(size_t)aux.pos[e] * S.d_out + 4 * c4]) = *reinterpret_cast<const f32x4*>(&rb[e * os + 4 * c4]);
+    }
+  } else {
+    for (int i = tid; i < nvalid * S.d_out; i += NT) {
+      const int e = i / S.d_out, c = i - e * S.d_out;
+      T.msg[(size_t)aux.pos[e] * S.d_out + c] = rb[e * os + c];
+    }
+  }
+  STAMP(9);
+  STAMP(23);  // s_memrealtime at exit
+#ifdef DDP_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < DDP_STAMP_WGS) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    ddp_stamp_buf[blockIdx.x * DDP_STAMP_SLOTS + 21] = ((unsigned long long)xcc << 32) | hw;
+    ddp_stamp_buf[blockIdx.x * DDP_STAMP_SLOTS + 37] = (unsigned long long)tile;
+  }
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------ host
-template <int ET>
-static int launch_conv(ConvLaunch& L, const ddp_conv_task_t* tasks, int ntasks, int fbuf_floats, void* stream) {
+template <int ET, typename K>
+static int launch_conv(K kernel, ConvLaunch& L, const ddp_conv_task_t* tasks, int ntasks, size_t lds_bytes, void* stream) {
   const ddp_conv_shape_t* shape = &L.shape;
   L.ntasks = 0;
   int tiles = 0;
@@ -943,14 +1170,11 @@ static int launch_conv(ConvLaunch& L, const ddp_conv_task_t* tasks, int ntasks, 
   }
   L.tile_start[L.ntasks] = tiles;
   if (tiles == 0) return 0;
-  const size_t lds_bytes = (size_t)(ET * shape->hs + fbuf_floats) * sizeof(float);
-  const size_t budget = (ET == 64) ? (160 * 1024 - 4096) : (160 * 1024 / 3 - 2560);   // minus the static TileAux
   if (lds_bytes > 160 * 1024 - 4096) return ddp_fail(DDP_ELIMIT, "ddp_conv_messages: LDS budget exceeded");
-  (void)budget;   // ET = 32 beyond a third of the LDS still runs, at two workgroups per CU
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(ddp_conv_messages_kernel<ET>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes);
   if (err != hipSuccess) return ddp_fail_hip(err, "hipFuncSetAttribute(conv)");
-  hipLaunchKernelGGL(ddp_conv_messages_kernel<ET>, dim3(tiles), dim3(ET * 8), lds_bytes, (hipStream_t)stream, L);
+  hipLaunchKernelGGL(kernel, dim3(tiles), dim3(ET * 8), lds_bytes, (hipStream_t)stream, L);
   err = hipGetLastError();
   if (err != hipSuccess) return ddp_fail_hip(err, "ddp_conv_messages launch");
   return 0;
@@ -963,7 +1187,7 @@ extern "C" int ddp_conv_messages(const ddp_conv_shape_t* shape, const ddp_conv_t
   if ((shape->kp1 & 7) || (shape->hp & 7) || (shape->hs & 3) || shape->hs < shape->kp1 || shape->hs < shape->hp)
     return ddp_fail(DDP_EINVAL, "ddp_conv_messages: kp1/hp must be multiples of 8 and hs >= both");
   const bool fact = (shape->g_cols[0] | shape->g_cols[1]) != 0;
-  int max_uc = 0, max_gc = shape->g_cols[0] > shape->g_cols[1] ? shape->g_cols[0] : shape->g_cols[1];
+  int frows = 0;
   for (int b = 0; b < shape->nblocks; ++b) {
     const ddp_block_t& B = shape->blk[b];
     if (B.C != 1 && B.C != 3) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: block C must be 1 or 3");
@@ -973,22 +1197,41 @@ extern "C" int ddp_conv_messages(const ddp_conv_shape_t* shape, const ddp_conv_t
     if (B.nseg < 0 || B.nseg > DDP_MAX_SEGS) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: nseg");
     if (B.g_slot > 1 || (B.g_slot >= 0 && (shape->g_cols[B.g_slot] < B.g_col0 + B.n || shape->g_cols[B.g_slot] > 128)))
       return ddp_fail(DDP_EINVAL, "ddp_conv_messages: factorised block outside its G row");
-    if (B.U * B.C > max_uc) max_uc = B.U * B.C;
+    if (B.out_off < 0 || B.out_off + B.n * B.C > shape->d_out) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: block outside the message row");
+    frows += B.U * B.C;
   }
   ConvLaunch L;
   L.shape = *shape;
-  static const bool force32 = getenv("DDP_FORCE_ET32") != nullptr;   // diagnostic: direct shapes on the 32-edge kernel too
-  if (fact || force32) {
-    // 32-edge workgroups.  fbuf: [0, tv_off) features / per-component partials (4 x 32 x 32), tv behind them; the
-    // edge_attr_ staging tile (32 x hs) may overlap tv, which is written after fc1.
+  if (fact) {
+    // 32-edge workgroups.  The role table must cover every tile of every block exactly once, at most two segments and four
+    // result components per wave, a vector segment never before a scalar one (register slots of phase 3).
+    int covered[DDP_MAX_BLOCKS] = {0, 0, 0, 0};
+    if (shape->nrounds < 0 || shape->nrounds > 4) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: nrounds");
+    for (int w = 0; w < DDP_CONV32_WAVES; ++w) {
+      const int ns = shape->nrole[w];
+      if (ns < 0 || ns > DDP_MAX_ROLE_SEGS) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: nrole");
+      int comps = 0;
+      for (int k = 0; k < ns; ++k) {
+        const ddp_role_seg_t& R = shape->role[w][k];
+        if (R.block < 0 || R.block >= shape->nblocks || R.count < 1 || R.tstride < 1 || R.tile0 < 0 ||
+            R.tile0 + (R.count - 1) * R.tstride >= shape->blk[R.block].ntiles || R.round < 0 || R.round >= shape->nrounds)
+          return ddp_fail(DDP_EINVAL, "ddp_conv_messages: role segment outside its block");
+        if (R.tstride != shape->blk[R.block].nsub) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: role segment stride != nsub");
+        covered[R.block] += R.count;
+        comps += shape->blk[R.block].C;
+        if (k == 1 && shape->blk[shape->role[w][0].block].C == 3) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: vector segment first");
+      }
+      if (comps > 4) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: more than 4 result components on a wave");
+    }
+    for (int b = 0; b < shape->nblocks; ++b)
+      if (covered[b] != shape->blk[b].ntiles) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: roles do not cover the tiles");
     const int ET = 32;
-    int tv_off = max_uc * (ET + 4);
-    if (tv_off < 4 * 1024) tv_off = 4 * 1024;
-    tv_off = (tv_off + 3) & ~3;
-    int fbuf = tv_off + ET * max_gc;
-    if (fbuf < ET * shape->hs) fbuf = ET * shape->hs;
-    L.tv_off = tv_off;
-    return launch_conv<32>(L, tasks, ntasks, fbuf, stream);
+    const int os = (shape->d_out + 3) & ~3;
+    int rbf = ET * shape->hs;                       // staging tile
+    if (rbf < frows * (ET + 4)) rbf = frows * (ET + 4);   // features of all blocks
+    if (rbf < ET * os) rbf = ET * os;               // message tile
+    L.tv_off = os;
+    return launch_conv<32>(ddp_conv32_kernel, L, tasks, ntasks, (size_t)(ET * shape->hs + rbf) * sizeof(float), stream);
   }
   // 64-edge workgroups: the host-provided fbuf_floats covers features, the 5 x 4096 partial regions of the 2x2 variant
   // and (never used on this path, kept for shapes built by older hosts) a tv region behind them
@@ -996,6 +1239,6 @@ extern "C" int ddp_conv_messages(const ddp_conv_shape_t* shape, const ddp_conv_t
     if (shape->blk[b].U * shape->blk[b].C * FS64 > shape->fbuf_floats || 5 * 4096 > shape->fbuf_floats)
       return ddp_fail(DDP_EINVAL, "ddp_conv_messages: fbuf_floats too small");
   if (64 * shape->hs > shape->fbuf_floats) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: fbuf_floats < staging tile");
-  L.tv_off = 5 * 4096;
-  return launch_conv<64>(L, tasks, ntasks, shape->fbuf_floats, stream);
+  L.tv_off = 0;
+  return launch_conv<64>(ddp_conv_messages_kernel, L, tasks, ntasks, (size_t)(64 * shape->hs + shape->fbuf_floats) * sizeof(float), stream);
 }

@@ -100,12 +100,19 @@ class ConvSpec:
             self.fbuf_floats += (64 * max(self.g_cols) + 3) // 4 * 4   # + the tv[64][g_cols] region of the factorised part
         if any(b.n > 64 or (b.C == 3 and b.n > 32) for b in self.blocks):
             raise NotImplementedError("HIP conv supports ns <= 64 and nv <= 32")
+        self.roles, self.nrounds = (conv32_roles(self.blocks) if self.factorized else ([[] for _ in range(CONV32_WAVES)], 0))
 
     def ctypes_shape(self) -> L.ConvShape:
         s = L.ConvShape()
         s.f_in, s.hid, s.kp1, s.hp, s.hs, s.nct1 = self.f_in, self.hid, self.kp1, self.hp, self.hs, self.nct1
         s.d_out, s.nblocks, s.fbuf_floats = self.d_out, len(self.blocks), self.fbuf_floats
         s.g_cols[0], s.g_cols[1] = self.g_cols
+        s.nrounds = self.nrounds
+        for w, segs in enumerate(self.roles):
+            s.nrole[w] = len(segs)
+            for k, (bi, t0, st, cnt, rnd) in enumerate(segs):
+                r = s.role[w][k]
+                r.block, r.tile0, r.tstride, r.count, r.round = bi, t0, st, cnt, rnd
         for i, b in enumerate(self.blocks):
             cb = s.blk[i]
             cb.U, cb.n, cb.C, cb.out_off = b.U, b.n, b.C, b.out_off
@@ -132,6 +139,101 @@ class ConvSpec:
         cols = sum(b.U * b.n for b in self.blocks)
         contr = sum(b.U * b.n * b.C for b in self.blocks)
         return 2 * self.f_in * self.hid + 2 * self.hid * cols + 2 * contr + 2 * self.hid * sum(self.g_cols)
+
+
+# ------------------------------------------------------------------------------------------------ 32-edge kernel roles
+CONV32_WAVES, MAX_ROLE_SEGS = 4, 2
+
+
+def conv32_roles(blocks: Sequence["BlockSpec"]):
+    """Static work split of the factorised (32-edge workgroup) kernel: which tiles each of its 4 waves runs.
+
+    An item is a set of tiles whose results land in the SAME output columns: a whole block (n <= 32: its tiles differ only
+    in the features u they cover) or one 32-column half of a block (n > 32: tiles u*2 + sub).  A wave that owns a whole item
+    accumulates it in registers with no cross-wave reduction at all.  To balance the four matrix pipes up to two items are cut
+    in two (by feature range); the two parts are then summed in LDS in a fixed order (part 0 in round 0, part 1 in round 1).
+    A wave holds at most MAX_ROLE_SEGS parts and at most 4 result components (16 registers each) at a time.
+    Returns ([per wave: [(block index, first tile, tile stride, tile count, round)]], number of rounds)."""
+    import itertools
+    items = []     # (block index, first tile, stride, count, C)
+    for bi, b in enumerate(blocks):
+        if b.ntiles == 0:
+            continue
+        if b.nsub > 1:
+            for sub in range(b.nsub):
+                items.append((bi, sub, b.nsub, b.U, b.C))
+        else:
+            items.append((bi, 0, 1, b.ntiles, b.C))
+    if not items:
+        return [[] for _ in range(CONV32_WAVES)], 0
+    total = sum(it[3] for it in items)
+    best = None
+
+    def assign(parts):
+        """parts: [(bi, t0, stride, count, C, round)] -> best (max load, waves) with <= 2 parts and <= 4 components per wave."""
+        n = len(parts)
+        if n > CONV32_WAVES * MAX_ROLE_SEGS:
+            return None
+        order = sorted(range(n), key=lambda i: -parts[i][3])
+        res = [None]
+
+        def rec(k, waves, loads, comps):
+            if res[0] is not None and max(loads) >= res[0][0]:
+                return
+            if k == n:
+                res[0] = (max(loads), [list(w) for w in waves])
+                return
+            i = order[k]
+            seen = set()
+            for w in range(CONV32_WAVES):
+                key = (loads[w], comps[w], len(waves[w]))
+                if key in seen or len(waves[w]) >= MAX_ROLE_SEGS or comps[w] + parts[i][4] > 4:
+                    continue
+                seen.add(key)
+                waves[w].append(i)
+                loads[w] += parts[i][3]
+                comps[w] += parts[i][4]
+                rec(k + 1, waves, loads, comps)
+                waves[w].pop()
+                loads[w] -= parts[i][3]
+                comps[w] -= parts[i][4]
+
+        rec(0, [[] for _ in range(CONV32_WAVES)], [0] * CONV32_WAVES, [0] * CONV32_WAVES)
+        return res[0]
+
+    ideal = -(-total // CONV32_WAVES)
+    for nsplit in (0, 1, 2):
+        for which in itertools.combinations(range(len(items)), nsplit):
+            cuts = [range(1, items[i][3]) for i in which]
+            for cut in itertools.product(*cuts):
+                parts = []
+                for i, it in enumerate(items):
+                    if i in which:
+                        c = cut[which.index(i)]
+                        bi, t0, st, cnt, C = it
+                        parts.append((bi, t0, st, c, C, 0))
+                        parts.append((bi, t0 + c * st, st, cnt - c, C, 1))
+                    else:
+                        parts.append(it + (0,))
+                got = assign(parts)
+                if got is None:
+                    continue
+                score = (got[0], nsplit)
+                if best is None or score < best[0]:
+                    best = (score, parts, got[1])
+                if got[0] == ideal:
+                    break
+            if best is not None and best[0][0] == ideal:
+                break
+        if best is not None and best[0][0] == ideal:
+            break
+    if best is None:
+        raise NotImplementedError("no role assignment for the 32-edge conv kernel (too many weight blocks with tiles)")
+    _, parts, waves = best
+    roles = [[(parts[i][0], parts[i][1], parts[i][2], parts[i][3], parts[i][5]) for i in sorted(w, key=lambda i: (parts[i][4], parts[i][0]))]
+             for w in waves]
+    nrounds = 1 + max(p[5] for p in parts)
+    return roles, nrounds
 
 
 def irreps_muls(ns, nv, i):

@@ -293,7 +293,7 @@ class ConvProfiler:
 
     def summary(self, kernel=None):
         """(launches, algorithmic FLOPs, ms) over all launches or over those of one kernel instantiation
-        ("ddp_conv_messages_kernel<32>": factorised shapes, "ddp_conv_messages_kernel<64>": direct shapes)."""
+        ("ddp_conv32_kernel": factorised shapes, "ddp_conv_messages_kernel": direct shapes)."""
         sel = [i for i, k in enumerate(self.kernel) if kernel is None or k == kernel]
         ms = sum(self.events[i][0].elapsed_time(self.events[i][1]) for i in sel)
         return len(sel), float(sum(self.flops[i] for i in sel)), float(ms)
@@ -365,7 +365,7 @@ def _launch_convs(spec: P.ConvSpec, tasks: List[L.ConvTask], flops_spec: Optiona
         prof.useful.append(spec.useful_flops_per_edge() * ne)
         prof.edges.append(ne)
         prof.boundary.append(ne * (4.0 * (flops_spec or spec).f_in + 32.0) + node_bytes)
-        prof.kernel.append("ddp_conv_messages_kernel<32>" if spec.factorized else "ddp_conv_messages_kernel<64>")
+        prof.kernel.append("ddp_conv32_kernel" if spec.factorized else "ddp_conv_messages_kernel")
 
 
 def _launch_reduce(x, ldx, n_nodes, d_out, sources, accumulate=True):

@@ -66,6 +66,15 @@ typedef struct {
   int32_t g_col0;
 } ddp_block_t;
 
+/* Work split of the 32-edge (factorised) kernel: wave w of a workgroup runs the tiles tile0 + j * tstride, j < count, of
+ * block `block` for each of its nrole[w] segments; segments of one block whose tile sets cover the same output columns are
+ * summed in LDS in `round` order (packing.conv32_roles). */
+#define DDP_CONV32_WAVES 4
+#define DDP_MAX_ROLE_SEGS 2
+typedef struct {
+  int32_t block, tile0, tstride, count, round;
+} ddp_role_seg_t;
+
 /* Static shape of a TensorProductConvLayer (models/score_model.py:84-107); shared by all tasks of a launch. */
 typedef struct {
   int32_t f_in;  /* n_edge_features = width of edge_attr_ (3*ns, final_conv: 2*ns) */
@@ -79,6 +88,10 @@ typedef struct {
   int32_t fbuf_floats; /* LDS floats reserved for the per-block feature / reduction buffer */
   int32_t g_cols[2];   /* columns per (node, k) row of the two G arrays (0 = unused) */
   ddp_block_t blk[DDP_MAX_BLOCKS];
+  /* factorised shapes only (g_cols != 0): */
+  int32_t nrounds;     /* LDS summation rounds of the role segments (0 = no block has tiles) */
+  int32_t nrole[DDP_CONV32_WAVES];
+  ddp_role_seg_t role[DDP_CONV32_WAVES][DDP_MAX_ROLE_SEGS];
 } ddp_conv_shape_t;
 
 /* One conv = one edge set + one set of weights.  Edge arrays are in CSR order of the RECEIVING node
@@ -214,7 +227,7 @@ int ddp_group_by_key(const int32_t* key, int n_items, int n_keys, const int32_t*
 
 int ddp_abi_version(void);
 const char* ddp_last_error(void);
-/* 16 hex digits of the SHA-256 over the sources (csrc/*.hip, csrc/ddp_internal.h, include/ddp_hip.h) the library was built from */
+/* 16 hex digits of the SHA-256 over the sources (every csrc .hip file, csrc/ddp_internal.h, include/ddp_hip.h) the library was built from */
 const char* ddp_source_hash(void);
 
 #ifdef __cplusplus

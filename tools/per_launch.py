@@ -29,5 +29,5 @@ tot = 0.0
 for (e0, e1), fl, ex, k in zip(prof.events, prof.flops, prof.executed, prof.kernel):
     ms = e0.elapsed_time(e1)
     tot += ms
-    print(f"{k[-4:]}  {ms:7.3f} ms  algorithmic {fl / 1e9:8.1f} GFLOP ({fl / ms / 1e9:6.1f} TF/s)  executed {ex / ms / 1e9:6.1f} TF/s")
+    print(f"{k[4:12]}  {ms:7.3f} ms  algorithmic {fl / 1e9:8.1f} GFLOP ({fl / ms / 1e9:6.1f} TF/s)  executed {ex / ms / 1e9:6.1f} TF/s")
 print(f"total {tot:.2f} ms")

@@ -27,7 +27,7 @@ import sys
 
 import pandas as pd
 
-CONV = ["ddp_conv_messages_kernel<32>", "ddp_conv_messages_kernel<64>"]
+CONV = ["ddp_conv32_kernel", "ddp_conv_messages_kernel"]
 OTHER = ["ddp_stage_a_mfma_kernel", "ddp_segment_reduce_kernel", "ddp_edge_featurize", "ddp_radius", "ddp_knn", "ddp_pose_update"]
 
 

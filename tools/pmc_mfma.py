@@ -16,7 +16,7 @@ import sys
 
 import pandas as pd
 
-KERNELS = ["ddp_conv_messages_kernel<32>", "ddp_conv_messages_kernel<64>", "ddp_stage_a_mfma_kernel"]
+KERNELS = ["ddp_conv32_kernel", "ddp_conv_messages_kernel", "ddp_stage_a_mfma_kernel"]
 
 
 def main():

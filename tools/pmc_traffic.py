@@ -17,7 +17,7 @@ import sys
 import pandas as pd
 
 
-KERNELS = {"ddp_conv_messages_kernel<32>": "ddp_conv_messages_kernel<32>", "ddp_conv_messages_kernel<64>": "ddp_conv_messages_kernel<64>"}
+KERNELS = {"ddp_conv32_kernel": "ddp_conv32_kernel", "ddp_conv_messages_kernel": "ddp_conv_messages_kernel"}
 
 
 def per_launch(d, counter, kernel):

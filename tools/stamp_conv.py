@@ -38,10 +38,10 @@ captured = {}
 WANT_G = "--direct" not in sys.argv
 
 
-def hooked(spec, tasks, flops_spec=None):
+def hooked(spec, tasks, **kw):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    orig(spec, tasks, flops_spec)
+    orig(spec, tasks, **kw)
     e1.record()
     torch.cuda.synchronize()
     sel = len(spec.blocks) == 4 and len(tasks) >= 5 and spec.factorized == WANT_G and spec.blocks[3].n == 60 and spec.blocks[2].n == 10 \
@@ -68,12 +68,17 @@ smp.step(2, get_t_schedule(20))
 st = captured["done"].astype(np.int64)
 st = st[np.argsort(st[:, 37], kind="stable")]      # rows in tile order (workgroup ids are remapped per XCD)
 captured["done"] = captured["done"][np.argsort(captured["done"][:, 37].astype(np.int64), kind="stable")]
-names = ["stage edge_attr_", "fc1"]
-for b in range(4):
-    names += [f"blk{b} features", f"blk{b} wave0 tiles", f"blk{b} wait other waves", f"blk{b} reduce+store"]
-idx = [0, 1, 2]
-for b in range(4):
-    idx += [3 + 4 * b, 4 + 4 * b, 5 + 4 * b, 6 + 4 * b]
+if WANT_G:   # ddp_conv32_kernel: stamps 0..9 (see the kernel)
+    names = ["stage edge_attr_", "fc1", "features (all blocks)", "wave0 role tiles", "wait other waves", "zero + park rounds",
+             "G pass (wave 0)", "wait other waves (G)", "store rows"]
+    idx = list(range(10))
+else:
+    names = ["stage edge_attr_", "fc1"]
+    for b in range(4):
+        names += [f"blk{b} features", f"blk{b} wave0 tiles", f"blk{b} wait other waves", f"blk{b} reduce+store"]
+    idx = [0, 1, 2]
+    for b in range(4):
+        idx += [3 + 4 * b, 4 + 4 * b, 5 + 4 * b, 6 + 4 * b]
 d = np.diff(st[:, idx], axis=1)
 tot = (st[:, idx[-1]] - st[:, 0]).mean()
 hw = captured["done"][:, 21]
@@ -94,12 +99,13 @@ print(f"workgroups {len(st)}  mean total ticks {tot:.0f} (s_memtime ticks; 100 M
 for n_, m in zip(names, d.mean(0)):
     print(f"  {n_:26s} {m:10.0f}  {100 * m / tot:5.1f} %")
 
-print(f"blk0 g_stage wave0 {(st[:,33]-st[:,35]).mean()*23.76:.0f} cycles; blk2 g_stage wave0 {(st[:,34]-st[:,32]).mean()*23.76:.0f} cycles")
-gph = (st[:, 3] - st[:, 2]).astype(np.float64)
-tot_wg = (st[:, 18] - st[:, 0]).astype(np.float64)
+if not WANT_G:
+    sys.exit(0)
+gph = (st[:, 7] - st[:, 6]).astype(np.float64)
+tot_wg = (st[:, 9] - st[:, 0]).astype(np.float64)
 start = (st[:, 22] - st[:, 22].min()) / 100.0
 o = 0
-print("per task (launch order): workgroups, mean blk0-features+G phase, mean workgroup total, mean start time us")
+print("per task (launch order): workgroups, mean G pass (wave 0), mean workgroup total, mean start time us")
 for ti, nt in enumerate(captured["tiles"]):
     sl = slice(o, o + nt)
     print(f"  task {ti}: {nt:6d} wgs  G phase {gph[sl].mean():9.0f}  total {tot_wg[sl].mean():9.0f}  start {start[sl].mean():8.0f}")
