@@ -56,7 +56,7 @@ class ConvTask(C.Structure):
 
 class ReduceSrc(C.Structure):
     _fields_ = [("msg", C.c_void_p), ("rowptr", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p),
-                ("n_edges", C.c_int32)]
+                ("n_edges", C.c_int32), ("rowmap", C.c_void_p)]
 
 
 def g_ld(hid: int, gcols: int) -> int:
@@ -115,7 +115,7 @@ def load():
     lib.ddp_knn.restype = C.c_int
     lib.ddp_group_by_key.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 11
     lib.ddp_group_by_key.restype = C.c_int
-    if lib.ddp_abi_version() != 5:
+    if lib.ddp_abi_version() != 6:
         raise DdpError("libddp_hip.so ABI version mismatch")
     lib.ddp_source_hash.restype = C.c_char_p
     if "DDP_HIP_LIB" not in os.environ:   # (diagnostic builds loaded through DDP_HIP_LIB carry extra -D flags, same sources)

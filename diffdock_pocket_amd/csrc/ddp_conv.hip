@@ -110,7 +110,7 @@ extern "C" int ddp_debug_read_stamps(unsigned long long* host_dst, int n_wgs) {
 
 struct ConvLaunch {
   ddp_conv_shape_t shape;
-  int tv_off;   // 32-edge kernel: row stride (floats) of the LDS message tile; unused by the 64-edge kernel
+  int tv_off;   // 32-edge kernels: row stride (floats) of the LDS message tile; unused by the 64-edge kernel
   int ntasks;
   int tile_start[DDP_MAX_TASKS + 1];
   ddp_conv_task_t task[DDP_MAX_TASKS];
@@ -124,18 +124,18 @@ __device__ __forceinline__ f32x16 splat16(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------ phase 2
-template <int ET>
+template <int ET, int NG = 8>
 __device__ __forceinline__ void build_features(const ddp_block_t& B, const ddp_conv_task_t& T, const int* s_src,
                                                const float (*s_sh)[4], float* fbuf, int tid) {
   constexpr int FS = ET + 4;
-  const int e = tid & (ET - 1), wave = tid / ET;   // 8 thread groups of ET threads
+  const int e = tid & (ET - 1), wave = tid / ET;   // NG thread groups of ET threads
   const float* xrow = T.x_src + (size_t)s_src[e] * T.ldx_src;
   const float s0 = s_sh[e][0], sx = s_sh[e][1], sy = s_sh[e][2], sz = s_sh[e][3];
   const float inv_sqrt3 = 0.57735026918962576f, inv_sqrt2 = 0.70710678118654752f;
   int ubase = 0;
   for (int si = 0; si < B.nseg; ++si) {
     const int kind = B.seg[si].kind, off = B.seg[si].in_off, cnt = B.seg[si].count;
-    for (int ul = wave; ul < cnt; ul += 8) {
+    for (int ul = wave; ul < cnt; ul += NG) {
       const int u = ubase + ul;
       if (kind == DDP_F_SCALAR_S0) {
         fbuf[u * FS + e] = xrow[off + ul] * s0;
@@ -212,7 +212,7 @@ __device__ __forceinline__ void g_add_out(float* outb, int os, const float (*sh)
   }
 }
 
-template <int ET>
+template <int ET, int NW = ET / 8, int KC = 16, int RD = 5>
 __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, const ddp_conv_task_t& T, const float* hbuf,
                                         float* outb, int os, const int* gmap, const TileAux<ET>& aux, int wave, int lane) {
   // One pass per G slot; a wave takes units wave, wave + NW, ...  For a unit (<= 8 edges of one source node)
@@ -229,7 +229,7 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
   // are flattened into one sequence and run through a 3-deep register ring: the loads of steps s+1 and s+2 are in
   // flight while step s computes; the A operands of a step are read up front (the uniform k < hp branches would
   // otherwise pin every LDS read right before its MFMAs and expose its latency 10 times per step).
-  constexpr int KC = 20, XK = 24, NW = ET / 8;   // NW waves per workgroup, at most 8 units per wave
+  constexpr int XK = 24;   // NW waves share the units of a tile, at most ET / NW units per wave; KC k per step, RD ring buffers
   const int gc = S.g_cols[slot];
   const float* __restrict__ G = T.g[slot];
   const float* __restrict__ Gb = G + 4 * (size_t)((S.hid + 3) >> 2) * gc;   // Gb[j] sits behind G[j] in the node's row
@@ -244,10 +244,10 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
   const int nsteps = nmine * nch;
   const size_t gstride = (size_t)(DDP_G_LD(S.hid, gc) / 4);               // node stride in 16-byte quads (128-byte aligned rows)
   const f32x4* __restrict__ G4 = reinterpret_cast<const f32x4*>(G);
-  // unit table of this wave in lanes 0..7 (a wave has at most 8 units): read with v_readlane instead of dependent LDS
+  // unit table of this wave in lanes 0 .. ET/NW - 1 (a wave has at most that many units): read with v_readlane instead of dependent LDS
   // round trips at every step
   int my_e0 = 0, my_len = 0, my_node = 0;
-  if (lane < 8 && wave + NW * lane < aux.nunits) {
+  if (lane < ET / NW && wave + NW * lane < aux.nunits) {
     const int u = wave + NW * lane;
     my_e0 = aux.ustart[u];
     my_len = aux.ustart[u + 1] - my_e0;
@@ -262,8 +262,8 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
     const int cb = 64 * pass;
     const bool act0 = lane < (pass ? nx : nmain);
     const int c0 = cb + (act0 ? lane : 0);
-    f32x4 bufA[KC / 4], bufB[KC / 4], bufC[KC / 4];
-    float biasA = 0.f, biasB = 0.f, biasC = 0.f;
+    f32x4 ring[RD][KC / 4];   // (indices are compile-time constants after unrolling: registers)
+    float rbias[RD];
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
     int i_ui = 0, i_ch = 0, c_ui = 0, c_ch = 0;   // (unit, chunk) of the next step to request / to compute
 
@@ -324,27 +324,21 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
       if (++c_ch == nch) { c_ch = 0; ++c_ui; }                                                                \
     }
 
-    DDP_G_ISSUE(0, bufA, biasA)
-    DDP_G_ISSUE(1, bufB, biasB)
+    // RD - 1 request steps in flight ahead of the step that computes
+#pragma unroll
+    for (int j = 0; j < RD - 1; ++j) DDP_G_ISSUE(j, ring[j], rbias[j])
     GSTAMP();   // 1: prologue requests issued
-    for (int s0 = 0; s0 < nsteps; s0 += 3) {
-      DDP_G_ISSUE(s0 + 2, bufC, biasC)
-      __builtin_amdgcn_sched_barrier(0);
-      DDP_G_COMPUTE(s0, bufA, biasA)
-      __builtin_amdgcn_sched_barrier(0);
-      if (s0 == 0) GSTAMP();   // 2: first step done
-      DDP_G_ISSUE(s0 + 3, bufA, biasA)
-      __builtin_amdgcn_sched_barrier(0);
-      DDP_G_COMPUTE(s0 + 1, bufB, biasB)
-      __builtin_amdgcn_sched_barrier(0);
-      if (s0 == 0) GSTAMP();   // 3: second step done
-      DDP_G_ISSUE(s0 + 4, bufB, biasB)
-      __builtin_amdgcn_sched_barrier(0);
-      DDP_G_COMPUTE(s0 + 2, bufC, biasC)
-      __builtin_amdgcn_sched_barrier(0);
-      if (s0 == 0 || s0 == 3) GSTAMP();   // 4, 5: steps 3 and 6 done
+    for (int s0 = 0; s0 < nsteps; s0 += RD) {
+#pragma unroll
+      for (int j = 0; j < RD; ++j) {
+        DDP_G_ISSUE(s0 + j + RD - 1, ring[(j + RD - 1) % RD], rbias[(j + RD - 1) % RD])
+        __builtin_amdgcn_sched_barrier(0);
+        DDP_G_COMPUTE(s0 + j, ring[j], rbias[j])
+        __builtin_amdgcn_sched_barrier(0);
+        if (s0 == 0 && j < 3) GSTAMP();   // 2, 3, 4: first three steps done
+      }
+      if (s0 == 0) GSTAMP();   // 5: first RD steps done
     }
-    if (nsteps <= 3) GSTAMP();
     GSTAMP();   // 6: main loop done
 #undef DDP_G_ISSUE
 #undef DDP_G_COMPUTE
@@ -737,10 +731,9 @@ __device__ __forceinline__ int xcd_tile() {
 }
 
 // phase 0: per-edge indices, harmonics, the units of the G pass, then the three row gathers of edge_attr_ into xa
-template <int ET>
+template <int ET, int NT = ET * 8>
 __device__ __forceinline__ void stage_edge_attr(const ddp_conv_shape_t& S, const ddp_conv_task_t& T, TileAux<ET>& aux, float* xa,
                                                 int p0, int nvalid, int tid) {
-  constexpr int NT = ET * 8;
   if (tid < 64) {   // wave 0, lane = edge
     const bool valid = tid < nvalid;
     const int p = p0 + min(tid, nvalid - 1);
@@ -812,9 +805,9 @@ __device__ __forceinline__ void stage_edge_attr(const ddp_conv_shape_t& S, const
 }
 
 // phase 1: h = relu(edge_attr_ @ W1 + b1)
-template <int ET>
+template <int ET, int NW = ET / 8>
 __device__ __forceinline__ void fc1_to_lds(const ddp_conv_shape_t& S, const ddp_conv_task_t& T, const float* xa, float* hbuf, int tid) {
-  constexpr int NW = ET / 8, RT = ET / 32;
+  constexpr int RT = ET / 32;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps tile/loop indices in SGPRs
   const int lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int nm1 = S.kp1 >> 3;
@@ -922,7 +915,7 @@ __global__ __launch_bounds__(512, 2) void ddp_conv_messages_kernel(const ConvLau
 //   phase 6  the tile leaves as whole message rows (16-byte coalesced stores)
 // Summation order of a message element: tiles of a segment in tile order, segments in round order, then the factorised part:
 // fixed, so results are bitwise reproducible.
-template <int C>
+template <int C, int RING = 4>
 __device__ __forceinline__ void seg_tiles(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
                                           const float* hbuf, const float* fblk, const ddp_role_seg_t& R, int lane, f32x16* out) {
   constexpr int FS = 36;
@@ -981,7 +974,6 @@ __device__ __forceinline__ void seg_tiles(const ddp_conv_shape_t& S, const ddp_b
     }
   };
   if (F > 0) {
-    f32x4 b0 = wfrag(), b1 = wfrag(), b2 = wfrag(), b3 = wfrag();
 #define DDP_SEG_STEP(BUF, OFF)                  \
     if (f + (OFF) < F) {                         \
       const f32x4 c_ = BUF;                      \
@@ -989,11 +981,20 @@ __device__ __forceinline__ void seg_tiles(const ddp_conv_shape_t& S, const ddp_b
       __builtin_amdgcn_sched_barrier(0);         \
       step(c_);                                  \
     }
-    for (int f = 0; f < F; f += 4) {
-      DDP_SEG_STEP(b0, 0)
-      DDP_SEG_STEP(b1, 1)
-      DDP_SEG_STEP(b2, 2)
-      DDP_SEG_STEP(b3, 3)
+    if constexpr (RING == 4) {
+      f32x4 b0 = wfrag(), b1 = wfrag(), b2 = wfrag(), b3 = wfrag();
+      for (int f = 0; f < F; f += 4) {
+        DDP_SEG_STEP(b0, 0)
+        DDP_SEG_STEP(b1, 1)
+        DDP_SEG_STEP(b2, 2)
+        DDP_SEG_STEP(b3, 3)
+      }
+    } else {   // (the 128-register budget of the 8-wave form)
+      f32x4 b0 = wfrag(), b1 = wfrag();
+      for (int f = 0; f < F; f += 2) {
+        DDP_SEG_STEP(b0, 0)
+        DDP_SEG_STEP(b1, 1)
+      }
     }
 #undef DDP_SEG_STEP
   }

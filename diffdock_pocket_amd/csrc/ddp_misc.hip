@@ -43,11 +43,18 @@ __global__ void ddp_segment_reduce_kernel(float* __restrict__ x, int ldx, int n_
     if (k < L.nsrc) {
       const ddp_reduce_src_t& s = L.src[k];
       const float* __restrict__ m = s.msg + ch;
+      const int32_t* __restrict__ rm = s.rowmap;
       float sum = 0.f;
       for (int p = p0[k]; p < p1[k]; p += 8) {
         float v[8];
+        int row[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = m[(size_t)min(p + i, p1[k] - 1) * d_out];
+        for (int i = 0; i < 8; ++i) {
+          const int q = min(p + i, p1[k] - 1);
+          row[i] = rm ? rm[q] : q;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = m[(size_t)row[i] * d_out];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
           if (p + i < p1[k]) sum += v[i];

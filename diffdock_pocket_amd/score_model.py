@@ -369,12 +369,15 @@ def _launch_convs(spec: P.ConvSpec, tasks: List[L.ConvTask], flops_spec: Optiona
 
 
 def _launch_reduce(x, ldx, n_nodes, d_out, sources, accumulate=True):
-    """sources: [(msg, csr, packed)] in the reference's summation order."""
+    """sources: [(msg, csr, packed[, rowmap])] in the reference's summation order; rowmap (int32 per CSR position, optional)
+    = the row of `msg` that holds the position's message."""
     lib = L.load()
     arr = (L.ReduceSrc * max(len(sources), 1))()
-    for i, (msg, csr, pk) in enumerate(sources):
+    for i, src_ in enumerate(sources):
+        msg, csr, pk = src_[:3]
         arr[i].msg, arr[i].rowptr = msg.data_ptr(), csr.rowptr.data_ptr()
         arr[i].bn_scale, arr[i].bn_shift, arr[i].n_edges = pk.bn_scale.data_ptr(), pk.bn_shift.data_ptr(), csr.n_edges
+        arr[i].rowmap = src_[3].data_ptr() if (len(src_) > 3 and src_[3] is not None) else 0
     prof = _PROFILER if (_PROFILER is not None and _PROFILER.hbm_on) else None
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -384,7 +387,7 @@ def _launch_reduce(x, ldx, n_nodes, d_out, sources, accumulate=True):
     if prof is not None:
         e1.record()
         # algorithmic bytes: every message row read once, every node row read and written once
-        ne = sum(csr.n_edges for _, csr, _ in sources)
+        ne = sum(s_[1].n_edges for s_ in sources)
         prof.hbm.setdefault("ddp_segment_reduce_kernel", []).append((e0, e1, 4.0 * d_out * (ne + 2 * n_nodes)))
 
 
@@ -496,6 +499,7 @@ class TensorProductScoreModel(nn.Module):
         self.factorize_min_degree = 3.0
         self.prune_last_receptor_layer = True   # layer L-2 receptor-side convs only where the final layer reads them
         self.share_layer0 = True       # layer-0 receptor-side convs once per batch of identical receptors (forward)
+        self.share_clean_layer1 = True  # layer-1 atom<-atom messages between atoms no ligand message has reached: once (forward)
         self._static_cache = {}        # see _cached()
         self.prune_async = True        # dead-output walk on a side stream behind the first layers (forward)
         self._side = None
@@ -940,6 +944,45 @@ class TensorProductScoreModel(nn.Module):
                     if csr.n_edges >= self.factorize_min_degree * uniq.shape[0]:
                         so_views[k] = G.SourceOrder(so_c.n_edges, so_c.recv, inv.to(torch.int32), so_c.eid, so_c.pos)
                         compact_src[k] = uniq
+        # Layer 1, atom<-atom, sampling batches of one rigid complex (shared0 has conv 3): after the shared layer 0 an atom's
+        # features differ between the samples only if an atom<-ligand message reached it (the atoms within 5 A of that
+        # sample's ligand, ~15 %).  A layer-1 atom<-atom message between two atoms without such a message ("clean") is
+        # therefore the same in every sample: those messages are computed ONCE on the complex's own edge list (e0 edges,
+        # rows [E, E + e0) of the message array) and the segmented mean reads them through a row map; only the edges with a
+        # touched end are computed per sample (source-ordered sub-list, stage A on their source rows only).  Messages of a
+        # clean pair are bitwise those the general path computes (same inputs, per-edge arithmetic), the mean sums the same
+        # values in the same order: the result is bitwise the general path's (GPU test).  Layer 1 must not be one of the pruned
+        # last layers (L >= 4).
+        clean1 = None
+        clean1_on = bool(self.share_clean_layer1 and 3 in shared0 and 3 in so_views and L_ >= 4 and c_aa.n_edges > 0)
+
+        def clean1_plan():
+            n0_, e0_, _ = shared0[3]
+            E_aa = c_aa.n_edges
+            so3 = so_views[3]
+            clean = (c_al.rowptr[1:] == c_al.rowptr[:-1]) if c_al.n_edges > 0 else torch.ones(Na, dtype=torch.bool, device=dev)
+            dirty_so = ~(clean[so3.recv.long()] & clean[so3.src.long()])
+            idx = dirty_so.nonzero(as_tuple=True)[0]                       # (host synchronisation: how many)
+            n_d = int(idx.shape[0])
+            self.last_stats["clean1_dirty_edges"] = n_d
+            if n_d > 0.8 * E_aa:
+                return None
+            uniq_d = so_d = None
+            if n_d > 0:
+                src_d = so3.src[idx]
+                uniq_d, inv = torch.unique_consecutive(src_d.long(), return_inverse=True)      # (second one)
+                so_d = G.SourceOrder(n_d, so3.recv[idx].contiguous(), inv.to(torch.int32).contiguous(), so3.eid[idx].contiguous(),
+                                     so3.pos[idx].contiguous())
+            dirty_csr = ~(clean[c_aa.recv.long()] & clean[c_aa.src.long()])
+            p_ = G.iota32(E_aa, dev)
+            rowmap = torch.where(dirty_csr, p_, E_aa + p_ % e0_).to(torch.int32).contiguous()
+            so_v = G.SourceOrder(e0_, so3.recv[:e0_], so3.src[:e0_], so3.eid[:e0_], (so3.pos[:e0_] + E_aa).contiguous())
+            first = clean.view(B, n0_).to(torch.uint8).argmax(0)      # a sample in which the atom is clean (0 if none: unused)
+            rows_v = first * n0_ + torch.arange(n0_, device=dev)
+            return {"so_d": so_d, "uniq_d": uniq_d, "rowmap": rowmap, "so_v": so_v, "rows_v": rows_v, "E": E_aa, "e0": e0_}
+
+        # The plan reads graph structure only and synchronises with the host twice: it runs on the side stream AFTER layer 0
+        # is queued (like the dead-output walk below), so that the device works on layer 0 while the host waits for the sizes.
         # ---- graph parts of the heads.  Their only host synchronisation (the edge counts) happened above; with flexible
         # side chains the side-chain graph is completed here because the dead-output walk below reads it, everything else
         # (centre graph, ligand torsion graph) is queued after the conv layers, behind which it costs no wall time
@@ -1022,7 +1065,7 @@ class TensorProductScoreModel(nn.Module):
         if prune_on and prune_after is None:
             pruned, pruned_so = prune_plan()
         inputs_ready = None
-        if prune_after is not None:
+        if prune_after is not None or clean1_on:
             inputs_ready = torch.cuda.Event()
             inputs_ready.record()
         mark("csr")
@@ -1045,6 +1088,17 @@ class TensorProductScoreModel(nn.Module):
                 pruned = {ll_: v for ll_, v in pruned.items() if ll_ > prune_after}
                 pruned_so = {ll_: v for ll_, v in pruned_so.items() if ll_ > prune_after}
                 mark("prune_plan")
+            if l == 1 and clean1_on:
+                if self.before_layers is None:
+                    side = self._side_stream(dev)
+                    side.wait_event(inputs_ready)
+                    with torch.cuda.stream(side):
+                        clean1 = clean1_plan()
+                        c1_ready = torch.cuda.Event()
+                        c1_ready.record()
+                    torch.cuda.current_stream().wait_event(c1_ready)
+                else:   # (resident sample groups order their streams themselves: plan on the current stream)
+                    clean1 = clean1_plan()
             layer_csr, layer_so = pruned.get(l, {}), pruned_so.get(l, {})
             tasks, tasks_g, msgs, keep = [], [], {}, []
             # per conv of this layer: (csr, source-ordered view or None, source-node array) after the layer-specific
@@ -1069,14 +1123,22 @@ class TensorProductScoreModel(nn.Module):
                         so_k = G.SourceOrder(e0, so_k.recv[:e0], so_k.src[:e0], so_k.eid[:e0], so_k.pos[:e0])
                     xs_k = x_src[:shared[k][2]]
                 per[k] = (csr, so_k, xs_k)
+            c1 = clean1 if (l == 1 and clean1 is not None and 3 in per and 3 not in layer_csr) else None
+            if c1 is not None:   # atom<-atom at layer 1: per-sample part = the edges with a touched end (see above)
+                xs_d = xa.index_select(0, c1["uniq_d"]) if c1["uniq_d"] is not None else xa[:0]
+                per[3] = (per[3][0], c1["so_d"], xs_d)
+                x_clean = xa.index_select(0, c1["rows_v"])
+                keep.append((xs_d, x_clean))
             keep.append(per)   # the launches below take raw pointers: per-layer views must outlive them
             # stage A of the factorised convs: one batched product per source-node array
             gmap, groups = {}, {}
             for k, (csr_k, so_k, xs_k) in per.items():
-                if so_k is not None and csr_k.n_edges > 0:
+                if so_k is not None and csr_k.n_edges > 0 and so_k.n_edges > 0:
                     groups.setdefault((xs_k.data_ptr(), xs_k.shape[0]), (xs_k, []))[1].append((k, self.conv_layers[9 * l + k]))
             for xs_k, grp in groups.values():
                 gmap.update(self._stage_a(l, grp, xs_k))
+            if c1 is not None:
+                gmap.update({("v", sl): g_ for (_, sl), g_ in self._stage_a(l, [(3, self.conv_layers[9 * l + 3])], x_clean).items()})
             keep.append(gmap)
             for k, csr, x_recv, x_src, e_base, sh, rt in plan:
                 if not active[rt]:
@@ -1084,6 +1146,21 @@ class TensorProductScoreModel(nn.Module):
                 conv = self.conv_layers[9 * l + k]
                 pkc = conv.packed(dev)
                 csr, so_k, xs_k = per[k]
+                if k == 3 and c1 is not None:
+                    # rows [0, E): per-sample messages at their CSR positions (only the touched edges are written and read),
+                    # rows [E, E + e0): the messages of the complex's own edge list between clean atoms
+                    msg = torch.empty((c1["E"] + c1["e0"], spec.d_out), device=dev, dtype=torch.float32)
+                    msgs[k] = (msg, csr, pkc, c1["rowmap"])
+                    pkg = conv.packed_g(dev)
+                    if so_k is not None and so_k.n_edges > 0:
+                        g = [gmap.get((k, sl)) for sl in (0, 1)]
+                        segs = [(e_base, so_k.eid, ns, ns), (x_recv, so_k.recv, ldx, ns), (xs_k, so_k.src, ldx, ns)]
+                        tasks_g.append(_make_task(pkg, xs_k, ldx, so_k, sh, segs, msg, g=g, pos=so_k.pos))
+                    sv = c1["so_v"]
+                    g = [gmap.get(("v", sl)) for sl in (0, 1)]
+                    segs = [(e_base, sv.eid, ns, ns), (x_clean, sv.recv, ldx, ns), (x_clean, sv.src, ldx, ns)]
+                    tasks_g.append(_make_task(pkg, x_clean, ldx, sv, sh, segs, msg, g=g, pos=sv.pos))
+                    continue
                 msg = torch.empty((csr.n_edges, spec.d_out), device=dev, dtype=torch.float32)
                 msgs[k] = (msg, csr, pkc)
                 if csr.n_edges == 0:

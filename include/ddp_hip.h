@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DDP_ABI_VERSION 5
+#define DDP_ABI_VERSION 6
 #define DDP_EINVAL (-1)   /* bad argument (shape not supported, null pointer, ...) */
 #define DDP_ELIMIT (-2)   /* exceeds a compiled-in limit (see DDP_MAX_*) */
 
@@ -139,6 +139,9 @@ typedef struct {
   const float* bn_scale; /* [d_out]  weight / sqrt(running_var + eps), broadcast over vector components */
   const float* bn_shift; /* [d_out]  bias - running_mean * scale on 0e channels, 0 elsewhere */
   int32_t n_edges;
+  const int32_t* rowmap; /* optional [n_edges]: row of `msg` that holds the message of CSR position p (NULL: row p).  Lets
+                            identical messages be stored once (score_model: layer-1 atom<-atom messages between atoms that no
+                            ligand message has reached are the same in every sample of a sampling batch) */
 } ddp_reduce_src_t;
 int ddp_segment_reduce(float* x, int ldx, int n_nodes, int d_out, const ddp_reduce_src_t* srcs, int nsrc,
                        int accumulate, void* stream);

@@ -411,6 +411,49 @@ def test_layer0_sharing_across_identical_receptors():
         assert torch.equal(x, y)
 
 
+def test_layer1_clean_pair_sharing_is_exact():
+    """score_model.share_clean_layer1: in a sampling batch of one rigid complex the layer-1 atom<-atom messages between atoms
+    that no ligand message has reached are computed once and read through ddp_segment_reduce's row map.  Bitwise the general
+    path (same per-edge arithmetic, same summation order), and actually taken: most of the edges are shared."""
+    from diffdock_pocket_amd.batch import collate, set_time
+    from diffdock_pocket_amd.synthetic import make_3dpf_complex
+    case, gold, batch, sd = case_inputs("cfg2_noflex")          # ns=60 nv=10 L=4, rigid receptor
+    dev = _dev()
+    model = _model_for(case, sd)
+    gs = []
+    g = torch.Generator().manual_seed(4)
+    for i in range(5):
+        c = make_3dpf_complex(seed=case.data_seed, flexible_sidechains=False, n_rec=40)
+        c["ligand"].pos = c["ligand"].pos + torch.randn(1, 3, generator=g) * 2.0
+        gs.append(c)
+    b = collate(gs)
+    set_time(b, 0.6, 0.6, 0.6, 0.6)
+    bd = b.to(dev)
+    model.share_clean_layer1 = True
+    fast = [t.clone() for t in model(bd)]
+    st = dict(model.last_stats)
+    assert "clean1_dirty_edges" in st and 0 < st["clean1_dirty_edges"] < 0.6 * st["E_aa"], st
+    model.share_clean_layer1 = False
+    slow = [t.clone() for t in model(bd)]
+    assert "clean1_dirty_edges" not in model.last_stats
+    for f, s_ in zip(fast, slow):
+        assert torch.equal(f, s_)
+    want = OracleScoreModel(case.oracle_config(), sd)(b)
+    for f, w in zip(fast, want):
+        if w.numel():
+            assert rel_err(f.float().cpu(), w) < TOL
+    # ligands far away: every atom is clean, nothing is computed per sample
+    b2 = collate(gs)
+    b2["ligand"].pos = b2["ligand"].pos + 30.0
+    set_time(b2, 0.6, 0.6, 0.6, 0.6)
+    model.share_clean_layer1 = True
+    far = [t.clone() for t in model(b2.to(dev))]
+    assert model.last_stats["clean1_dirty_edges"] == 0
+    model.share_clean_layer1 = False
+    for f, s_ in zip(far, model(b2.to(dev))):
+        assert torch.equal(f, s_)
+
+
 @pytest.mark.parametrize("name", ["cfg2_noflex", "cfg2_small", "cfg1_full", "ns24_l3"])
 def test_last_receptor_layer_pruning_is_exact(name):
     """Dead-output elimination over the last layers (score_model.prune_last_receptor_layer): the receptor-side convs of

@@ -68,10 +68,15 @@ smp.step(2, get_t_schedule(20))
 st = captured["done"].astype(np.int64)
 st = st[np.argsort(st[:, 37], kind="stable")]      # rows in tile order (workgroup ids are remapped per XCD)
 captured["done"] = captured["done"][np.argsort(captured["done"][:, 37].astype(np.int64), kind="stable")]
-if WANT_G:   # ddp_conv32_kernel: stamps 0..9 (see the kernel)
+W4 = True
+if WANT_G and W4:   # ddp_conv32_kernel (4 waves): stamps 0..9 (see the kernel)
     names = ["stage edge_attr_", "fc1", "features (all blocks)", "wave0 role tiles", "wait other waves", "zero + park rounds",
              "G pass (wave 0)", "wait other waves (G)", "store rows"]
     idx = list(range(10))
+elif WANT_G:        # ddp_conv32x6_kernel: 0 1 2 3 | 4 tile wave 0 done | 5 barrier | 6 parked | 9 stored; 7 = G wave 4 done
+    names = ["stage edge_attr_", "fc1", "features (all blocks)", "wave0 role tiles", "wait other tile waves / G waves", "park rounds",
+             "store rows"]
+    idx = [0, 1, 2, 3, 4, 5, 6, 9]
 else:
     names = ["stage edge_attr_", "fc1"]
     for b in range(4):
@@ -101,7 +106,8 @@ for n_, m in zip(names, d.mean(0)):
 
 if not WANT_G:
     sys.exit(0)
-gph = (st[:, 7] - st[:, 6]).astype(np.float64)
+gph = (st[:, 7] - st[:, 6]).astype(np.float64) if W4 else (st[:, 7] - st[:, 3]).astype(np.float64)
+print(f"G pass of the first G wave: {gph.mean():.0f} ticks")
 tot_wg = (st[:, 9] - st[:, 0]).astype(np.float64)
 start = (st[:, 22] - st[:, 22].min()) / 100.0
 o = 0
