@@ -311,6 +311,7 @@ def main(argv=None):
         pmc, pmc_src = load_pmc(workload_key)
         poses = n_total * args.steps / 20.0
         if args.launch_log:
+            os.makedirs(os.path.dirname(os.path.abspath(args.launch_log)), exist_ok=True)
             with open(args.launch_log, "w") as f:
                 json.dump({"workload": workload_key, "src_sha16": source_hash(), "warmup_steps": args.warmup, "steps": args.steps,
                            "launches": [{"kernel": k, "edges": e, "useful_flops": u, "algorithmic_flops": a}

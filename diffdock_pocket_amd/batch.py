@@ -142,6 +142,8 @@ def collate(graphs: Iterable[HeteroBatch]) -> HeteroBatch:
     offsets: Dict[str, List[int]] = {}
     for nt in node_types:
         sts = [g[nt] for g in graphs]
+        if all(len(s) == 0 for s in sts):   # a store that only exists because it was looked up (no flexible residues)
+            continue
         counts = [s.num_nodes for s in sts]
         off = [0]
         for c in counts:

@@ -648,10 +648,14 @@ class TensorProductScoreModel(nn.Module):
     def _weights_version(self):
         """Sum of the autograd version counters of every parameter and buffer: any in-place update (optimizer step,
         `ema.copy_to(model.parameters())`, `param.data.copy_`, BatchNorm buffer edits) bumps it."""
-        return sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers())
+        ts = self.__dict__.get("_weight_tensors")
+        if ts is None:   # (the list is rebuilt when modules change device / dtype: _apply)
+            ts = self.__dict__["_weight_tensors"] = list(self.parameters()) + list(self.buffers())
+        return sum(t._version for t in ts)
 
     def invalidate_packed(self):
         self._weights_seen = None
+        self.__dict__["_weight_tensors"] = None
         self._stage_a_stacks = {}
         for m in self.modules():
             if isinstance(m, TensorProductConvLayer):

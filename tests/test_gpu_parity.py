@@ -555,6 +555,37 @@ def test_three_step_trajectory_matches_the_cpu_oracle_trajectory():
     assert float((s_cpu.lig_pos - g["ligand"].pos).abs().max()) > 1.0
 
 
+def test_csv_driver_on_device(tmp_path):
+    """BASELINE configs[3] in miniature: inference.run_csv over a two-row csv (the reference's example complex, with and
+    without flexible side chains, ESM rows from a dict) with the HIP score model and the HIP confidence model: poses are ranked
+    by confidence, and the run is reproducible bit for bit."""
+    import os
+    from diffdock_pocket_amd import inference as INF
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    csv_path = tmp_path / "c.csv"
+    csv_path.write_text("complex_name,experimental_protein,ligand,pocket_center_x,pocket_center_y,pocket_center_z,flexible_sidechains\n"
+                        "a,3dpf_protein.pdb,3dpf_ligand.sdf,,,,A:160-A:193-A:197-A:198\n"
+                        "b,3dpf_protein.pdb,3dpf_ligand.sdf\n")
+    dev = _dev()
+    case = CASES["cfg1_full"]
+    model = _model_for(case, case_inputs(case.name)[3])
+    conf_case = CASES["conf_ns24_l5"]
+    conf_model = _model_for(conf_case, case_inputs(conf_case.name)[3])
+    n_res = INF.build_row_graph(INF.load_protein_ligand_csv(str(csv_path))[0], root=gdir)["receptor"].x.shape[0]
+    esm = {k: torch.randn(n_res, 1280, generator=torch.Generator().manual_seed(i)) for i, k in enumerate("ab")}
+
+    def run():
+        return INF.run_csv(str(csv_path), model, dev, confidence_model=conf_model, samples_per_complex=6, inference_steps=4,
+                           esm_embeddings=esm, root=gdir, seed=1)
+
+    r1, r2 = run(), run()
+    for a, b in zip(r1, r2):
+        assert a.skipped is None and a.ligand_pos.shape[0] == 6 and torch.isfinite(a.ligand_pos).all()
+        assert torch.equal(a.ligand_pos, b.ligand_pos) and torch.equal(a.order, b.order)
+        key = a.confidence[:, 0] if a.confidence.dim() == 2 else a.confidence
+        assert bool((key[:-1] >= key[1:]).all())
+
+
 def test_forward_on_graph_from_the_input_pipeline():
     """a complex graph built from PDB / SDF text (inputs.build_complex_graph, the reference's example
     complex with the README's flexible residues) goes through the HIP forward and matches the oracle on the same batch."""

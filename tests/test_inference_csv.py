@@ -1,0 +1,109 @@
+"""The csv batch driver (diffdock_pocket_amd/inference.py; reference inference.py:459-493 + datasets/pdbbind.py:1005-1066) on
+the CPU with a stub score function: row cleaning, skipped rows, ranking, and bitwise shard invariance of the sample-sharded
+2-rank run (gloo) against the single-process run."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from diffdock_pocket_amd import inference as INF
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class Stub:
+    """Deterministic stand-in for the score model (pure function of the batch positions); CPU only."""
+    flexible_sidechains = True
+
+    def __call__(self, b):
+        B = b.num_graphs
+        lp = b["ligand"].pos.reshape(B, -1, 3)
+        c = lp.mean(1)
+        tr = -0.05 * c
+        rot = 0.02 * torch.stack([c[:, 1], -c[:, 0], c[:, 2]], 1)
+        T = int(b["ligand"].edge_mask.sum())
+        tor = 0.01 * lp[:, :1, 0].expand(B, T // B).reshape(-1) if T else torch.empty(0)
+        S = b["flexResidues"].edge_idx.shape[0] if len(b["flexResidues"]) > 0 else 0
+        sc = 0.01 * torch.ones(S)
+        return tr, rot, tor, sc
+
+
+class StubConfidence:
+    def __call__(self, b):
+        B = b.num_graphs
+        return -b["ligand"].pos.reshape(B, -1, 3).mean(1).norm(dim=1)       # closer to the pocket centre = more confident
+
+
+def _write_csv(tmp_path):
+    p = tmp_path / "complexes.csv"
+    p.write_text(
+        "complex_name,experimental_protein,ligand,pocket_center_x,pocket_center_y,pocket_center_z,flexible_sidechains\n"
+        "3dpf_flex,3dpf_protein.pdb,3dpf_ligand.sdf,,,,A:160-A:193-A:197\n"
+        "3dpf_smiles,3dpf_protein.pdb,COc(cc1)ccc1C#N\n"
+        "3dpf_noligand,3dpf_protein.pdb,\n"
+        "3dpf_rigid,3dpf_protein.pdb,3dpf_ligand.sdf\n")
+    return str(p)
+
+
+def _run(csv_path, rank=0, world=1, dist=None, shard="samples"):
+    return INF.run_csv(csv_path, Stub(), torch.device("cpu"), confidence_model=StubConfidence(), samples_per_complex=5,
+                       inference_steps=3, root=GOLDEN, seed=2, rank=rank, world=world, dist=dist, shard=shard)
+
+
+def test_rows_are_cleaned_like_the_reference_loader(tmp_path):
+    rows = INF.load_protein_ligand_csv(_write_csv(tmp_path))
+    assert [r["complex_name"] for r in rows] == ["3dpf_flex", "3dpf_smiles", "3dpf_rigid"]      # the row without a ligand is dropped
+    assert rows[0]["flexible_sidechains"] == "A:160-A:193-A:197" and rows[0]["pocket_center"] is None
+    assert rows[2]["flexible_sidechains"] is None
+
+
+def test_csv_run_ranks_poses_and_skips_unreadable_rows(tmp_path):
+    res = _run(_write_csv(tmp_path))
+    assert [r.name for r in res] == ["3dpf_flex", "3dpf_smiles", "3dpf_rigid"]
+    assert res[1].skipped is not None and "SDF" in res[1].skipped and res[1].ligand_pos is None
+    for r in (res[0], res[2]):
+        assert r.skipped is None and r.ligand_pos.shape[0] == 5 and torch.isfinite(r.ligand_pos).all()
+        assert sorted(r.order.tolist()) == [0, 1, 2, 3, 4]
+        assert bool((r.confidence[:-1] >= r.confidence[1:]).all())        # best first
+
+
+def _worker(rank, world, csv_path, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = _run(csv_path, rank, world, dist)
+    if rank == 0:
+        q.put([(r.name, r.skipped, r.ligand_pos, r.confidence) for r in res])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sample_sharding_equals_the_single_process_run(tmp_path):
+    csv_path = _write_csv(tmp_path)
+    full = _run(csv_path)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [ctx.Process(target=_worker, args=(r, 2, csv_path, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for (name, skipped, lig, conf), ref in zip(got, full):
+        assert name == ref.name and (skipped is None) == (ref.skipped is None)
+        if ref.ligand_pos is not None:
+            assert torch.equal(lig, ref.ligand_pos) and torch.equal(conf, ref.confidence)
+
+
+def test_complex_sharding_follows_array_split(tmp_path):
+    csv_path = _write_csv(tmp_path)
+    r0, r1 = _run(csv_path, 0, 2, shard="complexes"), _run(csv_path, 1, 2, shard="complexes")
+    done0 = [r.name for r in r0 if r.ligand_pos is not None or r.skipped]
+    done1 = [r.name for r in r1 if r.ligand_pos is not None or r.skipped]
+    assert done0 == ["3dpf_flex", "3dpf_smiles"] and done1 == ["3dpf_rigid"]       # np.array_split([0, 1, 2], 2)

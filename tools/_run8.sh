@@ -1,0 +1,24 @@
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r2g
+mkdir -p $O
+cd $R
+timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
+timeout 400 python bench.py --steps 20 --warmup 2 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+timeout 200 python bench.py --steps 20 --warmup 2 --flex --no-cpu-baseline > $O/bench_flex.json 2>> $O/bench.err
+timeout 200 python bench.py --samples 5 --steps 20 --warmup 2 --no-cpu-baseline > $O/bench_5samples.json 2>> $O/bench.err
+timeout 200 env DDP_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 6 --warmup 1 --no-cpu-baseline --scaling strong 2>> $O/bench.err | grep -v "^\[Gloo\]" > $O/bench_2rank_gloo_strong.json
+cd /tmp; export TMPDIR=/tmp
+B="python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-hbm-pass --no-other-workloads"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- $B > $O/prof.log 2>&1; echo "prof rc=$?"
+P="python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-hbm-pass --no-other-workloads"
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $P --launch-log $O/pmc_fetch/launches.json > $O/pmc_fetch.log 2>&1; echo "fetch rc=$?"
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $P --launch-log $O/pmc_write/launches.json > $O/pmc_write.log 2>&1; echo "write rc=$?"
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- $P --launch-log $O/pmc_mfma/launches.json > $O/pmc_mfma.log 2>&1; echo "mfma rc=$?"
+cd $R
+python3 tools/pmc_collect.py $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/r02_pmc.json > $O/pmc_collect.log 2>&1; echo "collect rc=$?"; tail -3 $O/pmc_collect.log
+python3 tools/gaps.py $O/prof > $O/gaps.log 2>&1; cat $O/gaps.log | head -12
+ls $O $O/prof/* | head -30
+# keep the merge small: drop the big traces, keep stats
+find $O -name "*kernel_trace.csv" -size +20M -delete
+find $O -name "*counter_collection.csv" -size +20M -delete
+du -sh $O
