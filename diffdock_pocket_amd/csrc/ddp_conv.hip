@@ -225,6 +225,9 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
   //  * extra columns 64.. : if there are at most 8 of them (6 of the 70 at ns = 60, nv = 10) the 16 MFMA blocks are
   //    used as nb = 1|2 column blocks x 16/nb K-slices and the slices are summed across lanes at the end of the unit
   //    (shfl_xor butterfly, fixed order): 1/8 of the MFMAs of a full pass.  Otherwise a second full pass.
+  // (Measured alternative, round 2: the same contraction on the vector ALU - h rows as wave-wide ds_read_b128 broadcasts,
+  // v_pk_fma_f32 on (even k, odd k) accumulator pairs, lane = column - is parity-exact but took 209 k cycles per workgroup
+  // against 100 k for this MFMA form: the 360 broadcast reads per unit and slot are LDS-return bound.)
   // Every G value is requested exactly once per wave (HBM / Infinity-Cache / L2), so the (unit, chunk) steps of a wave
   // are flattened into one sequence and run through a 3-deep register ring: the loads of steps s+1 and s+2 are in
   // flight while step s computes; the A operands of a step are read up front (the uniform k < hp branches would
@@ -304,7 +307,8 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
       }                                                                                                       \
       _Pragma("unroll") for (int q4 = 0; q4 < DDP_ABL_NQ(KC / 4); ++q4)                                       \
         if (c_ch * (KC / 4) + q4 < nq) {   /* (h and G are exactly 0 on [hid, 4 nq)) */                       \
-          /* four independent accumulation chains (even / odd k per 4-edge group) keep the matrix pipe issuing */ \
+          /* four independent accumulation chains (even / odd k per 4-edge group) keep the matrix pipe issuing; a unit of \
+             <= 4 edges could skip the second group: measured, the branch costs more than the 4x4x1 MFMAs it saves */ \
           acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q4][0], BUF[q4][0], acc0, 0, 0, 0);                    \
           acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q4][0], BUF[q4][0], acc1, 0, 0, 0);                    \
           acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q4][1], BUF[q4][1], acc2, 0, 0, 0);                    \
@@ -1023,10 +1027,17 @@ __device__ __forceinline__ void seg_park(const ddp_block_t& B, const ddp_role_se
   float* o = outb + B.out_off + ncol * C + 4 * hh * os;
   for (int s = 0; s < B.ups; ++s) {
     if (valid && us == s) {
+      if (R.round == 0 && s == 0) {   // the first writer of these elements: plain stores (the tile is not zeroed under them)
 #pragma unroll
-      for (int c = 0; c < C; ++c)
+        for (int c = 0; c < C; ++c)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o[((i & 3) + 8 * (i >> 2)) * os + c] += res[c][i];
+          for (int i = 0; i < 16; ++i) o[((i & 3) + 8 * (i >> 2)) * os + c] = res[c][i];
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[((i & 3) + 8 * (i >> 2)) * os + c] += res[c][i];
+      }
     }
   }
 }
@@ -1102,9 +1113,17 @@ __global__ __launch_bounds__(256, 3) void ddp_conv32_kernel(const ConvLaunch L) 
   __syncthreads();   // every wave is done with F: region B becomes the message tile
   STAMP(5);
 
-  // ---- phase 4: zero, then the segments round by round
-  for (int i = tid; i < (ET * os) >> 2; i += NT) reinterpret_cast<f32x4*>(rb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
+  // ---- phase 4: the segments round by round.  Round 0 stores (every column of a block with tiles has a round-0 writer:
+  // the parts of an item cover the same columns); the columns of blocks WITHOUT tiles (all their features factorised) only
+  // receive the G pass and are zeroed here, in the same round (disjoint columns)
+  for (int bi = 0; bi < S.nblocks; ++bi) {
+    const ddp_block_t& B = S.blk[bi];
+    if (B.ntiles == 0) {
+      const int w = B.n * B.C;
+      for (int i = tid; i < ET * w; i += NT) rb[(i / w) * os + B.out_off + (i % w)] = 0.f;
+    }
+  }
+  if (S.nrounds == 0) __syncthreads();
   for (int rnd = 0; rnd < S.nrounds; ++rnd) {
     if (nseg > 0 && S.role[wave][0].round == rnd) {
       const ddp_role_seg_t& R0 = S.role[wave][0];
