@@ -1,6 +1,6 @@
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r2g
-mkdir -p $O
+O=$R/gpurun_out/r2i
+mkdir -p $O $O/pmc_fetch $O/pmc_write $O/pmc_mfma
 cd $R
 timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
 timeout 400 python bench.py --steps 20 --warmup 2 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
