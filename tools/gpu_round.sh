@@ -1,5 +1,8 @@
+# Everything the round-end evidence comes from, in one gpurun call:  gpurun --timeout 3600 -- "bash tools/gpu_round.sh <name>"
+# GPU tests, bench lines (configs[1] with sub-records, configs[2], a 5-sample shard, a 2-rank gloo run), rocprofv3 kernel stats,
+# the three PMC passes + tools/pmc_collect.py, device-idle analysis.  Outputs under gpurun_out/<name>/.
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r2i
+O=$R/gpurun_out/${1:-round}
 mkdir -p $O $O/pmc_fetch $O/pmc_write $O/pmc_mfma
 cd $R
 timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
