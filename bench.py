@@ -71,6 +71,9 @@ def parse_args(argv=None):
     ap.add_argument("--launch-log", default=None,
                     help="write the per-launch (kernel, edges, useful FLOPs) list of every conv launch to this JSON file "
                          "(tools/pmc_collect.py matches it with the PMC dispatches of the same run)")
+    ap.add_argument("--dry-run-ranks", action="store_true",
+                    help="launcher test (no GPU needed): every rank prints its RANK / WORLD_SIZE / sample slice as one JSON line and "
+                         "exits, rank DDP_BENCH_FAIL_RANK (if set) with code 3")
     ap.add_argument("--cpu-samples", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=32)
@@ -241,6 +244,12 @@ def main(argv=None):
                          f"(or without WORLD_SIZE, then bench.py starts the ranks itself)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if args.dry_run_ranks:
+        n_total = args.samples * world if args.scaling == "weak" else args.samples
+        sl = shard_slice(rank, world, n_total, None)
+        print(json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "master": os.environ.get("MASTER_ADDR"),
+                          "port": os.environ.get("MASTER_PORT"), "samples_total": n_total, "slice": [sl.start, sl.stop]}), flush=True)
+        sys.exit(3 if os.environ.get("DDP_BENCH_FAIL_RANK") == str(rank) else 0)
 
     import torch
     if not torch.cuda.is_available():
