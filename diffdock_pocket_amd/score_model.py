@@ -500,6 +500,11 @@ class TensorProductScoreModel(nn.Module):
         self.prune_last_receptor_layer = True   # layer L-2 receptor-side convs only where the final layer reads them
         self.share_layer0 = True       # layer-0 receptor-side convs once per batch of identical receptors (forward)
         self.share_clean_layer1 = True  # layer-1 atom<-atom messages between atoms no ligand message has reached: once (forward)
+        # Both plans above (and the dead-output walk) cost host time - ~100 small launches and a few synchronisations, 2.7 ms
+        # for the walk - that is hidden behind the conv layers of a large batch but sits on the critical path of a small one
+        # (5 samples of 3dpf: 9.9 ms per step, host bound).  They pay when the layers they run behind take longer than they
+        # do: measured cross-over at ~12 samples of 3dpf, expressed in atom-atom edges so that it scales with the complex
+        self.plan_min_edges = 100_000
         self._static_cache = {}        # see _cached()
         self.prune_async = True        # dead-output walk on a side stream behind the first layers (forward)
         self._side = None
@@ -958,7 +963,8 @@ class TensorProductScoreModel(nn.Module):
         # values in the same order: the result is bitwise the general path's (GPU test).  Layer 1 must not be one of the pruned
         # last layers (L >= 4).
         clean1 = None
-        clean1_on = bool(self.share_clean_layer1 and 3 in shared0 and 3 in so_views and L_ >= 4 and c_aa.n_edges > 0)
+        clean1_on = bool(self.share_clean_layer1 and 3 in shared0 and 3 in so_views and L_ >= 4 and c_aa.n_edges > 0
+                         and c_aa.n_edges >= self.plan_min_edges)
 
         def clean1_plan():
             n0_, e0_, _ = shared0[3]
@@ -1064,7 +1070,8 @@ class TensorProductScoreModel(nn.Module):
         # structure only, not features - so that it hides behind those layers instead of delaying the first one.  A layer
         # that is already queued when the plan arrives simply runs unpruned (always exact).
         pruned, pruned_so = {}, {}
-        prune_on = self.prune_last_receptor_layer and L_ >= 2 and not self.confidence_mode
+        prune_on = (self.prune_last_receptor_layer and L_ >= 2 and not self.confidence_mode
+                    and c_aa.n_edges >= self.plan_min_edges)
         prune_after = (L_ - 4) if (prune_on and self.prune_async and L_ >= 4 and self.before_layers is None) else None
         if prune_on and prune_after is None:
             pruned, pruned_so = prune_plan()
