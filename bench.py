@@ -118,7 +118,9 @@ def load_pmc(workload_key):
     if pmc.get("src_sha16") != source_hash() or pmc.get("workload") != workload_key:
         src["stale"] = True
         return {}, src
-    return pmc.get("kernels", {}), src
+    kernels = dict(pmc.get("kernels", {}))
+    kernels["_per_step"] = pmc.get("_per_step")
+    return kernels, src
 
 
 def model_kwargs(cfg, flex):
