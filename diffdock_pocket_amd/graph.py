@@ -116,6 +116,7 @@ class RadiusSearch:
         if ny > 0:
             L.check(lib.ddp_radius_count(xc.data_ptr(), xptr.data_ptr(), yc.data_ptr(), ybatch.data_ptr(), ny, r, cap, ds,
                                          counts.data_ptr(), torch.cuda.current_stream().cuda_stream), "ddp_radius_count")
+        self.counts = counts                     # matches per query
         self.offs = torch.zeros(ny + 1, dtype=torch.int32, device=xc.device)
         self.offs[1:] = torch.cumsum(counts, 0)
 

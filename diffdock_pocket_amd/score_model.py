@@ -816,6 +816,13 @@ class TensorProductScoreModel(nn.Module):
         else:
             s_lr = G.RadiusSearch(rpos, lpos, self.cross_max_distance, lay_r, lay_l, max_num_neighbors=10000)
         s_la = G.RadiusSearch(apos, lpos, self.lig_max_radius, lay_a, lay_l, max_num_neighbors=10000)
+        # the atoms that occur as sources of ligand<-atom edges = the atoms with a ligand atom of their graph within the
+        # radius: marked by the same search with the roles swapped (count pass only: 37 candidates per atom), so that their
+        # NUMBER rides in the searches' one host synchronisation and the compact source numbering of that conv (below) needs
+        # no synchronisation of its own (it was a torch.unique_consecutive: a second wait in the host-paced front)
+        near_atom = None
+        if self.factorize_min_degree > 0:
+            near_atom = G.RadiusSearch(lpos, apos, self.lig_max_radius, lay_l, lay_a, max_num_neighbors=10000).counts > 0
         num_flex = 0
         # (:327, literally: a PyG HeteroData answers `in` by attribute names, not node types, and creates the store on access)
         if self.flexible_sidechains and len(data["flexResidues"]) > 0:
@@ -847,7 +854,11 @@ class TensorProductScoreModel(nn.Module):
             if num_flex > 0 and lay_a.uniform:   # side chains usually differ between the samples: asked in the same copy
                 av = apos.reshape(B, lay_a.nmax, 3)
                 flags.append((av == av[:1]).all())
-        counts = G.resolve([s_ll, s_lr, s_la] + [p["search"] for p in pending], extra=flags)
+        mark("before_sync")
+        extra = flags + ([near_atom.sum()] if near_atom is not None else [])
+        counts = G.resolve([s_ll, s_lr, s_la] + [p["search"] for p in pending], extra=extra)
+        mark("sync")
+        n_near = counts.pop() if near_atom is not None else 0
         for p, e in zip(pending, counts[3:]):
             p["E"] = e
         one_time = bool(flags) and bool(counts[-len(flags)])
@@ -948,10 +959,11 @@ class TensorProductScoreModel(nn.Module):
                 elif k == 2 and csr.n_edges > 0:
                     # ligand<-atom: few edges per atom over ALL atoms, but the edges leave only the atoms around the ligand.
                     # Degree over the atoms that occur: factorise with stage A on those rows only (compact copy of x per layer)
-                    so_c = G.source_order(csr, Na)
-                    uniq, inv = torch.unique_consecutive(so_c.src.long(), return_inverse=True)
-                    if csr.n_edges >= self.factorize_min_degree * uniq.shape[0]:
-                        so_views[k] = G.SourceOrder(so_c.n_edges, so_c.recv, inv.to(torch.int32), so_c.eid, so_c.pos)
+                    if near_atom is not None and csr.n_edges >= self.factorize_min_degree * max(n_near, 1):
+                        so_c = G.source_order(csr, Na)
+                        uniq = torch.nonzero_static(near_atom, size=n_near).squeeze(1)          # ascending = source order
+                        rank = torch.cumsum(near_atom, 0) - 1
+                        so_views[k] = G.SourceOrder(so_c.n_edges, so_c.recv, rank[so_c.src.long()].to(torch.int32), so_c.eid, so_c.pos)
                         compact_src[k] = uniq
         # Layer 1, atom<-atom, sampling batches of one rigid complex (shared0 has conv 3): after the shared layer 0 an atom's
         # features differ between the samples only if an atom<-ligand message reached it (the atoms within 5 A of that
