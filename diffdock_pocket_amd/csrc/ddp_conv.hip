@@ -919,89 +919,94 @@ __global__ __launch_bounds__(512, 2) void ddp_conv_messages_kernel(const ConvLau
 //   phase 6  the tile leaves as whole message rows (16-byte coalesced stores)
 // Summation order of a message element: tiles of a segment in tile order, segments in round order, then the factorised part:
 // fixed, so results are bitwise reproducible.
-template <int C, int RING = 4>
+// NM > 0: the number of 8-k groups of a tile (hp / 8) as a compile-time constant: the k loop of a tile is fully unrolled, the
+// register ring of weight fragments is indexed statically and no load sits under a condition, so hipcc keeps the exact
+// vmcnt distance of RING - 1 fragments in flight.  NM = 0: any hp (runtime loop, one fragment ahead).
+// Why: the round-1 form of this loop (lambdas, `if (f + k < F)` guards around the unrolled ring, the bias load and the
+// contraction under conditions inside the step) compiled to vmcnt(0) .. vmcnt(4) waits at its control-flow joins and ran a
+// LONE wave at 52 % of the MFMA rate - 11.4 k cycles per 5.9 k-cycle tile (in-kernel stamps with one workgroup per CU).
+template <int C, int NM>
 __device__ __forceinline__ void seg_tiles(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
                                           const float* hbuf, const float* fblk, const ddp_role_seg_t& R, int lane, f32x16* out) {
-  constexpr int FS = 36;
+  constexpr int FS = 36, RING = 4;
+  constexpr int NMP = (NM + RING - 1) / RING * RING;     // steps per tile incl. prefetch-only ones: keeps fragment k in slot k % RING
   const int r = lane & 31, hh = lane >> 5;
-  const int nm = S.hp >> 3;
+  const int nm = (NM > 0) ? NM : (S.hp >> 3);
   const int t0 = R.tile0, ts = R.tstride, count = R.count;
   const f32x4* __restrict__ w2p = reinterpret_cast<const f32x4*>(T.w2p);
   const float* arow = &hbuf[r * S.hs + 4 * hh];
 #pragma unroll
   for (int c = 0; c < C; ++c) out[c] = splat16(0.f);
-  // The segment's (tile, k-group) steps are flattened into one sequence; the 16-byte weight fragment of step f + 4 is requested
-  // before the 4 MFMAs of step f (register ring of four, sched_barriers pin the requests: hipcc otherwise sinks them to
-  // their first use).  Fragments of one tile are 64 f32x4 apart, tiles of the segment ts * nm * 64.
-  const int F = count * nm;
-  const f32x4* __restrict__ wp = w2p + ((size_t)(B.tile0 + t0) * nm * 2 + hh) * 32 + r;
-  const size_t tile_jump = (size_t)ts * nm * 64 - (size_t)(nm - 1) * 64;
-  int pm = 0, pleft = F;
-  auto wfrag = [&]() -> f32x4 {
-    const f32x4 v = DDP_ABL_B(*wp);
-    if (pleft > 1) {
-      --pleft;
-      if (++pm == nm) { pm = 0; wp += tile_jump; } else wp += 64;
-    }
-    return v;
-  };
-  f32x16 acc = splat16(0.f);
+  if (count <= 0) return;
+  // fragments of one tile are 64 f32x4 apart, tiles of the segment ts * nm * 64
+  const f32x4* __restrict__ wt = w2p + ((size_t)(B.tile0 + t0) * nm * 2 + hh) * 32 + r;
+  const size_t tstep = (size_t)ts * nm * 64;
   f32x4 anext = *reinterpret_cast<const f32x4*>(arow);
-  float bias_next = (count > 0) ? T.b2p[(B.tile0 + t0) * 32 + r] : 0.f;
-  int sj = 0, sm = 0;                                  // (tile, k-group) of the step being computed
-  auto step = [&](const f32x4 bcur) {
-    if (sm == 0) {
-      acc = splat16(bias_next);
-      bias_next = T.b2p[(B.tile0 + t0 + min(sj + 1, count - 1) * ts) * 32 + r];   // next tile's bias, a whole tile ahead
-    }
-    const f32x4 a = anext;
-    anext = DDP_ABL_A(*reinterpret_cast<const f32x4*>(arow + 8 * ((sm + 1 == nm) ? 0 : sm + 1)), anext);  // h is tile independent: wrap
+  float bias = T.b2p[(B.tile0 + t0) * 32 + r];
+  f32x4 ring[RING];
+  if constexpr (NM > 0) {
+    static_assert(NM >= RING, "a tile needs at least RING k-groups");
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[i], acc, 0, 0, 0);
-    if (++sm == nm) {
-      // contraction with the basis features, in the MFMA C/D layout: reg i <-> edge row (i&3) + 8*(i>>2) + 4*hh
-      int u, ncol, us;
-      bool valid;
-      tile_lane_map(B, t0 + sj * ts, r, u, ncol, us, valid);
+    for (int k = 0; k < RING; ++k) ring[k] = DDP_ABL_B(wt[k * 64]);
+  } else {
+    ring[0] = DDP_ABL_B(wt[0]);
+  }
+  for (int j = 0; j < count; ++j) {
+    const f32x4* __restrict__ wnx = wt + ((j + 1 < count) ? tstep : 0);   // next tile (the last one re-requests itself: unused)
+    f32x16 acc = splat16(bias);
+    bias = T.b2p[(B.tile0 + t0 + min(j + 1, count - 1) * ts) * 32 + r];   // next tile's bias, a whole tile ahead
+    if constexpr (NM > 0) {
 #pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const float* frow = &fblk[(u * C + c) * FS + 4 * hh];
+      for (int m = 0; m < NMP; ++m) {
+        const f32x4 bcur = ring[m % RING];
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int q = m + RING;                    // fragment to request into the slot this step frees
+        if (q < NM) ring[m % RING] = DDP_ABL_B(wt[q * 64]);
+        else if (q >= NMP) ring[m % RING] = DDP_ABL_B(wnx[(q - NMP) * 64]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (m < NM) {
+          const f32x4 a = anext;
+          anext = DDP_ABL_A(*reinterpret_cast<const f32x4*>(arow + 8 * ((m + 1 == NM) ? 0 : m + 1)), anext);  // h is tile independent: wrap
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const f32x4 f = *reinterpret_cast<const f32x4*>(frow + 8 * q4);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) out[c][4 * q4 + q] += f[q] * acc[4 * q4 + q];
+          for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[i], acc, 0, 0, 0);
         }
       }
-      sm = 0;
-      ++sj;
-    }
-  };
-  if (F > 0) {
-#define DDP_SEG_STEP(BUF, OFF)                  \
-    if (f + (OFF) < F) {                         \
-      const f32x4 c_ = BUF;                      \
-      BUF = wfrag();                             \
-      __builtin_amdgcn_sched_barrier(0);         \
-      step(c_);                                  \
-    }
-    if constexpr (RING == 4) {
-      f32x4 b0 = wfrag(), b1 = wfrag(), b2 = wfrag(), b3 = wfrag();
-      for (int f = 0; f < F; f += 4) {
-        DDP_SEG_STEP(b0, 0)
-        DDP_SEG_STEP(b1, 1)
-        DDP_SEG_STEP(b2, 2)
-        DDP_SEG_STEP(b3, 3)
-      }
-    } else {   // (the 128-register budget of the 8-wave form)
-      f32x4 b0 = wfrag(), b1 = wfrag();
-      for (int f = 0; f < F; f += 2) {
-        DDP_SEG_STEP(b0, 0)
-        DDP_SEG_STEP(b1, 1)
+    } else {
+      for (int m = 0; m < nm; ++m) {
+        const f32x4 bcur = ring[0];
+        ring[0] = DDP_ABL_B((m + 1 < nm) ? wt[(m + 1) * 64] : wnx[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 a = anext;
+        anext = DDP_ABL_A(*reinterpret_cast<const f32x4*>(arow + 8 * ((m + 1 == nm) ? 0 : m + 1)), anext);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[i], acc, 0, 0, 0);
       }
     }
-#undef DDP_SEG_STEP
+    wt = wnx;
+    // contraction with the basis features, in the MFMA C/D layout: reg i <-> edge row (i&3) + 8*(i>>2) + 4*hh
+    int u, ncol, us;
+    bool valid;
+    tile_lane_map(B, t0 + j * ts, r, u, ncol, us, valid);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float* frow = &fblk[(u * C + c) * FS + 4 * hh];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 f = *reinterpret_cast<const f32x4*>(frow + 8 * q4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[c][4 * q4 + q] += f[q] * acc[4 * q4 + q];
+      }
+    }
   }
+}
+
+// the k-group counts with an unrolled tile loop: hp = 184 (ns = 60: the README score model); everything else runs the generic loop
+template <int C>
+__device__ __forceinline__ void seg_tiles_any(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
+                                              const float* hbuf, const float* fblk, const ddp_role_seg_t& R, int lane, f32x16* out) {
+  if (S.hp == 184) seg_tiles<C, 23>(S, B, T, hbuf, fblk, R, lane, out);
+  else seg_tiles<C, 0>(S, B, T, hbuf, fblk, R, lane, out);
 }
 
 // adds a segment's register tile to the LDS message tile.  Lane (r, hh) of the C/D layout holds column r of the 32-column
@@ -1099,15 +1104,15 @@ __global__ __launch_bounds__(256, 3) void ddp_conv32_kernel(const ConvLaunch L) 
     const ddp_role_seg_t& R0 = S.role[wave][0];
     c0 = S.blk[R0.block].C;
     for (int bi = 0; bi < R0.block; ++bi) f0 += S.blk[bi].U * S.blk[bi].C;
-    if (c0 == 1) seg_tiles<1>(S, S.blk[R0.block], T, hbuf, rb + f0 * FS, R0, lane, res);
-    else seg_tiles<3>(S, S.blk[R0.block], T, hbuf, rb + f0 * FS, R0, lane, res + 1);
+    if (c0 == 1) seg_tiles_any<1>(S, S.blk[R0.block], T, hbuf, rb + f0 * FS, R0, lane, res);
+    else seg_tiles_any<3>(S, S.blk[R0.block], T, hbuf, rb + f0 * FS, R0, lane, res + 1);
   }
   if (nseg > 1) {
     const ddp_role_seg_t& R1 = S.role[wave][1];
     c1 = S.blk[R1.block].C;
     for (int bi = 0; bi < R1.block; ++bi) f1 += S.blk[bi].U * S.blk[bi].C;
-    if (c1 == 1) seg_tiles<1>(S, S.blk[R1.block], T, hbuf, rb + f1 * FS, R1, lane, res + 1);
-    else seg_tiles<3>(S, S.blk[R1.block], T, hbuf, rb + f1 * FS, R1, lane, res + 1);
+    if (c1 == 1) seg_tiles_any<1>(S, S.blk[R1.block], T, hbuf, rb + f1 * FS, R1, lane, res + 1);
+    else seg_tiles_any<3>(S, S.blk[R1.block], T, hbuf, rb + f1 * FS, R1, lane, res + 1);
   }
   STAMP(4);
   __syncthreads();   // every wave is done with F: region B becomes the message tile
