@@ -587,6 +587,99 @@ __device__ __forceinline__ void run_block_full(const ddp_conv_shape_t& S, const 
   STAMP(sbase + 2);
 }
 
+// NM > 0: the number of 8-k groups of a tile (hp / 8) as a compile-time constant: the k loop of a tile is fully unrolled, the
+// register ring of weight fragments is indexed statically and no load sits under a condition, so hipcc keeps the exact
+// vmcnt distance of RING - 1 fragments in flight.  NM = 0: any hp (runtime loop, one fragment ahead).
+// Why: the round-1 form of this loop (lambdas, `if (f + k < F)` guards around the unrolled ring, the bias load and the
+// contraction under conditions inside the step) compiled to vmcnt(0) .. vmcnt(4) waits at its control-flow joins and ran a
+// LONE wave at 52 % of the MFMA rate - 11.4 k cycles per 5.9 k-cycle tile (in-kernel stamps with one workgroup per CU).
+template <int C, int NM, int FS>
+__device__ __forceinline__ void seg_tiles(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
+                                          const float* hbuf, const float* fblk, const ddp_role_seg_t& R, int lane, int rt,
+                                          f32x16* out) {
+  // FS: row stride of the feature buffer F[u * C + c][edge] (edge tile + 4); rt: the 32-edge row tile this wave works on
+  constexpr int RING = 4;
+  constexpr int NMP = (NM + RING - 1) / RING * RING;     // steps per tile incl. prefetch-only ones: keeps fragment k in slot k % RING
+  const int r = lane & 31, hh = lane >> 5;
+  const int nm = (NM > 0) ? NM : (S.hp >> 3);
+  const int t0 = R.tile0, ts = R.tstride, count = R.count;
+  const f32x4* __restrict__ w2p = reinterpret_cast<const f32x4*>(T.w2p);
+  const float* arow = &hbuf[(rt * 32 + r) * S.hs + 4 * hh];
+#pragma unroll
+  for (int c = 0; c < C; ++c) out[c] = splat16(0.f);
+  if (count <= 0) return;
+  // fragments of one tile are 64 f32x4 apart, tiles of the segment ts * nm * 64
+  const f32x4* __restrict__ wt = w2p + ((size_t)(B.tile0 + t0) * nm * 2 + hh) * 32 + r;
+  const size_t tstep = (size_t)ts * nm * 64;
+  f32x4 anext = *reinterpret_cast<const f32x4*>(arow);
+  float bias = T.b2p[(B.tile0 + t0) * 32 + r];
+  f32x4 ring[RING];
+  if constexpr (NM > 0) {
+    static_assert(NM >= RING, "a tile needs at least RING k-groups");
+#pragma unroll
+    for (int k = 0; k < RING; ++k) ring[k] = DDP_ABL_B(wt[k * 64]);
+  } else {
+    ring[0] = DDP_ABL_B(wt[0]);
+  }
+  for (int j = 0; j < count; ++j) {
+    const f32x4* __restrict__ wnx = wt + ((j + 1 < count) ? tstep : 0);   // next tile (the last one re-requests itself: unused)
+    f32x16 acc = splat16(bias);
+    bias = T.b2p[(B.tile0 + t0 + min(j + 1, count - 1) * ts) * 32 + r];   // next tile's bias, a whole tile ahead
+    if constexpr (NM > 0) {
+#pragma unroll
+      for (int m = 0; m < NMP; ++m) {
+        const f32x4 bcur = ring[m % RING];
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int q = m + RING;                    // fragment to request into the slot this step frees
+        if (q < NM) ring[m % RING] = DDP_ABL_B(wt[q * 64]);
+        else if (q >= NMP) ring[m % RING] = DDP_ABL_B(wnx[(q - NMP) * 64]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (m < NM) {
+          const f32x4 a = anext;
+          anext = DDP_ABL_A(*reinterpret_cast<const f32x4*>(arow + 8 * ((m + 1 == NM) ? 0 : m + 1)), anext);  // h is tile independent: wrap
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[i], acc, 0, 0, 0);
+        }
+      }
+    } else {
+      for (int m = 0; m < nm; ++m) {
+        const f32x4 bcur = ring[0];
+        ring[0] = DDP_ABL_B((m + 1 < nm) ? wt[(m + 1) * 64] : wnx[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 a = anext;
+        anext = DDP_ABL_A(*reinterpret_cast<const f32x4*>(arow + 8 * ((m + 1 == nm) ? 0 : m + 1)), anext);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[i], acc, 0, 0, 0);
+      }
+    }
+    wt = wnx;
+    // contraction with the basis features, in the MFMA C/D layout: reg i <-> edge row (i&3) + 8*(i>>2) + 4*hh
+    int u, ncol, us;
+    bool valid;
+    tile_lane_map(B, t0 + j * ts, r, u, ncol, us, valid);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float* frow = &fblk[(u * C + c) * FS + rt * 32 + 4 * hh];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 f = *reinterpret_cast<const f32x4*>(frow + 8 * q4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[c][4 * q4 + q] += f[q] * acc[4 * q4 + q];
+      }
+    }
+  }
+}
+
+// the k-group counts with an unrolled tile loop: hp = 184 (ns = 60: the README score model); everything else runs the generic loop
+template <int C, int FS = 36>
+__device__ __forceinline__ void seg_tiles_any(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
+                                              const float* hbuf, const float* fblk, const ddp_role_seg_t& R, int lane, f32x16* out,
+                                              int rt = 0) {
+  if (S.hp == 184) seg_tiles<C, 23, FS>(S, B, T, hbuf, fblk, R, lane, rt, out);
+  else seg_tiles<C, 0, FS>(S, B, T, hbuf, fblk, R, lane, rt, out);
+}
+
 template <int ET, int C>
 __device__ __forceinline__ void run_block_rows(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
                                           const float* hbuf, float* fbuf, int tid,
@@ -595,77 +688,17 @@ __device__ __forceinline__ void run_block_rows(const ddp_conv_shape_t& S, const 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps tile/loop indices in SGPRs
   const int lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int rt = wave >> 2, wq = wave & 3;   // ET = 32: four waves, all on row tile 0
-  const int nm = S.hp >> 3;
   const int ngroups = B.ntiles;
-  const f32x4* __restrict__ w2p = reinterpret_cast<const f32x4*>(T.w2p);
-  const float* arow = &hbuf[(rt * 32 + r) * S.hs + 4 * hh];
-
+  // wave (rt, wq) runs the tiles wq, wq + 4, .. of the block on row tile rt: one segment of the unrolled tile loop (seg_tiles)
   f32x16 out[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) out[c] = splat16(0.f);
-
-  // The wave's (tile, k-group) steps are flattened into one sequence f = j * nm + m (tile g = wq + 4 j).  The 16-byte
-  // weight fragment of step f + 2 is requested before the 4 MFMAs of step f (two register buffers, loop unrolled by two;
-  // sched_barriers pin the requests: hipcc otherwise sinks them to their first use).  With a lone wave per SIMD in a
-  // tile loop one k-group (256 cycles) does not cover an L2 round trip: dropping the loads altogether made the layer
-  // launches 9 % faster with the unpinned one-step prefetch this replaces (tools/per_launch.py with -DDDP_ABLATE=1); this form
-  // recovers 2 % of it.
-  const int nmine = (ngroups > wq) ? (ngroups - wq + 3) >> 2 : 0;
-  const int F = nmine * nm;
-  // request pointer of the next fragment to fetch: fragments of one tile are 64 f32x4 apart, tiles of this wave
-  // 4 * nm * 64; kept incrementally (pm = k-group inside the tile), clamped at the last fragment
-  const f32x4* __restrict__ wp = w2p + ((size_t)(B.tile0 + wq) * nm * 2 + hh) * 32 + r;
-  int pm = 0, pleft = F;
-  auto wfrag = [&]() -> f32x4 {
-    const f32x4 v = DDP_ABL_B(*wp);
-    if (pleft > 1) {
-      --pleft;
-      if (++pm == nm) { pm = 0; wp += (size_t)(3 * nm + 1) * 64; } else wp += 64;
-    }
-    return v;
-  };
-  f32x16 acc = splat16(0.f);
-  f32x4 anext = *reinterpret_cast<const f32x4*>(arow);
-  int sj = 0, sm = 0;                                  // (tile, k-group) of the step being computed
-  auto step = [&](const f32x4 bcur) {
-    if (sm == 0) acc = splat16(T.b2p[(B.tile0 + wq + 4 * sj) * 32 + r]);
-    const f32x4 a = anext;
-    anext = DDP_ABL_A(*reinterpret_cast<const f32x4*>(arow + 8 * ((sm + 1 == nm) ? 0 : sm + 1)), anext);  // h is tile independent: wrap
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[i], acc, 0, 0, 0);
-    if (++sm == nm) {
-      // contraction with the basis features, in the MFMA C/D layout: reg i <-> edge row (i&3) + 8*(i>>2) + 4*hh
-      int u, ncol, us;
-      bool valid;
-      tile_lane_map(B, wq + 4 * sj, r, u, ncol, us, valid);
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const float* frow = &fbuf[(u * C + c) * FS + rt * 32 + 4 * hh];
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const f32x4 f = *reinterpret_cast<const f32x4*>(frow + 8 * q4);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) out[c][4 * q4 + q] += f[q] * acc[4 * q4 + q];
-        }
-      }
-      sm = 0;
-      ++sj;
-    }
-  };
-  if (F > 0) {
-    f32x4 b0 = wfrag(), b1 = wfrag();
-#define DDP_ROWS_STEP(BUF, OFF)                 \
-    if (f + (OFF) < F) {                         \
-      const f32x4 c_ = BUF;                      \
-      BUF = wfrag();                             \
-      __builtin_amdgcn_sched_barrier(0);         \
-      step(c_);                                  \
-    }
-    for (int f = 0; f < F; f += 2) {   // (a four-deep ring measured the same within noise)
-      DDP_ROWS_STEP(b0, 0)
-      DDP_ROWS_STEP(b1, 1)
-    }
-#undef DDP_ROWS_STEP
+  {
+    ddp_role_seg_t seg;
+    seg.block = 0;
+    seg.tile0 = wq;
+    seg.tstride = 4;
+    seg.count = (ngroups > wq) ? (ngroups - wq + 3) >> 2 : 0;
+    seg.round = 0;
+    seg_tiles_any<C, FS>(S, B, T, hbuf, fbuf, seg, lane, out, rt);
   }
 
   // ---- phase 4: deterministic cross-wave / cross-lane reduction.  Every wave parks a 32-row partial tile in its own
@@ -809,12 +842,14 @@ __device__ __forceinline__ void stage_edge_attr(const ddp_conv_shape_t& S, const
 }
 
 // phase 1: h = relu(edge_attr_ @ W1 + b1)
-template <int ET, int NW = ET / 8>
-__device__ __forceinline__ void fc1_to_lds(const ddp_conv_shape_t& S, const ddp_conv_task_t& T, const float* xa, float* hbuf, int tid) {
-  constexpr int RT = ET / 32;
+// NM1 > 0: kp1 / 8 as a compile-time constant - the K loop of a column tile is fully unrolled with a static 4-deep register
+// ring of weight fragments and no load under a condition (exact vmcnt distances, see seg_tiles); NM1 = 0: any kp1.
+template <int ET, int NW, int NM1>
+__device__ __forceinline__ void fc1_tiles(const ddp_conv_shape_t& S, const ddp_conv_task_t& T, const float* xa, float* hbuf, int tid) {
+  constexpr int RT = ET / 32, RING = 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps tile/loop indices in SGPRs
   const int lane = tid & 63, r = lane & 31, hh = lane >> 5;
-  const int nm1 = S.kp1 >> 3;
+  const int nm1 = (NM1 > 0) ? NM1 : (S.kp1 >> 3);
   const f32x4* __restrict__ w1p = reinterpret_cast<const f32x4*>(T.w1p);
   // RT * nct1 (row tile, column tile) pairs over the waves: pair t -> wave t % NW, i.e. SIMD t % 4, so the four matrix
   // pipes get the same number of tiles (ET = 64: 12 tiles at hid = 180, 3 per SIMD)
@@ -822,22 +857,41 @@ __device__ __forceinline__ void fc1_to_lds(const ddp_conv_shape_t& S, const ddp_
     const int rt = t1 % RT, ct = t1 / RT;
     f32x16 acc = splat16(T.b1p[ct * 32 + r]);
     const f32x4* __restrict__ wp = w1p + ((size_t)ct * nm1 * 2 + hh) * 32 + r;
-    // the whole K panel of this column tile is 23 KiB per wave: request 4 k-groups ahead (the loop is short and
-    // latency bound otherwise: 4 MFMAs = 256 cycles per k-group)
-    f32x4 q0 = wp[0], q1 = wp[64 * min(1, nm1 - 1)], q2 = wp[64 * min(2, nm1 - 1)], q3 = wp[64 * min(3, nm1 - 1)];
-    for (int m = 0; m < nm1; m += 4) {
-#define DDP_FC1_STEP(Q, K)                                                                                   \
-      if (m + K < nm1) {                                                                                   \
-        const f32x4 b = Q;                                                                                 \
-        Q = wp[64 * min(m + K + 4, nm1 - 1)];                                                              \
-        const f32x4 a = *reinterpret_cast<const f32x4*>(&xa[(rt * 32 + r) * S.hs + 8 * (m + K) + 4 * hh]); \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0); \
+    const float* arow = &xa[(rt * 32 + r) * S.hs + 4 * hh];
+    if constexpr (NM1 > 0) {
+      static_assert(NM1 >= RING, "a column tile needs at least RING k-groups");
+      f32x4 ring[RING];
+#pragma unroll
+      for (int k = 0; k < RING; ++k) ring[k] = wp[64 * k];
+      f32x4 anext = *reinterpret_cast<const f32x4*>(arow);
+#pragma unroll
+      for (int m = 0; m < NM1; ++m) {
+        const f32x4 b = ring[m % RING];
+        if (m + RING < NM1) ring[m % RING] = wp[64 * (m + RING)];
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 a = anext;
+        if (m + 1 < NM1) anext = *reinterpret_cast<const f32x4*>(arow + 8 * (m + 1));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
       }
-      DDP_FC1_STEP(q0, 0)
-      DDP_FC1_STEP(q1, 1)
-      DDP_FC1_STEP(q2, 2)
-      DDP_FC1_STEP(q3, 3)
+    } else {
+      // the whole K panel of this column tile is 23 KiB per wave: request 4 k-groups ahead (the loop is short and
+      // latency bound otherwise: 4 MFMAs = 256 cycles per k-group)
+      f32x4 q0 = wp[0], q1 = wp[64 * min(1, nm1 - 1)], q2 = wp[64 * min(2, nm1 - 1)], q3 = wp[64 * min(3, nm1 - 1)];
+      for (int m = 0; m < nm1; m += 4) {
+#define DDP_FC1_STEP(Q, K)                                                                                   \
+        if (m + K < nm1) {                                                                                   \
+          const f32x4 b = Q;                                                                                 \
+          Q = wp[64 * min(m + K + 4, nm1 - 1)];                                                              \
+          const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 8 * (m + K));                               \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0); \
+        }
+        DDP_FC1_STEP(q0, 0)
+        DDP_FC1_STEP(q1, 1)
+        DDP_FC1_STEP(q2, 2)
+        DDP_FC1_STEP(q3, 3)
 #undef DDP_FC1_STEP
+      }
     }
     const int col = ct * 32 + r;
     if (col < S.hp) {
@@ -848,6 +902,12 @@ __device__ __forceinline__ void fc1_to_lds(const ddp_conv_shape_t& S, const ddp_
       }
     }
   }
+}
+
+template <int ET, int NW = ET / 8>
+__device__ __forceinline__ void fc1_to_lds(const ddp_conv_shape_t& S, const ddp_conv_task_t& T, const float* xa, float* hbuf, int tid) {
+  if (S.kp1 == 184) fc1_tiles<ET, NW, 23>(S, T, xa, hbuf, tid);     // ns = 60 (the README score model): unrolled
+  else fc1_tiles<ET, NW, 0>(S, T, xa, hbuf, tid);
   __syncthreads();
 }
 
@@ -919,96 +979,6 @@ __global__ __launch_bounds__(512, 2) void ddp_conv_messages_kernel(const ConvLau
 //   phase 6  the tile leaves as whole message rows (16-byte coalesced stores)
 // Summation order of a message element: tiles of a segment in tile order, segments in round order, then the factorised part:
 // fixed, so results are bitwise reproducible.
-// NM > 0: the number of 8-k groups of a tile (hp / 8) as a compile-time constant: the k loop of a tile is fully unrolled, the
-// register ring of weight fragments is indexed statically and no load sits under a condition, so hipcc keeps the exact
-// vmcnt distance of RING - 1 fragments in flight.  NM = 0: any hp (runtime loop, one fragment ahead).
-// Why: the round-1 form of this loop (lambdas, `if (f + k < F)` guards around the unrolled ring, the bias load and the
-// contraction under conditions inside the step) compiled to vmcnt(0) .. vmcnt(4) waits at its control-flow joins and ran a
-// LONE wave at 52 % of the MFMA rate - 11.4 k cycles per 5.9 k-cycle tile (in-kernel stamps with one workgroup per CU).
-template <int C, int NM>
-__device__ __forceinline__ void seg_tiles(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
-                                          const float* hbuf, const float* fblk, const ddp_role_seg_t& R, int lane, f32x16* out) {
-  constexpr int FS = 36, RING = 4;
-  constexpr int NMP = (NM + RING - 1) / RING * RING;     // steps per tile incl. prefetch-only ones: keeps fragment k in slot k % RING
-  const int r = lane & 31, hh = lane >> 5;
-  const int nm = (NM > 0) ? NM : (S.hp >> 3);
-  const int t0 = R.tile0, ts = R.tstride, count = R.count;
-  const f32x4* __restrict__ w2p = reinterpret_cast<const f32x4*>(T.w2p);
-  const float* arow = &hbuf[r * S.hs + 4 * hh];
-#pragma unroll
-  for (int c = 0; c < C; ++c) out[c] = splat16(0.f);
-  if (count <= 0) return;
-  // fragments of one tile are 64 f32x4 apart, tiles of the segment ts * nm * 64
-  const f32x4* __restrict__ wt = w2p + ((size_t)(B.tile0 + t0) * nm * 2 + hh) * 32 + r;
-  const size_t tstep = (size_t)ts * nm * 64;
-  f32x4 anext = *reinterpret_cast<const f32x4*>(arow);
-  float bias = T.b2p[(B.tile0 + t0) * 32 + r];
-  f32x4 ring[RING];
-  if constexpr (NM > 0) {
-    static_assert(NM >= RING, "a tile needs at least RING k-groups");
-#pragma unroll
-    for (int k = 0; k < RING; ++k) ring[k] = DDP_ABL_B(wt[k * 64]);
-  } else {
-    ring[0] = DDP_ABL_B(wt[0]);
-  }
-  for (int j = 0; j < count; ++j) {
-    const f32x4* __restrict__ wnx = wt + ((j + 1 < count) ? tstep : 0);   // next tile (the last one re-requests itself: unused)
-    f32x16 acc = splat16(bias);
-    bias = T.b2p[(B.tile0 + t0 + min(j + 1, count - 1) * ts) * 32 + r];   // next tile's bias, a whole tile ahead
-    if constexpr (NM > 0) {
-#pragma unroll
-      for (int m = 0; m < NMP; ++m) {
-        const f32x4 bcur = ring[m % RING];
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int q = m + RING;                    // fragment to request into the slot this step frees
-        if (q < NM) ring[m % RING] = DDP_ABL_B(wt[q * 64]);
-        else if (q >= NMP) ring[m % RING] = DDP_ABL_B(wnx[(q - NMP) * 64]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (m < NM) {
-          const f32x4 a = anext;
-          anext = DDP_ABL_A(*reinterpret_cast<const f32x4*>(arow + 8 * ((m + 1 == NM) ? 0 : m + 1)), anext);  // h is tile independent: wrap
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[i], acc, 0, 0, 0);
-        }
-      }
-    } else {
-      for (int m = 0; m < nm; ++m) {
-        const f32x4 bcur = ring[0];
-        ring[0] = DDP_ABL_B((m + 1 < nm) ? wt[(m + 1) * 64] : wnx[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        const f32x4 a = anext;
-        anext = DDP_ABL_A(*reinterpret_cast<const f32x4*>(arow + 8 * ((m + 1 == nm) ? 0 : m + 1)), anext);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[i], acc, 0, 0, 0);
-      }
-    }
-    wt = wnx;
-    // contraction with the basis features, in the MFMA C/D layout: reg i <-> edge row (i&3) + 8*(i>>2) + 4*hh
-    int u, ncol, us;
-    bool valid;
-    tile_lane_map(B, t0 + j * ts, r, u, ncol, us, valid);
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const float* frow = &fblk[(u * C + c) * FS + 4 * hh];
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const f32x4 f = *reinterpret_cast<const f32x4*>(frow + 8 * q4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) out[c][4 * q4 + q] += f[q] * acc[4 * q4 + q];
-      }
-    }
-  }
-}
-
-// the k-group counts with an unrolled tile loop: hp = 184 (ns = 60: the README score model); everything else runs the generic loop
-template <int C>
-__device__ __forceinline__ void seg_tiles_any(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
-                                              const float* hbuf, const float* fblk, const ddp_role_seg_t& R, int lane, f32x16* out) {
-  if (S.hp == 184) seg_tiles<C, 23>(S, B, T, hbuf, fblk, R, lane, out);
-  else seg_tiles<C, 0>(S, B, T, hbuf, fblk, R, lane, out);
-}
-
 // adds a segment's register tile to the LDS message tile.  Lane (r, hh) of the C/D layout holds column r of the 32-column
 // tile for the 16 edge rows (i&3) + 8*(i>>2) + 4*hh; a block with n <= 32 packs `ups` features per tile, whose lane groups
 // add one after the other (the wave's LDS operations execute in program order).
