@@ -32,6 +32,10 @@
 #include "ddp_hip.h"
 #include "ddp_internal.h"
 
+#ifndef DDP_GPRIO
+#define DDP_GPRIO 3
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -101,6 +105,16 @@ extern "C" int ddp_debug_read_stamps(unsigned long long* host_dst, int n_wgs) {
 #define DDP_ABL_NQ(n) 1
 #else
 #define DDP_ABL_NQ(n) (n)
+#endif
+#if defined(DDP_ABLATE) && DDP_ABLATE == 5   // G pass without its per-unit epilogue (no read-modify-write of the message tile)
+#define DDP_ABL_EPI (S.hid < 0)
+#else
+#define DDP_ABL_EPI true
+#endif
+#if defined(DDP_ABLATE) && DDP_ABLATE == 6   // G pass without the K-sliced extra columns
+#define DDP_ABL_KSLICE false
+#else
+#define DDP_ABL_KSLICE true
 #endif
 #if defined(DDP_ABLATE) && DDP_ABLATE == 2
 #define DDP_ABL_A(x, old) ((old) * 1.0001f)
@@ -212,6 +226,81 @@ __device__ __forceinline__ void g_add_out(float* outb, int os, const float (*sh)
   }
 }
 
+// Main pass of g_stage for one 64-column group, with the steps of a unit as compile-time constants: KQ k-quads per step, NM steps
+// per unit (NM * KQ = the k quads of a G row), RING steps of G values in registers.  The body of the unit loop is ONE
+// straight-line sequence - every load unconditional (beyond the wave's last unit it re-requests the last unit's lines), ring
+// slots and LDS offsets static, the bias word of the next unit requested a unit ahead - which is what lets hipcc's waitcnt
+// insertion keep the exact distance: RING steps of loads stay in flight behind the step that computes.  (The generic loop
+// below has uniform branches inside a step - k range, first / last chunk of a unit, tail steps - and at every such join the
+// pass fell back to "all but the last step's loads have landed": vmcnt(5..8) with 25 loads issued, i.e. each step paid a
+// full memory round trip, 2.3 k ticks under load whatever else it did.)
+template <int ET, int KQ, int NM, int RING>
+__device__ __forceinline__ void g_main_static(const ddp_conv_shape_t& S, const float* __restrict__ Gb, const f32x4* __restrict__ G4,
+                                              size_t gstride, int gc, int gm_, bool act0, int c0, int nmine, int my_e0, int my_len,
+                                              int my_node, const float* hbuf, float* outb, int os, const TileAux<ET>& aux, int lane) {
+  static_assert(NM % RING == 0, "fragment f of every unit lives in ring slot f % RING");
+  if (nmine <= 0) return;
+  f32x4 ring[RING][KQ];
+  int node = __builtin_amdgcn_readlane(my_node, 0);
+  const f32x4* __restrict__ gp = G4 + (size_t)node * gstride + c0;
+  // (the bias word is requested BEFORE the ring: at the loop header the waitcnt pass merges this state with the back edge's,
+  // where the bias of the next unit has a whole unit of younger loads behind it - requested last here, the merge is vmcnt(0))
+  float bias = Gb[(size_t)node * (4 * gstride) + c0];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int f = 0; f < RING; ++f)
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) ring[f][q] = DDP_ABL_G(gp[(size_t)(f * KQ + q) * gc], q);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int ui = 0; ui < nmine; ++ui) {
+    const int un = min(ui + 1, nmine - 1);
+    const int node_n = __builtin_amdgcn_readlane(my_node, un);
+    const f32x4* __restrict__ gpn = G4 + (size_t)node_n * gstride + c0;
+    const float bias_n = Gb[(size_t)node_n * (4 * gstride) + c0];
+    const int e0 = __builtin_amdgcn_readlane(my_e0, ui), len = __builtin_amdgcn_readlane(my_len, ui);
+    f32x4 acc0 = {bias, bias, bias, bias}, acc1 = acc0, acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = acc2;
+    const float* hrow0 = &hbuf[(e0 + (lane & 3)) * S.hs];
+    const float* hrow1 = hrow0 + 4 * S.hs;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      f32x4 a0[KQ], a1[KQ];
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+        a0[q] = *reinterpret_cast<const f32x4*>(hrow0 + 4 * (m * KQ + q));
+        a1[q] = *reinterpret_cast<const f32x4*>(hrow1 + 4 * (m * KQ + q));
+      }
+      __builtin_amdgcn_sched_barrier(0);   // (without the fences the scheduler sinks each refill load to its use, RING steps later)
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+        const f32x4 b = ring[m % RING][q];
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q][0], b[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q][0], b[0], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q][1], b[1], acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q][1], b[1], acc3, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q][2], b[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q][2], b[2], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q][3], b[3], acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q][3], b[3], acc3, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const int f = m + RING;   // the fragment that takes this slot: of this unit, or of the next one
+#pragma unroll
+      for (int q = 0; q < KQ; ++q)
+        ring[m % RING][q] = DDP_ABL_G((f < NM) ? gp[(size_t)(f * KQ + q) * gc] : gpn[(size_t)((f - NM) * KQ + q) * gc], q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (act0 && DDP_ABL_EPI) {   // rows >= len of the two 4-edge groups are never stored
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < len) g_add_out(outb, os, aux.sh, e0 + i, gm_, acc0[i] + acc2[i]);
+        if (4 + i < len) g_add_out(outb, os, aux.sh, e0 + 4 + i, gm_, acc1[i] + acc3[i]);
+      }
+    }
+    gp = gpn;
+    bias = bias_n;
+  }
+}
+
 template <int ET, int NW = ET / 8, int KC = 16, int RD = 5>
 __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, const ddp_conv_task_t& T, const float* hbuf,
                                         float* outb, int os, const int* gmap, const TileAux<ET>& aux, int wave, int lane) {
@@ -265,6 +354,12 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
     const int cb = 64 * pass;
     const bool act0 = lane < (pass ? nx : nmain);
     const int c0 = cb + (act0 ? lane : 0);
+    if (nq == 45 || nq == 18) {   // hid = 180 (ns = 60), hid = 72 (ns = 24): steps of a unit unrolled (g_main_static)
+      const int gmv = gmap[cb + (act0 ? lane : 0)];
+      if (nq == 45) g_main_static<ET, 3, 15, 5>(S, Gb, G4, gstride, gc, gmv, act0, c0, nmine, my_e0, my_len, my_node, hbuf, outb, os, aux, lane);
+      else g_main_static<ET, 3, 6, 6>(S, Gb, G4, gstride, gc, gmv, act0, c0, nmine, my_e0, my_len, my_node, hbuf, outb, os, aux, lane);
+      continue;
+    }
     f32x4 ring[RD][KC / 4];   // (indices are compile-time constants after unrolling: registers)
     float rbias[RD];
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
@@ -318,7 +413,7 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
           acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q4][3], BUF[q4][3], acc2, 0, 0, 0);                    \
           acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q4][3], BUF[q4][3], acc3, 0, 0, 0);                    \
         }                                                                                                     \
-      if (c_ch == nch - 1 && act0) {   /* rows >= len of the two 4-edge groups are never stored */            \
+      if (c_ch == nch - 1 && act0 && DDP_ABL_EPI) {   /* rows >= len of the two 4-edge groups are never stored */ \
         const int gm_ = gmap[cb + lane];                                                                      \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
           if (i < len) g_add_out(outb, os, aux.sh, e0 + i, gm_, acc0[i] + acc2[i]);                           \
@@ -348,7 +443,7 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
 #undef DDP_G_COMPUTE
   }
 
-  if (kslice) {
+  if (kslice && DDP_ABL_KSLICE) {
     // lane = (block b, j): K-slice p = b / xnb, extra column cj = 4 * (b % xnb) + j; A rows as in the main pass
     const int b = lane >> 2, p = b / xnb, cj = 4 * (b - p * xnb) + (lane & 3);
     const bool colv = cj < nx;
@@ -356,9 +451,9 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
     const int qx0 = kx0 >> 2;
     f32x4 gx[XK / 4], gn[XK / 4];
     float bx = 0.f, bn = 0.f;
-#define DDP_GX_LOAD(UI, DST, BDST)                                                                            \
-    if ((UI) < nmine) {                                                                                       \
-      const int node_ = __builtin_amdgcn_readlane(my_node, (UI));                                             \
+#define DDP_GX_LOAD(UI, DST, BDST)   /* unconditional: past the last unit it re-requests that unit's lines */  \
+    {                                                                                                         \
+      const int node_ = __builtin_amdgcn_readlane(my_node, min((UI), max(nmine - 1, 0)));                     \
       const f32x4* __restrict__ gp_ = G4 + (size_t)node_ * gstride + cx;                                      \
       _Pragma("unroll") for (int q4 = 0; q4 < XK / 4; ++q4) DST[q4] = gp_[(size_t)min(qx0 + q4, nq - 1) * gc]; \
       BDST = Gb[(size_t)node_ * (4 * gstride) + cx];                                                          \
@@ -1115,8 +1210,10 @@ __global__ __launch_bounds__(256, 3) void ddp_conv32_kernel(const ConvLaunch L) 
   STAMP(6);
 
   // ---- phase 5: factorised features (one pass per G slot)
+  __builtin_amdgcn_s_setprio(DDP_GPRIO);
   for (int slot = 0; slot < 2; ++slot)
     if (S.g_cols[slot] > 0) g_stage<ET>(S, slot, T, hbuf, rb, os, gmap[slot], aux, wave, lane);
+  __builtin_amdgcn_s_setprio(0);
   STAMP(7);
   __syncthreads();
   STAMP(8);
@@ -1165,6 +1262,11 @@ static int launch_conv(K kernel, ConvLaunch& L, const ddp_conv_task_t* tasks, in
   }
   L.tile_start[L.ntasks] = tiles;
   if (tiles == 0) return 0;
+#ifdef DDP_STAMPS
+  // diagnostic builds only (tools/stamp_conv.py): DDP_STAMP_LDS_PAD_KB=n asks for n KB of unused LDS on top in the 32-edge kernel,
+  // which lowers the number of workgroups a CU holds (1 / 2 / 3 resident: how much of a phase is contention, how much is its own)
+  if (const char* pad = (ET == 32) ? getenv("DDP_STAMP_LDS_PAD_KB") : nullptr) lds_bytes += (size_t)atoi(pad) * 1024;
+#endif
   if (lds_bytes > 160 * 1024 - 4096) return ddp_fail(DDP_ELIMIT, "ddp_conv_messages: LDS budget exceeded");
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds_bytes);
