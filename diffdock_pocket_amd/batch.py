@@ -184,14 +184,26 @@ def collate(graphs: Iterable[HeteroBatch]) -> HeteroBatch:
 
 def set_time(batch: HeteroBatch, t_tr, t_rot, t_tor, t_sc_tor, device=None) -> HeteroBatch:
     """Counterpart of reference utils/diffusion_utils.py:124-165 for the all-atom case: constant per-node and
-    per-graph time tensors."""
+    per-graph time tensors.  One `torch.full` per distinct time value and store (the sampler passes the same t four times:
+    the four keys then share one tensor, which nothing downstream writes to) instead of `v * torch.ones(n)` per key."""
     device = device or batch["ligand"].pos.device
     b = batch.num_graphs
+    items = (("tr", t_tr), ("rot", t_rot), ("tor", t_tor), ("sc_tor", t_sc_tor))
+
+    def const(n):
+        made, out = {}, {}
+        for k, v in items:
+            if torch.is_tensor(v):
+                out[k] = v * torch.ones(n, device=device)
+                continue
+            key = float(v)
+            if key not in made:
+                made[key] = torch.full((n,), key, device=device)
+            out[k] = made[key]
+        return out
+
     for nt in ("ligand", "receptor", "atom"):
         if nt in batch:
-            n = batch[nt].num_nodes
-            batch[nt].node_t = {k: v * torch.ones(n, device=device)
-                                for k, v in (("tr", t_tr), ("rot", t_rot), ("tor", t_tor), ("sc_tor", t_sc_tor))}
-    batch.complex_t = {k: v * torch.ones(b, device=device)
-                       for k, v in (("tr", t_tr), ("rot", t_rot), ("tor", t_tor), ("sc_tor", t_sc_tor))}
+            batch[nt].node_t = const(batch[nt].num_nodes)
+    batch.complex_t = const(b)
     return batch

@@ -32,6 +32,9 @@
 #include "ddp_hip.h"
 #include "ddp_internal.h"
 
+#ifndef DDP_TILE_RING
+#define DDP_TILE_RING 4   // weight fragments (k-groups of 4 MFMAs) in flight per wave in the tile loops
+#endif
 #ifndef DDP_GPRIO
 #define DDP_GPRIO 3
 #endif
@@ -693,7 +696,7 @@ __device__ __forceinline__ void seg_tiles(const ddp_conv_shape_t& S, const ddp_b
                                           const float* hbuf, const float* fblk, const ddp_role_seg_t& R, int lane, int rt,
                                           f32x16* out) {
   // FS: row stride of the feature buffer F[u * C + c][edge] (edge tile + 4); rt: the 32-edge row tile this wave works on
-  constexpr int RING = 4;
+  constexpr int RING = DDP_TILE_RING;
   constexpr int NMP = (NM + RING - 1) / RING * RING;     // steps per tile incl. prefetch-only ones: keeps fragment k in slot k % RING
   const int r = lane & 31, hh = lane >> 5;
   const int nm = (NM > 0) ? NM : (S.hp >> 3);

@@ -37,12 +37,17 @@ def t_to_sigma(t_tr, t_rot, t_tor, t_sc_tor, args: SigmaRanges):
             one(t_sc_tor, args.sidechain_tor_sigma_min, args.sidechain_tor_sigma_max))
 
 
+@functools.lru_cache(maxsize=16)
+def _frequencies(half: int, max_positions: int, device):
+    """w_k of sinusoidal_embedding (a constant of the embedding size: built once per device, not per call)."""
+    return torch.exp(torch.arange(half, dtype=torch.float32, device=device) * -(math.log(max_positions) / (half - 1)))
+
+
 def sinusoidal_embedding(timesteps: torch.Tensor, dim: int, scale: float = 1.0, max_positions: int = 10000):
     """[sin(s*t*w_k), cos(s*t*w_k)], w_k = exp(-k ln(max_positions)/(half-1)); zero-padded if dim is odd."""
     assert timesteps.dim() == 1
     half = dim // 2
-    freq = torch.exp(torch.arange(half, dtype=torch.float32, device=timesteps.device)
-                     * -(math.log(max_positions) / (half - 1)))
+    freq = _frequencies(half, max_positions, timesteps.device)
     arg = scale * timesteps.float()[:, None] * freq[None, :]
     emb = torch.cat([torch.sin(arg), torch.cos(arg)], dim=1)
     if dim % 2 == 1:

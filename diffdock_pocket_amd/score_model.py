@@ -905,7 +905,7 @@ class TensorProductScoreModel(nn.Module):
         # ---- edge featurisation (the per-node `pre` tables were prepared ahead of the searches, see above)
         pk = epk["ll"]
         pre_ll = pre["ll"][ll[0]]
-        pre_ll[:bond_ei.shape[1]] += bond_pre
+        pre_ll[:bond_ei.shape[1]].add_(bond_pre)
         e_ll, sh_ll = _edge_featurize(pk, self.lig_distance_expansion, lpos, ll32[0], lpos, ll32[1], pre_ll,
                                       G.iota32(ll.shape[1], dev))
         e_rr, sh_rr = _edge_featurize(epk["rr"], self.rec_distance_expansion, rpos, rr32[0], rpos, rr32[1], pre["rr"], rr32[0])
@@ -1223,7 +1223,7 @@ class TensorProductScoreModel(nn.Module):
                         n0 = shared[[k for k in order[rt] if k in shared][0]][0]
                         u0 = torch.empty((n0, spec.d_out), device=dev, dtype=torch.float32)
                         _launch_reduce(u0, spec.d_out, n0, spec.d_out, com, accumulate=False)
-                        x.view(B, n0, ldx)[:, :, :spec.d_out] += u0
+                        x.view(B, n0, ldx)[:, :, :spec.d_out].add_(u0)   # (`+=` on the slice would copy the sum onto itself)
             mark("reduce")
 
         if self.confidence_mode:   # (:329-353) mean of the scalar channels per graph -> MLP
