@@ -94,12 +94,12 @@ extern "C" int ddp_debug_read_stamps(unsigned long long* host_dst, int n_wgs) {
 
 // Timing-only ablations for tools/ablate_conv.py (never defined in the product build): DDP_ABLATE=1 drops the weight
 // loads of the scalar-block main loop, =2 drops its LDS A-operand reads; results are then wrong by construction.
-#if defined(DDP_ABLATE) && DDP_ABLATE == 1
-#define DDP_ABL_B(x) (f32x4{1e-9f, 2e-9f, 3e-9f, 4e-9f} * (float)(mn + 1))
+#if defined(DDP_ABLATE) && (DDP_ABLATE == 1 || DDP_ABLATE == 7)   // 7 = 1 + 3: neither weight nor G loads
+#define DDP_ABL_B(x) (f32x4{1e-9f, 2e-9f, 3e-9f, 4e-9f} * (float)(lane + 1))
 #else
 #define DDP_ABL_B(x) (x)
 #endif
-#if defined(DDP_ABLATE) && DDP_ABLATE == 3   // G pass without its global loads
+#if defined(DDP_ABLATE) && (DDP_ABLATE == 3 || DDP_ABLATE == 7)   // G pass without its global loads
 #define DDP_ABL_G(x, q) (f32x4{1e-12f, 2e-12f, 3e-12f, 4e-12f} * (float)((q) + lane))
 #else
 #define DDP_ABL_G(x, q) (x)
@@ -710,7 +710,11 @@ __device__ __forceinline__ void seg_tiles(const ddp_conv_shape_t& S, const ddp_b
   const f32x4* __restrict__ wt = w2p + ((size_t)(B.tile0 + t0) * nm * 2 + hh) * 32 + r;
   const size_t tstep = (size_t)ts * nm * 64;
   f32x4 anext = *reinterpret_cast<const f32x4*>(arow);
+  // the bias word is requested BEFORE the ring and pinned there: at the tile-loop header the waitcnt pass merges this state
+  // with the back edge's (next tile's bias: a whole tile of younger loads behind it); with the bias requested after the ring
+  // the merge was vmcnt(0) at the top of EVERY tile - the four weight fragments in flight drained 54 times per workgroup
   float bias = T.b2p[(B.tile0 + t0) * 32 + r];
+  __builtin_amdgcn_sched_barrier(0);
   f32x4 ring[RING];
   if constexpr (NM > 0) {
     static_assert(NM >= RING, "a tile needs at least RING k-groups");
@@ -719,6 +723,7 @@ __device__ __forceinline__ void seg_tiles(const ddp_conv_shape_t& S, const ddp_b
   } else {
     ring[0] = DDP_ABL_B(wt[0]);
   }
+  __builtin_amdgcn_sched_barrier(0);
   for (int j = 0; j < count; ++j) {
     const f32x4* __restrict__ wnx = wt + ((j + 1 < count) ? tstep : 0);   // next tile (the last one re-requests itself: unused)
     f32x16 acc = splat16(bias);
