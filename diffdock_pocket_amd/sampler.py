@@ -102,7 +102,7 @@ def apply_sidechain_torsions_hip(pos, edge_idx_i32, sub_i32, map_i32, angles):
     angles = angles.contiguous().float()
     L.check(lib.ddp_sidechain_update(pos.data_ptr(), pos.shape[0], pos.shape[1], angles.data_ptr(), angles.shape[1],
                                      edge_idx_i32.data_ptr(), sub_i32.data_ptr(), map_i32.data_ptr(), out.data_ptr(),
-                                     torch.cuda.current_stream().cuda_stream), "ddp_sidechain_update")
+                                     torch._C._cuda_getCurrentRawStream(pos.device.index)), "ddp_sidechain_update")
     return out
 
 
@@ -120,7 +120,7 @@ def modify_conformer_hip(pos, tr, rot, tor, bonds_i32, mask_u8):
     L.check(lib.ddp_pose_update(pos.data_ptr(), pos.shape[0], pos.shape[1], tr.data_ptr(), rot.data_ptr(),
                                 tor.data_ptr() if has_tor else None, tor.shape[1] if has_tor else 0,
                                 bonds_i32.data_ptr() if has_tor else None, mask_u8.data_ptr() if has_tor else None,
-                                out.data_ptr(), torch.cuda.current_stream().cuda_stream), "ddp_pose_update")
+                                out.data_ptr(), torch._C._cuda_getCurrentRawStream(pos.device.index)), "ddp_pose_update")
     return out
 
 

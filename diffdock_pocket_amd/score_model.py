@@ -242,15 +242,20 @@ class TensorProductConvLayer(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------ launch helpers
+_DEVICE_INDEX = [0]      # set by _require_hip (the device of the batch): `torch.cuda.current_stream()` costs ~9 us of Python per call
+                         # and a step makes ~90 of them; the raw-handle query in _stream() is a single C call
+
+
 def _require_hip(t: torch.Tensor):
     if not t.is_cuda:
         raise L.DdpError("the MI355X score model runs on a HIP device only (no CPU/eager fallback); "
                          "move the batch to cuda:<n>")
     L.load()
+    _DEVICE_INDEX[0] = t.device.index if t.device.index is not None else torch.cuda.current_device()
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(_DEVICE_INDEX[0]))
 
 
 def _ptr(t: Optional[torch.Tensor]):
