@@ -691,7 +691,7 @@ __device__ __forceinline__ void run_block_full(const ddp_conv_shape_t& S, const 
 // Why: the round-1 form of this loop (lambdas, `if (f + k < F)` guards around the unrolled ring, the bias load and the
 // contraction under conditions inside the step) compiled to vmcnt(0) .. vmcnt(4) waits at its control-flow joins and ran a
 // LONE wave at 52 % of the MFMA rate - 11.4 k cycles per 5.9 k-cycle tile (in-kernel stamps with one workgroup per CU).
-template <int C, int NM, int FS>
+template <int C, int NM, int FS, bool TAIL = false>
 __device__ __forceinline__ void seg_tiles(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
                                           const float* hbuf, const float* fblk, const ddp_role_seg_t& R, int lane, int rt,
                                           f32x16* out) {
@@ -735,14 +735,26 @@ __device__ __forceinline__ void seg_tiles(const ddp_conv_shape_t& S, const ddp_b
         constexpr int dummy = 0;
         (void)dummy;
         const int q = m + RING;                    // fragment to request into the slot this step frees
-        if (q < NM) ring[m % RING] = DDP_ABL_B(wt[q * 64]);
+        // TAIL (hid = 8 NM - 4, e.g. 180): the upper half of the last k-group is padding.  Both lane halves then fetch the LOWER
+        // half's quad (k = 8 NM - 8 .. 8 NM - 5) of the weights and of h, and two MFMAs on (k, k + 2) pairs replace the four
+        if (q < NM) ring[m % RING] = DDP_ABL_B(wt[q * 64 - ((TAIL && q == NM - 1) ? hh * 32 : 0)]);
         else if (q >= NMP) ring[m % RING] = DDP_ABL_B(wnx[(q - NMP) * 64]);
         __builtin_amdgcn_sched_barrier(0);
-        if (m < NM) {
+        if (TAIL && m == NM - 1) {
           const f32x4 a = anext;
-          anext = DDP_ABL_A(*reinterpret_cast<const f32x4*>(arow + 8 * ((m + 1 == NM) ? 0 : m + 1)), anext);  // h is tile independent: wrap
+          anext = DDP_ABL_A(*reinterpret_cast<const f32x4*>(arow), anext);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hh ? a[2] : a[0], hh ? bcur[2] : bcur[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hh ? a[3] : a[1], hh ? bcur[3] : bcur[1], acc, 0, 0, 0);
+        } else if (m < NM) {
+          const f32x4 a = anext;
+          anext = DDP_ABL_A(*reinterpret_cast<const f32x4*>(arow + 8 * ((m + 1 == NM) ? 0 : m + 1) - ((TAIL && m + 2 == NM) ? 4 * hh : 0)), anext);  // h is tile independent: wrap
+#if defined(DDP_ABLATE) && DDP_ABLATE == 9   // half of the tile loops' MFMAs, everything else unchanged: is the launch bound by the matrix pipe?
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0] + a[1], bcur[0] + bcur[1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2] + a[3], bcur[2] + bcur[3], acc, 0, 0, 0);
+#else
 #pragma unroll
           for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[i], acc, 0, 0, 0);
+#endif
         }
       }
     } else {
@@ -779,7 +791,7 @@ template <int C, int FS = 36>
 __device__ __forceinline__ void seg_tiles_any(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
                                               const float* hbuf, const float* fblk, const ddp_role_seg_t& R, int lane, f32x16* out,
                                               int rt = 0) {
-  if (S.hp == 184) seg_tiles<C, 23, FS>(S, B, T, hbuf, fblk, R, lane, rt, out);
+  if (S.hp == 184 && S.hid == 180) seg_tiles<C, 23, FS, true>(S, B, T, hbuf, fblk, R, lane, rt, out);   // ns = 60: the README score model
   else seg_tiles<C, 0, FS>(S, B, T, hbuf, fblk, R, lane, rt, out);
 }
 
@@ -947,7 +959,7 @@ __device__ __forceinline__ void stage_edge_attr(const ddp_conv_shape_t& S, const
 // phase 1: h = relu(edge_attr_ @ W1 + b1)
 // NM1 > 0: kp1 / 8 as a compile-time constant - the K loop of a column tile is fully unrolled with a static 4-deep register
 // ring of weight fragments and no load under a condition (exact vmcnt distances, see seg_tiles); NM1 = 0: any kp1.
-template <int ET, int NW, int NM1>
+template <int ET, int NW, int NM1, bool TAIL = false>
 __device__ __forceinline__ void fc1_tiles(const ddp_conv_shape_t& S, const ddp_conv_task_t& T, const float* xa, float* hbuf, int tid) {
   constexpr int RT = ET / 32, RING = 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps tile/loop indices in SGPRs
@@ -970,12 +982,18 @@ __device__ __forceinline__ void fc1_tiles(const ddp_conv_shape_t& S, const ddp_c
 #pragma unroll
       for (int m = 0; m < NM1; ++m) {
         const f32x4 b = ring[m % RING];
-        if (m + RING < NM1) ring[m % RING] = wp[64 * (m + RING)];
+        // TAIL (f_in = 8 NM1 - 4): the last k-group as in seg_tiles - both lane halves fetch its lower quad, two MFMAs
+        if (m + RING < NM1) ring[m % RING] = wp[64 * (m + RING) - ((TAIL && m + RING == NM1 - 1) ? hh * 32 : 0)];
         __builtin_amdgcn_sched_barrier(0);
         const f32x4 a = anext;
-        if (m + 1 < NM1) anext = *reinterpret_cast<const f32x4*>(arow + 8 * (m + 1));
+        if (m + 1 < NM1) anext = *reinterpret_cast<const f32x4*>(arow + 8 * (m + 1) - ((TAIL && m + 2 == NM1) ? 4 * hh : 0));
+        if (TAIL && m == NM1 - 1) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hh ? a[2] : a[0], hh ? b[2] : b[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hh ? a[3] : a[1], hh ? b[3] : b[1], acc, 0, 0, 0);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
+          for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
+        }
       }
     } else {
       // the whole K panel of this column tile is 23 KiB per wave: request 4 k-groups ahead (the loop is short and
@@ -1009,7 +1027,7 @@ __device__ __forceinline__ void fc1_tiles(const ddp_conv_shape_t& S, const ddp_c
 
 template <int ET, int NW = ET / 8>
 __device__ __forceinline__ void fc1_to_lds(const ddp_conv_shape_t& S, const ddp_conv_task_t& T, const float* xa, float* hbuf, int tid) {
-  if (S.kp1 == 184) fc1_tiles<ET, NW, 23>(S, T, xa, hbuf, tid);     // ns = 60 (the README score model): unrolled
+  if (S.kp1 == 184 && S.f_in == 180) fc1_tiles<ET, NW, 23, true>(S, T, xa, hbuf, tid);     // ns = 60 (the README score model): unrolled
   else fc1_tiles<ET, NW, 0>(S, T, xa, hbuf, tid);
   __syncthreads();
 }
