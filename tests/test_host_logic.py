@@ -370,3 +370,19 @@ def test_radius_cap_keeps_the_first_matches_by_index_like_torch_cluster_on_a_gpu
         assert torch.equal(capped[1][capped[0] == q], want)
         differs += int(not torch.equal(near[1][near[0] == q], want))
     assert differs > 0
+
+
+def test_set_time_builds_one_tensor_per_distinct_value():
+    """set_time (reference utils/diffusion_utils.py:124-165): constant per-node / per-graph time tensors.  Equal python values
+    share one tensor per store (nothing downstream writes to them); distinct values and tensor inputs get their own."""
+    from diffdock_pocket_amd.batch import collate, set_time
+    from diffdock_pocket_amd.synthetic import make_3dpf_complex
+    g = make_3dpf_complex(seed=0, flexible_sidechains=False, n_rec=12)
+    b = collate([g, g])
+    set_time(b, 0.5, 0.5, 0.25, 0.5)
+    nt = b["ligand"].node_t
+    assert nt["tr"] is nt["rot"] is nt["sc_tor"] and nt["tor"] is not nt["tr"]
+    assert nt["tr"].shape == (b["ligand"].num_nodes,) and float(nt["tr"][0]) == 0.5 and float(nt["tor"][-1]) == 0.25
+    assert b.complex_t["tr"].shape == (2,) and torch.equal(b.complex_t["tor"], torch.full((2,), 0.25))
+    set_time(b, torch.tensor(0.75), 0.5, 0.5, 0.5)          # a tensor-valued time is multiplied through as before
+    assert torch.equal(b["atom"].node_t["tr"], torch.full((b["atom"].num_nodes,), 0.75))
