@@ -709,6 +709,24 @@ __device__ __forceinline__ void seg_tiles(const ddp_conv_shape_t& S, const ddp_b
   // fragments of one tile are 64 f32x4 apart, tiles of the segment ts * nm * 64
   const f32x4* __restrict__ wt = w2p + ((size_t)(B.tile0 + t0) * nm * 2 + hh) * 32 + r;
   const size_t tstep = (size_t)ts * nm * 64;
+  // tile -> feature of this lane, incrementally: tile_lane_map divides by B.nsub / B.n, ~60 instructions per tile epilogue.
+  // nsub > 1 (segment = one 32-column part of a block, tile stride a multiple of nsub): u = t / nsub advances by ts / nsub and
+  // the lane's column is fixed; nsub == 1: the lane's feature slot us = r / n is fixed and u = t * ups + us advances by ts * ups
+  const bool lm_inc = (B.nsub == 1) || (ts % B.nsub == 0);
+  int lm_u0 = 0, lm_du = 0;
+  bool lm_ok = false;
+  if (lm_inc) {
+    if (B.nsub > 1) {
+      lm_u0 = t0 / B.nsub;
+      lm_du = ts / B.nsub;
+      lm_ok = (t0 % B.nsub) * 32 + r < B.n;
+    } else {
+      const int us = r / B.n;
+      lm_u0 = t0 * B.ups + us;
+      lm_du = ts * B.ups;
+      lm_ok = us < B.ups;
+    }
+  }
   f32x4 anext = *reinterpret_cast<const f32x4*>(arow);
   // the bias word is requested BEFORE the ring and pinned there: at the tile-loop header the waitcnt pass merges this state
   // with the back edge's (next tile's bias: a whole tile of younger loads behind it); with the bias requested after the ring
@@ -770,9 +788,15 @@ __device__ __forceinline__ void seg_tiles(const ddp_conv_shape_t& S, const ddp_b
     }
     wt = wnx;
     // contraction with the basis features, in the MFMA C/D layout: reg i <-> edge row (i&3) + 8*(i>>2) + 4*hh
-    int u, ncol, us;
-    bool valid;
-    tile_lane_map(B, t0 + j * ts, r, u, ncol, us, valid);
+    int u;
+    if (lm_inc) {   // the lane's feature of tile t0 + j ts without the divisions of tile_lane_map (see lm_u0 above)
+      u = lm_u0 + j * lm_du;
+      if (!(lm_ok && u < B.U)) u = 0;
+    } else {
+      int ncol, us;
+      bool valid;
+      tile_lane_map(B, t0 + j * ts, r, u, ncol, us, valid);
+    }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const float* frow = &fblk[(u * C + c) * FS + rt * 32 + 4 * hh];
