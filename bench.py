@@ -92,12 +92,23 @@ def spawn_ranks(args, argv):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
-    rc = 0
-    for r, p in enumerate(procs):
-        code = p.wait()
-        if code != 0:
-            print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
-            rc = rc or code or 1
+    # poll: as soon as one rank fails the others are terminated (they would otherwise sit in RCCL init / the final
+    # all_gather until a timeout)
+    rc, live = 0, dict(enumerate(procs))
+    while live:
+        for r, p in list(live.items()):
+            code = p.poll()
+            if code is None:
+                continue
+            del live[r]
+            if code != 0:
+                print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+                if rc == 0:
+                    rc = code or 1
+                    for q in live.values():
+                        q.terminate()
+        if live:
+            time.sleep(0.05)
     return rc
 
 

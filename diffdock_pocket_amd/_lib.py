@@ -18,7 +18,7 @@ FS = 68  # feature-buffer row stride of ddp_conv.hip
 
 DDP_MAX_GEMM_BATCH = 16
 EXPORTS = ["ddp_conv_messages", "ddp_segment_reduce", "ddp_edge_featurize", "ddp_torsion_sh", "ddp_stage_a",
-           "ddp_pose_update", "ddp_sidechain_update", "ddp_radius_count", "ddp_radius_fill", "ddp_knn", "ddp_group_by_key", "ddp_abi_version", "ddp_last_error", "ddp_source_hash"]
+           "ddp_pose_update", "ddp_sidechain_update", "ddp_radius_count", "ddp_radius_fill", "ddp_knn", "ddp_group_by_key", "ddp_node_linear", "ddp_abi_version", "ddp_last_error", "ddp_source_hash"]
 
 
 class Seg(C.Structure):
@@ -59,6 +59,20 @@ class ReduceSrc(C.Structure):
                 ("n_edges", C.c_int32), ("rowmap", C.c_void_p)]
 
 
+DDP_MAX_NODE_JOBS, DDP_MAX_NODE_CAT = 8, 16
+
+
+class NodeJob(C.Structure):
+    """ddp_node_job_t of include/ddp_hip.h."""
+    _fields_ = [("n_rows", C.c_int32), ("cat", C.c_void_p), ("ld_cat", C.c_int32), ("n_cat", C.c_int32), ("table", C.c_void_p),
+                ("feat_off", C.c_int32 * DDP_MAX_NODE_CAT), ("emb_dim", C.c_int32), ("emb_mode", C.c_int32),
+                ("dense", C.c_void_p * 2), ("ld_dense", C.c_int32 * 2), ("n_dense", C.c_int32 * 2),
+                ("t", C.c_void_p), ("t_stride", C.c_int32), ("scale", C.c_float), ("freq", C.c_void_p),
+                ("sig_emb", C.c_void_p), ("ld_sig", C.c_int32), ("sd", C.c_int32), ("sig_out", C.c_void_p), ("ld_sig_out", C.c_int32),
+                ("w", C.c_void_p), ("bias", C.c_void_p),
+                ("out", C.c_void_p), ("ld_out", C.c_int32), ("ncols", C.c_int32), ("zero_to", C.c_int32)]
+
+
 def g_ld(hid: int, gcols: int) -> int:
     """DDP_G_LD of include/ddp_hip.h: floats per node of a G array (rows start on 128-byte boundaries)."""
     return (((hid + 3) // 4 * 4 + 1) * gcols + 31) // 32 * 32
@@ -90,9 +104,9 @@ def load():
     lib.ddp_segment_reduce.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(ReduceSrc), C.c_int, C.c_int,
                                        C.c_void_p]
     lib.ddp_segment_reduce.restype = C.c_int
-    lib.ddp_edge_featurize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
-                                       C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ddp_edge_featurize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ddp_edge_featurize.restype = C.c_int
     lib.ddp_torsion_sh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.ddp_torsion_sh.restype = C.c_int
@@ -115,7 +129,9 @@ def load():
     lib.ddp_knn.restype = C.c_int
     lib.ddp_group_by_key.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 11
     lib.ddp_group_by_key.restype = C.c_int
-    if lib.ddp_abi_version() != 6:
+    lib.ddp_node_linear.argtypes = [C.POINTER(NodeJob), C.c_int, C.c_void_p]
+    lib.ddp_node_linear.restype = C.c_int
+    if lib.ddp_abi_version() != 7:
         raise DdpError("libddp_hip.so ABI version mismatch")
     lib.ddp_source_hash.restype = C.c_char_p
     if "DDP_HIP_LIB" not in os.environ:   # (diagnostic builds loaded through DDP_HIP_LIB carry extra -D flags, same sources)

@@ -1,25 +1,36 @@
 """Build libddp_hip.so in-tree for gfx950:  python -m diffdock_pocket_amd.build
-(hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the gpurun snapshot)."""
+(hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the gpurun snapshot).
+
+Every translation unit is compiled to its own object (cached under csrc/.obj/, keyed by the hash of the unit + the headers +
+the flags), so that an edit of one kernel file recompiles that file only.  The library carries the SHA-256 of ALL its sources
+as a tagged string (`DDP_SRC_SHA16=<16 hex digits>`, also returned by ddp_source_hash()): `built_hash` reads it from the file
+bytes - no dlopen in the building process, so a stale library is never left loaded behind a rebuild."""
+import hashlib
 import os
+import re
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SOURCES = ["ddp_conv.hip", "ddp_misc.hip", "ddp_gemm.hip", "ddp_pose.hip", "ddp_graph.hip", "ddp_views.hip", "ddp_capi.hip"]
+SOURCES = ["ddp_conv.hip", "ddp_misc.hip", "ddp_gemm.hip", "ddp_pose.hip", "ddp_graph.hip", "ddp_views.hip", "ddp_node.hip",
+           "ddp_capi.hip"]
+HEADERS = [os.path.join(HERE, "csrc", "ddp_internal.h"), os.path.join(HERE, "csrc", "ddp_conv_diag.h"),
+           os.path.join(ROOT, "include", "ddp_hip.h")]
 OUT = os.path.join(HERE, "libddp_hip.so")
+OBJ_DIR = os.path.join(HERE, "csrc", ".obj")
+_TAG = re.compile(rb"DDP_SRC_SHA16=([0-9a-f]{16})")
 
 
 def _deps():
-    return [os.path.join(HERE, "csrc", s) for s in SOURCES] + [os.path.join(HERE, "csrc", "ddp_internal.h"),
-                                                               os.path.join(ROOT, "include", "ddp_hip.h")]
+    return [os.path.join(HERE, "csrc", s) for s in SOURCES] + [h for h in HEADERS if os.path.exists(h)]
 
 
 def source_hash():
     """16 hex digits of the SHA-256 over every source the library is compiled from, in a fixed order.  Compiled into the
     library (-DDDP_SRC_SHA16, exported as ddp_source_hash()) and checked by _lib.load(): the binary that runs is provably
     the one built from the sources in the tree."""
-    import hashlib
     h = hashlib.sha256()
     for d in _deps():
         h.update(os.path.basename(d).encode() + b"\0")
@@ -29,17 +40,14 @@ def source_hash():
 
 
 def built_hash(path=None):
-    """ddp_source_hash() of an existing library (None if it is missing or predates the export)."""
-    import ctypes
+    """Source hash an existing library was built from (None if it is missing or carries no tag), read from the file."""
     path = path or OUT
-    if not os.path.exists(path):
-        return None
     try:
-        lib = ctypes.CDLL(path)
-        lib.ddp_source_hash.restype = ctypes.c_char_p
-        return lib.ddp_source_hash().decode()
-    except (OSError, AttributeError):
+        with open(path, "rb") as f:
+            m = _TAG.search(f.read())
+    except OSError:
         return None
+    return m.group(1).decode() if m else None
 
 
 def needs_build():
@@ -48,34 +56,55 @@ def needs_build():
     return built_hash() != source_hash()
 
 
-def build(force=False, verbose=True, stamps=False, ablate=0, defs=(), tag=""):
-    if defs:   # tuning variants (tools/): extra -D flags, library name suffixed with `tag`
-        out = os.path.join(HERE, f"libddp_hip_{tag}.so")
-        cmd = [os.environ.get("HIPCC", "hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-               "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), "-o", out]
-        cmd += [f"-D{d}" for d in defs] + [os.path.join(HERE, "csrc", s) for s in SOURCES]
+def _compile(src, flags, verbose):
+    """One translation unit -> cached object file."""
+    path = os.path.join(HERE, "csrc", src)
+    h = hashlib.sha256(" ".join(flags).encode())
+    for d in [path] + [x for x in HEADERS if os.path.exists(x)]:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    obj = os.path.join(OBJ_DIR, f"{os.path.splitext(src)[0]}.{h.hexdigest()[:16]}.o")
+    if not os.path.exists(obj):
+        for old in os.listdir(OBJ_DIR):      # one object per unit and flag set is enough
+            if old.startswith(os.path.splitext(src)[0] + ".") and len(os.listdir(OBJ_DIR)) > 64:
+                os.remove(os.path.join(OBJ_DIR, old))
+        cmd = [os.environ.get("HIPCC", "hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c"] + flags + \
+              ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), "-o", obj + ".tmp", path]
+        if verbose:
+            print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        return out
-    if ablate or stamps:
-        # diagnostic variants, never loaded by the product: -DDDP_STAMPS = in-kernel phase stamps (tools/stamp_conv.py),
-        # -DDDP_ABLATE=n = timing-only ablations whose results are wrong by construction (tools/ablate_conv.py)
-        out = os.path.join(HERE, "libddp_hip" + ("_stamps" if stamps else "") + (f"_ablate{ablate}" if ablate else "") + ".so")
-        cmd = [os.environ.get("HIPCC", "hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-               "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), "-o", out]
-        cmd += (["-DDDP_STAMPS"] if stamps else []) + ([f"-DDDP_ABLATE={ablate}"] if ablate else [])
-        cmd += [os.path.join(HERE, "csrc", s) for s in SOURCES]
-        subprocess.check_call(cmd)
-        return out
-    if not force and not needs_build():
-        return OUT
-    hipcc = os.environ.get("HIPCC", "hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", f'-DDDP_SRC_SHA16="{source_hash()}"',
-           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), "-o", OUT]
-    cmd += [os.path.join(HERE, "csrc", s) for s in SOURCES]
+        os.replace(obj + ".tmp", obj)
+    return obj
+
+
+def _link(out, defs, verbose):
+    # the source hash is a define of ddp_capi.hip only: the other units' cached objects survive an edit elsewhere
+    sha = f'-DDDP_SRC_SHA16="{source_hash()}"'
+    flags = [f"-D{d}" for d in defs]
+    with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, flags + ([sha] if s == "ddp_capi.hip" else []), verbose), SOURCES))
+    cmd = [os.environ.get("HIPCC", "hipcc"), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out + ".tmp"] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return OUT
+    os.replace(out + ".tmp", out)
+    return out
+
+
+def build(force=False, verbose=True, stamps=False, ablate=0, defs=(), tag=""):
+    """The product library, or a diagnostic variant that the product never loads (its name carries a suffix; loaded through
+    DDP_HIP_LIB by the tools): `defs` = extra -D flags (library name suffixed with `tag`), stamps = in-kernel phase stamps
+    (tools/stamp_conv.py), ablate = n: timing-only ablations whose results are wrong by construction (tools/ablate_conv.py).
+    Every variant carries the source hash."""
+    if defs:
+        return _link(os.path.join(HERE, f"libddp_hip_{tag}.so"), list(defs), verbose)
+    if ablate or stamps:
+        out = os.path.join(HERE, "libddp_hip" + ("_stamps" if stamps else "") + (f"_ablate{ablate}" if ablate else "") + ".so")
+        return _link(out, (["DDP_STAMPS"] if stamps else []) + ([f"DDP_ABLATE={ablate}"] if ablate else []), verbose)
+    if not force and not needs_build():
+        return OUT
+    return _link(OUT, [], verbose)
 
 
 if __name__ == "__main__":

@@ -25,4 +25,6 @@ extern "C" const char* ddp_last_error(void) { return g_err; }
 #ifndef DDP_SRC_SHA16
 #define DDP_SRC_SHA16 "unknown"
 #endif
-extern "C" const char* ddp_source_hash(void) { return DDP_SRC_SHA16; }
+// (the tag in front lets build.built_hash() find the hash in the file bytes without loading the library)
+static const char ddp_src_tag[] = "DDP_SRC_SHA16=" DDP_SRC_SHA16;
+extern "C" const char* ddp_source_hash(void) { return ddp_src_tag + 14; }

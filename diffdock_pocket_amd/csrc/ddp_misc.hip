@@ -92,10 +92,11 @@ extern "C" int ddp_segment_reduce(float* x, int ldx, int n_nodes, int d_out, con
 #define EF_NS 64
 __global__ __launch_bounds__(256) void ddp_edge_featurize_kernel(
     const float* __restrict__ pos_a, const int* __restrict__ ia, const float* __restrict__ pos_b,
-    const int* __restrict__ ib, int n_edges, const float* __restrict__ offset, int k_rbf, float coeff,
-    const float* __restrict__ pre, const int* __restrict__ pre_idx, int ld_pre, const float* __restrict__ w1d,
-    const float* __restrict__ w2, const float* __restrict__ b2, int ns, float* __restrict__ out,
-    float* __restrict__ sh) {
+    const int* __restrict__ ib, int n_edges, const int* __restrict__ n_edges_dev, const float* __restrict__ offset, int k_rbf,
+    float coeff, const float* __restrict__ pre, const int* __restrict__ pre_idx, int ld_pre, const float* __restrict__ pre2,
+    int n_pre2, int ld_pre2, const float* __restrict__ w1d, const float* __restrict__ w2, const float* __restrict__ b2, int ns,
+    float* __restrict__ out, float* __restrict__ sh) {
+  if (n_edges_dev) n_edges = min(n_edges, *n_edges_dev);   // device-side edge count: n_edges is then the capacity
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_w1 = smem;                       // [k_rbf][64]
   float* s_w2 = s_w1 + k_rbf * EF_NS;       // [64][64]
@@ -126,6 +127,12 @@ __global__ __launch_bounds__(256) void ddp_edge_featurize_kernel(
     const float* prow = pre + (size_t)pre_idx[ec] * ld_pre;
 #pragma unroll
     for (int j = 0; j < EF_NS; ++j) hid[j] = (j < ns) ? prow[j] : 0.f;
+    if (ec < n_pre2) {
+      const float* p2 = pre2 + (size_t)ec * ld_pre2;
+#pragma unroll
+      for (int j = 0; j < EF_NS; ++j)
+        if (j < ns) hid[j] = hid[j] + p2[j];
+    }
     for (int k = 0; k < k_rbf; ++k) {
       const float t = d - s_off[k];
       const float rb = expf(coeff * (t * t));
@@ -182,10 +189,11 @@ typedef float ef_f32x16 __attribute__((ext_vector_type(16)));
 #define EF_HS 68   // LDS row stride of the hidden tile
 __global__ __launch_bounds__(256) void ddp_edge_featurize_mfma_kernel(
     const float* __restrict__ pos_a, const int* __restrict__ ia, const float* __restrict__ pos_b,
-    const int* __restrict__ ib, int n_edges, const float* __restrict__ offset, int k_rbf, float coeff,
-    const float* __restrict__ pre, const int* __restrict__ pre_idx, int ld_pre, const float* __restrict__ w1d,
-    const float* __restrict__ w2, const float* __restrict__ b2, int ns, float* __restrict__ out,
-    float* __restrict__ sh) {
+    const int* __restrict__ ib, int n_edges, const int* __restrict__ n_edges_dev, const float* __restrict__ offset, int k_rbf,
+    float coeff, const float* __restrict__ pre, const int* __restrict__ pre_idx, int ld_pre, const float* __restrict__ pre2,
+    int n_pre2, int ld_pre2, const float* __restrict__ w1d, const float* __restrict__ w2, const float* __restrict__ b2, int ns,
+    float* __restrict__ out, float* __restrict__ sh) {
+  if (n_edges_dev) n_edges = min(n_edges, *n_edges_dev);   // device-side edge count: n_edges is then the capacity
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_w1 = smem;                         // packed [k_rbf/8][2 hh][64 cols][4]
   float* s_w2 = s_w1 + k_rbf * EF_NS;         // packed [8][2][64][4]
@@ -226,9 +234,15 @@ __global__ __launch_bounds__(256) void ddp_edge_featurize_mfma_kernel(
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-      const float* prow = pre + (size_t)pre_idx[min(base + row, n_edges - 1)] * ld_pre;
+      const int er = min(base + row, n_edges - 1);
+      const float* prow = pre + (size_t)pre_idx[er] * ld_pre;
       acc0[i] = (r < ns) ? prow[r] : 0.f;
       acc1[i] = (32 + r < ns) ? prow[32 + r] : 0.f;
+      if (er < n_pre2) {   // rows of a second table added to the first n_pre2 edges (bond-type columns of lig_edge_embedding)
+        const float* p2 = pre2 + (size_t)er * ld_pre2;
+        if (r < ns) acc0[i] = acc0[i] + p2[r];
+        if (32 + r < ns) acc1[i] = acc1[i] + p2[32 + r];
+      }
     }
     for (int m = 0; m < nm1; ++m) {
       const f32x4 b0 = w1q[(m * 2 + hh) * EF_NS + r], b1 = w1q[(m * 2 + hh) * EF_NS + 32 + r];
@@ -277,10 +291,12 @@ __global__ __launch_bounds__(256) void ddp_edge_featurize_mfma_kernel(
 }
 
 extern "C" int ddp_edge_featurize(const float* pos_a, const int32_t* ia, const float* pos_b, const int32_t* ib,
-                                  int n_edges, const float* offset, int k_rbf, float coeff, const float* pre,
-                                  const int32_t* pre_idx, int ld_pre, const float* w1d, const float* w2, const float* b2,
-                                  int ns, float* out, float* sh, void* stream) {
+                                  int n_edges, const int32_t* n_edges_dev, const float* offset, int k_rbf, float coeff,
+                                  const float* pre, const int32_t* pre_idx, int ld_pre, const float* pre2, int n_pre2, int ld_pre2,
+                                  const float* w1d, const float* w2, const float* b2, int ns, float* out, float* sh, void* stream) {
   if (n_edges <= 0) return 0;
+  if (n_pre2 > 0 && !pre2) return ddp_fail(DDP_EINVAL, "ddp_edge_featurize: n_pre2 > 0 but pre2 is null");
+  if (!pre2) n_pre2 = 0;
   if (!pos_a || !ia || !pos_b || !ib || !offset || !pre || !pre_idx || !w1d || !w2 || !b2 || !out || !sh)
     return ddp_fail(DDP_EINVAL, "ddp_edge_featurize: null argument");
   if (ns < 1 || ns > EF_NS) return ddp_fail(DDP_ELIMIT, "ddp_edge_featurize: ns > 64");
@@ -293,7 +309,7 @@ extern "C" int ddp_edge_featurize(const float* pos_a, const int32_t* ia, const f
     int blocks_m = (n_edges + 127) / 128;
     if (blocks_m > 1024) blocks_m = 1024;
     hipLaunchKernelGGL(ddp_edge_featurize_mfma_kernel, dim3(blocks_m), dim3(256), lds_m, (hipStream_t)stream, pos_a, ia, pos_b,
-                       ib, n_edges, offset, k_rbf, coeff, pre, pre_idx, ld_pre, w1d, w2, b2, ns, out, sh);
+                       ib, n_edges, n_edges_dev, offset, k_rbf, coeff, pre, pre_idx, ld_pre, pre2, n_pre2, ld_pre2, w1d, w2, b2, ns, out, sh);
     e2 = hipGetLastError();
     if (e2 != hipSuccess) return ddp_fail_hip(e2, "ddp_edge_featurize (mfma) launch");
     return 0;
@@ -305,7 +321,7 @@ extern "C" int ddp_edge_featurize(const float* pos_a, const int32_t* ia, const f
   int blocks = (n_edges + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(ddp_edge_featurize_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, pos_a, ia, pos_b, ib,
-                     n_edges, offset, k_rbf, coeff, pre, pre_idx, ld_pre, w1d, w2, b2, ns, out, sh);
+                     n_edges, n_edges_dev, offset, k_rbf, coeff, pre, pre_idx, ld_pre, pre2, n_pre2, ld_pre2, w1d, w2, b2, ns, out, sh);
   err = hipGetLastError();
   if (err != hipSuccess) return ddp_fail_hip(err, "ddp_edge_featurize launch");
   return 0;

@@ -39,8 +39,10 @@ def t_to_sigma(t_tr, t_rot, t_tor, t_sc_tor, args: SigmaRanges):
 
 @functools.lru_cache(maxsize=16)
 def _frequencies(half: int, max_positions: int, device):
-    """w_k of sinusoidal_embedding (a constant of the embedding size: built once per device, not per call)."""
-    return torch.exp(torch.arange(half, dtype=torch.float32, device=device) * -(math.log(max_positions) / (half - 1)))
+    """w_k of sinusoidal_embedding (a constant of the embedding size: built once per device, not per call).  Evaluated on the
+    CPU and uploaded: the arguments scale * t * w_k reach ~1000, where one ulp of w_k (a device exp against the host's) moves
+    sin / cos by 3e-5 - the parity target is the reference's CPU path."""
+    return torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(max_positions) / (half - 1))).to(device)
 
 
 def sinusoidal_embedding(timesteps: torch.Tensor, dim: int, scale: float = 1.0, max_positions: int = 10000):

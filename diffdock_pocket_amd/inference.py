@@ -61,28 +61,24 @@ def load_protein_ligand_csv(path: str) -> List[Dict]:
     return rows
 
 
-def _esm_rows(esm_embeddings, name, n_res):
+def _esm_rows(esm_embeddings, name):
+    """The ESM embedding stored for a complex (None if there is none): a tensor / array, or a list of per-chain ones."""
     if esm_embeddings is None:
         return None
     if isinstance(esm_embeddings, dict):
-        e = esm_embeddings.get(name)
-    else:
-        e = None
-        for ext in (".pt", ".npy"):
-            p = os.path.join(esm_embeddings, name + ext)
-            if os.path.exists(p):
-                e = torch.load(p, weights_only=True) if ext == ".pt" else np.load(p)
-                break
-    if e is None:
-        return None
-    e = np.asarray(e.cpu() if torch.is_tensor(e) else e, dtype=np.float32)
-    if e.shape[0] != n_res or e.shape[1] != 1280:
-        raise ValueError(f"{name}: ESM block {e.shape}, receptor has {n_res} residues")
-    return e
+        return esm_embeddings.get(name)
+    for ext in (".pt", ".npy"):
+        p = os.path.join(esm_embeddings, name + ext)
+        if os.path.exists(p):
+            return torch.load(p, weights_only=True) if ext == ".pt" else np.load(p)
+    return None
 
 
-def build_row_graph(row: Dict, esm_embeddings=None, root: str = "", **graph_kwargs):
-    """One csv row -> complex graph (receptor.x = [residue index | 1280 ESM columns]; zeros if no embedding is given)."""
+def build_row_graph(row: Dict, esm_embeddings=None, root: str = "", allow_zero_esm: bool = False, **graph_kwargs):
+    """One csv row -> complex graph (receptor.x = [residue index | 1280 ESM columns]).  The stored embedding may cover the
+    whole structure (per chain or concatenated): it is sliced with the kept-residue indices like the reference does
+    (inputs.slice_lm_embeddings).  A row without an embedding is an ERROR (-> the row is reported as skipped) unless
+    `allow_zero_esm` asks for a zero block, which is out of the model's training distribution and is announced loudly."""
     lig = row["ligand"]
     if not lig.lower().endswith(".sdf"):
         raise NotImplementedError(f"ligand '{lig}': only SDF files are read without rdkit")
@@ -90,20 +86,50 @@ def build_row_graph(row: Dict, esm_embeddings=None, root: str = "", **graph_kwar
         pdb_text = f.read()
     with open(os.path.join(root, lig)) as f:
         sdf_text = f.read()
+    e = _esm_rows(esm_embeddings, row["complex_name"])
+    if e is None and not allow_zero_esm:
+        raise ValueError(f"{row['complex_name']}: no ESM embedding found (pass allow_zero_esm=True to run on a zero block)")
     g = I.build_complex_graph(pdb_text, sdf_text, name=row["complex_name"], pocket_center=row.get("pocket_center"),
-                              flexible_sidechains=row.get("flexible_sidechains"), **graph_kwargs)
-    n_res = g["receptor"].x.shape[0]
-    e = _esm_rows(esm_embeddings, row["complex_name"], n_res)
-    block = torch.from_numpy(e) if e is not None else torch.zeros(n_res, 1280)
-    g["receptor"].x = torch.cat([g["receptor"].x.float()[:, :1], block], 1)
+                              flexible_sidechains=row.get("flexible_sidechains"), lm_embeddings=e, **graph_kwargs)
+    if e is None:
+        import warnings
+        warnings.warn(f"{row['complex_name']}: no ESM embedding - the receptor gets a ZERO language-model block "
+                      f"(out-of-distribution input; allow_zero_esm=True)", RuntimeWarning, stacklevel=2)
+        n_res = g["receptor"].x.shape[0]
+        g["receptor"].x = torch.cat([g["receptor"].x.float()[:, :1], torch.zeros(n_res, 1280)], 1)
     return g
 
 
 def run_csv(csv_path: str, model, device, *, confidence_model=None, samples_per_complex: int = 40, inference_steps: int = 20,
             esm_embeddings=None, root: str = "", seed: int = 0, rank: int = 0, world: int = 1, shard: str = "samples",
-            dist=None, sampler_cfg: Optional[SamplerConfig] = None, graph_kwargs: Optional[Dict] = None) -> List[ComplexResult]:
+            dist=None, sampler_cfg: Optional[SamplerConfig] = None, graph_kwargs: Optional[Dict] = None,
+            allow_zero_esm: bool = False) -> List[ComplexResult]:
     """See the module docstring.  `dist`: an initialised torch.distributed module (world > 1 and shard == "samples").
-    Returns one ComplexResult per csv row (on every rank; with shard == "complexes" only this rank's rows are filled)."""
+    Returns one ComplexResult per csv row (on every rank; with shard == "complexes" only this rank's rows are filled).
+
+    A row that fails on ANY rank (unreadable file, unsupported ligand format, missing ESM embedding, a parsing error: every
+    Exception, like the reference's per-complex try / except, inference.py:282-287) is skipped on ALL ranks: with sample
+    sharding the ranks agree on the outcome (one all_reduce of an ok flag per row) before anyone enters the sampling loop and
+    its final all_gather, so a rank-local failure cannot leave the others waiting in a collective."""
+    dev = torch.device(device)
+    if dev.type == "cuda":      # kernels are queued on the CURRENT device's stream: make `device` current for the whole run
+        with torch.cuda.device(dev):
+            return _run_csv(csv_path, model, dev, confidence_model, samples_per_complex, inference_steps, esm_embeddings, root,
+                            seed, rank, world, shard, dist, sampler_cfg, graph_kwargs, allow_zero_esm)
+    return _run_csv(csv_path, model, dev, confidence_model, samples_per_complex, inference_steps, esm_embeddings, root, seed,
+                    rank, world, shard, dist, sampler_cfg, graph_kwargs, allow_zero_esm)
+
+
+def _all_ok(dist, ok: bool, device) -> bool:
+    """True iff `ok` on every rank."""
+    on_gpu = device.type == "cuda" and str(dist.get_backend()).lower() == "nccl"
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if on_gpu else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
+
+
+def _run_csv(csv_path, model, device, confidence_model, samples_per_complex, inference_steps, esm_embeddings, root, seed, rank,
+             world, shard, dist, sampler_cfg, graph_kwargs, allow_zero_esm) -> List[ComplexResult]:
     rows = load_protein_ligand_csv(csv_path)
     if shard not in ("samples", "complexes"):
         raise ValueError(shard)
@@ -117,15 +143,20 @@ def run_csv(csv_path: str, model, device, *, confidence_model=None, samples_per_
         out.append(res)
         if i not in mine:
             continue
+        split = shard == "samples" and world > 1
+        g = None
         try:
-            g = build_row_graph(row, esm_embeddings, root, **(graph_kwargs or {}))
-        except (NotImplementedError, OSError, ValueError) as e:      # the reference skips a failing complex and goes on
+            g = build_row_graph(row, esm_embeddings, root, allow_zero_esm=allow_zero_esm, **(graph_kwargs or {}))
+        except Exception as e:      # noqa: BLE001 - the reference skips a failing complex and goes on (inference.py:282-287)
             res.skipped = f"{type(e).__name__}: {e}"
+        if split and not _all_ok(dist, g is not None, device):
+            res.skipped = res.skipped or "skipped: the row failed on another rank"
+            continue
+        if g is None:
             continue
         flex = bool(getattr(model, "flexible_sidechains", False)) and len(g["flexResidues"]) > 0
         cfg = sampler_cfg or SamplerConfig(inference_steps=inference_steps, flexible_sidechains=flex)
         n = samples_per_complex
-        split = shard == "samples" and world > 1
         sl = slice(rank * n // world, (rank + 1) * n // world) if split else slice(0, n)
         smp = Sampler(model, g, n, device, cfg, seed=seed + i, sample_slice=sl)
         smp.randomize()

@@ -424,6 +424,10 @@ class Receptor:
     ca: np.ndarray
     n: np.ndarray
     c: np.ndarray
+    lm_index: Optional[List[Tuple[int, int]]] = None   # per kept residue: (chain number in the structure, index among that
+                                                       # chain's amino-acid residues BEFORE the pocket selector) = its row in
+                                                       # the reference's per-chain ESM embeddings (process_mols.py:346,395-397)
+    chain_lengths: Optional[List[int]] = None          # amino-acid residues per chain (rows of a per-chain embedding)
 
 
 def extract_receptor(residues: Sequence[PdbResidue], lig_pos: np.ndarray, cutoff: float = 10.0,
@@ -432,12 +436,17 @@ def extract_receptor(residues: Sequence[PdbResidue], lig_pos: np.ndarray, cutoff
     without CA, N and C, applies the pocket selector (pdbbind.py:775-784, all-atom rule: any atom inside the sphere), and
     keeps the chains that come within `cutoff` of the ligand (the closest chain when none does)."""
     chains: Dict[str, List[PdbResidue]] = {}
+    seq_pos: Dict[int, Tuple[int, int]] = {}     # id(residue) -> (chain number, index among the chain's amino-acid residues)
+    n_aa: Dict[str, int] = {}
     for r in residues:
         chains.setdefault(r.chain, [])
+        n_aa.setdefault(r.chain, 0)
         if r.resname == "HOH":
             continue
         if r.atom("CA") is None or r.atom("N") is None or r.atom("C") is None:
             continue
+        seq_pos[id(r)] = (list(chains).index(r.chain), n_aa[r.chain])     # counted before the selector (`atom_idx`, :346)
+        n_aa[r.chain] += 1
         if pocket is not None:
             xyz = np.array([a.coord for a in r.atoms])
             if not (np.linalg.norm(xyz - pocket[0], axis=1) < pocket[1]).any():
@@ -458,7 +467,38 @@ def extract_receptor(residues: Sequence[PdbResidue], lig_pos: np.ndarray, cutoff
     def vec(name):
         return np.array([r.atom(name).coord for r in kept], dtype=np.float32)
 
-    return Receptor(kept, vec("CA"), vec("N"), vec("C"))
+    return Receptor(kept, vec("CA"), vec("N"), vec("C"), lm_index=[seq_pos[id(r)] for r in kept],
+                    chain_lengths=[n_aa[cid] for cid in ids])
+
+
+def slice_lm_embeddings(lm_embeddings, rec: Receptor) -> torch.Tensor:
+    """ESM rows of the kept residues, [n_kept, 1280] (see build_complex_graph for the accepted forms)."""
+    def as_t(a):
+        return torch.as_tensor(np.asarray(a.cpu() if torch.is_tensor(a) else a), dtype=torch.float32)
+
+    n_kept = len(rec.residues)
+    if isinstance(lm_embeddings, (list, tuple)):
+        chains = [as_t(c) for c in lm_embeddings]
+        rows = []
+        for ci, ri in rec.lm_index:
+            if ci >= len(chains):    # process_mols.py:391-392
+                raise ValueError("Encountered valid chain id that was not present in the LM embeddings")
+            if ri >= chains[ci].shape[0]:
+                raise ValueError(f"LM embedding of chain {ci} has {chains[ci].shape[0]} rows, residue {ri} requested")
+            rows.append(chains[ci][ri])
+        lm = torch.stack(rows, 0)
+    else:
+        lm = as_t(lm_embeddings)
+        total = sum(rec.chain_lengths)
+        if lm.shape[0] == total and total != n_kept:
+            starts = np.concatenate([[0], np.cumsum(rec.chain_lengths)[:-1]])
+            lm = lm[[int(starts[ci]) + ri for ci, ri in rec.lm_index]]
+        elif lm.shape[0] != n_kept:
+            raise ValueError(f"lm_embeddings has {lm.shape[0]} rows; the receptor keeps {n_kept} of the structure's {total} "
+                             f"amino-acid residues (give per-chain arrays, all {total} rows, or exactly the kept rows)")
+    if lm.dim() != 2 or lm.shape[1] != 1280:
+        raise ValueError(f"lm_embeddings rows must have 1280 columns, got {tuple(lm.shape)}")
+    return lm
 
 
 def rec_residue_features(rec: Receptor) -> torch.Tensor:
@@ -628,8 +668,11 @@ def build_complex_graph(pdb_text: str, sdf_text: str, *, name: str = "complex", 
     receptor_radius 15, 24 C-alpha neighbours, hydrogens removed).  `pocket_center` overrides the centre computed from the
     ligand pose (reference pdbbind.py:585-596: the radius is then the ligand's own extent).  Flexible residues: an explicit
     list 'A:160-A:193' (inference.py:57) or every residue with a side-chain atom within `flexdist` of the pocket sphere
-    (pdbbind.py:343-349, metric 'L2').  `lm_embeddings`: [n_residues_kept, 1280] ESM rows in residue order, or None
-    (receptor.x then holds the residue index only)."""
+    (pdbbind.py:343-349, metric 'L2').  `lm_embeddings`: None (receptor.x then holds the residue index only), or the ESM rows
+    in one of three forms: a list with one [chain length, 1280] array per chain of the structure (the reference's
+    `lm_embedding_chains`, sliced as process_mols.py:389-397 does: rows of the kept chains, minus the residues the pocket
+    selector discarded), ONE array over all chains' amino-acid residues in structure order (sliced the same way), or exactly
+    the [n_residues_kept, 1280] rows."""
     mol = parse_sdf(sdf_text)
     x_l, pos_l, ei_l, ea_l, edge_mask, mask_rotate = ligand_graph(mol, keep_hs=not remove_hs)
     residues = parse_pdb(pdb_text)
@@ -655,10 +698,7 @@ def build_complex_graph(pdb_text: str, sdf_text: str, *, name: str = "complex", 
     data["ligand", "ligand"] = Store(edge_index=torch.from_numpy(ei_l), edge_attr=torch.from_numpy(ea_l))
     res_x = rec_residue_features(rec)
     if lm_embeddings is not None:
-        lm = torch.as_tensor(np.asarray(lm_embeddings), dtype=torch.float32)
-        if lm.shape[0] != res_x.shape[0]:
-            raise ValueError(f"lm_embeddings has {lm.shape[0]} rows for {res_x.shape[0]} receptor residues")
-        res_x = torch.cat([res_x, lm], 1)
+        res_x = torch.cat([res_x, slice_lm_embeddings(lm_embeddings, rec)], 1)
     data["receptor"] = Store(x=res_x, pos=torch.from_numpy(rec.ca - protein_centre))
     data["receptor", "receptor"] = Store(edge_index=torch.from_numpy(rr))
     data["atom"] = Store(x=torch.from_numpy(atom_x), pos=torch.from_numpy(atom_pos - protein_centre))

@@ -242,7 +242,7 @@ class Sampler:
         b["ligand"].pos = self.lig_pos.reshape(-1, 3)
         b["atom"].pos = self.atom_pos.reshape(-1, 3)
         set_time(b, t, t, t, t, device=dev)
-        tr_score, rot_score, tor_score, sc_score = self.model(b)
+        tr_score, rot_score, tor_score, sc_score = self._call_model(self.model, b)
 
         def perturb(score, g, sigma, lo, hi, k, zz):
             if cfg.ode:
@@ -275,6 +275,19 @@ class Sampler:
         else:
             self.lig_pos = modify_conformer(self.lig_pos, tr_p, rot_p, tor_p, self.bonds, self.rot_idx)
 
+    def _call_model(self, model, b):
+        """The weights' VALUE fingerprint (score_model._refresh_weight_caches: one host synchronisation) is checked on the
+        first call of a run only; the remaining steps trust the version counters."""
+        seen = self.__dict__.setdefault("_weights_checked", set())
+        if not hasattr(model, "check_weight_values") or id(model) not in seen:
+            seen.add(id(model))
+            return model(b)
+        prev, model.check_weight_values = model.check_weight_values, False
+        try:
+            return model(b)
+        finally:
+            model.check_weight_values = prev
+
     # -- confidence pass + ranking (reference utils/sampling.py:263-283, inference.py:212-219) ------------------------
     def confidence(self, confidence_model):
         """Runs the confidence model (TensorProductScoreModel(confidence_mode=True)) on the final poses at t = 0 and
@@ -284,12 +297,13 @@ class Sampler:
         b["ligand"].pos = self.lig_pos.reshape(-1, 3)
         b["atom"].pos = self.atom_pos.reshape(-1, 3)
         set_time(b, 0.0, 0.0, 0.0, 0.0, device=self.device)
-        conf = confidence_model(b)
+        conf = self._call_model(confidence_model, b)
         key = conf[:, 0] if conf.dim() == 2 else conf
         return conf, torch.argsort(key, descending=True)
 
     def run(self, schedule: Optional[np.ndarray] = None):
         schedule = get_t_schedule(self.cfg.inference_steps) if schedule is None else schedule
+        self.__dict__["_weights_checked"] = set()      # a run re-checks the weights' values once
         for i in range(len(schedule)):
             self.step(i, schedule)
         return self.lig_pos, self.atom_pos

@@ -415,7 +415,9 @@ class _EdgeMLPPack:
         self.W1, self.b1 = W1, b1
 
 
-def _edge_featurize(pack: _EdgeMLPPack, dist: GaussianSmearing, pos_a, ia, pos_b, ib, pre, pre_idx):
+def _edge_featurize(pack: _EdgeMLPPack, dist: GaussianSmearing, pos_a, ia, pos_b, ib, pre, pre_idx, pre2=None):
+    """pre: [*, >= ns] rows with unit column stride (a column slice of a wider table is fine); pre2 (optional, [n2, ns]) is
+    added to the first n2 edges' rows (the bond-type columns of lig_edge_embedding's first Linear)."""
     lib = L.load()
     E = int(ia.shape[0])
     dev = pos_a.device
@@ -423,12 +425,76 @@ def _edge_featurize(pack: _EdgeMLPPack, dist: GaussianSmearing, pos_a, ia, pos_b
     sh = torch.empty((E, 4), device=dev, dtype=torch.float32)
     if E == 0:
         return out, sh
-    pre = pre.contiguous()
-    L.check(lib.ddp_edge_featurize(_ptr(pos_a), _ptr(ia), _ptr(pos_b), _ptr(ib), E, _ptr(dist.offset), pack.k,
-                                   C.c_float(dist.coeff), _ptr(pre), _ptr(pre_idx), pre.shape[1], _ptr(pack.w1d),
+    if pre.stride(1) != 1:
+        pre = pre.contiguous()
+    n2 = 0 if pre2 is None else int(pre2.shape[0])
+    L.check(lib.ddp_edge_featurize(_ptr(pos_a), _ptr(ia), _ptr(pos_b), _ptr(ib), E, None, _ptr(dist.offset), pack.k,
+                                   C.c_float(dist.coeff), _ptr(pre), _ptr(pre_idx), pre.stride(0),
+                                   _ptr(pre2) if n2 else None, n2, pre2.stride(0) if n2 else 0, _ptr(pack.w1d),
                                    _ptr(pack.w2), _ptr(pack.b2), pack.ns, _ptr(out), _ptr(sh), _stream()),
             "ddp_edge_featurize")
     return out, sh
+
+
+class _EncoderPack:
+    """Weights of one node encoder laid out for ddp_node_linear (csrc/ddp_node.hip): the embedding tables stacked row-wise
+    with their first rows, the Linear weights transposed to [K, ns].  AtomEncoder (models/score_model.py:54-82) is ONE job
+    [emb_sum | ESM | sigma_emb] @ W^T + b; OldAtomEncoder (:17-52, legacy slicing kept literally: with an ESM block its
+    "scalar features" are the first sigma_embed_dim ESM columns and its "ESM block" the last 1280 columns of
+    [ESM | sigma_emb]) is a job `emb_sum + scalars @ W_s^T + b_s` followed, with ESM, by a second one over
+    [stage 1 | ESM[sd:] | sigma_emb]."""
+
+    def __init__(self, enc, dev):
+        tabs = [e.weight.detach().float() for e in enc.atom_embedding_list]
+        self.table = torch.cat(tabs, 0).contiguous().to(dev)
+        self.feat_off = [0]
+        for t in tabs[:-1]:
+            self.feat_off.append(self.feat_off[-1] + t.shape[0])
+        self.n_cat, self.emb_dim = len(tabs), tabs[0].shape[1]
+        self.old = isinstance(enc, OldAtomEncoder)
+        if self.old:
+            self.has_lm = enc.lm_embedding_type is not None
+            self.n_scalar = enc.num_scalar_features
+            if self.n_scalar > 0:
+                self.w1, self.b1 = enc.linear.weight.detach().float().t().contiguous().to(dev), enc.linear.bias.detach().float().to(dev)
+            if self.has_lm:
+                lin = enc.lm_embedding_layer
+                self.w2, self.b2 = lin.weight.detach().float().t().contiguous().to(dev), lin.bias.detach().float().to(dev)
+        else:
+            self.has_extra = enc.additional_features_dim > 0
+            if self.has_extra:
+                lin = enc.additional_features_embedder
+                self.w, self.b = lin.weight.detach().float().t().contiguous().to(dev), lin.bias.detach().float().to(dev)
+
+
+def _node_job(n_rows, out, ncols, w, bias, zero_to=0, cat=None, pack=None, emb_mode=0, dense=(), sigma=None, sig_out=None):
+    """One ddp_node_job_t.  dense: [(tensor [n, ld] float32 with unit column stride, first column, width)]; sigma:
+    None | ("t", t [n] (any stride), scale, freq [sd/2], sd) | ("emb", tensor [n, sd])."""
+    j = L.NodeJob()
+    j.n_rows, j.out, j.ld_out, j.ncols, j.zero_to = n_rows, out.data_ptr(), out.stride(0), ncols, zero_to
+    j.w, j.bias = w.data_ptr(), (bias.data_ptr() if bias is not None else 0)
+    if cat is not None and emb_mode:
+        j.cat, j.ld_cat, j.n_cat, j.table, j.emb_dim, j.emb_mode = cat.data_ptr(), cat.stride(0), pack.n_cat, pack.table.data_ptr(), pack.emb_dim, emb_mode
+        for f, o in enumerate(pack.feat_off):
+            j.feat_off[f] = o
+    for d, (ten, c0, n) in enumerate(dense):
+        j.dense[d], j.ld_dense[d], j.n_dense[d] = ten.data_ptr() + 4 * c0, ten.stride(0), n
+    if sigma is not None and sigma[0] == "t":
+        _, t, scale, freq, sd = sigma
+        j.t, j.t_stride, j.scale, j.freq, j.sd = t.data_ptr(), (t.stride(0) if t.numel() > 1 else 0), scale, freq.data_ptr(), sd
+    elif sigma is not None:
+        j.sig_emb, j.ld_sig, j.sd = sigma[1].data_ptr(), sigma[1].stride(0), sigma[1].shape[1]
+    if sig_out is not None:
+        j.sig_out, j.ld_sig_out = sig_out.data_ptr(), sig_out.stride(0)
+    return j
+
+
+def _launch_node_jobs(jobs):
+    lib = L.load()
+    for i in range(0, len(jobs), L.DDP_MAX_NODE_JOBS):
+        part = jobs[i:i + L.DDP_MAX_NODE_JOBS]
+        arr = (L.NodeJob * len(part))(*part)
+        L.check(lib.ddp_node_linear(arr, len(part), _stream()), "ddp_node_linear")
 
 
 # ------------------------------------------------------------------------------------------------ the model
@@ -520,6 +586,11 @@ class TensorProductScoreModel(nn.Module):
                                        # give each its own slot so that they do not evict each other's entries
         self._stage_a_stacks = {}      # (layer, conv ids) -> stacked stage-A right-hand sides, see _stage_a()
         self.section_timer = None      # optional SectionTimer (tools/time_sections.py): per-section GPU + host time
+        self.check_weight_values = True  # see _refresh_weight_caches
+        self.debug_conv_outputs = None  # set to a dict: forward then stores the output [n_out, d_out] of every conv call in it
+                                        # (conv_layers.<9l+k>, final_conv, tor_bond_conv, sc_tor_bond_conv: the tensors the
+                                        # reference's forward hooks see, tests/golden `conv_stats`) and runs the general path
+                                        # (no layer-0 sharing, no clean-pair sharing, no dead-output pruning)
         for i in range(num_conv_layers):
             mi, mo = P.irreps_muls(ns, nv, i), P.irreps_muls(ns, nv, i + 1)
             spec = P.faster_tp_spec(mi, mo, 3 * ns)
@@ -655,17 +726,46 @@ class TensorProductScoreModel(nn.Module):
                 out[5], out[8] = (na, e, nr), (nr, e, na)
         return out
 
-    def _weights_version(self):
-        """Sum of the autograd version counters of every parameter and buffer: any in-place update (optimizer step,
-        `ema.copy_to(model.parameters())`, `param.data.copy_`, BatchNorm buffer edits) bumps it."""
-        ts = self.__dict__.get("_weight_tensors")
+    def _weight_tensors(self):
+        ts = self.__dict__.get("_weight_tensors_")
         if ts is None:   # (the list is rebuilt when modules change device / dtype: _apply)
-            ts = self.__dict__["_weight_tensors"] = list(self.parameters()) + list(self.buffers())
-        return sum(t._version for t in ts)
+            ts = self.__dict__["_weight_tensors_"] = list(self.parameters()) + list(self.buffers())
+        return ts
+
+    def _weights_version(self):
+        """Sum of the autograd version counters of every parameter and buffer: in-place updates THROUGH the parameter
+        (optimizer steps, `param.copy_` under no_grad, BatchNorm buffer edits) bump it.  Updates through `param.data` do NOT:
+        `.data` is a detached alias with a version counter of its own - and that is what the reference's EMA does
+        (utils/utils.py:216,239 `param.data.copy_`) - so the version sum is only the free first line; `_weights_fingerprint`
+        is the second."""
+        return sum(t._version for t in self._weight_tensors())
+
+    def _weights_fingerprint(self):
+        """Value fingerprint of every floating-point parameter and buffer: their L1 and L2 norms (two multi-tensor launches,
+        one device-to-host copy of ~2 x 600 numbers = one host synchronisation).  Catches what the version counters cannot
+        see: `param.data.copy_`, `ema.copy_to(model.parameters())`, `ema.restore(...)` (reference utils/utils.py:206-240)."""
+        ts = [t.detach() for t in self._weight_tensors() if t.is_floating_point() and t.numel() > 0]
+        if not ts:
+            return ()
+        parts = torch._foreach_norm(ts, 1) + torch._foreach_norm(ts, 2)
+        return tuple(torch.stack([p.double() for p in parts]).tolist())
+
+    def _refresh_weight_caches(self):
+        """Packed weights, edge-MLP packs, stage-A stacks and the cached encoder parts bake the weights in: dropped when any
+        parameter / buffer changed since they were built.  Called at the top of every forward; `check_weight_values = False`
+        (set by sampler.Sampler around the steps of one run, after one full check) skips the value fingerprint and its host
+        synchronisation."""
+        wv = self._weights_version()
+        fp = self._weights_fingerprint() if self.check_weight_values else self.__dict__.get("_weights_seen_fp")
+        if self.__dict__.get("_weights_seen") != wv or self.__dict__.get("_weights_seen_fp") != fp:
+            self.invalidate_packed()
+            self._weights_seen = wv
+            self._weights_seen_fp = fp if self.check_weight_values else self._weights_fingerprint()
 
     def invalidate_packed(self):
         self._weights_seen = None
-        self.__dict__["_weight_tensors"] = None
+        self._weights_seen_fp = None
+        self.__dict__["_weight_tensors_"] = None
         self._stage_a_stacks = {}
         for m in self.modules():
             if isinstance(m, TensorProductConvLayer):
@@ -699,6 +799,79 @@ class TensorProductScoreModel(nn.Module):
         if pk is None or pk.w1d.device != dev:
             pk = self._edge_packs[name] = _EdgeMLPPack(getattr(self, name), rbf_slice, dev)
         return pk
+
+    def _sigma_spec(self, t, dev):
+        """How ddp_node_linear gets the sigma embedding of the times `t`: evaluated in the kernel when timestep_emb_func is
+        this package's sinusoidal embedding (diffusion.get_timestep_embedding), otherwise computed by calling it."""
+        from .diffusion import _frequencies, sinusoidal_embedding
+        f = self.timestep_emb_func
+        kw = getattr(f, "keywords", None) or {}
+        if getattr(f, "func", None) is sinusoidal_embedding and not getattr(f, "args", ()) and "dim" in kw \
+                and set(kw) <= {"dim", "scale", "max_positions"} and kw["dim"] >= 4:
+            return ("t", t.float(), float(kw.get("scale", 1.0)), _frequencies(kw["dim"] // 2, kw.get("max_positions", 10000), dev),
+                    int(kw["dim"]))
+        return ("emb", f(t).float().contiguous())
+
+    def _node_tables(self, lig, rec, atom, dev):
+        """Node encoders (all_atom_score_model.py:249,254,259 -> models/score_model.py:54-82 / :17-52), the sinusoidal sigma
+        embedding of every node (:453,495,520) and the per-node `pre` tables of the edge-embedding MLPs (the part of their
+        first Linear that depends on the node only: W1[:, sigma columns] @ node_sigma_emb + b1) in ONE ddp_node_linear launch
+        (two when an OldAtomEncoder carries an ESM block).  Returns the node-feature arrays [N, ldx] (encoder output in the
+        first ns columns, zeros behind) and {edge set: [N, ns] view of its pre table}."""
+        ns, ldx, sd = self.ns, self._ldx, self.sigma_embed_dim
+        nf, dd = self.in_lig_edge_features, self.distance_embed_dim
+        pre_specs = {"ligand": [("ll", "lig_edge_embedding", nf), ("lr", "lr_edge_embedding", 0), ("la", "la_edge_embedding", 0)]
+                     + ([] if self.confidence_mode else [("center", "center_edge_embedding", dd)]),
+                     "receptor": [("rr", "rec_edge_embedding", 0)],
+                     "atom": [("aa", "atom_edge_embedding", 0), ("ar", "ar_edge_embedding", 0)]}
+        jobs, jobs2, xs, pre, keep = [], [], [], {}, []
+        for name, st, enc in (("ligand", lig, self.lig_node_embedding), ("receptor", rec, self.rec_node_embedding),
+                              ("atom", atom, self.atom_node_embedding)):
+            pk = self._edge_packs.get("enc_" + name)
+            if pk is None or pk.table.device != dev:
+                pk = self._edge_packs["enc_" + name] = _EncoderPack(enc, dev)
+            N = st.x.shape[0]
+            ncat, n_lm = pk.n_cat, st.x.shape[1] - pk.n_cat
+            cat = self._cached("cat_" + name, (st.x,), lambda st=st, ncat=ncat: st.x[:, :ncat].to(torch.int32).contiguous())
+            xf = None
+            if n_lm > 0:
+                xf = self._cached("xf_" + name, (st.x,), lambda st=st: st.x.float().contiguous())
+            sigma = self._sigma_spec(st.node_t["tr"], dev)
+            sig_out = torch.empty((N, sd), device=dev)
+            st.node_sigma_emb = sig_out                       # (:453,495,520) the reference leaves it on the batch
+            x = torch.empty((N, ldx), device=dev)
+            xs.append(x)
+            keep += [cat, xf, sigma]
+            if not pk.old:
+                if not pk.has_extra:
+                    raise NotImplementedError("AtomEncoder without additional features (sigma_embed_dim = 0, no ESM)")
+                if pk.w.shape[0] != pk.emb_dim + n_lm + sd:
+                    raise ValueError(f"{name}.x has {st.x.shape[1]} columns, the encoder expects {pk.w.shape[0] - pk.emb_dim - sd + ncat}")
+                jobs.append(_node_job(N, x, ns, pk.w, pk.b, zero_to=ldx, cat=cat, pack=pk, emb_mode=1,
+                                      dense=[(xf, ncat, n_lm)] if n_lm else [], sigma=sigma, sig_out=sig_out))
+            elif not pk.has_lm:
+                jobs.append(_node_job(N, x, ns, pk.w1, pk.b1, zero_to=ldx, cat=cat, pack=pk, emb_mode=2, sigma=sigma, sig_out=sig_out))
+            else:   # scalars = the first n_scalar columns behind the categorical ones, "ESM" = the last 1280 of [ESM | sigma]
+                tmp = torch.empty((N, ns), device=dev)
+                keep.append(tmp)
+                jobs.append(_node_job(N, tmp, ns, pk.w1, pk.b1, cat=cat, pack=pk, emb_mode=2, dense=[(xf, ncat, pk.n_scalar)]))
+                jobs2.append(_node_job(N, x, ns, pk.w2, pk.b2, zero_to=ldx,
+                                       dense=[(tmp, 0, ns), (xf, ncat + n_lm + sd - 1280, 1280 - sd)], sigma=sigma, sig_out=sig_out))
+            specs = pre_specs[name]
+            ppk = self._edge_packs.get("pre_" + name)
+            if ppk is None or ppk[0].device != dev:
+                ws = [getattr(self, mlp)[0].weight.detach().float()[:, s0:s0 + sd].t() for _, mlp, s0 in specs]
+                bs = [getattr(self, mlp)[0].bias.detach().float() for _, mlp, _ in specs]
+                ppk = self._edge_packs["pre_" + name] = (torch.cat(ws, 1).contiguous().to(dev), torch.cat(bs).contiguous().to(dev))
+            buf = torch.empty((N, len(specs) * ns), device=dev)
+            jobs.append(_node_job(N, buf, len(specs) * ns, ppk[0], ppk[1], sigma=sigma))
+            for i, (key, _, _) in enumerate(specs):
+                pre[key] = buf[:, i * ns:(i + 1) * ns]
+        _launch_node_jobs(jobs)
+        if jobs2:
+            _launch_node_jobs(jobs2)
+        self._keep_alive = keep      # raw pointers were handed to the launches above
+        return xs[0], xs[1], xs[2], pre
 
     def _so3_score_norm(self, sigma):
         """reference utils/so3.py:85-89 (float32 arithmetic like numpy on a float32 array)."""
@@ -741,12 +914,7 @@ class TensorProductScoreModel(nn.Module):
         lig, rec, atom = data["ligand"], data["receptor"], data["atom"]
         _require_hip(lig.pos)
         dev = lig.pos.device
-        # packed weights, edge-MLP packs, stage-A stacks and the cached encoder parts bake the weights in: dropped when any
-        # parameter / buffer was updated in place since they were built
-        wv = self._weights_version()
-        if self.__dict__.get("_weights_seen") != wv:
-            self.invalidate_packed()
-            self._weights_seen = wv
+        self._refresh_weight_caches()
         ns, L_ = self.ns, self.num_conv_layers
         B = int(data.num_graphs)
         mark = self.section_timer.mark if self.section_timer is not None else (lambda name: None)
@@ -765,48 +933,24 @@ class TensorProductScoreModel(nn.Module):
         lay_r = self._cached("lay_r", (rbatch,), lambda: G.DenseLayout.build(rbatch, B))
         lay_a = self._cached("lay_a", (abatch,), lambda: G.DenseLayout.build(abatch, B))
 
-        # node sigma embeddings (all_atom_score_model.py:453,495,520) and node encoders (:249,254,259)
-        for st in (lig, rec, atom):
-            st.node_sigma_emb = self.timestep_emb_func(st.node_t["tr"])
+        # node encoders, sigma embeddings and the per-node part of the edge-embedding MLPs' first Linear: one HIP launch,
+        # queued ahead of the searches' host synchronisation (it depends on the diffusion time and the node features only)
         ldx = self._ldx
-        xl = torch.zeros((Nl, ldx), device=dev)
-        xr = torch.zeros((Nr, ldx), device=dev)
-        xa = torch.zeros((Na, ldx), device=dev)
-        ncat_r = len(REC_RESIDUE_FEATURE_DIMS)
-        if isinstance(self.rec_node_embedding, AtomEncoder) and self.rec_node_embedding.additional_features_dim > 0:
-            # node encoders (:249,254,259) with their step-independent part kept across calls
-            xl[:, :ns] = self.lig_node_embedding.forward_split(
-                lig.x, None, lig.node_sigma_emb, lambda f: self._cached("enc_l", (lig.x,), f))
-            xr[:, :ns] = self.rec_node_embedding.forward_split(
-                rec.x[:, :ncat_r], rec.x[:, ncat_r:], rec.node_sigma_emb, lambda f: self._cached("enc_r", (rec.x,), f))
-            xa[:, :ns] = self.atom_node_embedding.forward_split(
-                atom.x, None, atom.node_sigma_emb, lambda f: self._cached("enc_a", (atom.x,), f))
-        else:
-            xl[:, :ns] = self.lig_node_embedding(lig.x, lig.node_sigma_emb)
-            xr[:, :ns] = self.rec_node_embedding(rec.x[:, :ncat_r], torch.cat([rec.x[:, ncat_r:].float(), rec.node_sigma_emb], 1))
-            xa[:, :ns] = self.atom_node_embedding(atom.x, atom.node_sigma_emb)
-
+        xl, xr, xa, pre = self._node_tables(lig, rec, atom, dev)
         mark("node_embed")
         # ---- graphs (:444-583)
         i32 = lambda t: t.to(torch.int32).contiguous()
         bond_ei = data["ligand", "ligand"].edge_index.long()
-        # Per-node `pre` tables of the edge-embedding MLPs (the non-RBF part of their first Linear: W1[:, sigma cols] @ emb + b1,
-        # [N, ns]).  They depend on the diffusion time only, so they are queued here, ahead of the searches' host
-        # synchronisation: whatever is queued before it runs behind the previous step's tail instead of in the host-paced
-        # window between the synchronisation and the first conv layer.
         sd_, dd, cd = self.sigma_embed_dim, self.distance_embed_dim, self.cross_distance_embed_dim
         nf = self.in_lig_edge_features
-        epk, pre = {}, {}
-        for key, name, rbf0, rbf_n, emb, sig0 in (
-                ("ll", "lig_edge_embedding", nf + sd_, dd, lig.node_sigma_emb, nf),
-                ("rr", "rec_edge_embedding", sd_, dd, rec.node_sigma_emb, 0),
-                ("aa", "atom_edge_embedding", sd_, dd, atom.node_sigma_emb, 0),
-                ("lr", "lr_edge_embedding", sd_, cd, lig.node_sigma_emb, 0),
-                ("la", "la_edge_embedding", sd_, cd, lig.node_sigma_emb, 0),
-                ("ar", "ar_edge_embedding", sd_, dd, atom.node_sigma_emb, 0)):
-            epk[key] = pk = self._edge_pack(name, slice(rbf0, rbf0 + rbf_n), dev)
-            pre[key] = torch.addmm(pk.b1, emb, pk.W1[:, sig0:sig0 + sd_].t())
-        bond_pre = data["ligand", "ligand"].edge_attr.float() @ epk["ll"].W1[:, :nf].t()     # bond-type columns, [E_bond, ns]
+        epk = {}
+        for key, name, rbf0, rbf_n in (("ll", "lig_edge_embedding", nf + sd_, dd), ("rr", "rec_edge_embedding", sd_, dd),
+                                       ("aa", "atom_edge_embedding", sd_, dd), ("lr", "lr_edge_embedding", sd_, cd),
+                                       ("la", "la_edge_embedding", sd_, cd), ("ar", "ar_edge_embedding", sd_, dd)):
+            epk[key] = self._edge_pack(name, slice(rbf0, rbf0 + rbf_n), dev)
+        # bond-type columns of lig_edge_embedding's first Linear, [E_bond, ns]: fixed for a batch
+        bond_attr = data["ligand", "ligand"].edge_attr
+        bond_pre = self._cached("bond_pre", (bond_attr,), lambda: bond_attr.float() @ epk["ll"].W1[:, :nf].t())
 
         # The neighbour searches that depend on the pose - ligand radius graph, ligand<-receptor, ligand<-atom and the heads'
         # bond-centre graphs - are COUNTED first and share one host synchronisation (G.resolve); the heads' graphs are
@@ -885,6 +1029,9 @@ class TensorProductScoreModel(nn.Module):
         #    source-ordered edge lists - and the resulting node update is added to every graph.
         # Any difference between the graphs -> the general path.
         shared0 = {}
+        dbg = self.debug_conv_outputs
+        if dbg is not None:
+            one_time = False
         if one_time and not atoms_alike:
             sh_ = self._cached("shared0_rec", (rec.x, rpos, rr),
                                lambda: self._shared_receptor_side(B, rec, atom, rpos, apos, lay_r, lay_a, rr, ar, aa, atoms=False))
@@ -908,11 +1055,8 @@ class TensorProductScoreModel(nn.Module):
 
         mark("graphs")
         # ---- edge featurisation (the per-node `pre` tables were prepared ahead of the searches, see above)
-        pk = epk["ll"]
-        pre_ll = pre["ll"][ll[0]]
-        pre_ll[:bond_ei.shape[1]].add_(bond_pre)
-        e_ll, sh_ll = _edge_featurize(pk, self.lig_distance_expansion, lpos, ll32[0], lpos, ll32[1], pre_ll,
-                                      G.iota32(ll.shape[1], dev))
+        e_ll, sh_ll = _edge_featurize(epk["ll"], self.lig_distance_expansion, lpos, ll32[0], lpos, ll32[1], pre["ll"], ll32[0],
+                                      pre2=bond_pre)
         e_rr, sh_rr = _edge_featurize(epk["rr"], self.rec_distance_expansion, rpos, rr32[0], rpos, rr32[1], pre["rr"], rr32[0])
         e_aa, sh_aa = _edge_featurize(epk["aa"], self.lig_distance_expansion, apos, aa32[0], apos, aa32[1], pre["aa"], aa32[0])
         e_lr, sh_lr = _edge_featurize(epk["lr"], self.cross_distance_expansion, lpos, lr32[0], rpos, lr32[1], pre["lr"], lr32[0])
@@ -1088,7 +1232,7 @@ class TensorProductScoreModel(nn.Module):
         # that is already queued when the plan arrives simply runs unpruned (always exact).
         pruned, pruned_so = {}, {}
         prune_on = (self.prune_last_receptor_layer and L_ >= 2 and not self.confidence_mode
-                    and c_aa.n_edges >= self.plan_min_edges)
+                    and c_aa.n_edges >= self.plan_min_edges and dbg is None)
         prune_after = (L_ - 4) if (prune_on and self.prune_async and L_ >= 4 and self.before_layers is None) else None
         if prune_on and prune_after is None:
             pruned, pruned_so = prune_plan()
@@ -1217,6 +1361,15 @@ class TensorProductScoreModel(nn.Module):
             _launch_convs(spec_g, tasks_g, flops_spec=spec, node_bytes=nb_g)
             _launch_convs(spec, tasks, node_bytes=nb_d)
             mark("conv_launch")
+            if dbg is not None:   # every conv's own output = segmented mean + BatchNorm of its messages alone
+                for k, ent in msgs.items():
+                    n_k = nodes[plan[k][6]][1]
+                    if ent[1].n_edges == 0:
+                        dbg[f"conv_layers.{9 * l + k}"] = torch.zeros((), device=dev)
+                        continue
+                    o_k = torch.zeros((n_k, spec.d_out), device=dev)
+                    _launch_reduce(o_k, spec.d_out, n_k, spec.d_out, [ent], accumulate=False)
+                    dbg[f"conv_layers.{9 * l + k}"] = o_k
             for rt in ("l", "a", "r"):
                 if active[rt]:
                     x, n = nodes[rt]
@@ -1257,8 +1410,7 @@ class TensorProductScoreModel(nn.Module):
         # one ulp in the centre is one ulp in tr / rot - seen as run-to-run differences at the full size)
         center = lay_l.dense(lpos, 0.0).sum(1) / cnt
         pk = self._edge_pack("center_edge_embedding", slice(0, dd), dev)
-        pre_c = torch.addmm(pk.b1, lig.node_sigma_emb, pk.W1[:, dd:dd + sd_].t())
-        e_c, sh_c = _edge_featurize(pk, self.center_distance_expansion, center, i32(lbatch), lpos, i32(ar_l), pre_c, i32(ar_l))
+        e_c, sh_c = _edge_featurize(pk, self.center_distance_expansion, center, i32(lbatch), lpos, i32(ar_l), pre["center"], i32(ar_l))
         c_c = self._cached("c_c", (lbatch,), lambda: G.build_csr(lbatch, ar_l, B, presorted=True))
         if pend_tor is not None:
             head_tor = self._torsion_finish(pend_tor, dev)
@@ -1271,6 +1423,8 @@ class TensorProductScoreModel(nn.Module):
         _launch_convs(fspec, [_make_task(pkc, xl, ldx, c_c, sh_c, [(e_c, c_c.eid, ns, ns), (xl, seg_idx, ldx, ns)], msg)])
         gp = torch.zeros((B, fspec.d_out), device=dev)
         _launch_reduce(gp, fspec.d_out, B, fspec.d_out, [(msg, c_c, pkc)], accumulate=False)
+        if dbg is not None:
+            dbg["final_conv"] = gp
         tr_pred = gp[:, :3] + gp[:, 6:9]
         rot_pred = gp[:, 3:6] + gp[:, 9:]
         data.graph_sigma_emb = self.timestep_emb_func(data.complex_t["tr"])
@@ -1287,14 +1441,14 @@ class TensorProductScoreModel(nn.Module):
         if head_tor is None:
             tor_pred = torch.empty(0, device=dev)
         else:
-            tor_pred = self._torsion_apply(self.tor_bond_conv, self.tor_final_layer, head_tor, xl, dev)
+            tor_pred = self._torsion_apply(self.tor_bond_conv, self.tor_final_layer, head_tor, xl, dev, "tor_bond_conv")
             if self.scale_by_sigma:
                 edge_sigma = tor_sigma[lbatch][bond_ei[0]][rot_bond_idx]
                 tor_pred = tor_pred * torch.sqrt(self._torus_score_norm(edge_sigma))
         if head_sc is None:
             sc_pred = torch.empty(0, device=dev)
         else:
-            sc_pred = self._torsion_apply(self.sc_tor_bond_conv, self.sc_tor_final_layer, head_sc, xa, dev)
+            sc_pred = self._torsion_apply(self.sc_tor_bond_conv, self.sc_tor_final_layer, head_sc, xa, dev, "sc_tor_bond_conv")
             if self.scale_by_sigma:
                 sc_pred = sc_pred * torch.sqrt(self._torus_score_norm(sc_sigma[data["flexResidues"].batch.long()]))
         mark("tor_heads")
@@ -1330,7 +1484,7 @@ class TensorProductScoreModel(nn.Module):
         csr = G.build_csr(r32[0], r32[1], T, presorted=True)
         return {"bonds": bonds, "T": T, "E": E, "e_t": e_t, "tor_sh": tor_sh, "csr": csr}
 
-    def _torsion_apply(self, conv: TensorProductConvLayer, final_layer, tg, x, dev):
+    def _torsion_apply(self, conv: TensorProductConvLayer, final_layer, tg, x, dev, name=None):
         """FullTensorProduct + tor_bond_conv + final layer (:386-434) on the graph of _torsion_graph; no host sync."""
         ns, ldx = self.ns, self._ldx
         bonds, csr, T, E = tg["bonds"], tg["csr"], tg["T"], tg["E"]
@@ -1341,4 +1495,6 @@ class TensorProductScoreModel(nn.Module):
         _launch_convs(spec, [_make_task(pkc, x, ldx, csr, tg["tor_sh"], segs, msg)])
         h = torch.zeros((T, spec.d_out), device=dev)
         _launch_reduce(h, spec.d_out, T, spec.d_out, [(msg, csr, pkc)], accumulate=False)
+        if self.debug_conv_outputs is not None and name:
+            self.debug_conv_outputs[name] = h
         return final_layer(h).squeeze(1)

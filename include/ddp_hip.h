@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DDP_ABI_VERSION 6
+#define DDP_ABI_VERSION 7
 #define DDP_EINVAL (-1)   /* bad argument (shape not supported, null pointer, ...) */
 #define DDP_ELIMIT (-2)   /* exceeds a compiled-in limit (see DDP_MAX_*) */
 
@@ -149,15 +149,19 @@ int ddp_segment_reduce(float* x, int ldx, int n_nodes, int d_out, const ddp_redu
 /* Edge featurisation: edge vector -> length -> Gaussian RBF -> 2-layer MLP, and spherical harmonics (lmax=1).
  *   vec = pos_b[ib[e]] - pos_a[ia[e]];  d = |vec|;  rbf_k = exp(coeff * (d - offset[k])^2)
  *   hidden = relu(pre[pre_idx[e]] + W1d^T rbf);  out[e] = W2^T hidden + b2;  sh[e] = [1, sqrt(3) vec/|vec|]
- * `pre` holds the part of the first Linear that does not depend on the distance (sigma embedding, bond type, bias).
+ * `pre` holds the part of the first Linear that does not depend on the distance (sigma embedding, bias): rows of ld_pre floats
+ * (ddp_node_linear writes them per node); `pre2` (optional) is a second table whose row e is added for the edges e < n_pre2
+ * (the bond-type columns for the bonds, which come first in the ligand edge list, all_atom_score_model.py:462-468).
+ * n_edges_dev (optional, device memory): the actual edge count, read by the kernel; n_edges is then the capacity of the edge
+ * arrays (see "Device-side counts" below).
  * Replaces GaussianSmearing (models/score_model.py:661-671), o3.spherical_harmonics and the *_edge_embedding MLPs
  * (models/all_atom_score_model.py:71-81,164-169,187-192,212-217 and the builders :444-636).
  * w1d: [k_rbf, 64] (zero padded columns), w2: [64, 64] (zero padded), b2: [64]; out: [E, ns]; sh: [E, 4]; vec_out
  * (optional, may be null): [E, 4] = (vec, d). */
 int ddp_edge_featurize(const float* pos_a, const int32_t* ia, const float* pos_b, const int32_t* ib, int n_edges,
-                       const float* offset, int k_rbf, float coeff, const float* pre, const int32_t* pre_idx, int ld_pre,
-                       const float* w1d, const float* w2, const float* b2, int ns, float* out, float* sh,
-                       void* stream);
+                       const int32_t* n_edges_dev, const float* offset, int k_rbf, float coeff, const float* pre,
+                       const int32_t* pre_idx, int ld_pre, const float* pre2, int n_pre2, int ld_pre2, const float* w1d,
+                       const float* w2, const float* b2, int ns, float* out, float* sh, void* stream);
 
 /* Torsion-head edge harmonics: the 1o block of FullTensorProduct(sh(edge), Y2(bond)) in closed form,
  *   t[e] = sqrt(3/2) * (3 (n.v) v - n),  n = unit(sh edge vector), v = unit(bond vector of bond ib[e])
@@ -227,6 +231,47 @@ int ddp_knn(const float* x, const int32_t* x_ptr, const int32_t* batch, int n, i
 int ddp_group_by_key(const int32_t* key, int n_items, int n_keys, const int32_t* pay0, const int32_t* pay1, const int32_t* pay2,
                      int32_t* rowptr, int32_t* perm, int32_t* out_key, int32_t* out0, int32_t* out1, int32_t* out2,
                      int32_t* scratch, void* stream);
+
+/* ---- node encoders + sigma-dependent columns of the edge-embedding MLPs (csrc/ddp_node.hip), one launch for all jobs.
+ * A job is a gathered-row Linear over n_rows nodes:
+ *   out[n, :ncols] = (emb_mode == 2 ? emb_sum(n) : 0) + bias + [ emb_sum(n) | dense[0](n) | dense[1](n) | sigma_emb(n) ] @ w
+ *   emb_sum(n)   = sum_f table[feat_off[f] + cat[n, f]]  in feature order, emb_dim wide   (models/score_model.py:75-76)
+ *                  emb_mode 0: absent; 1: a K segment of the Linear (AtomEncoder, :78-80); 2: added to the result instead
+ *                  (OldAtomEncoder: x_embedding += linear(scalars), :46-47; emb_dim >= ncols)
+ *   dense[d](n)  = dense[d][n * ld_dense[d] .. + n_dense[d])   (the ESM block of the receptor, :80 / :50)
+ *   sigma_emb(n) = sig_emb[n * ld_sig .. + sd) if sig_emb is given, otherwise the sinusoidal timestep embedding of
+ *                  utils/diffusion_utils.py:73-84,106 evaluated in the kernel: a = scale * t[n * t_stride];
+ *                  [sin(a * freq[k]) | cos(a * freq[k]) | 0 if sd is odd], k < sd / 2, freq = exp(-k ln(10000) / (sd/2 - 1))
+ *                  handed over as a device array (t_stride = 0: one time for all rows)
+ *   w            = [K, ncols] row-major (the nn.Linear weight transposed), K = the widths of the present segments in the
+ *                  order above; bias [ncols] or NULL.  Columns [ncols, zero_to) of out are set to 0 (zero_to <= 0: none):
+ *                  the node-feature rows are allocated at their final irreps width (all_atom_score_model.py:315-324 pads).
+ * Also used for OldAtomEncoder's second stage (lm_embedding_layer over [x_embedding | ESM], :48-50: two dense parts). */
+#define DDP_MAX_NODE_JOBS 8
+#define DDP_MAX_NODE_CAT 16
+typedef struct {
+  int32_t n_rows;
+  const int32_t* cat;      /* [n_rows, ld_cat] categorical features (n_cat used columns) */
+  int32_t ld_cat, n_cat;
+  const float* table;      /* all embedding tables of the encoder stacked row-wise, [sum dims, emb_dim] */
+  int32_t feat_off[DDP_MAX_NODE_CAT]; /* first table row of feature f */
+  int32_t emb_dim, emb_mode;
+  const float* dense[2];
+  int32_t ld_dense[2], n_dense[2];
+  const float* t;          /* diffusion time per row (node_t['tr'], all_atom_score_model.py:453,495,520) */
+  int32_t t_stride;
+  float scale;             /* embedding_scale */
+  const float* freq;       /* [sd / 2] */
+  const float* sig_emb;    /* precomputed embedding instead of (t, scale, freq), or NULL */
+  int32_t ld_sig, sd;
+  float* sig_out;          /* optional: the sigma embedding rows are also written here (data[node type].node_sigma_emb) */
+  int32_t ld_sig_out;
+  const float* w;
+  const float* bias;
+  float* out;
+  int32_t ld_out, ncols, zero_to;
+} ddp_node_job_t;
+int ddp_node_linear(const ddp_node_job_t* jobs, int njobs, void* stream);
 
 int ddp_abi_version(void);
 const char* ddp_last_error(void);

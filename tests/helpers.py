@@ -48,6 +48,33 @@ def elementwise_excess(a, b, rtol=1e-4, atol_frac=1e-6):
     return float(((a - b).abs() / bound).max())
 
 
+def rowwise_excess(a, b, rtol=1e-4, atol_frac=1e-6):
+    """Per-row parity metric for the [B, 3] tr / rot score arrays: one graph with a large score must not hide an error on a
+    graph with a small one.  max over rows of |a_row - b_row|_inf / (rtol * |b_row|_inf + atol_frac * max|b|); <= 1 passes."""
+    if a.numel() == 0 and b.numel() == 0:
+        return 0.0
+    assert a.shape == b.shape, (a.shape, b.shape)
+    a, b = a.double().reshape(a.shape[0], -1), b.double().reshape(b.shape[0], -1)
+    bound = rtol * b.abs().amax(1) + atol_frac * b.abs().max().clamp_min(1e-30)
+    return float(((a - b).abs().amax(1) / bound).max())
+
+
+def conv_stats_excess(got, stats, rtol=1e-4, atol_frac=1e-4):
+    """Compares one conv output [n, d] of the HIP model with the golden `conv_stats` entry the reference's forward hook left
+    (oracle/make_golden.py: shape, mean|.|, a 64-point strided sample of the flattened output).  Returns the worst ratio of
+    |sample difference| to (rtol * |ref| + atol_frac * mean|ref|) and the relative difference of mean|.|."""
+    import torch
+    assert list(got.shape) == list(stats["shape"]), (tuple(got.shape), stats["shape"])
+    flat = got.reshape(-1).double().cpu()
+    ref = stats["sample"].double()
+    if flat.numel() > ref.numel():
+        flat = flat[torch.linspace(0, flat.numel() - 1, ref.numel()).long()]
+    bound = rtol * ref.abs() + atol_frac * max(stats["mean_abs"], 1e-30)
+    worst = float(((flat - ref).abs() / bound).max()) if ref.numel() else 0.0
+    mean_rel = abs(float(got.abs().mean()) - stats["mean_abs"]) / max(stats["mean_abs"], 1e-30) if got.numel() else 0.0
+    return worst, mean_rel
+
+
 class PyGLikeStore:
     """Storage of PyGLikeBatch: attributes live in a mapping; `len` = number of attributes, `in` by attribute name."""
 

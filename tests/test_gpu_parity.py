@@ -11,7 +11,7 @@ from oracle import thirdparty as tp
 from oracle.cases import CASES
 from oracle.ref_model import OracleConfig, OracleScoreModel, gaussian_smearing
 
-from helpers import case_inputs, elementwise_excess, rel_err
+from helpers import case_inputs, conv_stats_excess, elementwise_excess, rel_err, rowwise_excess
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -53,6 +53,9 @@ def test_forward_matches_oracle_and_golden(name):
         if k in ("tor", "sc_tor"):   # per-bond arrays: every element on its own, |d| <= 1e-4 |ref| + ATOL_FRAC max|ref|
             assert elementwise_excess(g, w, TOL, ATOL_FRAC) <= 1.0, (name, k, "element-wise vs oracle", elementwise_excess(g, w, TOL, ATOL_FRAC))
             assert elementwise_excess(g, gold["outputs"][k], TOL, ATOL_FRAC) <= 1.0, (name, k, "element-wise vs golden")
+        if k in ("tr", "rot"):       # per graph: |d_row|_inf <= 1e-4 |ref_row|_inf + ATOL_FRAC max|ref|
+            assert rowwise_excess(g, w, TOL, ATOL_FRAC) <= 1.0, (name, k, "row-wise vs oracle", rowwise_excess(g, w, TOL, ATOL_FRAC))
+            assert rowwise_excess(g, gold["outputs"][k], TOL, ATOL_FRAC) <= 1.0, (name, k, "row-wise vs golden")
     st = model.last_stats
     assert st["E_aa"] == gold["edge_counts"]["aa"]
     assert st["E_lr"] == int(oracle.record["lr"].shape[1]) and st["E_la"] == int(oracle.record["la"].shape[1])
@@ -88,7 +91,7 @@ def test_bench_batch_samples_match_oracle(flex):
     """BASELINE configs[1] (rigid receptor) / configs[2] (flexible side chains) exactly as bench.py runs them: the 40-sample
     batch of the full 3dpf complex through the cfg2 model (ns=60 nv=10 L=6), built by bench.build_model / the sampler with
     bench.py's seeds.  One HIP forward of the whole batch at the first schedule position and one after ten denoising
-    steps (mid schedule: other cutoffs, other edge sets, moved side chains); samples 0, 17 and 39 of each are compared
+    steps (mid schedule: other cutoffs, other edge sets, moved side chains); eight samples of each are compared
     with the CPU oracle run on those three graphs alone (reference semantics: a graph's scores do not depend on its
     batch mates)."""
     import bench
@@ -107,7 +110,7 @@ def test_bench_batch_samples_match_oracle(flex):
     smp = Sampler(model, g, 40, dev, SamplerConfig(inference_steps=20, flexible_sidechains=flex), seed=0)
     smp.randomize()
     sched = get_t_schedule(20)
-    picks = [0, 17, 39]
+    picks = [0, 5, 11, 17, 23, 29, 34, 39]
     for t_idx in (0, 10):
         while getattr(smp, "_steps_done", 0) < t_idx:
             smp.step(getattr(smp, "_steps_done", 0), sched)
@@ -134,6 +137,98 @@ def test_bench_batch_samples_match_oracle(flex):
             assert rel_err(a, w) < TOL, (flex, t_idx, k, rel_err(a, w))
             if k in ("tor", "sc_tor"):
                 assert elementwise_excess(a, w, TOL, ATOL_FRAC) <= 1.0, (flex, t_idx, k, elementwise_excess(a, w, TOL, ATOL_FRAC))
+            if k in ("tr", "rot"):
+                assert rowwise_excess(a, w, TOL, ATOL_FRAC) <= 1.0, (flex, t_idx, k, rowwise_excess(a, w, TOL, ATOL_FRAC))
+
+
+@pytest.mark.parametrize("name", ["cfg2_full_noflex", "cfg2_full_flex", "cfg1_full", "ns24_l3"])
+def test_every_conv_output_matches_the_reference_hooks(name):
+    """The goldens hold, for every conv call of the reference's forward (forward hooks on conv_layers[0..9L), final_conv,
+    tor_bond_conv, sc_tor_bond_conv: oracle/make_golden.py), the output shape, mean|.| and a 64-point strided sample.  The HIP
+    model's debug hook returns the same tensors (segmented mean + BatchNorm of each conv's messages alone); parity at the
+    four outputs alone could hide a wrong block behind the BatchNorm-ed residual sums."""
+    case, gold, batch, sd = case_inputs(name)
+    model = _model_for(case, sd)
+    model.debug_conv_outputs = {}
+    model(batch.to(_dev()))
+    torch.cuda.synchronize()
+    stats = gold["conv_stats"]
+    assert set(model.debug_conv_outputs) == set(stats), (sorted(set(stats) ^ set(model.debug_conv_outputs)))
+    worst = {}
+    for key, st in stats.items():
+        w, m = conv_stats_excess(model.debug_conv_outputs[key], st, rtol=TOL, atol_frac=TOL)
+        worst[key] = (w, m)
+    bad = {k: v for k, v in worst.items() if v[0] > 1.0 or v[1] > TOL}
+    assert not bad, (name, bad)
+
+
+@pytest.mark.parametrize("name", ["cfg2_small", "cfg1_edge", "ns24_l3", "cfg2_full_noflex"])
+def test_node_encoders_and_sigma_tables_match_oracle(name):
+    """AtomEncoder / OldAtomEncoder (models/score_model.py:54-82, :17-52), the sinusoidal sigma
+    embedding (utils/diffusion_utils.py:73-84) and the node-dependent part of the edge-embedding MLPs' first Linear, all from
+    ONE ddp_node_linear launch (csrc/ddp_node.hip, fp32 MFMA), against the oracle's restatement on the same batch.
+    cfg1_edge is the legacy encoder with an ESM block (two stages, literal legacy column slicing)."""
+    from diffdock_pocket_amd.synthetic import LIG_FEATURE_DIMS, REC_ATOM_FEATURE_DIMS, REC_RESIDUE_FEATURE_DIMS
+    case, gold, batch, sd = case_inputs(name)
+    dev = _dev()
+    oracle = OracleScoreModel(case.oracle_config(), sd)
+    model = _model_for(case, sd)
+    b = batch.to(dev)
+    xl, xr, xa, pre = model._node_tables(b["ligand"], b["receptor"], b["atom"], dev)
+    torch.cuda.synchronize()
+    cb = case.make_batch()
+    ns, sdim = model.ns, model.sigma_embed_dim
+    embs = {}
+    for nt, prefix, ncat, x in (("ligand", "lig_node_embedding", len(LIG_FEATURE_DIMS), xl),
+                                ("receptor", "rec_node_embedding", len(REC_RESIDUE_FEATURE_DIMS), xr),
+                                ("atom", "atom_node_embedding", len(REC_ATOM_FEATURE_DIMS), xa)):
+        st = cb[nt]
+        emb = embs[nt] = oracle._emb(st.node_t["tr"])
+        want = oracle._atom_encoder(prefix, torch.cat([st.x.float(), emb], 1), ncat)
+        got = x.cpu()
+        assert got.shape == (st.x.shape[0], model._ldx)
+        assert rel_err(got[:, :ns], want) < 2e-5, (nt, rel_err(got[:, :ns], want))
+        assert float(got[:, ns:].abs().max()) == 0.0                       # the irreps of later layers start at zero
+        assert float((b[nt].node_sigma_emb.cpu() - emb).abs().max()) < 2e-6, nt   # the side effect the reference leaves
+    nf, dd = model.in_lig_edge_features, model.distance_embed_dim
+    for key, mlp, nt, s0 in (("ll", "lig_edge_embedding", "ligand", nf), ("lr", "lr_edge_embedding", "ligand", 0),
+                             ("la", "la_edge_embedding", "ligand", 0), ("rr", "rec_edge_embedding", "receptor", 0),
+                             ("aa", "atom_edge_embedding", "atom", 0), ("ar", "ar_edge_embedding", "atom", 0),
+                             ("center", "center_edge_embedding", "ligand", dd)):
+        W, bias = sd[mlp + ".0.weight"], sd[mlp + ".0.bias"]
+        want = embs[nt].double() @ W[:, s0:s0 + sdim].t().double() + bias.double()
+        assert rel_err(pre[key].cpu(), want.float()) < 2e-5, (key, rel_err(pre[key].cpu(), want.float()))
+
+
+def test_weight_edits_through_param_data_invalidate_the_packed_weights():
+    """The reference's EMA writes weights with `param.data.copy_` (utils/utils.py:216,239), which no autograd version counter
+    sees.  After a first forward (packed weights, stage-A stacks and edge packs built) an `fc.3.weight`, an edge-embedding
+    weight and a BatchNorm buffer are overwritten through `.data`: the next forward must equal, bit for bit, a fresh model
+    loaded with the edited weights - and an unchanged model must keep its packed weights (no repacking per call)."""
+    case, gold, batch, sd = case_inputs("cfg2_small")
+    dev = _dev()
+    model = _model_for(case, sd)
+    b = case.make_batch().to(dev)
+    out0 = [t.clone() for t in model(b)]
+    packed_before = model.conv_layers[0]._packed
+    out0b = [t.clone() for t in model(b)]
+    assert model.conv_layers[0]._packed is packed_before            # nothing changed: caches kept
+    assert all(torch.equal(x, y) for x, y in zip(out0, out0b))
+    g = torch.Generator().manual_seed(5)
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    for key in ("conv_layers.4.fc.3.weight", "lig_edge_embedding.0.weight", "conv_layers.1.batch_norm.running_var"):
+        sd2[key] = sd2[key] * (1.0 + 0.2 * torch.rand(sd2[key].shape, generator=g))
+    params = dict(model.named_parameters())
+    params.update(dict(model.named_buffers()))
+    for key in ("conv_layers.4.fc.3.weight", "lig_edge_embedding.0.weight", "conv_layers.1.batch_norm.running_var"):
+        v0 = params[key]._version
+        params[key].data.copy_(sd2[key].to(dev))
+        assert params[key]._version == v0                           # invisible to the version counters
+    out1 = [t.clone() for t in model(b)]
+    fresh = _model_for(case, sd2)
+    want = fresh(case.make_batch().to(dev))
+    assert all(torch.equal(x, y) for x, y in zip(out1, want))
+    assert not all(torch.equal(x, y) for x, y in zip(out1, out0))
 
 
 @pytest.mark.parametrize("name", ["cfg2_small", "cfg1_edge"])
@@ -573,7 +668,10 @@ def test_csv_driver_on_device(tmp_path):
     model = _model_for(case, case_inputs(case.name)[3])
     conf_case = CASES["conf_ns24_l5"]
     conf_model = _model_for(conf_case, case_inputs(conf_case.name)[3])
-    n_res = INF.build_row_graph(INF.load_protein_ligand_csv(str(csv_path))[0], root=gdir)["receptor"].x.shape[0]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        n_res = INF.build_row_graph(INF.load_protein_ligand_csv(str(csv_path))[0], root=gdir, allow_zero_esm=True)["receptor"].x.shape[0]
     esm = {k: torch.randn(n_res, 1280, generator=torch.Generator().manual_seed(i)) for i, k in enumerate("ab")}
 
     def run():

@@ -49,7 +49,7 @@ def _write_csv(tmp_path):
 
 def _run(csv_path, rank=0, world=1, dist=None, shard="samples"):
     return INF.run_csv(csv_path, Stub(), torch.device("cpu"), confidence_model=StubConfidence(), samples_per_complex=5,
-                       inference_steps=3, root=GOLDEN, seed=2, rank=rank, world=world, dist=dist, shard=shard)
+                       inference_steps=3, root=GOLDEN, seed=2, rank=rank, world=world, dist=dist, shard=shard, allow_zero_esm=True)
 
 
 def test_rows_are_cleaned_like_the_reference_loader(tmp_path):
@@ -67,6 +67,48 @@ def test_csv_run_ranks_poses_and_skips_unreadable_rows(tmp_path):
         assert r.skipped is None and r.ligand_pos.shape[0] == 5 and torch.isfinite(r.ligand_pos).all()
         assert sorted(r.order.tolist()) == [0, 1, 2, 3, 4]
         assert bool((r.confidence[:-1] >= r.confidence[1:]).all())        # best first
+
+
+def test_rows_without_an_esm_embedding_are_skipped_unless_asked_for(tmp_path):
+    """A missing ESM embedding is not silently replaced by zeros: the row is reported as skipped with the reason."""
+    csv_path = _write_csv(tmp_path)
+    res = INF.run_csv(csv_path, Stub(), torch.device("cpu"), samples_per_complex=2, inference_steps=1, root=GOLDEN, seed=2)
+    assert all(r.skipped is not None and r.ligand_pos is None for r in res)
+    assert "no ESM embedding" in res[0].skipped and "SDF" in res[1].skipped
+    with pytest.warns(RuntimeWarning, match="ZERO language-model block"):
+        INF.build_row_graph(INF.load_protein_ligand_csv(csv_path)[0], root=GOLDEN, allow_zero_esm=True)
+
+
+def test_full_structure_esm_embeddings_are_sliced_to_the_kept_residues(tmp_path):
+    """ESM files cover the whole chain; the reference slices them with its kept-residue mask (process_mols.py:389-397).  Per-chain
+    arrays, one concatenated array and the exact kept rows must give the same receptor block."""
+    from diffdock_pocket_amd import inputs as I
+    pdb, sdf = open(os.path.join(GOLDEN, "3dpf_protein.pdb")).read(), open(os.path.join(GOLDEN, "3dpf_ligand.sdf")).read()
+    res = I.parse_pdb(pdb)
+    g0 = I.build_complex_graph(pdb, sdf)
+    mol = I.parse_sdf(sdf)
+    import numpy as np
+    centre, radius = I.binding_pocket(np.array([r.atom("CA").coord for r in res if r.atom("CA") is not None], dtype=np.float32),
+                                      I.ligand_graph(mol)[1], 5.0, 0.0)
+    rec = I.extract_receptor(res, I.ligand_graph(mol)[1].astype(np.float64), pocket=(centre, radius + 10.0))
+    n_kept, total = len(rec.residues), sum(rec.chain_lengths)
+    assert n_kept == g0["receptor"].x.shape[0] and total > n_kept and len(rec.lm_index) == n_kept
+    gen = torch.Generator().manual_seed(0)
+    chains = [torch.randn(n, 1280, generator=gen) for n in rec.chain_lengths]
+    g_chain = I.build_complex_graph(pdb, sdf, lm_embeddings=chains)
+    g_full = I.build_complex_graph(pdb, sdf, lm_embeddings=torch.cat(chains, 0))
+    want = torch.stack([chains[c][i] for c, i in rec.lm_index])
+    g_kept = I.build_complex_graph(pdb, sdf, lm_embeddings=want)
+    for g in (g_chain, g_full, g_kept):
+        assert g["receptor"].x.shape == (n_kept, 1281) and torch.equal(g["receptor"].x[:, 1:], want)
+    with pytest.raises(ValueError):
+        I.build_complex_graph(pdb, sdf, lm_embeddings=torch.zeros(n_kept + 1, 1280))
+    # through the csv driver: a full-structure file is accepted
+    csv_path = _write_csv(tmp_path)
+    row = INF.load_protein_ligand_csv(csv_path)[2]
+    assert row["complex_name"] == "3dpf_rigid"
+    g = INF.build_row_graph(row, {"3dpf_rigid": torch.cat(chains, 0)}, GOLDEN)
+    assert torch.equal(g["receptor"].x[:, 1:], want)
 
 
 def _worker(rank, world, csv_path, port, q):
