@@ -18,7 +18,8 @@ FS = 68  # feature-buffer row stride of ddp_conv.hip
 
 DDP_MAX_GEMM_BATCH = 16
 EXPORTS = ["ddp_conv_messages", "ddp_segment_reduce", "ddp_edge_featurize", "ddp_torsion_sh", "ddp_stage_a",
-           "ddp_pose_update", "ddp_sidechain_update", "ddp_radius_count", "ddp_radius_fill", "ddp_knn", "ddp_group_by_key", "ddp_node_linear", "ddp_abi_version", "ddp_last_error", "ddp_source_hash"]
+           "ddp_pose_update", "ddp_sidechain_update", "ddp_radius_count", "ddp_radius_fill", "ddp_knn", "ddp_group_by_key", "ddp_node_linear", "ddp_scan_jobs", "ddp_mark_jobs", "ddp_rowcopy_jobs", "ddp_select_jobs",
+           "ddp_gather_rows", "ddp_clean_pair_maps", "ddp_radius_search_jobs", "ddp_group_by_key_jobs", "ddp_abi_version", "ddp_last_error", "ddp_source_hash"]
 
 
 class Seg(C.Structure):
@@ -51,15 +52,47 @@ class ConvTask(C.Structure):
                 ("seg_idx", C.c_void_p * DDP_MAX_SEGS), ("seg_ld", C.c_int32 * DDP_MAX_SEGS),
                 ("seg_n", C.c_int32 * DDP_MAX_SEGS), ("w1p", C.c_void_p), ("b1p", C.c_void_p), ("w2p", C.c_void_p),
                 ("b2p", C.c_void_p), ("msg", C.c_void_p), ("g", C.c_void_p * 2),
-                ("pos", C.c_void_p)]
+                ("pos", C.c_void_p), ("n_edges_dev", C.c_void_p)]
 
 
 class ReduceSrc(C.Structure):
     _fields_ = [("msg", C.c_void_p), ("rowptr", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p),
-                ("n_edges", C.c_int32), ("rowmap", C.c_void_p)]
+                ("n_edges", C.c_int32), ("rowmap", C.c_void_p), ("n_edges_dev", C.c_void_p)]
 
 
 DDP_MAX_NODE_JOBS, DDP_MAX_NODE_CAT = 8, 16
+DDP_MAX_LIST_JOBS = 12
+_P, _I = C.c_void_p, C.c_int32
+
+
+class ScanJob(C.Structure):
+    _fields_ = [("n", _I), ("n_dev", _P), ("flag", _P), ("val", _P), ("rowptr", _P), ("base", _I), ("excl", _P), ("excl2", _P),
+                ("list", _P), ("total", _P)]
+
+
+class MarkJob(C.Structure):
+    _fields_ = [("idx", _P), ("n", _I), ("n_dev", _P), ("mask", _P)]
+
+
+class RowcopyJob(C.Structure):
+    _fields_ = [("n_rows", _I), ("keep", _P), ("old_rowptr", _P), ("new_rowptr", _P), ("inp", _P * 3), ("out", _P * 3)]
+
+
+class SelectJob(C.Structure):
+    _fields_ = [("n", _I), ("n_dev", _P), ("mask_a", _P), ("idx_a", _P), ("mask_b", _P), ("idx_b", _P), ("out_idx", _P),
+                ("pay", _P * 4), ("pay_add", _I * 4), ("out", _P * 4), ("total", _P), ("block_count", _P), ("block_off", _P)]
+
+
+class RadiusJob(C.Structure):
+    _fields_ = [("x", _P), ("x_ptr", _P), ("y", _P), ("y_batch", _P), ("ny", _I), ("r", C.c_float), ("max_neighbors", _I),
+                ("flags", _I), ("graph_div", _P), ("counts", _P), ("offsets", _P), ("base", _I), ("total", _P), ("out_query", _P),
+                ("out_x", _P), ("capacity", _I)]
+
+
+class GroupJob(C.Structure):
+    _fields_ = [("key", _P), ("n_items", _I), ("n_items_dev", _P), ("n_keys", _I), ("pay", _P * 3), ("rowptr", _P), ("perm", _P),
+                ("out_key", _P), ("out", _P * 3), ("key_map", _P), ("scratch", _P)]
+
 
 
 class NodeJob(C.Structure):
@@ -102,16 +135,16 @@ def load():
     lib.ddp_conv_messages.argtypes = [C.POINTER(ConvShape), C.POINTER(ConvTask), C.c_int, C.c_void_p]
     lib.ddp_conv_messages.restype = C.c_int
     lib.ddp_segment_reduce.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(ReduceSrc), C.c_int, C.c_int,
-                                       C.c_void_p]
+                                       C.c_int, C.c_int, C.c_void_p]
     lib.ddp_segment_reduce.restype = C.c_int
     lib.ddp_edge_featurize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ddp_edge_featurize.restype = C.c_int
-    lib.ddp_torsion_sh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.ddp_torsion_sh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ddp_torsion_sh.restype = C.c_int
-    lib.ddp_stage_a.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_int, C.c_int,
-                                C.c_void_p, C.c_int, C.c_void_p]
+    lib.ddp_stage_a.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_int,
+                                C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     lib.ddp_stage_a.restype = C.c_int
     lib.ddp_pose_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]
@@ -129,6 +162,15 @@ def load():
     lib.ddp_knn.restype = C.c_int
     lib.ddp_group_by_key.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 11
     lib.ddp_group_by_key.restype = C.c_int
+    for name, job in (("ddp_scan_jobs", ScanJob), ("ddp_mark_jobs", MarkJob), ("ddp_rowcopy_jobs", RowcopyJob),
+                      ("ddp_select_jobs", SelectJob), ("ddp_radius_search_jobs", RadiusJob), ("ddp_group_by_key_jobs", GroupJob)):
+        getattr(lib, name).argtypes = [C.POINTER(job), C.c_int, C.c_void_p]
+        getattr(lib, name).restype = C.c_int
+    lib.ddp_gather_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.ddp_gather_rows.restype = C.c_int
+    lib.ddp_clean_pair_maps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]
+    lib.ddp_clean_pair_maps.restype = C.c_int
     lib.ddp_node_linear.argtypes = [C.POINTER(NodeJob), C.c_int, C.c_void_p]
     lib.ddp_node_linear.restype = C.c_int
     if lib.ddp_abi_version() != 7:

@@ -206,4 +206,10 @@ def set_time(batch: HeteroBatch, t_tr, t_rot, t_tor, t_sc_tor, device=None) -> H
         if nt in batch:
             batch[nt].node_t = const(batch[nt].num_nodes)
     batch.complex_t = const(b)
+    # what the score model would otherwise have to ask the device (a host synchronisation per forward): do all receptor-side
+    # nodes sit at ONE translation time?  The hint names the tensors it describes (identity + version counter), so that time
+    # tensors edited or replaced afterwards are not covered by it.
+    if "receptor" in batch and "atom" in batch:
+        ts = (batch["receptor"].node_t["tr"], batch["atom"].node_t["tr"])
+        batch.ddp_time_hint = (tuple(id(t) for t in ts), tuple(t._version for t in ts), not torch.is_tensor(t_tr))
     return batch

@@ -58,6 +58,7 @@ struct ConvLaunch {
   ddp_conv_shape_t shape;
   int tv_off;   // 32-edge kernels: row stride (floats) of the LDS message tile; unused by the 64-edge kernel
   int ntasks;
+  int dev_counts;   // some task carries n_edges_dev: tile table rebuilt on the device (conv_tile)
   int tile_start[DDP_MAX_TASKS + 1];
   ddp_conv_task_t task[DDP_MAX_TASKS];
 };
@@ -830,9 +831,49 @@ __device__ __forceinline__ void run_block_rows(const ddp_conv_shape_t& S, const 
 // workgroup id -> tile.  XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), so
 // id -> tile is remapped to give every XCD one contiguous range of tiles: neighbouring tiles share source nodes (G rows,
 // x rows) and all tiles of a conv share its packed weights.
-__device__ __forceinline__ int xcd_tile() {
-  const int ntl = (int)gridDim.x, q = ntl >> 3, rem = ntl & 7, x = (int)blockIdx.x & 7;
+__device__ __forceinline__ int xcd_tile(int ntl) {
+  const int q = ntl >> 3, rem = ntl & 7, x = (int)blockIdx.x & 7;
   return ((x < rem) ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + ((int)blockIdx.x >> 3);
+}
+
+// workgroup -> (task, first edge, valid edges).  Host-side counts: the tile table of the launch.  Device-side counts
+// (ConvLaunch::dev_counts; include/ddp_hip.h "Device-side counts"): the grid covers the tasks' CAPACITIES, every workgroup
+// reads the actual edge counts, rebuilds the tile table from them and leaves if it lies behind the last tile - the XCD-aware
+// order is then the one of a launch of exactly that many tiles.
+template <int ET>
+__device__ __forceinline__ bool conv_tile(const ConvLaunch& L, int& t, int& p0, int& nvalid) {
+  if (!L.dev_counts) {
+    const int tile = xcd_tile((int)gridDim.x);
+    t = 0;
+    while (t + 1 < L.ntasks && tile >= L.tile_start[t + 1]) ++t;
+    p0 = (tile - L.tile_start[t]) * ET;
+    nvalid = min(ET, L.task[t].n_edges - p0);
+    return true;
+  }
+  int total = 0;
+  for (int i = 0; i < L.ntasks; ++i) {
+    const ddp_conv_task_t& T = L.task[i];
+    const int n = T.n_edges_dev ? max(0, min(*T.n_edges_dev, T.n_edges)) : T.n_edges;
+    total += (n + ET - 1) / ET;
+  }
+  if ((int)blockIdx.x >= total) return false;
+  const int tile = xcd_tile(total);
+  int base = 0;
+  t = 0;
+  p0 = 0;
+  nvalid = 0;
+  for (int i = 0; i < L.ntasks; ++i) {
+    const ddp_conv_task_t& T = L.task[i];
+    const int n = T.n_edges_dev ? max(0, min(*T.n_edges_dev, T.n_edges)) : T.n_edges;
+    const int nt = (n + ET - 1) / ET;
+    if (tile >= base && tile < base + nt) {
+      t = i;
+      p0 = (tile - base) * ET;
+      nvalid = min(ET, n - p0);
+    }
+    base += nt;
+  }
+  return true;
 }
 
 // phase 0: per-edge indices, harmonics, the units of the G pass, then the three row gathers of edge_attr_ into xa
@@ -993,12 +1034,9 @@ __global__ __launch_bounds__(512, 2) void ddp_conv_messages_kernel(const ConvLau
   __shared__ TileAux<ET> aux;
   const ddp_conv_shape_t& S = L.shape;
   const int tid = threadIdx.x;
-  const int tile = xcd_tile();
-  int t = 0;
-  while (t + 1 < L.ntasks && tile >= L.tile_start[t + 1]) ++t;
+  int t, p0, nvalid;
+  if (!conv_tile<ET>(L, t, p0, nvalid)) return;
   const ddp_conv_task_t& T = L.task[t];
-  const int p0 = (tile - L.tile_start[t]) * ET;
-  const int nvalid = min(ET, T.n_edges - p0);
   float* hbuf = lds;
   float* fbuf = lds + ET * S.hs;
   float* xa = fbuf;  // edge_attr_ staging aliases the feature buffer
@@ -1032,7 +1070,7 @@ __global__ __launch_bounds__(512, 2) void ddp_conv_messages_kernel(const ConvLau
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     ddp_stamp_buf[blockIdx.x * DDP_STAMP_SLOTS + 21] = ((unsigned long long)xcc << 32) | hw;
-    ddp_stamp_buf[blockIdx.x * DDP_STAMP_SLOTS + 37] = (unsigned long long)tile;
+    ddp_stamp_buf[blockIdx.x * DDP_STAMP_SLOTS + 37] = (unsigned long long)(p0 / ET);
   }
 #endif
 }
@@ -1098,12 +1136,9 @@ __global__ __launch_bounds__(256, 3) void ddp_conv32_kernel(const ConvLaunch L) 
   __shared__ int gmap[2][128];   // G column -> message column | (C << 16)
   const ddp_conv_shape_t& S = L.shape;
   const int tid = threadIdx.x;
-  const int tile = xcd_tile();
-  int t = 0;
-  while (t + 1 < L.ntasks && tile >= L.tile_start[t + 1]) ++t;
+  int t, p0, nvalid;
+  if (!conv_tile<ET>(L, t, p0, nvalid)) return;
   const ddp_conv_task_t& T = L.task[t];
-  const int p0 = (tile - L.tile_start[t]) * ET;
-  const int nvalid = min(ET, T.n_edges - p0);
   const int os = L.tv_off;       // row stride of the message tile
   float* hbuf = lds;
   float* rb = lds + ET * S.hs;   // region B: staging tile -> features -> message tile
@@ -1218,7 +1253,7 @@ __global__ __launch_bounds__(256, 3) void ddp_conv32_kernel(const ConvLaunch L) 
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     ddp_stamp_buf[blockIdx.x * DDP_STAMP_SLOTS + 21] = ((unsigned long long)xcc << 32) | hw;
-    ddp_stamp_buf[blockIdx.x * DDP_STAMP_SLOTS + 37] = (unsigned long long)tile;
+    ddp_stamp_buf[blockIdx.x * DDP_STAMP_SLOTS + 37] = (unsigned long long)(p0 / ET);
   }
 #endif
 }
@@ -1228,9 +1263,11 @@ template <int ET, typename K>
 static int launch_conv(K kernel, ConvLaunch& L, const ddp_conv_task_t* tasks, int ntasks, size_t lds_bytes, void* stream) {
   const ddp_conv_shape_t* shape = &L.shape;
   L.ntasks = 0;
+  L.dev_counts = 0;
   int tiles = 0;
   for (int i = 0; i < ntasks; ++i) {
     if (tasks[i].n_edges <= 0) continue;  // an empty conv sends no message (models/score_model.py:109-111)
+    if (tasks[i].n_edges_dev) L.dev_counts = 1;
     for (int gs = 0; gs < 2; ++gs)
       if (shape->g_cols[gs] > 0 && (!tasks[i].g[gs] || (reinterpret_cast<size_t>(tasks[i].g[gs]) & 15)))
         return ddp_fail(DDP_EINVAL, "ddp_conv_messages: factorised shape but task.g is null (or not 16-byte aligned)");

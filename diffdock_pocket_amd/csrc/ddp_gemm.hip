@@ -34,12 +34,16 @@ struct GemmOffs {
 // fetch it with scalar loads (through a pointer read from a struct it falls back to 60 per-lane loads per row: 5x slower).
 template <int KT, int CPL>
 __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_kernel(const float* __restrict__ x, int ldx, int nrows,
+                                                                           const int32_t* __restrict__ rows,
+                                                                           const int32_t* __restrict__ nrows_dev, int out_rows,
                                                                            const GemmOffs offs, const float* __restrict__ w,
                                                                            int k, int ncols, float* __restrict__ out, int ldo) {
   constexpr int KP = (KT > 0) ? KT / 2 : 32;                  // k pairs held in registers
   const int K = (KT > 0) ? KT : k;
   const int z = (int)blockIdx.z;
+  if (nrows_dev) nrows = min(nrows, *nrows_dev);              // device-side length of the row list (nrows = its capacity)
   const int r0 = (int)blockIdx.y * DDP_GEMM_ROWS;
+  if (r0 >= nrows) return;
   const int r1 = min(nrows, r0 + DDP_GEMM_ROWS);
   const int col = ((int)blockIdx.x * DDP_GEMM_THREADS + (int)threadIdx.x) * CPL;
   bool act[CPL];
@@ -62,9 +66,10 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_kernel(const 
     }
   }
   const bool vec = act[CPL - 1] && ((ldo & (CPL - 1)) == 0);     // aligned CPL-wide store
-  float* __restrict__ o = out + ((size_t)z * nrows + r0) * ldo + col;
-  const float* __restrict__ xr = x + (size_t)r0 * ldx + offs.off[z];   // wave-uniform: scalar loads
-  for (int j = r0; j < r1; ++j, xr += ldx, o += ldo) {
+  for (int j = r0; j < r1; ++j) {
+    const int row = rows ? rows[j] : j;                         // (wave-uniform: x row j arrives through scalar loads)
+    float* __restrict__ o = out + ((size_t)z * out_rows + row) * ldo + col;
+    const float* __restrict__ xr = x + (size_t)row * ldx + offs.off[z];
     f32x2 acc[CPL];                                             // even / odd k partial sums
 #pragma unroll
     for (int q = 0; q < CPL; ++q) acc[q] = f32x2{0.f, 0.f};
@@ -110,8 +115,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 template <int KT>
 __global__ __launch_bounds__(DDP_GEMM_THREADS, DDP_SA_WPE) void ddp_stage_a_mfma_kernel(const float* __restrict__ x, int ldx, int nrows,
+                                                                                const int32_t* __restrict__ rows,
+                                                                                const int32_t* __restrict__ nrows_dev, int out_rows,
                                                                                 const GemmOffs offs, const float* __restrict__ w,
                                                                                 int ncols, float* __restrict__ out, int ldo) {
+  if (nrows_dev) nrows = min(nrows, *nrows_dev);              // device-side length of the row list (nrows = its capacity)
+  if ((int)blockIdx.y * DDP_GEMM_MROWS >= nrows) return;
   constexpr int KH = KT / 2, CT = DDP_SA_CT;
   constexpr bool LAG = (4 + 3 * (KH / 4) <= KH - 1);   // room for the lagged stores between a block's MFMAs
   constexpr int XS = KT + 1;                                    // odd LDS row stride: conflict-free ds_read_b32 down a column
@@ -145,7 +154,8 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, DDP_SA_WPE) void ddp_stage_a_mfma
     for (int v = 0; v < NV; ++v) {
       const int i = tid + v * DDP_GEMM_THREADS;                 // piece i = (row i / (KT/4), quad i % (KT/4))
       const int rr = min(i / (KT / 4), 31), q = i % (KT / 4);
-      const float* __restrict__ p = xb + (size_t)min(row0 + rr, nrows - 1) * ldx + 4 * q;
+      const int ri = min(row0 + rr, nrows - 1);
+      const float* __restrict__ p = xb + (size_t)(rows ? rows[ri] : ri) * ldx + 4 * q;
       if (al4)
         xv[v] = *reinterpret_cast<const f32x4*>(p);
       else
@@ -166,6 +176,7 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, DDP_SA_WPE) void ddp_stage_a_mfma
   // pending block of this wave (parked in LDS, not yet written out)
   float* pend_ob = nullptr;
   int pend_c0 = 0, pend_rows = 0, pend_buf = 0, pbuf = 0;
+  int pend_ri[4] = {0, 0, 0, 0};   // out rows of this lane's four 16-byte pieces of the pending block
   f32x4 dv = {0.f, 0.f, 0.f, 0.f};
   auto drain_read = [&](int p) {
     if (pend_ob) dv = *reinterpret_cast<const f32x4*>(&st[wave][pend_buf][(8 * p + (lane >> 3)) * TS + 4 * (lane & 7)]);
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, DDP_SA_WPE) void ddp_stage_a_mfma
   auto drain_store = [&](int p) {
     if (pend_ob) {
       const int rr = 8 * p + (lane >> 3), c = pend_c0 + 4 * (lane & 7);
-      if (rr < pend_rows && c < ncols) *reinterpret_cast<f32x4*>(&pend_ob[(size_t)rr * ldo + c]) = dv;
+      if (rr < pend_rows && c < ncols) *reinterpret_cast<f32x4*>(&pend_ob[(size_t)pend_ri[p] * ldo + c]) = dv;
     }
   };
   fetch(R0);
@@ -192,7 +203,13 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, DDP_SA_WPE) void ddp_stage_a_mfma
     // one column tile at a time: its 32 x 32 block is stored while the next tile's MFMAs run (a single accumulator
     // chain already issues at the full rate: issue interval = dependent latency = 64 cycles); C/D layout: register i of
     // lane (r, hh) = out[row0 + (i&3) + 8*(i>>2) + 4*hh][col r], i.e. every store instruction writes two 128-byte row pieces
-    float* __restrict__ ob = out + ((size_t)z * nrows + row0) * ldo;
+    float* __restrict__ ob = out + (size_t)z * out_rows * ldo;   // the batch slice; row indices below are absolute
+    int blk_ri[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ri = min(row0 + 8 * p + (lane >> 3), R1 - 1);
+      blk_ri[p] = rows ? rows[ri] : ri;
+    }
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
       f32x16 acc;
@@ -218,6 +235,8 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, DDP_SA_WPE) void ddp_stage_a_mfma
 #pragma unroll
         for (int i = 0; i < 16; ++i) tl[((i & 3) + 8 * (i >> 2) + 4 * hh) * TS + r] = acc[i];
         pend_ob = ob;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) pend_ri[p] = blk_ri[p];
         pend_c0 = col0 + 32 * t;
         pend_rows = R1 - row0;
         pend_buf = pbuf;
@@ -236,7 +255,7 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, DDP_SA_WPE) void ddp_stage_a_mfma
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int rr = (i & 3) + 8 * (i >> 2) + 4 * hh;
-            if (row0 + rr < R1) ob[(size_t)rr * ldo + c] = acc[i];
+            if (row0 + rr < R1) ob[(size_t)(rows ? rows[row0 + rr] : row0 + rr) * ldo + c] = acc[i];
           }
         }
       }
@@ -253,8 +272,10 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, DDP_SA_WPE) void ddp_stage_a_mfma
   }
 }
 
-extern "C" int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* offs, int nbatch, const float* w, int k, int ncols,
-                           float* out, int ldo, void* stream) {
+extern "C" int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows,
+                           const int32_t* offs, int nbatch, const float* w, int k, int ncols, float* out, int ldo, void* stream) {
+  if (!rows) out_rows = nrows;                       // dense: out[b] has one row per x row
+  if (out_rows < 1 && nrows > 0) return ddp_fail(DDP_EINVAL, "ddp_stage_a: out_rows");
   if (nbatch < 0 || nbatch > DDP_MAX_GEMM_BATCH) return ddp_fail(DDP_ELIMIT, "ddp_stage_a: nbatch > DDP_MAX_GEMM_BATCH");
   if (k < 2 || k > 64 || (k & 1)) return ddp_fail(DDP_ELIMIT, "ddp_stage_a: K must be even and in [2, 64]");
   if (ncols < 1 || nrows < 0 || ldo < ncols) return ddp_fail(DDP_EINVAL, "ddp_stage_a: ncols / nrows / ldo");
@@ -268,11 +289,11 @@ extern "C" int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* of
   const int nry = (nrows + DDP_GEMM_ROWS - 1) / DDP_GEMM_ROWS;
 #define DDP_GEMM_LAUNCH(KT, CPL)                                                                                 \
   hipLaunchKernelGGL((ddp_stage_a_kernel<KT, CPL>), dim3((ncols + CPL * DDP_GEMM_THREADS - 1) / (CPL * DDP_GEMM_THREADS), nry, nbatch), \
-                     dim3(DDP_GEMM_THREADS), 0, s, x, ldx, nrows, O, w, k, ncols, out, ldo)
+                     dim3(DDP_GEMM_THREADS), 0, s, x, ldx, nrows, rows, nrows_dev, out_rows, O, w, k, ncols, out, ldo)
   const bool wide = ((ncols | ldo) & 3) == 0 && ncols >= 4 * DDP_GEMM_THREADS && (reinterpret_cast<size_t>(out) & 15) == 0;
 #define DDP_GEMM_MFMA(KT)                                                                                        \
   hipLaunchKernelGGL((ddp_stage_a_mfma_kernel<KT>), dim3((ncols + 128 * DDP_SA_CT - 1) / (128 * DDP_SA_CT), (nrows + DDP_GEMM_MROWS - 1) / DDP_GEMM_MROWS, nbatch), \
-                     dim3(DDP_GEMM_THREADS), 0, s, x, ldx, nrows, O, w, ncols, out, ldo)
+                     dim3(DDP_GEMM_THREADS), 0, s, x, ldx, nrows, rows, nrows_dev, out_rows, O, w, ncols, out, ldo)
   static const bool no_mfma = getenv("DDP_STAGE_A_VALU") != nullptr;   // diagnostic: force the VALU form
   if (ncols >= 512 && !no_mfma && (k == 60 || k == 64 || k == 32 || k == 24 || k == 16)) {
     switch (k) {

@@ -28,19 +28,40 @@ __device__ __forceinline__ float sqdist(const float* __restrict__ a, const float
   return (xx + yy) + zz;
 }
 
+// point j of `p`, divided by `div` when the search runs on per-graph scaled coordinates (the reference's dynamic cross
+// cutoff divides both point sets by 3 sigma + 20 and searches with r = 1, models/all_atom_score_model.py:548-556: the same
+// correctly rounded divisions, so the strict comparison sees the same values)
+__device__ __forceinline__ void load_pt(const float* __restrict__ p, size_t j, bool scaled, float div, float out[3]) {
+  out[0] = p[3 * j];
+  out[1] = p[3 * j + 1];
+  out[2] = p[3 * j + 2];
+  if (scaled) {
+    out[0] = __fdiv_rn(out[0], div);
+    out[1] = __fdiv_rn(out[1], div);
+    out[2] = __fdiv_rn(out[2], div);
+  }
+}
+
+__device__ __forceinline__ float sqdist_to(const float* __restrict__ yq, const float* __restrict__ x, size_t j, bool scaled, float div) {
+  float xj[3];
+  load_pt(x, j, scaled, div, xj);
+  return sqdist(yq, xj);
+}
+
 // cut distance of a capped query: the cap-th smallest squared distance among the matches (d2 < r2); matches with
 // d2 <= cut are kept.  cap <= DDP_CUT_LIST: one pass that keeps the cap smallest distances in a sorted register list
 // (the side-chain torsion head searches 1111-atom graphs with cap 32).  Larger caps (they only bind on graphs with more
 // than that many neighbours inside r, which the default 10000 never does): O(matches * n) counting.
 #define DDP_CUT_LIST 64
-__device__ float radius_cut(const float* __restrict__ x, int j0, int j1, const float* __restrict__ yq, float r2, int cap) {
+__device__ float radius_cut(const float* __restrict__ x, int j0, int j1, const float* __restrict__ yq, float r2, int cap, bool scaled,
+                            float div) {
   if (cap <= DDP_CUT_LIST) {
     float best[DDP_CUT_LIST];
 #pragma unroll
     for (int i = 0; i < DDP_CUT_LIST; ++i) best[i] = __builtin_inff();
     float worst = __builtin_inff();                 // = best[cap - 1]
     for (int j = j0; j < j1; ++j) {
-      float d = sqdist(yq, x + 3 * (size_t)j);
+      float d = sqdist_to(yq, x, (size_t)j, scaled, div);
       if (!(d < r2) || !(d < worst)) continue;
       bool shifting = false;
 #pragma unroll
@@ -58,11 +79,11 @@ __device__ float radius_cut(const float* __restrict__ x, int j0, int j1, const f
   }
   float cut = r2;
   for (int i = j0; i < j1; ++i) {
-    const float di = sqdist(yq, x + 3 * (size_t)i);
+    const float di = sqdist_to(yq, x, (size_t)i, scaled, div);
     if (!(di < r2) || !(di < cut)) continue;
     int le = 0;
     for (int j = j0; j < j1; ++j) {
-      const float dj = sqdist(yq, x + 3 * (size_t)j);
+      const float dj = sqdist_to(yq, x, (size_t)j, scaled, div);
       le += (dj < r2 && dj <= di) ? 1 : 0;
     }
     if (le >= cap) cut = di;   // smallest d with #(d2 <= d) >= cap
@@ -73,19 +94,32 @@ __device__ float radius_cut(const float* __restrict__ x, int j0, int j1, const f
 // One WAVE per query (the ligand-side searches have ~1.5 k queries against ~1.1 k points each: one thread per query
 // leaves the chip empty and every thread in a 1111-iteration latency chain): lane l tests points j0 + l, + 64, ...;
 // a 64-point chunk's matches are placed with a ballot / prefix-popcount, which keeps the ascending-x order.
+// One launch serves several searches (jobs); a fill pass never writes behind a job's capacity.
+struct RadiusLaunch {
+  int njobs;
+  int blk_start[DDP_MAX_LIST_JOBS + 1];
+  ddp_radius_job_t job[DDP_MAX_LIST_JOBS];
+};
+
 template <bool FILL>
-__global__ __launch_bounds__(256) void ddp_radius_kernel(const float* __restrict__ x, const int32_t* __restrict__ x_ptr,
-                                                         const float* __restrict__ y, const int32_t* __restrict__ y_batch, int ny,
-                                                         float r2, int cap, int flags, int32_t* __restrict__ counts,
-                                                         const int32_t* __restrict__ offsets, int32_t* __restrict__ out_q,
-                                                         int32_t* __restrict__ out_x) {
-  const int q = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
-  if (q >= ny) return;
-  const int g = y_batch[q];
-  const int j0 = x_ptr[g], j1 = x_ptr[g + 1];
-  const float yq[3] = {y[3 * (size_t)q], y[3 * (size_t)q + 1], y[3 * (size_t)q + 2]};
+__global__ __launch_bounds__(256) void ddp_radius_kernel(const RadiusLaunch L) {
+  int jb_ = 0;
+  while (jb_ + 1 < L.njobs && (int)blockIdx.x >= L.blk_start[jb_ + 1]) ++jb_;
+  const ddp_radius_job_t& J = L.job[jb_];
+  const int q = ((int)blockIdx.x - L.blk_start[jb_]) * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+  if (q >= J.ny) return;
+  if (FILL && !J.out_x) return;                      // a count-only job
+  const float* __restrict__ x = J.x;
+  const int g = J.y_batch[q];
+  const int j0 = J.x_ptr[g], j1 = J.x_ptr[g + 1];
+  const bool scaled = J.graph_div != nullptr;
+  const float div = scaled ? J.graph_div[g] : 1.f;
+  const float r2 = J.r * J.r;
+  const int cap = J.max_neighbors, flags = J.flags;
+  float yq[3];
+  load_pt(J.y, (size_t)q, scaled, div, yq);
   int n = 0;
-  for (int j = j0 + lane; j < j1; j += 64) n += (sqdist(yq, x + 3 * (size_t)j) < r2) ? 1 : 0;
+  for (int j = j0 + lane; j < j1; j += 64) n += (sqdist_to(yq, x, (size_t)j, scaled, div) < r2) ? 1 : 0;
 #pragma unroll
   for (int m = 32; m > 0; m >>= 1) n += __shfl_xor(n, m);
   const bool drop_self = (flags & DDP_RADIUS_DROP_SELF) != 0, nearest = (flags & DDP_RADIUS_NEAREST) != 0;
@@ -93,17 +127,17 @@ __global__ __launch_bounds__(256) void ddp_radius_kernel(const float* __restrict
   bool capped = false;
   if (n > cap && nearest) { // ... or, capped to the nearest, d2 <= cut (rare: one lane selects, the wave takes its answer)
     float c = 0.f;
-    if (lane == 0) c = radius_cut(x, j0, j1, yq, r2, cap);
+    if (lane == 0) c = radius_cut(x, j0, j1, yq, r2, cap, scaled, div);
     lim = __shfl(c, 0);
     capped = true;
   }
   int kept = 0, seen = 0;   // pairs emitted / matches met so far (the self pair counts towards the cap, then is dropped)
-  const int obase = FILL ? offsets[q] : 0;
+  const int obase = FILL ? J.offsets[q] : 0;
   for (int jb = j0; jb < j1; jb += 64) {
     const int j = jb + lane;
     bool match = false;
     if (j < j1) {
-      const float d = sqdist(yq, x + 3 * (size_t)j);
+      const float d = sqdist_to(yq, x, (size_t)j, scaled, div);
       match = capped ? (d < r2 && d <= lim) : (d < r2);
     }
     const unsigned long long mm = __ballot(match);
@@ -113,13 +147,15 @@ __global__ __launch_bounds__(256) void ddp_radius_kernel(const float* __restrict
     const unsigned long long mk = __ballot(ok);
     if (FILL && ok) {
       const int o = obase + kept + __popcll(mk & ((1ull << lane) - 1ull));
-      out_q[o] = q;
-      out_x[o] = j;
+      if (o < J.capacity) {
+        J.out_query[o] = q;
+        J.out_x[o] = j;
+      }
     }
     kept += __popcll(mk);
     if (!nearest && seen >= cap) break;   // (wave-uniform)
   }
-  if (!FILL && lane == 0) counts[q] = kept;
+  if (!FILL && lane == 0) J.counts[q] = kept;
 }
 
 // kNN: one wave per query.  Round t selects the t-th nearest: every lane scans its share of the graph's points for the
@@ -164,35 +200,79 @@ __global__ __launch_bounds__(256) void ddp_knn_kernel(const float* __restrict__ 
   }
 }
 
-static int radius_args_ok(const float* x, const int32_t* x_ptr, const float* y, const int32_t* y_batch, int ny, float r, int cap) {
-  if (ny < 0 || cap < 1 || !(r > 0.f)) return ddp_fail(DDP_EINVAL, "ddp_radius: ny / max_neighbors / r");
-  if (ny > 0 && (!x || !x_ptr || !y || !y_batch)) return ddp_fail(DDP_EINVAL, "ddp_radius: null argument");
+static int radius_job_ok(const ddp_radius_job_t& J) {
+  if (J.ny < 0 || J.max_neighbors < 1 || !(J.r > 0.f)) return ddp_fail(DDP_EINVAL, "ddp_radius: ny / max_neighbors / r");
+  if (J.ny > 0 && (!J.x || !J.x_ptr || !J.y || !J.y_batch)) return ddp_fail(DDP_EINVAL, "ddp_radius: null argument");
+  return 0;
+}
+
+template <bool FILL>
+static int radius_launch(const ddp_radius_job_t* jobs, int njobs, void* stream) {
+  RadiusLaunch L;
+  L.njobs = 0;
+  int blocks = 0;
+  for (int i = 0; i < njobs; ++i) {
+    if (jobs[i].ny <= 0 || (FILL && !jobs[i].out_x)) continue;
+    L.blk_start[L.njobs] = blocks;
+    L.job[L.njobs++] = jobs[i];
+    blocks += (jobs[i].ny + 3) / 4;
+  }
+  L.blk_start[L.njobs] = blocks;
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL((ddp_radius_kernel<FILL>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return ddp_fail_hip(err, "ddp_radius launch");
   return 0;
 }
 
 extern "C" int ddp_radius_count(const float* x, const int32_t* x_ptr, const float* y, const int32_t* y_batch, int ny, float r,
                                 int max_neighbors, int flags, int32_t* counts, void* stream) {
-  if (int rc = radius_args_ok(x, x_ptr, y, y_batch, ny, r, max_neighbors)) return rc;
+  ddp_radius_job_t J = {};
+  J.x = x; J.x_ptr = x_ptr; J.y = y; J.y_batch = y_batch; J.ny = ny; J.r = r; J.max_neighbors = max_neighbors; J.flags = flags;
+  J.counts = counts;
+  if (int rc = radius_job_ok(J)) return rc;
   if (ny == 0) return 0;
   if (!counts) return ddp_fail(DDP_EINVAL, "ddp_radius_count: null counts");
-  hipLaunchKernelGGL((ddp_radius_kernel<false>), dim3((ny + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, x_ptr, y, y_batch,
-                     ny, r * r, max_neighbors, flags, counts, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
-  const hipError_t err = hipGetLastError();
-  if (err != hipSuccess) return ddp_fail_hip(err, "ddp_radius_count launch");
-  return 0;
+  return radius_launch<false>(&J, 1, stream);
 }
 
 extern "C" int ddp_radius_fill(const float* x, const int32_t* x_ptr, const float* y, const int32_t* y_batch, int ny, float r,
                                int max_neighbors, int flags, const int32_t* offsets, int32_t* out_query, int32_t* out_x,
                                void* stream) {
-  if (int rc = radius_args_ok(x, x_ptr, y, y_batch, ny, r, max_neighbors)) return rc;
+  ddp_radius_job_t J = {};
+  J.x = x; J.x_ptr = x_ptr; J.y = y; J.y_batch = y_batch; J.ny = ny; J.r = r; J.max_neighbors = max_neighbors; J.flags = flags;
+  J.offsets = const_cast<int32_t*>(offsets); J.out_query = out_query; J.out_x = out_x; J.capacity = 0x7fffffff;
+  if (int rc = radius_job_ok(J)) return rc;
   if (ny == 0) return 0;
   if (!offsets || !out_query || !out_x) return ddp_fail(DDP_EINVAL, "ddp_radius_fill: null argument");
-  hipLaunchKernelGGL((ddp_radius_kernel<true>), dim3((ny + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, x_ptr, y, y_batch,
-                     ny, r * r, max_neighbors, flags, (int32_t*)nullptr, offsets, out_query, out_x);
-  const hipError_t err = hipGetLastError();
-  if (err != hipSuccess) return ddp_fail_hip(err, "ddp_radius_fill launch");
-  return 0;
+  return radius_launch<true>(&J, 1, stream);
+}
+
+// Several searches without a host round trip: count pass -> exclusive scan of the per-query counts (offsets[q] = base +
+// matches of the queries before q; offsets[ny] and *total = base + all matches) -> fill pass.  Three launches for all jobs.
+extern "C" int ddp_radius_search_jobs(const ddp_radius_job_t* jobs, int njobs, void* stream) {
+  if (njobs < 0 || njobs > DDP_MAX_LIST_JOBS) return ddp_fail(DDP_ELIMIT, "ddp_radius_search_jobs: njobs");
+  if (njobs == 0) return 0;
+  if (!jobs) return ddp_fail(DDP_EINVAL, "ddp_radius_search_jobs: null jobs");
+  ddp_scan_job_t scans[DDP_MAX_LIST_JOBS];
+  int ns = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const ddp_radius_job_t& J = jobs[i];
+    if (int rc = radius_job_ok(J)) return rc;
+    if (!J.counts) return ddp_fail(DDP_EINVAL, "ddp_radius_search_jobs: null counts");
+    if (J.out_x && (!J.out_query || !J.offsets || J.capacity < 0)) return ddp_fail(DDP_EINVAL, "ddp_radius_search_jobs: fill outputs");
+    if (!J.offsets && !J.total) continue;
+    ddp_scan_job_t& S = scans[ns++];
+    S = ddp_scan_job_t{};
+    S.n = J.ny;
+    S.val = J.counts;
+    S.base = J.base;
+    S.excl = J.offsets;
+    S.total = J.total;
+  }
+  if (int rc = radius_launch<false>(jobs, njobs, stream)) return rc;
+  if (int rc = ddp_scan_jobs(scans, ns, stream)) return rc;
+  return radius_launch<true>(jobs, njobs, stream);
 }
 
 extern "C" int ddp_knn(const float* x, const int32_t* x_ptr, const int32_t* batch, int n, int k, int32_t* out_neighbors,

@@ -1,0 +1,331 @@
+// ddp_lists.hip - index-list primitives with DEVICE-SIDE counts (gfx950), so that a denoising step needs no host
+// synchronisation: the sizes of the pose-dependent edge lists (radius graphs, their CSR / source-order views, the pruned and
+// "touched" sub-lists of the exact work eliminations) live in device memory, every consumer is launched on a grid sized for
+// the list's CAPACITY and reads the actual count itself.  All primitives are batched: one launch serves up to
+// DDP_MAX_LIST_JOBS independent jobs (a step has ~10 views / ~6 searches / ~8 sub-lists; each would otherwise be its own
+// chain of small launches).  Everything is bitwise deterministic: no result depends on the order in which atomics land.
+//
+//   ddp_scan_jobs      exclusive prefix sum of per-item values (flags, counts, CSR row lengths), optional compaction of the
+//                      flagged indices; one workgroup of 1024 threads per job
+//   ddp_mark_jobs      mask[idx[i]] = 1
+//   ddp_rowcopy_jobs   compaction of whole CSR rows (keep mask per row)
+//   ddp_select_jobs    stable compaction of the items with maskA[idxA[i]] | maskB[idxB[i]] and of their payloads
+//   ddp_gather_rows    out[i, :] = x[idx[i], :]
+//   ddp_clean_pair_maps  the two index maps of the layer-1 clean-pair sharing (score_model)
+// The reference has no counterpart: it calls torch_cluster / torch.sort / boolean indexing per forward and synchronises with
+// the host every time (models/all_atom_score_model.py:444-636); these kernels stand for that host-side list handling.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ddp_hip.h"
+#include "ddp_internal.h"
+
+template <typename J>
+struct ListLaunch {
+  int njobs;
+  int blk_start[DDP_MAX_LIST_JOBS + 1];
+  J job[DDP_MAX_LIST_JOBS];
+};
+
+__device__ __forceinline__ int list_job_of(const int* blk_start, int njobs, int b) {
+  int j = 0;
+  while (j + 1 < njobs && b >= blk_start[j + 1]) ++j;
+  return j;
+}
+
+__device__ __forceinline__ int dev_count(int cap, const int32_t* n_dev) {
+  if (!n_dev) return cap;
+  const int n = *n_dev;
+  return n < cap ? (n < 0 ? 0 : n) : cap;
+}
+
+// ------------------------------------------------------------------------------------------------ scan
+__device__ __forceinline__ int scan_value(const ddp_scan_job_t& J, int i) {
+  int v = 1;
+  if (J.val) v = J.val[i];
+  else if (J.rowptr) v = J.rowptr[i + 1] - J.rowptr[i];
+  if (J.flag && J.flag[i] == 0) v = 0;
+  return v;
+}
+
+__global__ __launch_bounds__(1024) void ddp_scan_jobs_kernel(const ListLaunch<ddp_scan_job_t> L) {
+  __shared__ int seg_total[16];
+  const ddp_scan_job_t& J = L.job[blockIdx.x];
+  const int n = dev_count(J.n, J.n_dev);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int S = (((n + 15) / 16) + 63) & ~63;      // contiguous segment per wave, a multiple of 64
+  const int lo = min(wave * S, n), hi = min(lo + S, n);
+  int run = 0;
+  for (int base = lo; base < hi; base += 64) {
+    const int i = base + lane;
+    int v = (i < hi) ? scan_value(J, i) : 0;
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+    run += v;
+  }
+  if (lane == 0) seg_total[wave] = run;
+  __syncthreads();
+  int offset = J.base;
+  for (int w = 0; w < wave; ++w) offset += seg_total[w];
+  run = offset;
+  for (int base = lo; base < hi; base += 64) {
+    const int i = base + lane;
+    const int v = (i < hi) ? scan_value(J, i) : 0;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(incl, off);
+      if (lane >= off) incl += u;
+    }
+    const int ex = run + incl - v;
+    if (i < hi) {
+      if (J.excl) J.excl[i] = ex;
+      if (J.excl2) J.excl2[i] = ex;
+      if (J.list && v != 0) J.list[ex] = i;        // (weights are 0 / 1 when a list is asked for)
+    }
+    run += __shfl(incl, 63);
+  }
+  if (threadIdx.x == 0) {
+    int total = J.base;
+    for (int w = 0; w < 16; ++w) total += seg_total[w];
+    if (J.excl) J.excl[n] = total;
+    if (J.total) *J.total = total;
+  }
+}
+
+static int check_jobs(int njobs, const void* jobs, const char* what) {
+  if (njobs < 0 || njobs > DDP_MAX_LIST_JOBS) return ddp_fail(DDP_ELIMIT, what);
+  if (njobs > 0 && !jobs) return ddp_fail(DDP_EINVAL, what);
+  return 0;
+}
+
+static int launch_ok(const char* what) {
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : ddp_fail_hip(err, what);
+}
+
+extern "C" int ddp_scan_jobs(const ddp_scan_job_t* jobs, int njobs, void* stream) {
+  if (int rc = check_jobs(njobs, jobs, "ddp_scan_jobs: njobs")) return rc;
+  if (njobs == 0) return 0;
+  ListLaunch<ddp_scan_job_t> L;
+  L.njobs = njobs;
+  for (int i = 0; i < njobs; ++i) {
+    if (jobs[i].n < 0 || (jobs[i].list && (jobs[i].val || jobs[i].rowptr)))
+      return ddp_fail(DDP_EINVAL, "ddp_scan_jobs: n < 0, or a list asked for with weights other than 0 / 1");
+    L.job[i] = jobs[i];
+  }
+  hipLaunchKernelGGL(ddp_scan_jobs_kernel, dim3(njobs), dim3(1024), 0, (hipStream_t)stream, L);
+  return launch_ok("ddp_scan_jobs launch");
+}
+
+// ------------------------------------------------------------------------------------------------ mark
+__global__ __launch_bounds__(256) void ddp_mark_jobs_kernel(const ListLaunch<ddp_mark_job_t> L) {
+  const int j = list_job_of(L.blk_start, L.njobs, blockIdx.x);
+  const ddp_mark_job_t& J = L.job[j];
+  const int n = dev_count(J.n, J.n_dev);
+  const int i = ((int)blockIdx.x - L.blk_start[j]) * 256 + (int)threadIdx.x;
+  if (i < n) J.mask[J.idx ? J.idx[i] : i] = 1;      // (every writer stores the same value)
+}
+
+extern "C" int ddp_mark_jobs(const ddp_mark_job_t* jobs, int njobs, void* stream) {
+  if (int rc = check_jobs(njobs, jobs, "ddp_mark_jobs: njobs")) return rc;
+  ListLaunch<ddp_mark_job_t> L;
+  L.njobs = 0;
+  int blocks = 0;
+  for (int i = 0; i < njobs; ++i) {
+    if (jobs[i].n <= 0) continue;
+    if (!jobs[i].mask) return ddp_fail(DDP_EINVAL, "ddp_mark_jobs: null mask");
+    L.blk_start[L.njobs] = blocks;
+    L.job[L.njobs++] = jobs[i];
+    blocks += (jobs[i].n + 255) / 256;
+  }
+  L.blk_start[L.njobs] = blocks;
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL(ddp_mark_jobs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+  return launch_ok("ddp_mark_jobs launch");
+}
+
+// ------------------------------------------------------------------------------------------------ row copy
+// one wave per row of the old CSR list: a kept row's entries move, in order, to their place in the new list
+__global__ __launch_bounds__(256) void ddp_rowcopy_jobs_kernel(const ListLaunch<ddp_rowcopy_job_t> L) {
+  const int j = list_job_of(L.blk_start, L.njobs, blockIdx.x);
+  const ddp_rowcopy_job_t& J = L.job[j];
+  const int row = ((int)blockIdx.x - L.blk_start[j]) * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+  if (row >= J.n_rows || J.keep[row] == 0) return;
+  const int ob = J.old_rowptr[row], m = J.old_rowptr[row + 1] - ob, nb = J.new_rowptr[row];
+  for (int a = lane; a < m; a += 64) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (J.out[k]) J.out[k][nb + a] = J.in[k][ob + a];
+  }
+}
+
+extern "C" int ddp_rowcopy_jobs(const ddp_rowcopy_job_t* jobs, int njobs, void* stream) {
+  if (int rc = check_jobs(njobs, jobs, "ddp_rowcopy_jobs: njobs")) return rc;
+  ListLaunch<ddp_rowcopy_job_t> L;
+  L.njobs = 0;
+  int blocks = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const ddp_rowcopy_job_t& J = jobs[i];
+    if (J.n_rows <= 0) continue;
+    if (!J.keep || !J.old_rowptr || !J.new_rowptr) return ddp_fail(DDP_EINVAL, "ddp_rowcopy_jobs: null argument");
+    for (int k = 0; k < 3; ++k)
+      if (J.out[k] && !J.in[k]) return ddp_fail(DDP_EINVAL, "ddp_rowcopy_jobs: output without input");
+    L.blk_start[L.njobs] = blocks;
+    L.job[L.njobs++] = J;
+    blocks += (J.n_rows + 3) / 4;
+  }
+  L.blk_start[L.njobs] = blocks;
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL(ddp_rowcopy_jobs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+  return launch_ok("ddp_rowcopy_jobs launch");
+}
+
+// ------------------------------------------------------------------------------------------------ select
+// Stable compaction in three launches: per-block counts (blocks of DDP_SELECT_BLOCK consecutive items), an exclusive scan of
+// the block counts (ddp_scan_jobs_kernel), and the scatter, in which every block recomputes its flags, ranks them with wave
+// ballots in item order and writes the kept indices and payloads behind its block offset.
+#define DDP_SELECT_BLOCK 2048   // items per workgroup of 256 threads: wave w owns items [512 w, 512 w + 512) in 8 rounds of 64
+
+__device__ __forceinline__ bool select_flag(const ddp_select_job_t& J, int i) {
+  bool f = false;
+  if (J.mask_a) f = J.mask_a[J.idx_a ? J.idx_a[i] : i] != 0;
+  if (J.mask_b) f = f || (J.mask_b[J.idx_b ? J.idx_b[i] : i] != 0);
+  return f;
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void ddp_select_jobs_kernel(const ListLaunch<ddp_select_job_t> L) {
+  __shared__ int wave_total[4];
+  const int j = list_job_of(L.blk_start, L.njobs, blockIdx.x);
+  const ddp_select_job_t& J = L.job[j];
+  const int n = dev_count(J.n, J.n_dev);
+  const int blk = (int)blockIdx.x - L.blk_start[j];
+  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  const int w0 = blk * DDP_SELECT_BLOCK + wave * 512;
+  if (blk * DDP_SELECT_BLOCK >= n) {                 // beyond the actual count: an empty block
+    if (!SCATTER && threadIdx.x == 0) J.block_count[blk] = 0;
+    return;
+  }
+  unsigned long long mm[8];
+  int cnt = 0;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int i = w0 + 64 * r + lane;
+    mm[r] = __ballot(i < n && select_flag(J, i));
+    cnt += __popcll(mm[r]);
+  }
+  if (lane == 0) wave_total[wave] = cnt;
+  __syncthreads();
+  if (!SCATTER) {
+    if (threadIdx.x == 0) J.block_count[blk] = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+    return;
+  }
+  int o = J.block_off[blk];
+  for (int w = 0; w < wave; ++w) o += wave_total[w];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int i = w0 + 64 * r + lane;
+    if ((mm[r] >> lane) & 1ull) {
+      const int p = o + __popcll(mm[r] & ((1ull << lane) - 1ull));
+      if (J.out_idx) J.out_idx[p] = i;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (J.out[k]) J.out[k][p] = J.pay[k][i] + J.pay_add[k];
+    }
+    o += __popcll(mm[r]);
+  }
+}
+
+extern "C" int ddp_select_jobs(const ddp_select_job_t* jobs, int njobs, void* stream) {
+  if (int rc = check_jobs(njobs, jobs, "ddp_select_jobs: njobs")) return rc;
+  ListLaunch<ddp_select_job_t> L;
+  ListLaunch<ddp_scan_job_t> S;
+  L.njobs = 0;
+  int blocks = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const ddp_select_job_t& J = jobs[i];
+    if (J.n <= 0) {                                  // an empty list: only its count is produced
+      if (J.total) {
+        const hipError_t e = hipMemsetAsync(J.total, 0, sizeof(int32_t), (hipStream_t)stream);
+        if (e != hipSuccess) return ddp_fail_hip(e, "ddp_select_jobs memset");
+      }
+      continue;
+    }
+    if (!J.block_count || !J.block_off || (!J.mask_a && !J.mask_b)) return ddp_fail(DDP_EINVAL, "ddp_select_jobs: null argument");
+    for (int k = 0; k < 4; ++k)
+      if (J.out[k] && !J.pay[k]) return ddp_fail(DDP_EINVAL, "ddp_select_jobs: output without payload");
+    const int nb = (J.n + DDP_SELECT_BLOCK - 1) / DDP_SELECT_BLOCK;
+    ddp_scan_job_t& sj = S.job[L.njobs];
+    sj = ddp_scan_job_t{};
+    sj.n = nb;
+    sj.val = J.block_count;
+    sj.excl = J.block_off;
+    sj.total = J.total;
+    L.blk_start[L.njobs] = blocks;
+    L.job[L.njobs++] = J;
+    blocks += nb;
+  }
+  L.blk_start[L.njobs] = blocks;
+  S.njobs = L.njobs;
+  if (blocks == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ddp_select_jobs_kernel<false>, dim3(blocks), dim3(256), 0, st, L);
+  hipLaunchKernelGGL(ddp_scan_jobs_kernel, dim3(S.njobs), dim3(1024), 0, st, S);
+  hipLaunchKernelGGL(ddp_select_jobs_kernel<true>, dim3(blocks), dim3(256), 0, st, L);
+  return launch_ok("ddp_select_jobs launch");
+}
+
+// ------------------------------------------------------------------------------------------------ gather rows
+__global__ __launch_bounds__(256) void ddp_gather_rows_kernel(const float* __restrict__ x, int ldx, const int32_t* __restrict__ idx,
+                                                              int n, const int32_t* __restrict__ n_dev, float* __restrict__ out,
+                                                              int ldo, int ncols) {
+  n = dev_count(n, n_dev);
+  const int row = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+  if (row >= n) return;
+  const float* __restrict__ src = x + (size_t)idx[row] * ldx;
+  float* __restrict__ dst = out + (size_t)row * ldo;
+  for (int c = lane; c < ncols; c += 64) dst[c] = src[c];
+}
+
+extern "C" int ddp_gather_rows(const float* x, int ldx, const int32_t* idx, int n, const int32_t* n_dev, float* out, int ldo,
+                               int ncols, void* stream) {
+  if (n <= 0 || ncols <= 0) return 0;
+  if (!x || !idx || !out) return ddp_fail(DDP_EINVAL, "ddp_gather_rows: null argument");
+  hipLaunchKernelGGL(ddp_gather_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, idx, n, n_dev, out,
+                     ldo, ncols);
+  return launch_ok("ddp_gather_rows launch");
+}
+
+// ------------------------------------------------------------------------------------------------ clean-pair maps
+// score_model, layer 1 atom<-atom of a sampling batch of one rigid complex (B samples x n0 atoms, E = B * e0 edges in CSR
+// order): `touched[a]` marks the atoms a ligand message reached.
+//   rowmap[p]  = p                      if the edge at CSR position p has a touched end (its message is computed per sample)
+//              = E + p % e0             otherwise (the message computed once on the complex's own edge list)
+//   rows_v[a0] = g * n0 + a0 for the first sample g in which atom a0 is untouched (g = 0 if there is none: then unused)
+__global__ __launch_bounds__(256) void ddp_clean_pair_maps_kernel(const int32_t* __restrict__ touched, const int32_t* __restrict__ recv,
+                                                                  const int32_t* __restrict__ src, int E, int e0, int B, int n0,
+                                                                  int32_t* __restrict__ rowmap, int32_t* __restrict__ rows_v) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < E) rowmap[i] = (touched[recv[i]] | touched[src[i]]) ? i : E + i % e0;
+  if (i < n0) {
+    int g = 0;
+    for (int b = 0; b < B; ++b)
+      if (touched[b * n0 + i] == 0) {
+        g = b;
+        break;
+      }
+    rows_v[i] = g * n0 + i;
+  }
+}
+
+extern "C" int ddp_clean_pair_maps(const int32_t* touched, const int32_t* recv, const int32_t* src, int n_edges, int e0, int n_graphs,
+                                   int n0, int32_t* rowmap, int32_t* rows_v, void* stream) {
+  if (n_edges <= 0 || e0 <= 0 || n_graphs <= 0 || n0 <= 0 || n_edges != e0 * n_graphs)
+    return ddp_fail(DDP_EINVAL, "ddp_clean_pair_maps: sizes");
+  if (!touched || !recv || !src || !rowmap || !rows_v) return ddp_fail(DDP_EINVAL, "ddp_clean_pair_maps: null argument");
+  const int n = n_edges > n0 ? n_edges : n0;
+  hipLaunchKernelGGL(ddp_clean_pair_maps_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, touched, recv, src,
+                     n_edges, e0, n_graphs, n0, rowmap, rows_v);
+  return launch_ok("ddp_clean_pair_maps launch");
+}

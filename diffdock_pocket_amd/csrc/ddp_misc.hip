@@ -22,13 +22,13 @@ struct ReduceLaunch {
 };
 
 __global__ void ddp_segment_reduce_kernel(float* __restrict__ x, int ldx, int n_nodes, int d_out, ReduceLaunch L,
-                                          int accumulate) {
+                                          int accumulate, int n_rep, int rep_stride) {
   const int node = blockIdx.x;
   const int ch = threadIdx.x;
   if (ch >= d_out) return;
   float* dst = x + (size_t)node * ldx + ch;
   // same association as the reference's `x + u_a + u_b + u_c` (all_atom_score_model.py:316,320,324)
-  float total = accumulate ? *dst : 0.f;
+  float total = (accumulate && n_rep <= 1) ? *dst : 0.f;
   // all row pointers first, then the message rows in batches of 8 independent loads that are summed IN ORDER: a node has
   // ~8 incoming edges per conv, so the whole segment is one memory round trip instead of a chain of them
   int p0[3], p1[3];
@@ -40,7 +40,8 @@ __global__ void ddp_segment_reduce_kernel(float* __restrict__ x, int ldx, int n_
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    if (k < L.nsrc) {
+    // (a conv whose device-side edge count is 0 contributes exactly 0, like one the host drops: score_model.py:109-111)
+    if (k < L.nsrc && !(L.src[k].n_edges_dev && *L.src[k].n_edges_dev <= 0)) {
       const ddp_reduce_src_t& s = L.src[k];
       const float* __restrict__ m = s.msg + ch;
       const int32_t* __restrict__ rm = s.rowmap;
@@ -64,11 +65,18 @@ __global__ void ddp_segment_reduce_kernel(float* __restrict__ x, int ldx, int n_
       total += mean * s.bn_scale[ch] + s.bn_shift[ch];
     }
   }
-  *dst = total;
+  if (n_rep <= 1) {
+    *dst = total;
+  } else {   // the update (summed from 0) added to the node's copy in every graph of the batch
+    for (int g = 0; g < n_rep; ++g) {
+      float* d = dst + (size_t)g * rep_stride * ldx;
+      *d = *d + total;
+    }
+  }
 }
 
 extern "C" int ddp_segment_reduce(float* x, int ldx, int n_nodes, int d_out, const ddp_reduce_src_t* srcs, int nsrc,
-                                  int accumulate, void* stream) {
+                                  int accumulate, int n_rep, int rep_stride, void* stream) {
   if (!x || (!srcs && nsrc > 0)) return ddp_fail(DDP_EINVAL, "ddp_segment_reduce: null argument");
   if (nsrc < 0 || nsrc > 3) return ddp_fail(DDP_ELIMIT, "ddp_segment_reduce: nsrc > 3");
   if (d_out < 1 || d_out > 1024) return ddp_fail(DDP_ELIMIT, "ddp_segment_reduce: d_out");
@@ -77,10 +85,11 @@ extern "C" int ddp_segment_reduce(float* x, int ldx, int n_nodes, int d_out, con
   L.nsrc = 0;
   for (int i = 0; i < nsrc; ++i)
     if (srcs[i].n_edges > 0) L.src[L.nsrc++] = srcs[i];  // an empty conv contributes exactly 0 (score_model.py:109-111)
-  if (L.nsrc == 0 && accumulate) return 0;
+  if (L.nsrc == 0 && (accumulate || n_rep > 1)) return 0;
+  if (n_rep > 1 && rep_stride < n_nodes) return ddp_fail(DDP_EINVAL, "ddp_segment_reduce: rep_stride < n_nodes");
   const int threads = ((d_out + 63) / 64) * 64;
   hipLaunchKernelGGL(ddp_segment_reduce_kernel, dim3(n_nodes), dim3(threads), 0, (hipStream_t)stream, x, ldx, n_nodes,
-                     d_out, L, accumulate);
+                     d_out, L, accumulate, n_rep, rep_stride);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return ddp_fail_hip(err, "ddp_segment_reduce launch");
   return 0;
@@ -331,7 +340,9 @@ extern "C" int ddp_edge_featurize(const float* pos_a, const int32_t* ia, const f
 // t = sqrt(3/2) * (3 (n.v) v - n): the 1o block of o3.FullTensorProduct(sh(lmax=1), "2e") applied to
 // (sh(edge), Y2(bond)) (reference models/all_atom_score_model.py:394-395,418-419).
 __global__ void ddp_torsion_sh_kernel(const float* __restrict__ sh_edge, const float* __restrict__ bond_vec,
-                                      const int* __restrict__ bond_of_edge, int n_edges, float* __restrict__ out) {
+                                      const int* __restrict__ bond_of_edge, int n_edges, const int* __restrict__ n_edges_dev,
+                                      float* __restrict__ out) {
+  if (n_edges_dev) n_edges = min(n_edges, *n_edges_dev);
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_edges) return;
   const f32x4 s = reinterpret_cast<const f32x4*>(sh_edge)[e];
@@ -347,11 +358,11 @@ __global__ void ddp_torsion_sh_kernel(const float* __restrict__ sh_edge, const f
 }
 
 extern "C" int ddp_torsion_sh(const float* sh_edge, const float* bond_vec, const int32_t* bond_of_edge, int n_edges,
-                              float* out, void* stream) {
+                              const int32_t* n_edges_dev, float* out, void* stream) {
   if (n_edges <= 0) return 0;
   if (!sh_edge || !bond_vec || !bond_of_edge || !out) return ddp_fail(DDP_EINVAL, "ddp_torsion_sh: null argument");
   hipLaunchKernelGGL(ddp_torsion_sh_kernel, dim3((n_edges + 255) / 256), dim3(256), 0, (hipStream_t)stream, sh_edge,
-                     bond_vec, bond_of_edge, n_edges, out);
+                     bond_vec, bond_of_edge, n_edges, n_edges_dev, out);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return ddp_fail_hip(err, "ddp_torsion_sh launch");
   return 0;

@@ -1,0 +1,777 @@
+"""The forward of the MI355X score model as a DEVICE-DRIVEN sequence of launches (reference models/all_atom_score_model.py:
+238-436, called once per denoising step from utils/sampling.py:119-120).
+
+Nothing in a steady-state step waits for the device: the sizes of the pose-dependent lists - the three radius graphs of
+build_lig / build_cross_conv_graph (:444-583), the heads' bond-centre graphs (:586-636), their CSR / source-order views and the
+sub-lists of the exact work eliminations - stay in device memory (launch.CountBlock); every consumer is launched on a grid
+sized for the list's CAPACITY (worst case from the graph sizes) and reads the actual count itself (include/ddp_hip.h,
+"Device-side counts").  What does synchronise, once per batch and cached (`model._cached`): the dense layouts of the batch
+vectors, the exact comparison that finds the receptor side identical across the samples, and - only when the caller did not
+say so through `batch.set_time` - the check that all receptor-side nodes sit at one diffusion time.
+
+    front()   node encoders + sigma tables (1 launch), neighbour searches (3), edge embeddings (6), CSR / source-order views (10)
+    lists()   the index lists of the exact eliminations: atoms a ligand message reaches, dead-output pruning of the last
+              receptor-side layers, layer-1 clean-pair sharing - all as batched device list primitives (csrc/ddp_lists.hip)
+    layers()  per layer: stage A of the factorised convs, the two conv launches, the segmented means
+    heads()   tr / rot head, torsion heads, confidence head
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections.abc import Mapping
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from . import graph as G
+from . import launch as K
+from . import packing as P
+from .graph import EdgeView
+
+SRC_TYPE = {0: "l", 1: "r", 2: "a", 3: "a", 4: "l", 5: "r", 6: "r", 7: "l", 8: "a"}
+RECV_TYPE = {0: "l", 1: "l", 2: "l", 3: "a", 4: "a", 5: "a", 6: "r", 7: "r", 8: "r"}
+RECV_OF = {"a": (3, 4, 5), "r": (6, 7, 8)}
+# summation order of the residual update (:316,:320,:324): lig u0+u2+u1, atom u3+u4+u5, rec u6+u8+u7
+ORDER = {"l": [0, 2, 1], "a": [3, 4, 5], "r": [6, 8, 7]}
+_DROP_SELF = 1
+
+
+class LazyStats(Mapping):
+    """Edge / node counts of the last forward.  The pose-dependent ones live on the device; they are copied to the host when
+    the mapping is first read (one synchronisation, outside the step)."""
+
+    def __init__(self, static: Dict[str, int], counts: Optional[K.CountBlock], names: Dict[str, str]):
+        self._static, self._counts, self._names, self._vals = dict(static), counts, dict(names), None
+
+    def _resolve(self):
+        if self._vals is None:
+            vals = dict(self._static)
+            if self._counts is not None:
+                host = self._counts.values()
+                for key, slot in self._names.items():
+                    if slot in host:
+                        vals[key] = host[slot]
+            self._vals = vals
+        return self._vals
+
+    def __getitem__(self, k):
+        return self._resolve()[k]
+
+    def __iter__(self):
+        return iter(self._resolve())
+
+    def __len__(self):
+        return len(self._resolve())
+
+
+def _i32(t):
+    return t.to(torch.int32).contiguous()
+
+
+class ForwardEngine:
+    def __init__(self, model):
+        self.m = model
+
+    # ================================================================================================ entry
+    @torch.no_grad()
+    def forward(self, data):
+        lig = data["ligand"]
+        K.require_hip(lig.pos)
+        with torch.cuda.device(lig.pos.device):      # every launch below goes to the current stream of THIS device
+            return self._forward(data)
+
+    def _forward(self, data):
+        m = self.m
+        lig, rec, atom = data["ligand"], data["receptor"], data["atom"]
+        dev = lig.pos.device
+        m._refresh_weight_caches()
+        mark = m.section_timer.mark if m.section_timer is not None else (lambda name: None)
+        mark("start")
+        if m.no_aminoacid_identities:
+            rec.x = rec.x * 0
+        S = self._static(data, lig, rec, atom, dev)
+        F = self._front(data, S, lig, rec, atom, dev, mark)
+        self._lists(S, F, dev)
+        mark("lists")
+        if m.exact_sizes:
+            self._exact(F)
+        if m.before_layers is not None:
+            m.before_layers()
+        self._layers(S, F, dev, mark)
+        out = self._heads(data, S, F, lig, rec, atom, dev, mark)
+        m.last_stats = LazyStats(S.stats, F.cnt, {"E_ll": "ll", "E_lr": "lr", "E_la": "la", "n_near": "near",
+                                                  "clean1_dirty_edges": "dirty"})
+        prof = K.profiler()
+        if prof is not None:
+            prof.hold = getattr(prof, "hold", [])
+            prof.hold.append(F.cnt.block)
+        return out
+
+    # ================================================================================================ static state
+    def _static(self, data, lig, rec, atom, dev):
+        """Everything that does not change between the denoising steps of one batch (kept by `model._cached` while the tensors
+        it was derived from are the same objects with the same version counters)."""
+        m = self.m
+        S = SimpleNamespace()
+        B = S.B = int(data.num_graphs)
+        lbatch, rbatch, abatch = lig.batch.long(), rec.batch.long(), atom.batch.long()
+        S.lbatch, S.rbatch, S.abatch = lbatch, rbatch, abatch
+        S.Nl, S.Nr, S.Na = lig.pos.shape[0], rec.pos.shape[0], atom.pos.shape[0]
+        S.lay_l = m._cached("lay_l", (lig.batch,), lambda: G.DenseLayout.build(lbatch, B))
+        S.lay_r = m._cached("lay_r", (rec.batch,), lambda: G.DenseLayout.build(rbatch, B))
+        S.lay_a = m._cached("lay_a", (atom.batch,), lambda: G.DenseLayout.build(abatch, B))
+        for lay in (S.lay_l, S.lay_r, S.lay_a):
+            G._ptr(lay)
+        bond_ei = data["ligand", "ligand"].edge_index
+        S.bond_ei = bond_ei
+        S.bond32 = m._cached("bond32", (bond_ei,), lambda: (_i32(bond_ei[0]), _i32(bond_ei[1])))
+        S.E_bond = int(bond_ei.shape[1])
+        rr, ar = data["receptor", "receptor"].edge_index, data["atom", "receptor"].edge_index
+        S.rr, S.ar = rr, ar
+        S.num_flex = 0
+        # (:327, literally: a PyG HeteroData answers `in` by attribute names, not node types, and creates the store on access)
+        if m.flexible_sidechains and len(data["flexResidues"]) > 0:
+            S.num_flex = int(data["flexResidues"].edge_idx.shape[0])
+        nl, nr, na = S.lay_l.counts_host, S.lay_r.counts_host, S.lay_a.counts_host
+        # worst-case sizes of the pose-dependent edge lists (per graph: every query x every point of its graph, or the cap)
+        S.cap_ll = S.E_bond + sum(n * min(max(n - 1, 0), 32) for n in nl)
+        S.cap_lr = sum(a * min(b, 10000) for a, b in zip(nl, nr))
+        S.cap_la = sum(a * min(b, 10000) for a, b in zip(nl, na))
+        S.stats = {"E_rr": int(rr.shape[1]), "E_ar": int(ar.shape[1]), "N_l": S.Nl, "N_r": S.Nr, "N_a": S.Na, "B": B}
+        S.tor = S.sc = None
+        if not m.confidence_mode:
+            if not m.no_torsion:
+                def tor_static():   # rotatable bonds, their graph index and dense layout: fixed for a batch
+                    idx = lig.edge_mask.bool().nonzero(as_tuple=True)[0]
+                    bnd = bond_ei[:, idx].long()
+                    bb = lbatch[bnd[0]]
+                    lay = G.DenseLayout.build(bb, B) if idx.shape[0] > 0 else None
+                    return SimpleNamespace(idx=idx, bonds=bnd, batch=bb, lay=lay, T=int(idx.shape[0]))
+                tor = m._cached("tor_static", (lig.edge_mask, bond_ei, lig.batch), tor_static)
+                if tor.T > 0:
+                    G._ptr(tor.lay)
+                    tor.cap = sum(t * min(n, 32) for t, n in zip(tor.lay.counts_host, nl))
+                    S.tor = tor
+            if S.num_flex > 0:
+                fr = data["flexResidues"]
+
+                def sc_static():
+                    sb = fr.batch.long()
+                    bonds = S.lay_a.starts[sb] + fr.edge_idx.t().long()     # get_sc_tor_bonds (:638-652)
+                    return SimpleNamespace(bonds=bonds, batch=sb, lay=G.DenseLayout.build(sb, B), T=int(sb.shape[0]),
+                                           flat32=_i32(bonds.reshape(-1)))
+                sc = m._cached("sc_static", (fr.batch, fr.edge_idx, atom.batch), sc_static)
+                G._ptr(sc.lay)
+                sc.cap = sum(t * min(n, 32) for t, n in zip(sc.lay.counts_host, na))
+                S.sc = sc
+        return S
+
+    def _one_time(self, data, lig, rec, atom):
+        """Do all receptor-side nodes sit at ONE diffusion time (the sampling batch)?  `batch.set_time` says so for the time
+        tensors it made; for any others the device is asked (one host synchronisation)."""
+        ts = (rec.node_t["tr"], atom.node_t["tr"])
+        hint = getattr(data, "ddp_time_hint", None)
+        if hint is not None and hint[0] == tuple(id(t) for t in ts) and hint[1] == tuple(t._version for t in ts):
+            return bool(hint[2])
+        t_nodes = torch.cat([t.reshape(-1) for t in ts])
+        return bool((t_nodes == t_nodes[0]).all().item()) if t_nodes.numel() else True
+
+    # ================================================================================================ front
+    def _front(self, data, S, lig, rec, atom, dev, mark):
+        m = self.m
+        ns, B = m.ns, S.B
+        F = SimpleNamespace()
+        cnt = F.cnt = K.CountBlock(dev)
+        if m.confidence_mode:   # (:245) the times are used as they are
+            F.sig = [data.complex_t[k] for k in ("tr", "rot", "tor", "sc_tor")]
+        else:
+            F.sig = m.t_to_sigma(*[data.complex_t[k] for k in ("tr", "rot", "tor", "sc_tor")])
+        lpos, rpos, apos = lig.pos.float().contiguous(), rec.pos.float().contiguous(), atom.pos.float().contiguous()
+        F.lpos, F.rpos, F.apos = lpos, rpos, apos
+        Nl, Nr, Na = S.Nl, S.Nr, S.Na
+        lay_l, lay_r, lay_a = S.lay_l, S.lay_r, S.lay_a
+        i32e = lambda n: torch.empty(n, dtype=torch.int32, device=dev)      # noqa: E731
+
+        # node encoders, sigma embeddings and the per-node part of the edge-embedding MLPs' first Linear: one HIP launch
+        F.xl, F.xr, F.xa, pre = m._node_tables(lig, rec, atom, dev)
+        F.pre = pre
+        mark("node_embed")
+        sd_, dd, cd, nf = m.sigma_embed_dim, m.distance_embed_dim, m.cross_distance_embed_dim, m.in_lig_edge_features
+        epk = {}
+        for key, name, rbf0, rbf_n in (("ll", "lig_edge_embedding", nf + sd_, dd), ("rr", "rec_edge_embedding", sd_, dd),
+                                       ("aa", "atom_edge_embedding", sd_, dd), ("lr", "lr_edge_embedding", sd_, cd),
+                                       ("la", "la_edge_embedding", sd_, cd), ("ar", "ar_edge_embedding", sd_, dd)):
+            epk[key] = m._edge_pack(name, slice(rbf0, rbf0 + rbf_n), dev)
+        # bond-type columns of lig_edge_embedding's first Linear, [E_bond, ns]: fixed for a batch
+        bond_attr = data["ligand", "ligand"].edge_attr
+        bond_pre = m._cached("bond_pre", (bond_attr,), lambda: (bond_attr.float() @ epk["ll"].W1[:, :nf].t()).contiguous())
+
+        # ---- the pose-dependent neighbour searches (:457,545-564,607,627): ONE batched count / scan / fill sequence, edge
+        # counts stay on the device.  The atom kNN graph (:524) and everything derived from it is rebuilt only when atoms move
+        ptr_l, ptr_r, ptr_a = lay_l._ptr32, lay_r._ptr32, lay_a._ptr32
+        b32_l, b32_r, b32_a = G._batch32(lay_l, Nl), G._batch32(lay_r, Nr), G._batch32(lay_a, Na)
+        rr = S.rr
+        kk = m.atom_max_neighbors if m.atom_max_neighbors else 32
+        aa = m._cached("aa", (atom.pos, atom.batch), lambda: G.knn_graph(apos, kk, lay_a))
+        data["atom", "atom"].edge_index = aa
+        F.aa = aa
+        S.stats["E_aa"] = int(aa.shape[1])
+        Eb = S.E_bond
+        ll0, ll1 = i32e(S.cap_ll), i32e(S.cap_ll)     # ligand edges = bonds (first) + radius graph (:462-468)
+        ll0[:Eb].copy_(S.bond32[0])
+        ll1[:Eb].copy_(S.bond32[1])
+        lr0, lr1, la0, la1 = i32e(S.cap_lr), i32e(S.cap_lr), i32e(S.cap_la), i32e(S.cap_la)
+        jobs = [K.radius_job(lpos, ptr_l, lpos, b32_l, m.lig_max_radius, 33, _DROP_SELF, i32e(Nl), i32e(Nl + 1), base=Eb,
+                             total=cnt["ll"], out_query=ll1, out_x=ll0, capacity=S.cap_ll)]
+        cut = None
+        if m.dynamic_max_cross:     # (:548-556) both point sets divided by 3 sigma_tr + 20, searched with r = 1
+            cut = (F.sig[0] * 3 + 20).float().contiguous()
+            jobs.append(K.radius_job(rpos, ptr_r, lpos, b32_l, 1.0, 10000, 0, i32e(Nl), i32e(Nl + 1), total=cnt["lr"],
+                                     out_query=lr0, out_x=lr1, capacity=S.cap_lr, graph_div=cut))
+        else:
+            jobs.append(K.radius_job(rpos, ptr_r, lpos, b32_l, m.cross_max_distance, 10000, 0, i32e(Nl), i32e(Nl + 1), total=cnt["lr"],
+                                     out_query=lr0, out_x=lr1, capacity=S.cap_lr))
+        jobs.append(K.radius_job(apos, ptr_a, lpos, b32_l, m.lig_max_radius, 10000, 0, i32e(Nl), i32e(Nl + 1), total=cnt["la"],
+                                 out_query=la0, out_x=la1, capacity=S.cap_la))
+        # atoms with a ligand atom of their graph within the radius = the sources of ligand<-atom edges = the atoms an
+        # atom<-ligand message reaches ("touched"): the same search with the roles swapped, count pass only
+        F.touched = i32e(Na)
+        jobs.append(K.radius_job(lpos, ptr_l, apos, b32_a, m.lig_max_radius, 10000, 0, F.touched))
+        F.tor = F.sc = None
+        for name, st, pos, ptr_x in (("tor", S.tor, lpos, ptr_l), ("sc", S.sc, apos, ptr_a)):
+            if st is None:
+                continue
+            # build_bond_conv_graph / build_sidechain_conv_graph (:586-636): atoms around the bond centres, default cap 32
+            h = SimpleNamespace(st=st)
+            h.bond_pos = ((pos[st.bonds[0]] + pos[st.bonds[1]]) / 2).contiguous()
+            h.q, h.x = i32e(st.cap), i32e(st.cap)
+            jobs.append(K.radius_job(pos, ptr_x, h.bond_pos, G._batch32(st.lay, st.T), m.lig_max_radius, 32, 0, i32e(st.T),
+                                     i32e(st.T + 1), total=cnt[name], out_query=h.q, out_x=h.x, capacity=st.cap))
+            setattr(F, name, h)
+        K.radius_search_jobs(jobs)
+        F.keep = [jobs, cut]
+        F.near_rows = i32e(Na)
+        K.scan_jobs([K.scan_job(Na, flag=F.touched, lst=F.near_rows, total=cnt["near"])])
+        mark("searches")
+
+        # ---- which receptor-side work is the same in every graph (sampling batch: N poses of ONE complex at one time)
+        shared0 = {}
+        if m.share_layer0 and B > 1 and m.debug_conv_outputs is None and self._one_time(data, lig, rec, atom):
+            ar = S.ar
+            if S.num_flex > 0:      # side chains move per sample: only the receptor-receptor part can be shared
+                sh_ = m._cached("shared0_rec", (rec.x, rec.pos, rr),
+                                lambda: m._shared_receptor_side(B, rec, atom, rpos, apos, lay_r, lay_a, rr.long(), ar.long(), aa, atoms=False))
+            else:
+                sh_ = m._cached("shared0", (rec.x, rec.pos, atom.x, atom.pos, rr, ar, aa),
+                                lambda: m._shared_receptor_side(B, rec, atom, rpos, apos, lay_r, lay_a, rr.long(), ar.long(), aa))
+            shared0 = {k: v for k, v in sh_.items() if v is not None}
+        F.shared0 = shared0
+
+        def rows32(name, ei, k):   # int32 rows of a step-independent edge set (kept across calls), graph 0 only when shared
+            r0, r1 = m._cached(name, (ei,), lambda: (_i32(ei[0]), _i32(ei[1])))
+            n = shared0[k][1] if k in shared0 else ei.shape[1]
+            return r0[:n], r1[:n]
+
+        rr32, aa32, ar32 = rows32("rr32", rr, 6), rows32("aa32", aa, 3), rows32("ar32", S.ar, 5)
+
+        # ---- edge embeddings + harmonics (the per-node `pre` tables came with the node encoders)
+        EF = K.edge_featurize
+        F.e, F.sh = {}, {}
+        F.e["ll"], F.sh["ll"] = EF(epk["ll"], m.lig_distance_expansion, lpos, ll0, lpos, ll1, pre["ll"], ll0, pre2=bond_pre,
+                                   n_edges=S.cap_ll, cnt=cnt["ll"])
+        F.e["rr"], F.sh["rr"] = EF(epk["rr"], m.rec_distance_expansion, rpos, rr32[0], rpos, rr32[1], pre["rr"], rr32[0])
+        F.e["aa"], F.sh["aa"] = EF(epk["aa"], m.lig_distance_expansion, apos, aa32[0], apos, aa32[1], pre["aa"], aa32[0])
+        F.e["lr"], F.sh["lr"] = EF(epk["lr"], m.cross_distance_expansion, lpos, lr0, rpos, lr1, pre["lr"], lr0, n_edges=S.cap_lr, cnt=cnt["lr"])
+        F.e["la"], F.sh["la"] = EF(epk["la"], m.cross_distance_expansion, lpos, la0, apos, la1, pre["la"], la0, n_edges=S.cap_la, cnt=cnt["la"])
+        F.e["ar"], F.sh["ar"] = EF(epk["ar"], m.rec_distance_expansion, apos, ar32[0], rpos, ar32[1], pre["ar"], ar32[0])
+        mark("edge_featurize")
+
+        # ---- CSR views per conv direction (receiver = edge_index[0] of the conv call) and source-ordered views of the
+        # factorised convs: two batched grouping calls for everything pose-dependent, the rest is static
+        def static_csr(name, k, ei, recv, src, n):
+            """CSR view of a step-independent edge set, kept across calls; edge ids modulo the per-graph edge count when
+            the edge embeddings exist for graph 0 only."""
+            if k in shared0:
+                e0 = shared0[k][1]
+
+                def modded():
+                    c = G.build_csr(recv, src, n)
+                    return G.CSR(c.n_edges, c.recv, c.src, (c.eid % e0).contiguous(), c.rowptr)
+                return m._cached(f"{name}_mod{e0}", (ei,), modded)
+            return m._cached(name, (ei,), lambda: G.build_csr(recv, src, n))
+
+        c = {}
+        c[3] = static_csr("c_aa", 3, aa, aa[0], aa[1], Na)
+        c[5] = static_csr("c_ar", 5, S.ar, S.ar[0], S.ar[1], Na)
+        c[6] = static_csr("c_rr", 6, rr, rr[0], rr[1], Nr)
+        c[8] = static_csr("c_ra", 8, S.ar, S.ar[1], S.ar[0], Nr)
+        g1 = []
+        v = SimpleNamespace(rp=i32e(Nl + 1), perm=i32e(S.cap_ll), key=i32e(S.cap_ll), o0=i32e(S.cap_ll))
+        g1.append(K.group_job(ll0, S.cap_ll, Nl, [ll1], v.rp, v.perm, v.key, [v.o0], i32e(Nl + S.cap_ll), n_dev=cnt["ll"]))
+        c[0] = EdgeView(S.cap_ll, v.key, v.o0, v.perm, rowptr=v.rp, cnt=cnt["ll"])
+        for k, q0, x1, cap, name in ((1, lr0, lr1, S.cap_lr, "lr"), (2, la0, la1, S.cap_la, "la")):
+            rp = i32e(Nl + 1)       # (query-major search output: already grouped by the receiving ligand atom)
+            g1.append(K.group_job(q0, cap, Nl, [], rp, scratch=i32e(Nl), n_dev=cnt[name]))
+            c[k] = EdgeView(cap, q0, x1, G.iota32(cap, dev), rowptr=rp, cnt=cnt[name])
+        for k, key, pay, cap, n_keys, name in ((4, la1, la0, S.cap_la, Na, "la"), (7, lr1, lr0, S.cap_lr, Nr, "lr")):
+            v = SimpleNamespace(rp=i32e(n_keys + 1), perm=i32e(cap), key=i32e(cap), o0=i32e(cap))
+            g1.append(K.group_job(key, cap, n_keys, [pay], v.rp, v.perm, v.key, [v.o0], i32e(n_keys + cap), n_dev=cnt[name]))
+            c[k] = EdgeView(cap, v.key, v.o0, v.perm, rowptr=v.rp, cnt=cnt[name])
+        for h, name in ((F.tor, "tor"), (F.sc, "sc")):
+            if h is not None:
+                h.rp = i32e(h.st.T + 1)
+                g1.append(K.group_job(h.q, h.st.cap, h.st.T, [], h.rp, scratch=i32e(h.st.T), n_dev=cnt[name]))
+                h.csr = EdgeView(h.st.cap, h.q, h.x, G.iota32(h.st.cap, dev), rowptr=h.rp, cnt=cnt[name])
+        K.group_jobs(g1)
+        F.keep.append(g1)
+        F.c = c
+        n_src = {"l": Nl, "a": Na, "r": Nr}
+        so = {}
+        F.fact = set()
+        if m.factorize_min_degree > 0:
+            # Source-node factorised convs (packing.faster_tp_spec(factorized=True)): every conv whose edge set has several
+            # edges per source node - all but receptor<-atom (one edge per atom).  Their edges are listed in source order.
+            F.fact = {0, 1, 2, 3, 4, 5, 6, 7}
+            for k in (3, 5, 6):
+                so[k] = m._cached(f"so_{k}", (c[k].src, c[k].eid), lambda k=k: G.source_order(c[k], n_src[SRC_TYPE[k]]))
+            # ligand<-receptor / ligand<-atom in source order = the receptor<-ligand / atom<-ligand CSR views read the other way
+            so[1] = EdgeView(S.cap_lr, c[7].src, c[7].recv, c[7].eid, pos=c[7].eid, cnt=cnt["lr"])
+            so[2] = EdgeView(S.cap_la, c[4].src, c[4].recv, c[4].eid, pos=c[4].eid, cnt=cnt["la"])
+            g2 = []
+            for k, cap, name in ((0, S.cap_ll, "ll"), (4, S.cap_la, "la"), (7, S.cap_lr, "lr")):
+                v = SimpleNamespace(rp=i32e(Nl + 1), perm=i32e(cap), key=i32e(cap), o0=i32e(cap), o1=i32e(cap))
+                g2.append(K.group_job(c[k].src, cap, Nl, [c[k].recv, c[k].eid], v.rp, v.perm, v.key, [v.o0, v.o1], i32e(Nl + cap),
+                                      n_dev=cnt[name]))
+                so[k] = EdgeView(cap, v.o0, v.key, v.o1, pos=v.perm, cnt=cnt[name])
+            K.group_jobs(g2)
+            F.keep.append(g2)
+        F.so = so
+        mark("views")
+        return F
+
+    # ================================================================================================ index lists
+    def _lists(self, S, F, dev):
+        """Index lists of the exact work eliminations, built on the device from graph STRUCTURE only (no features)."""
+        m = self.m
+        L_, B = m.num_conv_layers, S.B
+        Nl, Nr, Na = S.Nl, S.Nr, S.Na
+        cnt, c, so = F.cnt, F.c, F.so
+        i32e = lambda n: torch.empty(n, dtype=torch.int32, device=dev)      # noqa: E731
+        i32z = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)      # noqa: E731
+        F.pruned, F.pruned_so, F.rows_a = {}, {}, {}
+        F.clean1 = None
+        n_of = {"l": Nl, "a": Na, "r": Nr}
+        dbg = m.debug_conv_outputs is not None
+        E_aa = c[3].n_edges
+
+        # ---- Dead-output elimination over the last layers.  What is read after the last layer: all ligand features (heads),
+        # with flexible side chains the atom features around the flexible bonds (side-chain torsion head), nothing of the
+        # receptor.  Walking backwards, a layer's receptor-side convs only have to produce the rows that are still read
+        # (by the residual of a needed node or as source / receiver of a kept edge of the next layer), so their edge lists
+        # are restricted to the edges that END in a needed node - exact, the other rows of x are simply left stale.
+        # Without flexible side chains this prunes layer L-2 (its atom outputs feed only the final ligand<-atom conv), with
+        # them layers L-1 and L-2; earlier layers feed (almost) everything and run in full.  Layer 0 is never touched.
+        prune_on = (m.prune_last_receptor_layer and L_ >= 2 and not m.confidence_mode and not dbg and E_aa >= m.plan_min_edges
+                    and not (m.flexible_sidechains and F.sc is None))
+        if prune_on:
+            layers = [l for l in (L_ - 1, L_ - 2) if l >= 1 and (l != L_ - 1 or m.flexible_sidechains)]
+            need = {"a": i32z(Na), "r": i32z(Nr)}
+            if F.sc is not None:    # the side-chain head reads the atoms of the flexible bonds and the atoms around them
+                K.mark_jobs([K.mark_job(need["a"], F.sc.st.flat32, 2 * F.sc.st.T),
+                             K.mark_job(need["a"], F.sc.csr.src, F.sc.csr.n_edges, cnt["sc"])])
+            else:                   # layer L-1 (ligand-receiving convs only): sources of ligand<-atom / ligand<-receptor
+                K.mark_jobs([K.mark_job(need["a"], c[2].src, c[2].n_edges, cnt["la"]),
+                             K.mark_job(need["r"], c[1].src, c[1].n_edges, cnt["lr"])])
+            for l in layers:
+                act = {"a": m.flexible_sidechains or l != L_ - 1}
+                act["r"] = act["a"] and l != L_ - 1
+                scans, copies, pl = [], [], {}
+                for rt in ("a", "r"):
+                    if not act[rt]:
+                        continue
+                    for k in RECV_OF[rt]:
+                        full = c[k]
+                        if full.n_edges == 0:
+                            continue
+                        name = f"p{l}_{k}"
+                        n = n_of[rt]
+                        v = EdgeView(full.n_edges, i32e(full.n_edges), i32e(full.n_edges), i32e(full.n_edges), rowptr=i32e(n + 1), cnt=cnt[name])
+                        scans.append(K.scan_job(n, flag=need[rt], rowptr=full.rowptr, excl=v.rowptr, total=cnt[name]))
+                        copies.append(K.rowcopy_job(n, need[rt], full.rowptr, v.rowptr, [full.recv, full.src, full.eid], [v.recv, v.src, v.eid]))
+                        pl[k] = v
+                K.scan_jobs(scans)
+                K.rowcopy_jobs(copies)
+                F.pruned[l] = pl
+                # source rows of this layer's factorised convs per source-node array (stage A runs on them only) ...
+                rows_mask = {"a": i32z(Na), "r": i32z(Nr)}
+                marks = []
+                for k in range(9):
+                    rt, st_ = RECV_TYPE[k], SRC_TYPE[k]
+                    if st_ == "l" or k == 2 or k not in F.fact or (rt != "l" and not act[rt]):
+                        continue
+                    vw = pl.get(k, c[k])
+                    if vw.n_edges > 0:
+                        marks.append(K.mark_job(rows_mask[st_], vw.src, vw.n_edges, vw.cnt))
+                # ... and the rows the NEXT (earlier) pruned layer has to produce: the needed rows themselves (residual) and the
+                # sources of every kept edge of this layer
+                nxt = None
+                if l != layers[-1]:
+                    nxt = {"a": need["a"].clone(), "r": need["r"].clone()}
+                    for k in range(9):
+                        rt, st_ = RECV_TYPE[k], SRC_TYPE[k]
+                        if st_ == "l" or (rt != "l" and not act[rt]):
+                            continue
+                        vw = pl.get(k, c[k])
+                        if vw.n_edges > 0:
+                            marks.append(K.mark_job(nxt[st_], vw.src, vw.n_edges, vw.cnt))
+                K.mark_jobs(marks)
+                lists = {}
+                scans = []
+                for t in ("a", "r"):
+                    rows = i32e(n_of[t])
+                    scans.append(K.scan_job(n_of[t], flag=rows_mask[t], lst=rows, total=cnt[f"rows{l}_{t}"]))
+                    lists[t] = (rows, cnt[f"rows{l}_{t}"])
+                K.scan_jobs(scans)
+                F.rows_a[l] = lists
+                if nxt is not None:
+                    need = nxt
+            # source-ordered views of the pruned factorised convs: one batched grouping call
+            gj = []
+            for l, pl in F.pruned.items():
+                for k, v in pl.items():
+                    if k in F.fact:
+                        n_keys = n_of[SRC_TYPE[k]]
+                        w = SimpleNamespace(rp=i32e(n_keys + 1), perm=i32e(v.n_edges), key=i32e(v.n_edges), o0=i32e(v.n_edges), o1=i32e(v.n_edges))
+                        gj.append(K.group_job(v.src, v.n_edges, n_keys, [v.recv, v.eid], w.rp, w.perm, w.key, [w.o0, w.o1],
+                                              i32e(n_keys + v.n_edges), n_dev=v.cnt))
+                        F.pruned_so.setdefault(l, {})[k] = EdgeView(v.n_edges, w.o0, w.key, w.o1, pos=w.perm, cnt=v.cnt)
+            K.group_jobs(gj)
+            F.keep.append(gj)
+
+        # ---- Layer 1, atom<-atom, sampling batches of one rigid complex (shared0 has conv 3): after the shared layer 0 an
+        # atom's features differ between the samples only if an atom<-ligand message reached it ("touched", the atoms within
+        # 5 A of that sample's ligand, ~15 %).  A layer-1 atom<-atom message between two untouched atoms is therefore the same
+        # in every sample: those messages are computed ONCE on the complex's own edge list (e0 edges, rows [E, E + e0) of
+        # the message array) and the segmented mean reads them through a row map; only the edges with a touched end are
+        # computed per sample (source-ordered sub-list, stage A on their source rows only).  Messages of a clean pair are
+        # bitwise those the general path computes (same inputs, per-edge arithmetic), the mean sums the same values in the
+        # same order: the result is bitwise the general path's (GPU test).  Layer 1 must not be one of the pruned layers.
+        if (m.share_clean_layer1 and 3 in F.shared0 and 3 in so and L_ >= 4 and E_aa > 0 and E_aa >= m.plan_min_edges and not dbg
+                and 1 not in F.pruned):
+            n0, e0, _ = F.shared0[3]
+            so3 = so[3]
+            d = SimpleNamespace(recv=i32e(E_aa), src=i32e(E_aa), eid=i32e(E_aa), pos=i32e(E_aa))
+            K.select_jobs([K.select_job(E_aa, F.touched, so3.recv, F.touched, so3.src, [so3.recv, so3.src, so3.eid, so3.pos],
+                                        [d.recv, d.src, d.eid, d.pos], cnt["dirty"], i32e(2 * ((E_aa + 2047) // 2048) + 1))])
+            so_d = EdgeView(E_aa, d.recv, d.src, d.eid, pos=d.pos, cnt=cnt["dirty"])
+            mask, rows_d = i32z(Na), i32e(Na)
+            K.mark_jobs([K.mark_job(mask, d.src, E_aa, cnt["dirty"])])
+            K.scan_jobs([K.scan_job(Na, flag=mask, lst=rows_d, total=cnt["rows_dirty"])])
+            rowmap, rows_v = i32e(E_aa), i32e(n0)
+            K.clean_pair_maps(F.touched, c[3].recv, c[3].src, E_aa, e0, B, n0, rowmap, rows_v)
+            so_v = m._cached(f"so_v{e0}", (so3.pos,), lambda: G.SourceOrder(e0, so3.recv[:e0], so3.src[:e0], so3.eid[:e0], (so3.pos[:e0] + E_aa).contiguous()))
+            F.clean1 = SimpleNamespace(so_d=so_d, rows_d=rows_d, rows_d_cnt=cnt["rows_dirty"], rowmap=rowmap, so_v=so_v, rows_v=rows_v,
+                                       E=E_aa, e0=e0, n0=n0)
+
+    def _exact(self, F):
+        """Test mode (`model.exact_sizes`): every device-side count is read back and every list cut to its actual length, so
+        that all kernels run with host-known sizes and exact grids - the results must not depend on the capacities."""
+        vals = F.cnt.values()
+        by_ptr = {F.cnt.block[i:i + 1].data_ptr(): vals[k] for k, i in F.cnt.index.items()}
+
+        def cut(v):
+            if v is None or v.cnt is None:
+                return v
+            n = by_ptr[v.cnt.data_ptr()]
+            return EdgeView(n, v.recv[:n], v.src[:n], v.eid[:n], v.rowptr, v.pos[:n] if v.pos is not None else None, None)
+
+        F.c = {k: cut(v) for k, v in F.c.items()}
+        F.so = {k: cut(v) for k, v in F.so.items()}
+        F.pruned = {l: {k: cut(v) for k, v in pl.items()} for l, pl in F.pruned.items()}
+        F.pruned_so = {l: {k: cut(v) for k, v in pl.items()} for l, pl in F.pruned_so.items()}
+        for h in (F.tor, F.sc):
+            if h is not None:
+                h.csr = cut(h.csr)
+        if F.clean1 is not None:
+            F.clean1.so_d = cut(F.clean1.so_d)
+        F.exact = by_ptr
+
+    # ================================================================================================ layers
+    def _stage_a(self, l, convs, x, n_rows, rows=None, rows_cnt=None, dense_rows=None):
+        """Stage A of the factorised convs of layer `l` that read the same source rows: ONE ddp_stage_a launch
+        rows[(conv, slot)] = x[:, scalars(slot)] @ Wg[(conv, slot)] = [G | Gb | pad] for all of them (weight-stationary
+        fp32-MFMA kernel, csrc/ddp_gemm.hip; bound by the HBM write of G).  convs: [(k, TensorProductConvLayer)].  With a row
+        list only the listed rows of the [n_rows]-row G arrays are computed.  Returns {(k, slot): G rows}."""
+        m = self.m
+        key = (l, tuple(k for k, _ in convs))
+        ent = m._stage_a_stacks.get(key)
+        if ent is None or ent[0].device != x.device:
+            Ws, meta = [], []
+            for k, conv in convs:
+                pk = conv.packed_g(x.device)
+                for slot in (0, 1):
+                    if pk.wg[slot] is not None:
+                        Ws.append(pk.wg[slot])
+                        meta.append((k, slot, pk.g_in_off[slot]))
+            ent = (torch.stack(Ws).contiguous(), meta, (C.c_int32 * len(meta))(*[mm[2] for mm in meta]))
+            m._stage_a_stacks[key] = ent
+        Wst, meta, offs = ent
+        nb = len(meta)
+        if nb > L.DDP_MAX_GEMM_BATCH:
+            raise L.DdpError("more (conv, slot) pairs per source array than DDP_MAX_GEMM_BATCH")
+        Gall = torch.empty((nb, n_rows, Wst.shape[2]), device=x.device, dtype=torch.float32)   # 128-byte aligned rows
+        prof = K.profiler(hbm=True)
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        n_list = n_rows if rows is None else int(rows.shape[0])
+        K.stage_a(x, n_list, offs, nb, Wst, Gall, rows=rows, rows_cnt=rows_cnt, out_rows=n_rows)
+        if prof is not None:
+            e1.record()
+            # algorithmic bytes: the G rows written once + the scalar columns of x read once per product + the weights
+            row_bytes = 4.0 * nb * (Wst.shape[2] + Wst.shape[1])
+
+            def nbytes(n_list=n_list, rows_cnt=rows_cnt, row_bytes=row_bytes, wn=Wst.numel()):
+                n = n_list if rows_cnt is None else min(n_list, int(rows_cnt.item()))
+                return row_bytes * n + 4.0 * wn
+            prof.hbm.setdefault("ddp_stage_a_mfma_kernel", []).append((e0, e1, nbytes))
+        return {(k, slot): Gall[i] for i, (k, slot, _) in enumerate(meta)}
+
+    def _layers(self, S, F, dev, mark):
+        m = self.m
+        ns, L_, B, ldx = m.ns, m.num_conv_layers, S.B, m._ldx
+        Nl, Nr, Na = S.Nl, S.Nr, S.Na
+        c, so = F.c, F.so
+        xl, xr, xa = F.xl, F.xr, F.xa
+        e, sh = F.e, F.sh
+        # conv k of a layer: (receiver x, source x, edge embedding, harmonics)
+        arr = {0: (xl, xl, "ll"), 1: (xl, xr, "lr"), 2: (xl, xa, "la"), 3: (xa, xa, "aa"), 4: (xa, xl, "la"), 5: (xa, xr, "ar"),
+               6: (xr, xr, "rr"), 7: (xr, xl, "lr"), 8: (xr, xa, "ar")}
+        nodes = {"l": (xl, Nl), "a": (xa, Na), "r": (xr, Nr)}
+        dbg = m.debug_conv_outputs
+        exact = getattr(F, "exact", None)
+        for l in range(L_):
+            spec, spec_g = m._layer_specs[l], m._layer_specs_g[l]
+            do_atom = m.flexible_sidechains or l != L_ - 1
+            active = {"l": True, "a": do_atom, "r": do_atom and l != L_ - 1}
+            shared = F.shared0 if l == 0 else {}
+            pl, pl_so = F.pruned.get(l, {}), F.pruned_so.get(l, {})
+            c1 = F.clean1 if (l == 1 and F.clean1 is not None and active["a"]) else None
+            keep = []
+            # ---- per conv: its CSR view (reduce / direct conv), its source-ordered view and the rows stage A has to produce
+            per, groups = {}, {}
+            for k in range(9):
+                rt, st_ = RECV_TYPE[k], SRC_TYPE[k]
+                if not active[rt]:
+                    continue
+                csr, so_k = c[k], so.get(k) if k in F.fact else None
+                x_src = arr[k][1]
+                rows = ("all", None, None, nodes[st_][1])                 # (group id, row list, its device count, rows of G)
+                if k in pl:             # edges that end in a node the final layers read
+                    csr, so_k = pl[k], pl_so.get(k)
+                    if st_ != "l":
+                        r_, rc = F.rows_a[l][st_]
+                        rows = (f"pr{l}", r_, rc, nodes[st_][1])
+                elif k in shared:       # graph 0's edges = a prefix of both orderings, graph 0's nodes = a prefix of x
+                    n0, e0, ns0 = shared[k]
+                    csr = csr.prefix(e0, n0)
+                    so_k = so_k.prefix(e0) if so_k is not None else None
+                    x_src = x_src[:ns0]
+                    rows = ("g0", None, None, ns0)
+                elif k == 2 and so_k is not None:    # ligand<-atom: only the atoms near a ligand occur as sources
+                    rows = ("near", F.near_rows, F.cnt["near"], Na)
+                    if exact is not None:
+                        rows = ("near", F.near_rows[:exact[F.cnt["near"].data_ptr()]], None, Na)
+                elif l in F.pruned and st_ != "l" and so_k is not None:   # an unpruned conv of a pruned layer (ligand<-receptor)
+                    r_, rc = F.rows_a[l][st_]
+                    rows = (f"pr{l}", r_, rc, nodes[st_][1])
+                if exact is not None and rows[2] is not None:
+                    rows = (rows[0], rows[1][:exact[rows[2].data_ptr()]], None, rows[3])
+                per[k] = (csr, so_k, x_src)
+                if so_k is not None and csr.n_edges > 0 and not (k == 3 and c1 is not None):
+                    groups.setdefault((st_, rows[0]), (x_src, rows, []))[2].append((k, m.conv_layers[9 * l + k]))
+            # ---- stage A: one batched product per (source-node array, row set)
+            gmap = {}
+            for (st_, gid), (x_src, rows, convs) in groups.items():
+                gmap.update(self._stage_a(l, convs, x_src, rows[3], rows=rows[1], rows_cnt=rows[2]))
+            x_clean = None
+            if c1 is not None:      # atom<-atom at layer 1: touched edges per sample + the clean pairs once
+                conv3 = m.conv_layers[9 * l + 3]
+                rows_d, rows_dc = c1.rows_d, c1.rows_d_cnt
+                if exact is not None:
+                    rows_d, rows_dc = rows_d[:exact[rows_dc.data_ptr()]], None
+                g_d = self._stage_a(l, [(3, conv3)], xa, Na, rows=rows_d, rows_cnt=rows_dc)
+                x_clean = torch.empty((c1.n0, ldx), device=dev)
+                K.gather_rows(xa, c1.rows_v, c1.n0, x_clean, ldx)
+                g_v = self._stage_a(l, [(3, conv3)], x_clean, c1.n0)
+                keep += [g_d, g_v, x_clean]
+            keep.append(gmap)
+            # ---- conv tasks
+            tasks, tasks_g, msgs = [], [], {}
+            nb_g = nb_d = 0.0
+            prof_on = K.profiler() is not None
+            for k, (csr, so_k, x_src) in per.items():
+                x_recv, _, ek = arr[k]
+                conv = m.conv_layers[9 * l + k]
+                pkc = conv.packed(dev)
+                e_base, sh_k = e[ek], sh[ek]
+                if k == 3 and c1 is not None:
+                    # rows [0, E): per-sample messages at their CSR positions (only the touched edges are written and read),
+                    # rows [E, E + e0): the messages of the complex's own edge list between clean atoms
+                    msg = torch.empty((c1.E + c1.e0, spec.d_out), device=dev)
+                    msgs[k] = (msg, csr, pkc, c1.rowmap)
+                    pkg = conv.packed_g(dev)
+                    sd_ = c1.so_d
+                    if sd_.n_edges > 0:
+                        segs = [(e_base, sd_.eid, ns, ns), (x_recv, sd_.recv, ldx, ns), (xa, sd_.src, ldx, ns)]
+                        tasks_g.append(K.make_task(pkg, xa, ldx, sd_, sh_k, segs, msg, g=[g_d.get((3, s_)) for s_ in (0, 1)]))
+                    sv = c1.so_v
+                    segs = [(e_base, sv.eid, ns, ns), (x_clean, sv.recv, ldx, ns), (x_clean, sv.src, ldx, ns)]
+                    tasks_g.append(K.make_task(pkg, x_clean, ldx, sv, sh_k, segs, msg, g=[g_v.get((3, s_)) for s_ in (0, 1)]))
+                    continue
+                msg = torch.empty((csr.n_edges, spec.d_out), device=dev)
+                msgs[k] = (msg, csr, pkc)
+                if csr.n_edges == 0:
+                    continue
+                if prof_on:     # algorithmic node bytes of the conv call (profiler only)
+                    d_in = P.irreps_dim(P.irreps_muls(ns, m.nv, l))
+                    b_ = 4.0 * (nodes[SRC_TYPE[k]][1] * d_in + nodes[RECV_TYPE[k]][1] * spec.d_out)
+                    if so_k is not None:
+                        nb_g += b_
+                    else:
+                        nb_d += b_
+                if so_k is not None:
+                    segs = [(e_base, so_k.eid, ns, ns), (x_recv, so_k.recv, ldx, ns), (x_src, so_k.src, ldx, ns)]
+                    tasks_g.append(K.make_task(conv.packed_g(dev), x_src, ldx, so_k, sh_k, segs, msg, g=[gmap.get((k, s_)) for s_ in (0, 1)]))
+                else:
+                    segs = [(e_base, csr.eid, ns, ns), (x_recv, csr.recv, ldx, ns), (x_src, csr.src, ldx, ns)]
+                    tasks.append(K.make_task(pkc, x_src, ldx, csr, sh_k, segs, msg))
+            mark("conv_prep")
+            K.launch_convs(spec_g, tasks_g, flops_spec=spec, node_bytes=nb_g)
+            K.launch_convs(spec, tasks, node_bytes=nb_d)
+            mark("conv_launch")
+            if dbg is not None:   # every conv's own output = segmented mean + BatchNorm of its messages alone
+                for k, ent in msgs.items():
+                    n_k = nodes[RECV_TYPE[k]][1]
+                    o_k = torch.zeros((n_k, spec.d_out), device=dev)
+                    K.launch_reduce(o_k, spec.d_out, n_k, spec.d_out, [ent], accumulate=False)
+                    dbg[f"conv_layers.{9 * l + k}"] = o_k
+            for rt in ("l", "a", "r"):
+                if not active[rt]:
+                    continue
+                x, n = nodes[rt]
+                own = [msgs[k] for k in ORDER[rt] if k not in shared]
+                if own:
+                    K.launch_reduce(x, ldx, n, spec.d_out, own, accumulate=True)
+                com = [msgs[k] for k in ORDER[rt] if k in shared]
+                if com:   # graph 0's update of the shared convs, added to every graph's copy of the node
+                    n0 = shared[[k for k in ORDER[rt] if k in shared][0]][0]
+                    K.launch_reduce(x, ldx, n0, spec.d_out, com, accumulate=True, n_rep=B, rep_stride=n0)
+            mark("reduce")
+            F.keep.append((keep, per, msgs, tasks, tasks_g))
+
+    # ================================================================================================ heads
+    def _heads(self, data, S, F, lig, rec, atom, dev, mark):
+        m = self.m
+        ns, L_, B, ldx = m.ns, m.num_conv_layers, S.B, m._ldx
+        Nl, Na = S.Nl, S.Na
+        xl, xa, lpos = F.xl, F.xa, F.lpos
+        lay_l, lay_a, lbatch, abatch = S.lay_l, S.lay_a, S.lbatch, S.abatch
+        tr_sigma, rot_sigma, tor_sigma, sc_sigma = F.sig
+        if m.confidence_mode:   # (:329-353) mean of the scalar channels per graph -> MLP
+            def scalars(x):
+                return torch.cat([x[:, :ns], x[:, m._d_final - ns:m._d_final]], dim=1) if L_ >= 3 else x[:, :ns]
+
+            def graph_mean(v, b):   # (dense per-graph sums in a fixed order - index_add_'s float atomics are not reproducible)
+                lay = G.DenseLayout.build(b, B)
+                return lay.dense(v, 0.0).sum(1) / lay.counts.clamp(min=1).unsqueeze(1)
+
+            conf_in = lay_l.dense(scalars(xl), 0.0).sum(1) / lay_l.counts.clamp(min=1).unsqueeze(1)   # (deterministic order)
+            if m.flexible_sidechains:
+                if S.num_flex > 0:
+                    fr = data["flexResidues"]
+                    bonds = lay_a.starts[fr.batch.long()] + fr.edge_idx.t().long()
+                    flex_atoms = torch.unique(bonds)
+                    conf_in = torch.cat([conf_in, graph_mean(scalars(xa)[flex_atoms], abatch[flex_atoms])], dim=1)
+                else:
+                    conf_in = torch.cat([conf_in, torch.zeros_like(conf_in)], dim=1)
+            return m.confidence_predictor(conf_in).squeeze(dim=-1)
+
+        dd = m.distance_embed_dim
+        # ---- translation / rotation head (:357-384): ligand atoms -> their graph's centre
+        ar_l = G.iota32(Nl, dev)
+        b32_l = G._batch32(lay_l, Nl)
+        # (a dense sum, not index_add_: float atomics land in an order that depends on what else the device is doing, and
+        # one ulp in the centre is one ulp in tr / rot - seen as run-to-run differences at the full size)
+        center = (lay_l.dense(lpos, 0.0).sum(1) / lay_l.counts.unsqueeze(1)).contiguous()
+        pk = m._edge_pack("center_edge_embedding", slice(0, dd), dev)
+        e_c, sh_c = K.edge_featurize(pk, m.center_distance_expansion, center, b32_l, lpos, ar_l, F.pre["center"], ar_l)
+        c_c = m._cached("c_c", (lig.batch,), lambda: G.build_csr(b32_l, ar_l, B, presorted=True))
+        fspec = m.final_conv.spec
+        pkc = m.final_conv.packed(dev)
+        msg = torch.empty((Nl, fspec.d_out), device=dev)
+        seg_idx = c_c.src if m.fixed_center_conv else c_c.recv
+        K.launch_convs(fspec, [K.make_task(pkc, xl, ldx, c_c, sh_c, [(e_c, c_c.eid, ns, ns), (xl, seg_idx, ldx, ns)], msg)])
+        gp = torch.zeros((B, fspec.d_out), device=dev)
+        K.launch_reduce(gp, fspec.d_out, B, fspec.d_out, [(msg, c_c, pkc)], accumulate=False)
+        if m.debug_conv_outputs is not None:
+            m.debug_conv_outputs["final_conv"] = gp
+        tr_pred = gp[:, :3] + gp[:, 6:9]
+        rot_pred = gp[:, 3:6] + gp[:, 9:]
+        data.graph_sigma_emb = m.timestep_emb_func(data.complex_t["tr"])
+        tr_norm = torch.linalg.vector_norm(tr_pred, dim=1).unsqueeze(1)
+        tr_pred = tr_pred / tr_norm * m.tr_final_layer(torch.cat([tr_norm, data.graph_sigma_emb], dim=1))
+        rot_norm = torch.linalg.vector_norm(rot_pred, dim=1).unsqueeze(1)
+        rot_pred = rot_pred / rot_norm * m.rot_final_layer(torch.cat([rot_norm, data.graph_sigma_emb], dim=1))
+        if m.scale_by_sigma:
+            tr_pred = tr_pred / tr_sigma.unsqueeze(1)
+            rot_pred = rot_pred * m._so3_score_norm(rot_sigma).unsqueeze(1)
+        mark("center_head")
+        # ---- torsion heads (:386-434)
+        tor_pred = torch.empty(0, device=dev)
+        if F.tor is not None:
+            tor_pred = self._torsion_head(F.tor, "final_edge_embedding", m.tor_bond_conv, m.tor_final_layer, xl, lpos, dev, "tor_bond_conv")
+            if m.scale_by_sigma:
+                edge_sigma = tor_sigma[lbatch][S.bond_ei[0].long()][S.tor.idx]
+                tor_pred = tor_pred * torch.sqrt(m._torus_score_norm(edge_sigma))
+        sc_pred = torch.empty(0, device=dev)
+        if F.sc is not None:
+            sc_pred = self._torsion_head(F.sc, "sidechain_final_edge_embedding", m.sc_tor_bond_conv, m.sc_tor_final_layer, xa, F.apos,
+                                         dev, "sc_tor_bond_conv")
+            if m.scale_by_sigma:
+                sc_pred = sc_pred * torch.sqrt(m._torus_score_norm(sc_sigma[data["flexResidues"].batch.long()]))
+        mark("tor_heads")
+        F.keep.append((center, e_c, sh_c, msg, gp))
+        return tr_pred, rot_pred, tor_pred, sc_pred
+
+    def _torsion_head(self, h, mlp_name, conv, final_layer, x, pos, dev, name):
+        """build_bond_conv_graph / build_sidechain_conv_graph (:586-636) on the searched bond-centre graph + FullTensorProduct
+        + tor_bond_conv + final layer (:386-434).  An empty graph gives zero scores (the reference fails there)."""
+        m = self.m
+        lib = L.load()
+        ns, ldx = m.ns, m._ldx
+        st, csr = h.st, h.csr
+        E, T, bonds = csr.n_edges, st.T, st.bonds
+        pk = m._edge_pack(mlp_name, slice(0, m.distance_embed_dim), dev)
+        pre = pk.b1.reshape(1, -1).contiguous()
+        zero_idx = m._cached("zeros_" + name, (st.bonds,), lambda: torch.zeros(st.cap, device=dev, dtype=torch.int32))
+        e_t, sh_e = K.edge_featurize(pk, m.lig_distance_expansion, h.bond_pos, csr.recv, pos, csr.src, pre, zero_idx[:E], n_edges=E, cnt=csr.cnt)
+        bond_vec = (pos[bonds[1]] - pos[bonds[0]]).contiguous()
+        tor_sh = torch.empty((E, 4), device=dev)
+        if E > 0:
+            L.check(lib.ddp_torsion_sh(K.ptr(sh_e), K.ptr(bond_vec), K.ptr(csr.recv), E, K.ptr(csr.cnt), K.ptr(tor_sh), K.stream()),
+                    "ddp_torsion_sh")
+        bond_attr = (x[bonds[0], :ns] + x[bonds[1], :ns]).contiguous()
+        spec, pkc = conv.spec, conv.packed(dev)
+        msg = torch.empty((E, spec.d_out), device=dev)
+        segs = [(e_t, csr.eid, ns, ns), (x, csr.src, ldx, ns), (bond_attr, csr.recv, ns, ns)]
+        if E > 0:
+            K.launch_convs(spec, [K.make_task(pkc, x, ldx, csr, tor_sh, segs, msg)])
+        hsum = torch.zeros((T, spec.d_out), device=dev)
+        K.launch_reduce(hsum, spec.d_out, T, spec.d_out, [(msg, csr, pkc)], accumulate=False)
+        if m.debug_conv_outputs is not None:
+            m.debug_conv_outputs[name] = hsum
+        h.keep = (e_t, sh_e, bond_vec, tor_sh, bond_attr, msg)
+        return final_layer(hsum).squeeze(1)

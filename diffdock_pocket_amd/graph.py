@@ -53,27 +53,29 @@ class DenseLayout:
     slot: torch.Tensor        # [N] position of node inside its graph
     index: torch.Tensor       # [B, nmax] global node id or -1
     uniform: bool
+    counts_host: tuple = ()   # the graph sizes as python ints (capacities of the pose-dependent edge lists are sized from them)
 
     @staticmethod
     def build(batch: torch.Tensor, B: int) -> "DenseLayout":
+        """(synchronises with the host once - the graph sizes are read back; a layout is built once per batch vector)"""
         counts = torch.bincount(batch, minlength=B)
         starts = torch.cumsum(counts, 0) - counts
-        nmax = int(counts.max().item()) if counts.numel() else 0
+        counts_host = tuple(int(c) for c in counts.tolist())
+        nmax = max(counts_host) if counts_host else 0
         n = batch.shape[0]
         slot = torch.arange(n, device=batch.device) - starts[batch]
         index = torch.full((B, max(nmax, 1)), -1, dtype=torch.long, device=batch.device)
         index[batch, slot] = torch.arange(n, device=batch.device)
-        uniform = bool((counts == nmax).all().item()) if counts.numel() else True
-        return DenseLayout(B, nmax, counts, starts, slot, index, uniform)
+        uniform = all(c == nmax for c in counts_host)
+        return DenseLayout(B, nmax, counts, starts, slot, index, uniform, counts_host)
 
     def dense(self, values: torch.Tensor, fill: float) -> torch.Tensor:
-        """[N, d] -> [B, nmax, d] (padding rows = fill)."""
+        """[N, d] -> [B, nmax, d] (padding rows = fill).  No host synchronisation (no boolean-mask indexing)."""
         if self.uniform:
             return values.reshape(self.B, self.nmax, *values.shape[1:])
-        out = values.new_full((self.B, max(self.nmax, 1)) + tuple(values.shape[1:]), fill)
-        valid = self.index >= 0
-        out[valid] = values[self.index[valid]]
-        return out
+        pad = self.index < 0
+        out = values[self.index.clamp(min=0)]
+        return out.masked_fill(pad.reshape(pad.shape + (1,) * (values.dim() - 1)), fill)
 
 
 def _sqdist(y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
@@ -207,7 +209,7 @@ def knn_graph(x, k, lx: DenseLayout):
         L.check(lib.ddp_knn(xc.data_ptr(), _ptr(lx).data_ptr(), _batch32(lx, n).data_ptr(), n, kk, nb.data_ptr(),
                             _raw_stream()), "ddp_knn")
         q = torch.arange(n, device=x.device).unsqueeze(1).expand(n, kk)
-        if lx.uniform or int(lx.counts.min().item()) > kk:       # every node has kk neighbours: no compaction
+        if lx.uniform or min(lx.counts_host) > kk:       # every node has kk neighbours: no compaction
             return torch.stack([nb.reshape(-1).long(), q.reshape(-1)], 0)
         keep = nb >= 0
         return torch.stack([nb[keep].long(), q[keep]], 0)
@@ -230,13 +232,35 @@ def knn_graph(x, k, lx: DenseLayout):
 
 
 @dataclass
-class CSR:
-    """Edges of one conv direction in CSR order of the receiving node (what ddp_conv_messages consumes)."""
+class EdgeView:
+    """Edges of one conv direction as the kernels consume them: CSR order of the receiving node (`rowptr` set) or source-node
+    order of a factorised conv (`pos` set: the message row of every listed edge).  `n_edges` is the CAPACITY of the arrays;
+    `cnt` (int32 [1] on the device, or None when the capacity IS the count) holds the actual number of edges
+    (include/ddp_hip.h, "Device-side counts")."""
     n_edges: int
-    recv: torch.Tensor     # int32 [E] receiving node per CSR position
-    src: torch.Tensor      # int32 [E] feature-source node per CSR position
+    recv: torch.Tensor     # int32 [E] receiving node per position
+    src: torch.Tensor      # int32 [E] feature-source node per position
     eid: torch.Tensor      # int32 [E] canonical edge id (row of edge_base / edge_sh)
-    rowptr: torch.Tensor   # int32 [n_recv + 1]
+    rowptr: Optional[torch.Tensor] = None   # int32 [n_recv + 1] (CSR views)
+    pos: Optional[torch.Tensor] = None      # int32 [E] message row (source-ordered views)
+    cnt: Optional[torch.Tensor] = None
+
+    def prefix(self, n: int, n_rows: Optional[int] = None) -> "EdgeView":
+        """The first n edges (and, for a CSR view, the first n_rows receiving nodes) with a host-known count."""
+        return EdgeView(n, self.recv[:n], self.src[:n], self.eid[:n],
+                        self.rowptr[:n_rows + 1] if (self.rowptr is not None and n_rows is not None) else self.rowptr,
+                        self.pos[:n] if self.pos is not None else None, None)
+
+
+def CSR(n_edges, recv, src, eid, rowptr) -> EdgeView:
+    """Edges in CSR order of the receiving node (what ddp_conv_messages / ddp_segment_reduce consume)."""
+    return EdgeView(n_edges, recv, src, eid, rowptr=rowptr)
+
+
+def SourceOrder(n_edges, recv, src, eid, pos) -> EdgeView:
+    """The edges of a CSR view re-listed in SOURCE-node order (for the factorised conv, which streams one G[j] per
+    source node): `pos` = the row of each listed edge in the receiver-CSR message array."""
+    return EdgeView(n_edges, recv, src, eid, pos=pos)
 
 
 def _group_by_key(key32, n_keys, pays, want_key=True, want_perm=True):
@@ -274,7 +298,7 @@ def _as_i32(t):
     return t if t.dtype == torch.int32 else t.to(torch.int32)
 
 
-def build_csr(recv: torch.Tensor, src: torch.Tensor, n_recv: int, presorted: bool = False) -> CSR:
+def build_csr(recv: torch.Tensor, src: torch.Tensor, n_recv: int, presorted: bool = False) -> EdgeView:
     """recv / src: int64 or int32 [E].  On the device this is ONE ddp_group_by_key call (5 launches); the PyTorch form below
     is its definition (CPU tests; tests/test_gpu_parity.py compares the two bit for bit)."""
     E = int(recv.shape[0])
@@ -301,18 +325,7 @@ def build_csr(recv: torch.Tensor, src: torch.Tensor, n_recv: int, presorted: boo
     return CSR(E, r_sorted.to(torch.int32), src[perm].to(torch.int32), perm.to(torch.int32), rowptr)
 
 
-@dataclass
-class SourceOrder:
-    """The edges of a CSR view re-listed in SOURCE-node order (for the factorised conv, which streams one G[j] per
-    source node): same fields as CSR plus `pos`, the row of each listed edge in the receiver-CSR message array."""
-    n_edges: int
-    recv: torch.Tensor
-    src: torch.Tensor
-    eid: torch.Tensor
-    pos: torch.Tensor
-
-
-def source_order(csr: CSR, n_src: Optional[int] = None) -> SourceOrder:
+def source_order(csr: EdgeView, n_src: Optional[int] = None) -> EdgeView:
     """n_src (number of source nodes, an upper bound of csr.src + 1) selects the device grouping kernel; without it the
     PyTorch stable sort is used (same result)."""
     if csr.n_edges == 0:

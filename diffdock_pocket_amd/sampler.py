@@ -340,7 +340,7 @@ class PipelinedSampler:
         torch.cuda.synchronize(device)
         self.n = hi - lo
         self.n_l, self.n_a = self.parts[0].n_l, self.parts[0].n_a
-        self.last_stats: dict = {}
+        self._stats: list = []
         self._warm = False
         self._done = None          # event after the most recent group step
 
@@ -373,7 +373,7 @@ class PipelinedSampler:
                     self._done = self._part_done[slot] = done
             finally:
                 self.model.before_layers = None
-            stats.append(dict(self.model.last_stats))
+            stats.append(self.model.last_stats)      # (read lazily: the edge counts live on the device)
             if not self._warm:   # weights are packed on first use: finished before another stream reads them
                 torch.cuda.synchronize(self.device)
         self.model.cache_slot = 0
@@ -384,8 +384,13 @@ class PipelinedSampler:
         self._each(lambda p: p.randomize())
 
     def step(self, t_idx: int, schedule: np.ndarray):
-        stats = self._each(lambda p: p.step(t_idx, schedule))
-        self.last_stats = {k: sum(s.get(k, 0) for s in stats) for k in stats[0]}   # edge / node / graph counts of the step
+        self._stats = self._each(lambda p: p.step(t_idx, schedule))
+
+    @property
+    def last_stats(self):
+        """Edge / node / graph counts of the last step, summed over the groups."""
+        stats = [dict(s) for s in self._stats]
+        return {k: sum(s.get(k, 0) for s in stats) for k in stats[0]} if stats else {}
 
     def _gather(self, name):
         torch.cuda.synchronize(self.device)

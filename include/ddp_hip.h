@@ -119,6 +119,8 @@ typedef struct {
                            up to 4): G[j][k/4][c][k%4]; then the g_cols[s] values Gb[j][c] (the fc.3 bias part); then
                            padding to a 128-byte multiple.  One ddp_stage_a product writes the whole row.  16-byte aligned */
   const int32_t* pos;   /* [E] message row per listed edge; NULL = identity */
+  const int32_t* n_edges_dev; /* optional, device memory: the actual edge count (see "Device-side counts"); n_edges is then the
+                           capacity of the edge arrays and sizes the grid */
 } ddp_conv_task_t;
 
 /* Fused fc -> tensor product -> per-edge message for up to 9 convs that share one shape.
@@ -142,9 +144,12 @@ typedef struct {
   const int32_t* rowmap; /* optional [n_edges]: row of `msg` that holds the message of CSR position p (NULL: row p).  Lets
                             identical messages be stored once (score_model: layer-1 atom<-atom messages between atoms that no
                             ligand message has reached are the same in every sample of a sampling batch) */
+  const int32_t* n_edges_dev; /* optional, device memory: the actual edge count (0 -> the conv contributes exactly 0) */
 } ddp_reduce_src_t;
+/* n_rep > 1: the update of node n - computed from 0 exactly as with accumulate = 0 - is ADDED to the rows n + g * rep_stride,
+ * g < n_rep, of x (the layer-0 update of a receptor shared by all samples of a batch, added to every sample's copy). */
 int ddp_segment_reduce(float* x, int ldx, int n_nodes, int d_out, const ddp_reduce_src_t* srcs, int nsrc,
-                       int accumulate, void* stream);
+                       int accumulate, int n_rep, int rep_stride, void* stream);
 
 /* Edge featurisation: edge vector -> length -> Gaussian RBF -> 2-layer MLP, and spherical harmonics (lmax=1).
  *   vec = pos_b[ib[e]] - pos_a[ia[e]];  d = |vec|;  rbf_k = exp(coeff * (d - offset[k])^2)
@@ -167,8 +172,8 @@ int ddp_edge_featurize(const float* pos_a, const int32_t* ia, const float* pos_b
  *   t[e] = sqrt(3/2) * (3 (n.v) v - n),  n = unit(sh edge vector), v = unit(bond vector of bond ib[e])
  * written as [0, t] so the conv kernel reads it like an edge_sh row.
  * Replaces all_atom_score_model.py:394-395,418-419 (o3.spherical_harmonics("2e") + o3.FullTensorProduct). */
-int ddp_torsion_sh(const float* sh_edge, const float* bond_vec, const int32_t* bond_of_edge, int n_edges, float* out,
-                   void* stream);
+int ddp_torsion_sh(const float* sh_edge, const float* bond_vec, const int32_t* bond_of_edge, int n_edges,
+                   const int32_t* n_edges_dev, float* out, void* stream);
 
 /* Stage A of the source-node factorisation (ddp_block_t::g_slot): the per-source-node tensors consumed through
  * ddp_conv_task_t::g, for all (conv, G slot) pairs that read one node-feature array x:
@@ -181,8 +186,11 @@ int ddp_torsion_sh(const float* sh_edge, const float* bond_vec, const int32_t* b
  * the rate of unaligned ones. */
 #define DDP_MAX_GEMM_BATCH 16
 #define DDP_G_LD(hid, gcols) ((((((hid) + 3) / 4) * 4 + 1) * (gcols) + 31) / 32 * 32)   /* floats per node of a G array */
-int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* offs, int nbatch, const float* w, int k, int ncols,
-                float* out, int ldo, void* stream);
+/* rows (optional, device int32 [nrows]): only the listed node rows are computed - x row rows[i] -> row rows[i] of out[b], which
+ * has out_rows rows per batch slice; the other rows of out are left as they are - and nrows_dev (optional, device) holds the
+ * length of the list (nrows = its capacity).  rows == NULL: out_rows is ignored (= nrows). */
+int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows, const int32_t* offs,
+                int nbatch, const float* w, int k, int ncols, float* out, int ldo, void* stream);
 
 /* The pose update between two score-model calls, for all samples of a batch in one launch:
  * modify_conformer(pos, tr_update, rot_update, torsion_updates) of utils/diffusion_utils.py:37-60 = rigid move about the
@@ -231,6 +239,122 @@ int ddp_knn(const float* x, const int32_t* x_ptr, const int32_t* batch, int n, i
 int ddp_group_by_key(const int32_t* key, int n_items, int n_keys, const int32_t* pay0, const int32_t* pay1, const int32_t* pay2,
                      int32_t* rowptr, int32_t* perm, int32_t* out_key, int32_t* out0, int32_t* out1, int32_t* out2,
                      int32_t* scratch, void* stream);
+
+/* ---- Device-side counts.  The sizes of the pose-dependent lists of a denoising step (radius graphs, their views, the sub-lists
+ * of the exact work eliminations) stay in device memory: where an entry point or a job takes `n` together with `n_dev`, a
+ * non-NULL n_dev points to the actual count, the kernels read it (clamped to n), and n is the CAPACITY that sizes the launch
+ * grid.  No entry point reads device memory on the host, so a whole step can be queued - or captured in a hipGraph - without
+ * a host synchronisation.  The list primitives (csrc/ddp_lists.hip, ddp_graph.hip, ddp_views.hip) are batched: one call serves up
+ * to DDP_MAX_LIST_JOBS independent jobs with a fixed number of launches. */
+#define DDP_MAX_LIST_JOBS 12
+
+/* Exclusive prefix sum over i < n of  value_i = (flag ? flag[i] != 0 : 1) * (val ? val[i] : rowptr ? rowptr[i+1] - rowptr[i] : 1):
+ *   excl[i] = excl2[i] = base + sum_{i' < i} value_i',  excl[n] = *total = base + sum of all (each output optional);
+ *   list[excl[i] - base ... ] : with 0 / 1 values (val == rowptr == NULL) list[excl[i]] = i for the flagged i, ascending. */
+typedef struct {
+  int32_t n;
+  const int32_t* n_dev;
+  const int32_t* flag;
+  const int32_t* val;
+  const int32_t* rowptr;
+  int32_t base;
+  int32_t* excl;
+  int32_t* excl2;
+  int32_t* list;
+  int32_t* total;
+} ddp_scan_job_t;
+int ddp_scan_jobs(const ddp_scan_job_t* jobs, int njobs, void* stream);
+
+/* mask[idx[i]] = 1 for i < n (idx == NULL: mask[i] = 1). */
+typedef struct {
+  const int32_t* idx;
+  int32_t n;
+  const int32_t* n_dev;
+  int32_t* mask;
+} ddp_mark_job_t;
+int ddp_mark_jobs(const ddp_mark_job_t* jobs, int njobs, void* stream);
+
+/* Compaction of whole CSR rows: the entries old_rowptr[r] .. old_rowptr[r+1] of in[k] move to new_rowptr[r] .. of out[k] for
+ * every row with keep[r] != 0 (new_rowptr = ddp_scan_jobs over (flag = keep, rowptr = old_rowptr)). */
+typedef struct {
+  int32_t n_rows;
+  const int32_t* keep;
+  const int32_t* old_rowptr;
+  const int32_t* new_rowptr;
+  const int32_t* in[3];
+  int32_t* out[3];
+} ddp_rowcopy_job_t;
+int ddp_rowcopy_jobs(const ddp_rowcopy_job_t* jobs, int njobs, void* stream);
+
+/* Stable compaction of the items i < n with  mask_a[idx_a ? idx_a[i] : i] | mask_b[idx_b ? idx_b[i] : i]  (a NULL mask counts as
+ * 0): out_idx[j] = i, out[k][j] = pay[k][i] + pay_add[k] in ascending i, *total = number kept.  block_count / block_off:
+ * (n + 2047) / 2048 (+ 1 for block_off) int32 of workspace each. */
+typedef struct {
+  int32_t n;
+  const int32_t* n_dev;
+  const int32_t* mask_a;
+  const int32_t* idx_a;
+  const int32_t* mask_b;
+  const int32_t* idx_b;
+  int32_t* out_idx;
+  const int32_t* pay[4];
+  int32_t pay_add[4];
+  int32_t* out[4];
+  int32_t* total;
+  int32_t* block_count;
+  int32_t* block_off;
+} ddp_select_job_t;
+int ddp_select_jobs(const ddp_select_job_t* jobs, int njobs, void* stream);
+
+/* out[i, :ncols] = x[idx[i], :ncols] for i < n. */
+int ddp_gather_rows(const float* x, int ldx, const int32_t* idx, int n, const int32_t* n_dev, float* out, int ldo, int ncols,
+                    void* stream);
+
+/* The two index maps of the layer-1 clean-pair sharing (see csrc/ddp_lists.hip); n_edges = e0 * n_graphs. */
+int ddp_clean_pair_maps(const int32_t* touched, const int32_t* recv, const int32_t* src, int n_edges, int e0, int n_graphs, int n0,
+                        int32_t* rowmap, int32_t* rows_v, void* stream);
+
+/* One neighbour search of ddp_radius_search_jobs = ddp_radius_count + prefix sum + ddp_radius_fill without the host in between:
+ * counts[ny] and offsets[ny + 1] are outputs (offsets[q] = base + pairs of the queries before q), *total = base + all pairs,
+ * pairs are written from index offsets[q] on and never at or behind `capacity`.  out_x == NULL: a count-only job.
+ * graph_div (optional, [n_graphs]): both point sets are divided by graph_div[graph] before the distance is formed (the
+ * reference's dynamic cross cutoff, models/all_atom_score_model.py:548-556). */
+typedef struct {
+  const float* x;
+  const int32_t* x_ptr;
+  const float* y;
+  const int32_t* y_batch;
+  int32_t ny;
+  float r;
+  int32_t max_neighbors;
+  int32_t flags;
+  const float* graph_div;
+  int32_t* counts;
+  int32_t* offsets;
+  int32_t base;
+  int32_t* total;
+  int32_t* out_query;
+  int32_t* out_x;
+  int32_t capacity;
+} ddp_radius_job_t;
+int ddp_radius_search_jobs(const ddp_radius_job_t* jobs, int njobs, void* stream);
+
+/* One grouping job of ddp_group_by_key_jobs (arguments as ddp_group_by_key; n_items_dev: device-side item count; key_map
+ * (optional): out_key[p] = key_map[key] instead of the key). */
+typedef struct {
+  const int32_t* key;
+  int32_t n_items;
+  const int32_t* n_items_dev;
+  int32_t n_keys;
+  const int32_t* pay[3];
+  int32_t* rowptr;
+  int32_t* perm;
+  int32_t* out_key;
+  int32_t* out[3];
+  const int32_t* key_map;
+  int32_t* scratch;
+} ddp_group_job_t;
+int ddp_group_by_key_jobs(const ddp_group_job_t* jobs, int njobs, void* stream);
 
 /* ---- node encoders + sigma-dependent columns of the edge-embedding MLPs (csrc/ddp_node.hip), one launch for all jobs.
  * A job is a gathered-row Linear over n_rows nodes:

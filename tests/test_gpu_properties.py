@@ -96,16 +96,16 @@ def test_work_eliminations_are_exact_at_full_size(setup):
         assert torch.equal(a, b)
     saved = (model.share_layer0, model.prune_last_receptor_layer, model.factorize_min_degree)
     try:
-        model.prune_async = False               # dead-output walk in the front instead of on the side stream: same plan
+        model.exact_sizes = True                # every device-side list size read back, exact grids: same bits
         for a, b in zip(want, _forward(model, graphs, dev)):
             assert torch.equal(a, b)
-        model.prune_async = True
+        model.exact_sizes = False
         model.share_layer0, model.prune_last_receptor_layer = False, False
         plain = _forward(model, graphs, dev)
         model.factorize_min_degree = 0          # every conv on the direct per-edge MFMA path
         direct = _forward(model, graphs, dev)
     finally:
-        model.prune_async = True
+        model.exact_sizes = False
         model.share_layer0, model.prune_last_receptor_layer, model.factorize_min_degree = saved
     for a, b, c in zip(want, plain, direct):
         assert rel_err(a, b) < 1e-4, rel_err(a, b)

@@ -34,7 +34,7 @@ def main():
         ldo = (ncols + 31) // 32 * 32
         out = torch.empty(nb, N, ldo, device=dev)
         offs = (C.c_int32 * nb)(*[120 * (i % 2) for i in range(nb)])
-        t_mine = timeit(lambda: L.check(lib.ddp_stage_a(x.data_ptr(), ldx, N, offs, nb, w.data_ptr(), k, ncols, out.data_ptr(), ldo, st), "a"))
+        t_mine = timeit(lambda: L.check(lib.ddp_stage_a(x.data_ptr(), ldx, N, None, None, N, offs, nb, w.data_ptr(), k, ncols, out.data_ptr(), ldo, st), "a"))
         A = torch.stack([x[:, 120 * (i % 2):120 * (i % 2) + k] for i in range(nb)])
         t_bmm = timeit(lambda: torch.bmm(A, w))
         t_mm = timeit(lambda: [torch.mm(A[i], w[i]) for i in range(nb)])
