@@ -48,7 +48,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 HBM_PEAK_GBS = 8000.0           # same guide: HBM3E ~8 TB/s
-PMC_FILE = os.path.join("profiles", "r02_pmc.json")
+PMC_FILE = os.path.join("profiles", "r03_pmc.json")
 
 
 def parse_args(argv=None):
@@ -57,7 +57,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--samples", type=int, default=40)
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="auto: one rank -> the 40-sample job; several ranks -> the STRONG split of the 40 samples is the headline "
+                         "(BASELINE configs[3]) and the weak run (40 samples per rank) is measured in the same invocation as a sub-record")
     ap.add_argument("--cfg", default="cfg2", choices=["cfg1", "cfg2"])
     ap.add_argument("--flex", action="store_true", help="flexible side chains (BASELINE configs[2])")
     ap.add_argument("--ways", type=int, default=1,
@@ -74,9 +76,11 @@ def parse_args(argv=None):
     ap.add_argument("--dry-run-ranks", action="store_true",
                     help="launcher test (no GPU needed): every rank prints its RANK / WORLD_SIZE / sample slice as one JSON line and "
                          "exits, rank DDP_BENCH_FAIL_RANK (if set) with code 3")
-    ap.add_argument("--cpu-samples", type=int, default=4)
+    ap.add_argument("--cpu-samples", type=int, default=40, help="sample graphs per CPU-baseline step (40 = the full workload)")
+    ap.add_argument("--cpu-batch", type=int, default=10, help="graphs per oracle forward (the reference's default --batch_size, inference.py)")
     ap.add_argument("--cpu-steps", type=int, default=2)
-    ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = os.cpu_count()")
+    ap.add_argument("--no-roofline-pass", action="store_true", help="skip the instrumented steps behind the timed region")
     return ap.parse_args(argv)
 
 
@@ -117,6 +121,12 @@ def source_hash():
     return h()
 
 
+def loaded_hash():
+    """ddp_source_hash() of the library that is actually loaded (a DDP_HIP_LIB override included)."""
+    from diffdock_pocket_amd import _lib
+    return _lib.load().ddp_source_hash().decode()
+
+
 def load_pmc(workload_key):
     """PMC-derived per-launch figures (tools/pmc_collect.py -> profiles/r02_pmc.json).  Returned only if they were collected
     on the kernel sources that are loaded now AND on this workload; otherwise {} (the fields are then null in the line)."""
@@ -126,7 +136,7 @@ def load_pmc(workload_key):
     except OSError:
         return {}, None
     src = {"file": PMC_FILE, "src_sha16": pmc.get("src_sha16"), "workload": pmc.get("workload")}
-    if pmc.get("src_sha16") != source_hash() or pmc.get("workload") != workload_key:
+    if pmc.get("src_sha16") != loaded_hash() or pmc.get("workload") != workload_key:
         src["stale"] = True
         return {}, src
     kernels = dict(pmc.get("kernels", {}))
@@ -164,60 +174,93 @@ def build_model(cfg, flex, device):
 
 
 def cpu_baseline(args, model, kw, complex_graph):
-    """Reference-equivalent CPU restatement (oracle/) on a bounded sample of the same workload."""
+    """Reference-equivalent CPU restatement (oracle/) timed as SURVEY section 8(d) asks: cfg2 = two FULL steps of the 40-sample
+    job (first and mid schedule position; the reference's loop feeds the score model `batch_size` = 10 graphs at a time,
+    inference.py / utils/sampling.py:112-120), extrapolated x10 to the 20-step job; cfg1 = the whole 4-sample x 20-step loop,
+    median of 3.  All host cores (count stated)."""
+    import statistics
     import numpy as np
     import torch
     from oracle.ref_model import OracleConfig, OracleScoreModel
     from diffdock_pocket_amd.batch import collate, set_time
-    n = args.cpu_samples
-    ocfg = OracleConfig(ns=kw["ns"], nv=kw["nv"], num_conv_layers=kw["num_conv_layers"],
-                        sigma_embed_dim=kw["sigma_embed_dim"], distance_embed_dim=kw["distance_embed_dim"],
-                        cross_distance_embed_dim=kw["cross_distance_embed_dim"],
-                        flexible_sidechains=kw["flexible_sidechains"], embedding_scale=1000.0)
-    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    oracle = OracleScoreModel(ocfg, sd)
-    torch.set_num_threads(min(os.cpu_count() or 1, args.cpu_threads))
+    from diffdock_pocket_amd.sampler import Sampler, SamplerConfig
+    from diffdock_pocket_amd.synthetic import make_3dpf_complex
+    n, bs = args.cpu_samples, max(1, args.cpu_batch)
+    torch.set_num_threads(args.cpu_threads or (os.cpu_count() or 1))
+
+    def oracle_for(m, k):
+        ocfg = OracleConfig(ns=k["ns"], nv=k["nv"], num_conv_layers=k["num_conv_layers"], sigma_embed_dim=k["sigma_embed_dim"],
+                            distance_embed_dim=k["distance_embed_dim"], cross_distance_embed_dim=k["cross_distance_embed_dim"],
+                            flexible_sidechains=k["flexible_sidechains"], embedding_scale=1000.0)
+        return OracleScoreModel(ocfg, {kk: v.detach().cpu() for kk, v in m.state_dict().items()})
+
+    oracle = oracle_for(model, kw)
     gs = []
     g = torch.Generator().manual_seed(7)
     for _ in range(n):
         c = complex_graph.clone()
         c["ligand"].pos = c["ligand"].pos + torch.randn(1, 3, generator=g) * 2.0
         gs.append(c)
+    with torch.no_grad():     # warm-up: one small forward (thread pool, allocator)
+        b = collate(gs[:2])
+        set_time(b, 1.0, 1.0, 1.0, 1.0)
+        oracle(b)
     times = []
     for t in (1.0, 0.5)[: args.cpu_steps]:
-        b = collate(gs)
-        set_time(b, t, t, t, t)
         t0 = time.perf_counter()
-        with torch.no_grad():
-            oracle(b)
+        for i in range(0, n, bs):
+            b = collate(gs[i:i + bs])
+            set_time(b, t, t, t, t)
+            with torch.no_grad():
+                oracle(b)
         times.append(time.perf_counter() - t0)
     s_per_step = float(np.mean(times))
-    return {"value": n / (s_per_step * 20.0), "unit": "poses/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} denoising step(s) (t=1.0,0.5) of {n} of the workload's 40 sample graphs through "
-                      f"oracle/ref_model.py (fp32 PyTorch-CPU, per-edge weights materialised); {s_per_step:.2f} s/step for {n} "
-                      f"graphs, linear in the graph count, extrapolated to 20 steps"}
+    out = {"value": n / (s_per_step * 20.0), "unit": "poses/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{len(times)} full denoising step(s) (t = 1.0, 0.5) of {n} sample graphs, {bs} graphs per forward (the reference's "
+                     f"batch_size), through oracle/ref_model.py (fp32 PyTorch-CPU, per-edge weights materialised): "
+                     f"{', '.join(f'{x:.1f}' for x in times)} s per step, extrapolated x{20 // max(len(times), 1)} to the 20-step job",
+           "seconds_per_step": times}
+    # BASELINE configs[0] in full: cfg1, 4 samples x 20 steps, the whole sampling loop on the CPU, median of 3
+    m1, kw1 = build_model("cfg1", True, torch.device("cpu"))
+    o1 = oracle_for(m1, kw1)
+    g1 = make_3dpf_complex(seed=0, flexible_sidechains=True)
+    runs = []
+    for _ in range(3):
+        smp = Sampler(lambda bb: o1(bb), g1, 4, torch.device("cpu"), SamplerConfig(inference_steps=20, flexible_sidechains=True), seed=0)
+        smp.randomize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            smp.run()
+        runs.append(time.perf_counter() - t0)
+    out["configs[0] cfg1 4 samples x 20 steps (whole loop, median of 3)"] = {
+        "value": 4.0 / statistics.median(runs), "unit": "poses/s", "seconds": runs, "cores": torch.get_num_threads()}
+    return out
 
 
-def timed_job(model, complex_graph, n_total, sl, device, flex, steps, warmup, ways=1, sync=lambda: None, dist=None, world=1):
-    """W warm-up steps, then exactly `steps` timed steps bracketed by barrier + synchronize; returns (seconds, sampler, final poses)."""
+def timed_job(model, complex_graph, n_total, sl, device, flex, steps, warmup, ways=1, sync=lambda: None, dist=None, world=1,
+              on_timed=None):
+    """`warmup` (at least 3) untimed steps on the sampler that is then timed - they fill the model's static caches and the
+    allocator and capture the step's hipGraph - then the job restarts from its first step (poses and noise stream restored)
+    and exactly `steps` steps are timed, bracketed by barrier + synchronize.  on_timed(sampler, snapshot, schedule) runs after
+    the timed region (the instrumented roofline pass).  Returns (seconds, sampler, final poses, gathered poses, schedule, info)."""
     import torch
     from diffdock_pocket_amd.diffusion import get_t_schedule
     from diffdock_pocket_amd.sampler import PipelinedSampler, Sampler, SamplerConfig
     scfg = SamplerConfig(inference_steps=20, flexible_sidechains=flex)
-
-    def make_sampler():
-        if ways > 1:
-            return PipelinedSampler(model, complex_graph, n_total, device, scfg, seed=0, sample_slice=sl, ways=ways)
-        return Sampler(model, complex_graph, n_total, device, scfg, seed=0, sample_slice=sl)
-
-    sampler = make_sampler()
+    if ways > 1:
+        sampler = PipelinedSampler(model, complex_graph, n_total, device, scfg, seed=0, sample_slice=sl, ways=ways)
+    else:
+        sampler = Sampler(model, complex_graph, n_total, device, scfg, seed=0, sample_slice=sl)
     sampler.randomize()
     schedule = get_t_schedule(20)
-    for i in range(warmup):
+    snap = sampler.snapshot() if ways == 1 else None
+    for i in range(max(warmup, 3)):
         sampler.step((i * 10) % 20, schedule)   # schedule positions 0, 10, ..: the largest edge sets (allocator) and a typical step
-    # restart from fresh poses so that the timed steps see the schedule's own edge counts
-    sampler = make_sampler()
-    sampler.randomize()
+    if snap is not None:
+        sampler.restore(snap)     # the timed steps see the schedule's own poses and edge counts
+    else:
+        sampler = PipelinedSampler(model, complex_graph, n_total, device, scfg, seed=0, sample_slice=sl, ways=ways)
+        sampler.randomize()
     torch.cuda.synchronize()
     sync()
     torch.cuda.synchronize()
@@ -225,19 +268,26 @@ def timed_job(model, complex_graph, n_total, sl, device, flex, steps, warmup, wa
     for i in range(steps):
         sampler.step(i % 20, schedule)
     final_pos = sampler.lig_pos.contiguous()
-    gathered = None
+    gathered, info = None, {"hip_graph": bool(getattr(sampler, "_graph", None))}
     if dist is not None:   # gather final ligand poses of all shards (RCCL over xGMI); shards may differ in size (strong scaling)
         sizes = [len(range(*shard_slice(r, world, n_total, None).indices(n_total))) for r in range(world)]
         pad = max(sizes)
         buf = torch.zeros((pad,) + tuple(final_pos.shape[1:]), device=device, dtype=final_pos.dtype)
         buf[: final_pos.shape[0]] = final_pos
         out = [torch.empty_like(buf) for _ in range(world)]
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
         dist.all_gather(out, buf)
+        torch.cuda.synchronize()
+        info["all_gather_ms"] = (time.perf_counter() - tg) * 1e3     # (includes waiting for the slowest rank's last step)
         gathered = torch.cat([o[:s] for o, s in zip(out, sizes)], 0)
     torch.cuda.synchronize()
     sync()
     torch.cuda.synchronize()
-    return time.perf_counter() - t0, sampler, final_pos, gathered, schedule
+    elapsed = time.perf_counter() - t0
+    if on_timed is not None:
+        on_timed(sampler, snap, schedule)
+    return elapsed, sampler, final_pos.clone(), gathered, schedule, info
 
 
 def shard_slice(rank, world, n_total, _):
@@ -257,11 +307,15 @@ def main(argv=None):
                          f"(or without WORLD_SIZE, then bench.py starts the ranks itself)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    scaling = args.scaling
+    if scaling == "auto":      # several ranks: the strong split of ONE complex's samples is the job BASELINE configs[3] names
+        scaling = "strong" if world > 1 else "weak"
     if args.dry_run_ranks:
-        n_total = args.samples * world if args.scaling == "weak" else args.samples
+        n_total = args.samples * world if scaling == "weak" else args.samples
         sl = shard_slice(rank, world, n_total, None)
         print(json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "master": os.environ.get("MASTER_ADDR"),
-                          "port": os.environ.get("MASTER_PORT"), "samples_total": n_total, "slice": [sl.start, sl.stop]}), flush=True)
+                          "port": os.environ.get("MASTER_PORT"), "samples_total": n_total, "slice": [sl.start, sl.stop],
+                          "scaling": scaling}), flush=True)
         sys.exit(3 if os.environ.get("DDP_BENCH_FAIL_RANK") == str(rank) else 0)
 
     import torch
@@ -291,33 +345,41 @@ def main(argv=None):
 
     model, kw = build_model(args.cfg, args.flex, device)
     complex_graph = make_3dpf_complex(seed=0, flexible_sidechains=args.flex)
-    n_total = args.samples * world if args.scaling == "weak" else args.samples
+    n_total = args.samples * world if scaling == "weak" else args.samples
     if n_total < world:
         raise SystemExit("bench.py: fewer samples than ranks")
     sl = shard_slice(rank, world, n_total, None)
     n_local = len(range(*sl.indices(n_total)))
+    ranks_seen = dist.get_world_size() if dist is not None else 1
 
-    prof = sm.ConvProfiler()
-    sm.set_conv_profiler(None)
-
-    # warm-up happens inside timed_job; the profiler must only see the timed steps -> switched on by a hook on the barrier
-    def sync_and_arm():
-        sync()
-        sm.set_conv_profiler(prof if not prof.events else None)   # armed at the first barrier, disarmed at the second
-
-    elapsed, sampler, final_pos, gathered, schedule = timed_job(model, complex_graph, n_total, sl, device, args.flex, args.steps,
-                                                                args.warmup, ways=args.ways, sync=sync_and_arm, dist=dist, world=world)
-    sm.set_conv_profiler(None)
-    # the HBM-bound kernels (stage A, segment reduce) are timed in two extra steps AFTER the timed region: ~45 more event
-    # pairs per step would otherwise sit inside it (measured: +4 % on ms_per_step)
-    prof_hbm = sm.ConvProfiler()
+    # Kernel-level figures (roofline): the timed region replays a captured hipGraph per step, into which no events can be
+    # placed; the same `steps` steps are therefore run once more behind it, launch by launch, with HIP events around every conv
+    # launch on the launch stream (prof) and, in two further steps, around the HBM-bound kernels (prof_hbm).
+    prof, prof_hbm = sm.ConvProfiler(), sm.ConvProfiler()
     prof_hbm.hbm_on = True
-    if rank == 0 and not args.no_hbm_pass:
-        sm.set_conv_profiler(prof_hbm)
-        for i in range(2):
-            sampler.step(5 + 10 * i, schedule)
+    sm.set_conv_profiler(None)
+
+    def roofline_pass(sampler, snap, schedule):
+        if rank != 0 or args.no_roofline_pass or snap is None:
+            return
+        sampler.restore(snap)
+        sampler.graph_enabled = False
+        sm.set_conv_profiler(prof)
+        for i in range(args.steps):
+            sampler.step(i % 20, schedule)
         torch.cuda.synchronize()
         sm.set_conv_profiler(None)
+        if not args.no_hbm_pass:
+            sm.set_conv_profiler(prof_hbm)
+            for i in range(2):
+                sampler.step(5 + 10 * i, schedule)
+            torch.cuda.synchronize()
+            sm.set_conv_profiler(None)
+        sampler.graph_enabled = True
+
+    elapsed, sampler, final_pos, gathered, schedule, info = timed_job(model, complex_graph, n_total, sl, device, args.flex, args.steps,
+                                                                      args.warmup, ways=args.ways, sync=sync, dist=dist, world=world,
+                                                                      on_timed=roofline_pass)
     rank_ms = [elapsed / args.steps * 1e3]
     if dist is not None:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -327,15 +389,30 @@ def main(argv=None):
         elapsed = max(float(x.item()) for x in allt)
         assert gathered.shape[0] == n_total
     assert torch.isfinite(final_pos).all(), "non-finite poses"
+    weak = None
+    if world > 1 and args.scaling == "auto":     # the weak figure (40 samples per rank) in the same invocation
+        nw = args.samples * world
+        slw = shard_slice(rank, world, nw, None)
+        elw, _, fpw, gw, _, infow = timed_job(model, complex_graph, nw, slw, device, args.flex, args.steps, args.warmup, sync=sync,
+                                              dist=dist, world=world)
+        tt = torch.tensor([elw], device=device, dtype=torch.float64)
+        allt = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        elw_max = max(float(x.item()) for x in allt)
+        assert torch.isfinite(fpw).all() and gw.shape[0] == nw
+        weak = {"scaling": "weak", "samples_total": nw, "value": nw * args.steps / 20.0 / elw_max, "unit": "poses/s",
+                "ms_per_step": elw_max / args.steps * 1e3, "ms_per_step_by_rank": [float(x.item()) / args.steps * 1e3 for x in allt],
+                "all_gather_ms": infow.get("all_gather_ms")}
 
     if rank == 0:
-        workload_key = f"{args.cfg} samples={args.samples} flex={args.flex} ways={args.ways} scaling={args.scaling} n_gpus={world}"
+        workload_key = f"{args.cfg} samples={args.samples} flex={args.flex} ways={args.ways} scaling={scaling} n_gpus={world}"
         pmc, pmc_src = load_pmc(workload_key)
         poses = n_total * args.steps / 20.0
         if args.launch_log:
+            prof._resolve()
             os.makedirs(os.path.dirname(os.path.abspath(args.launch_log)), exist_ok=True)
             with open(args.launch_log, "w") as f:
-                json.dump({"workload": workload_key, "src_sha16": source_hash(), "warmup_steps": args.warmup, "steps": args.steps,
+                json.dump({"workload": workload_key, "src_sha16": loaded_hash(), "warmup_steps": args.warmup, "steps": args.steps,
                            "launches": [{"kernel": k, "edges": e, "useful_flops": u, "algorithmic_flops": a}
                                         for k, e, u, a in zip(prof.kernel, prof.edges, prof.useful, prof.flops)]}, f)
         # the dominant kernel = the instantiation with the larger share of the timed region
@@ -375,7 +452,7 @@ def main(argv=None):
                 p = pmc.get(kname, {})
                 return {"kernel": kname, "bound": "hbm", "launches": n_, "avg_launch_ms": ms_ / n_, "achieved": gbs, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_mb_per_launch": by_ / n_ / 1e6,
-                        "ms_per_step": ms_ / 2.0, "measured": "2 extra steps after the timed region",
+                        "ms_per_step": ms_ / 2.0, "measured": "2 extra steps (schedule positions 5, 15) behind the instrumented pass",
                         "traffic": p.get("hbm_bytes_per_launch"), "mfma_busy_pmc": p.get("mfma_busy_frac")}
             roof["other_kernels"] += [e for e in (hbm_entry("ddp_stage_a_mfma_kernel"), hbm_entry("ddp_segment_reduce_kernel")) if e]
             # whole step: HBM bytes the PMC passes saw against the algorithmic boundary bytes of the convs
@@ -388,31 +465,44 @@ def main(argv=None):
             roof["per_step"] = step
         line = {"metric": "ligand poses/sec (40 samples x 20 steps) on 3dpf", "value": poses / elapsed, "unit": "poses/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"3dpf ({sampler.n_l} lig atoms, 139 residues, {sampler.n_a} pocket atoms), "
                                        f"{n_total} samples over {world} GPU(s) ({n_local} on rank 0) x 20-step schedule, score model "
                                        f"{args.cfg} (ns={kw['ns']} nv={kw['nv']} L={kw['num_conv_layers']}), "
                                        f"flexible_sidechains={args.flex}", "samples_total": n_total, "samples_rank0": n_local,
                            "parallelism": f"samples sharded over {world} rank(s), one final all_gather of poses",
-                           "ways": args.ways, "ms_per_step_by_rank": rank_ms, "src_sha16": source_hash(),
-                           "edges_last_step": getattr(sampler, "last_stats", None) or model.last_stats},
+                           "ways": args.ways, "ms_per_step_by_rank": rank_ms, "src_sha16": loaded_hash(),
+                           "hip_graph_replay": info.get("hip_graph"), "rccl_ranks_seen": ranks_seen, "backend": backend,
+                           "all_gather_ms": info.get("all_gather_ms"),
+                           "edges_last_step": dict(getattr(sampler, "last_stats", None) or model.last_stats)},
                 "roofline": roof}
+        if weak is not None:
+            line["weak_scaling"] = weak
+        if roof is not None:
+            roof["measured"] = (f"{args.steps} instrumented steps behind the timed region (same poses, noise and schedule positions, "
+                                "launch by launch with HIP events on the launch stream); the timed region itself replays one captured "
+                                "hipGraph per step")
         default_workload = args.samples == 40 and args.cfg == "cfg2" and not args.flex and args.ways == 1
         if world == 1 and default_workload and not args.no_other_workloads:
             # BASELINE configs[2] and configs[0] in the same driver-run line (short runs: 20 and 20 steps)
             others = {}
             m2, kw2 = build_model("cfg2", True, device)
             g2 = make_3dpf_complex(seed=0, flexible_sidechains=True)
-            el2, s2, fp2, _, _ = timed_job(m2, g2, 40, slice(0, 40), device, True, 20, 2)
+            el2, s2, fp2, _, _, _ = timed_job(m2, g2, 40, slice(0, 40), device, True, 20, 3)
             assert torch.isfinite(fp2).all() and torch.isfinite(s2.atom_pos).all()
             others["configs[2] 3dpf flexible side chains, 40 samples, cfg2"] = {
-                "value": 40.0 / el2, "unit": "poses/s", "ms_per_step": el2 / 20 * 1e3, "steps": 20, "edges_last_step": m2.last_stats}
+                "value": 40.0 / el2, "unit": "poses/s", "ms_per_step": el2 / 20 * 1e3, "steps": 20, "edges_last_step": dict(m2.last_stats)}
             del m2, s2
             m0, kw0 = build_model("cfg1", True, device)
-            el0, s0, fp0, _, _ = timed_job(m0, g2, 4, slice(0, 4), device, True, 20, 2)
+            el0, s0, fp0, _, _, _ = timed_job(m0, g2, 4, slice(0, 4), device, True, 20, 3)
             assert torch.isfinite(fp0).all()
             others["configs[0] 3dpf 4 samples, cfg1 (ns=16 nv=4 L=2), flexible side chains"] = {
-                "value": 4.0 / el0, "unit": "poses/s", "ms_per_step": el0 / 20 * 1e3, "steps": 20, "edges_last_step": m0.last_stats}
+                "value": 4.0 / el0, "unit": "poses/s", "ms_per_step": el0 / 20 * 1e3, "steps": 20, "edges_last_step": dict(m0.last_stats)}
+            # BASELINE configs[3]'s shard: 5 of the 40 samples on this GPU (what one of 8 ranks runs under the strong split)
+            el5, s5, fp5, _, _, _ = timed_job(model, complex_graph, 40, slice(0, 5), device, False, 20, 3)
+            others["configs[3] shard: samples [0, 5) of the 40 on one GPU, cfg2"] = {
+                "value": 5.0 / el5, "unit": "poses/s per GPU", "ms_per_step": el5 / 20 * 1e3, "steps": 20}
+            del s5
             del m0, s0
             line["other_workloads"] = others
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (the other ranks must not wait for it)

@@ -18,7 +18,7 @@ FS = 68  # feature-buffer row stride of ddp_conv.hip
 
 DDP_MAX_GEMM_BATCH = 16
 EXPORTS = ["ddp_conv_messages", "ddp_segment_reduce", "ddp_edge_featurize", "ddp_torsion_sh", "ddp_stage_a",
-           "ddp_pose_update", "ddp_sidechain_update", "ddp_radius_count", "ddp_radius_fill", "ddp_knn", "ddp_group_by_key", "ddp_node_linear", "ddp_scan_jobs", "ddp_mark_jobs", "ddp_rowcopy_jobs", "ddp_select_jobs",
+           "ddp_pose_update", "ddp_sidechain_update", "ddp_sde_update", "ddp_radius_count", "ddp_radius_fill", "ddp_knn", "ddp_group_by_key", "ddp_node_linear", "ddp_scan_jobs", "ddp_mark_jobs", "ddp_rowcopy_jobs", "ddp_select_jobs",
            "ddp_gather_rows", "ddp_clean_pair_maps", "ddp_radius_search_jobs", "ddp_group_by_key_jobs", "ddp_abi_version", "ddp_last_error", "ddp_source_hash"]
 
 
@@ -87,6 +87,10 @@ class RadiusJob(C.Structure):
     _fields_ = [("x", _P), ("x_ptr", _P), ("y", _P), ("y_batch", _P), ("ny", _I), ("r", C.c_float), ("max_neighbors", _I),
                 ("flags", _I), ("graph_div", _P), ("counts", _P), ("offsets", _P), ("base", _I), ("total", _P), ("out_query", _P),
                 ("out_x", _P), ("capacity", _I)]
+
+
+class SdeArgs(C.Structure):
+    _fields_ = [("score", _P * 4), ("z", _P * 4), ("out", _P * 4), ("n", _I * 4)]
 
 
 class GroupJob(C.Structure):
@@ -166,6 +170,8 @@ def load():
                       ("ddp_select_jobs", SelectJob), ("ddp_radius_search_jobs", RadiusJob), ("ddp_group_by_key_jobs", GroupJob)):
         getattr(lib, name).argtypes = [C.POINTER(job), C.c_int, C.c_void_p]
         getattr(lib, name).restype = C.c_int
+    lib.ddp_sde_update.argtypes = [C.c_void_p, C.POINTER(SdeArgs), C.c_void_p]
+    lib.ddp_sde_update.restype = C.c_int
     lib.ddp_gather_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.ddp_gather_rows.restype = C.c_int
     lib.ddp_clean_pair_maps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -264,3 +264,40 @@ extern "C" int ddp_sidechain_update(const float* pos_in, int n_samples, int n_at
   if (err != hipSuccess) return ddp_fail_hip(err, "ddp_sidechain_update launch");
   return 0;
 }
+
+// ---- scores -> pose updates: the reverse SDE / ODE step of utils/sampling.py:146-193 for the four components at once,
+//   out[k][i] = a[k] * score[k][i] + b[k] * z[k][i],   coef = [a_tr b_tr a_rot b_rot a_tor b_tor a_sc b_sc] in DEVICE memory
+// (a = g^2 dt (lambda + temp psi / 2), b = g sqrt(dt (1 + psi)) with low-temperature sampling; the host writes them per step
+// together with the noise, so a captured step needs no kernel arguments that change).  Products and sum are rounded
+// separately, as the PyTorch expression `a * score + b * z` does.
+struct SdeLaunch {
+  ddp_sde_args_t a;
+};
+__global__ __launch_bounds__(256) void ddp_sde_update_kernel(const float* __restrict__ coef, const SdeLaunch L) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (i < L.a.n[k]) {
+      const float p = coef[2 * k] * L.a.score[k][i];
+      const float q = L.a.z[k] ? coef[2 * k + 1] * L.a.z[k][i] : 0.f;
+      L.a.out[k][i] = L.a.z[k] ? p + q : p;
+    }
+  }
+}
+
+extern "C" int ddp_sde_update(const float* coef, const ddp_sde_args_t* args, void* stream) {
+  if (!coef || !args) return ddp_fail(DDP_EINVAL, "ddp_sde_update: null argument");
+  int nmax = 0;
+  for (int k = 0; k < 4; ++k) {
+    if (args->n[k] < 0 || (args->n[k] > 0 && (!args->score[k] || !args->out[k]))) return ddp_fail(DDP_EINVAL, "ddp_sde_update: component");
+    if (args->n[k] > nmax) nmax = args->n[k];
+  }
+  if (nmax == 0) return 0;
+  SdeLaunch L;
+  L.a = *args;
+  hipLaunchKernelGGL(ddp_sde_update_kernel, dim3((nmax + 255) / 256), dim3(256), 0, (hipStream_t)stream, coef, L);
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return ddp_fail_hip(err, "ddp_sde_update launch");
+  return 0;
+}

@@ -149,6 +149,8 @@ class SamplerConfig:
     ode: bool = False
     flexible_sidechains: bool = True
     no_torsion: bool = False
+    hip_graph: bool = True     # on a HIP device: capture one denoising step (forward + SDE step + pose update) in a hipGraph
+                               # after two ordinary steps and replay it from then on (no host work per launch)
 
 
 class Sampler:
@@ -185,17 +187,198 @@ class Sampler:
         self.batch = collate([g] * self.n).to(device)
         self.lig_pos = self.batch["ligand"].pos.reshape(self.n, self.n_l, 3).clone()
         self.atom_pos = self.batch["atom"].pos.reshape(self.n, self.n_a, 3).clone()
+        self.on_hip = torch.device(device).type == "cuda"
+        self._graph = None
+        self.graph_enabled = True      # False: the step is launched kernel by kernel even if a graph has been captured
+        self._steps_run = 0
+        if self.on_hip:
+            self._init_step_buffers()
+
+    # -- device-resident step state (HIP) ------------------------------------------------------------------------
+    def _init_step_buffers(self):
+        """One device buffer holds everything that changes from step to step and is not computed on the device: the diffusion
+        time, the SDE coefficients (ddp_sde_update) and the step's noise - written by ONE host-to-device copy per step.  The
+        batch's time tensors are stride-0 views of the time slot, the poses are updated in place: a step has no argument that
+        changes, so it can be captured once and replayed."""
+        dev, n = self.device, self.n
+        T, S_ = (self.T if not self.cfg.no_torsion else 0), self.S
+        self._off = {"t": 0, "coef": 8, "z_tr": 16, "z_rot": 16 + 3 * n, "z_tor": 16 + 6 * n, "z_sc": 16 + 6 * n + n * T}
+        self._n_par = 16 + 6 * n + n * T + n * S_
+        self.params = torch.zeros(self._n_par, device=dev)
+        o = self._off
+        self.t_dev = self.params[0:1]
+        self.coef = self.params[o["coef"]:o["coef"] + 8]
+        self.z_tr = self.params[o["z_tr"]:o["z_tr"] + 3 * n].view(n, 3)
+        self.z_rot = self.params[o["z_rot"]:o["z_rot"] + 3 * n].view(n, 3)
+        self.z_tor = self.params[o["z_tor"]:o["z_tor"] + n * T].view(n, T) if T > 0 else None
+        self.z_sc = self.params[o["z_sc"]:o["z_sc"] + n * S_].view(n, S_) if S_ > 0 else None
+        self.upd = {"tr": torch.zeros(n, 3, device=dev), "rot": torch.zeros(n, 3, device=dev),
+                    "tor": torch.zeros(n, T, device=dev) if T > 0 else None, "sc": torch.zeros(n, S_, device=dev) if S_ > 0 else None}
+        self._views = {}
+        self._bind_batch()
+
+    def _bind_batch(self):
+        """Poses and times of the batch = views of the sampler's device buffers (re-installed if a caller put other tensors
+        there, e.g. batch.set_time for a one-off forward)."""
+        b = self.batch
+        if self._views and all(b[nt].node_t is self._views[nt] for nt in ("ligand", "receptor", "atom")) \
+                and b.complex_t is self._views["complex"] and b["ligand"].pos is self._views["lpos"] and b["atom"].pos is self._views["apos"]:
+            return
+        b["ligand"].pos = self._views["lpos"] = self.lig_pos.view(-1, 3)
+        b["atom"].pos = self._views["apos"] = self.atom_pos.view(-1, 3)
+        for nt in ("ligand", "receptor", "atom"):
+            tn = self.t_dev.expand(b[nt].num_nodes)
+            b[nt].node_t = self._views[nt] = {k: tn for k in ("tr", "rot", "tor", "sc_tor")}
+        tb = self.t_dev.expand(b.num_graphs)
+        b.complex_t = self._views["complex"] = {k: tb for k in ("tr", "rot", "tor", "sc_tor")}
+        ts = (b["receptor"].node_t["tr"], b["atom"].node_t["tr"])
+        b.ddp_time_hint = (tuple(id(t) for t in ts), tuple(t._version for t in ts), True)    # one time for all nodes (batch.set_time)
+
+    def scores(self, t: float):
+        """The score model on the current poses at diffusion time t (no pose update)."""
+        if not self.on_hip:
+            b = self.batch
+            b["ligand"].pos, b["atom"].pos = self.lig_pos.reshape(-1, 3), self.atom_pos.reshape(-1, 3)
+            set_time(b, t, t, t, t, device=self.device)
+            return self.model(b)
+        with torch.cuda.device(self.device):
+            self._bind_batch()
+            self.t_dev.fill_(t)
+            return self.model(self.batch)
+
+    def snapshot(self):
+        """(poses, generator state): `restore` puts the sampler back there (bench.py warms up - and captures - on the timed
+        sampler itself and then restarts the job from its first step)."""
+        return self.lig_pos.clone(), self.atom_pos.clone(), self.gen.get_state()
+
+    def restore(self, snap):
+        self._set_pos("lig_pos", snap[0])
+        self._set_pos("atom_pos", snap[1])
+        self.gen.set_state(snap[2])
+
+    def _step_coefficients(self, t_idx, schedule):
+        """(t, [a_tr b_tr a_rot b_rot a_tor b_tor a_sc b_sc], noise on) of a step: update_k = a_k * score_k + b_k * z_k
+        (reference utils/sampling.py:125-193)."""
+        cfg, sg = self.cfg, self.cfg.sigma
+        steps = len(schedule)
+        t = float(schedule[t_idx])
+        dt = float(schedule[t_idx] - schedule[t_idx + 1]) if t_idx < steps - 1 else float(schedule[t_idx])
+        noise_off = cfg.no_random or (cfg.no_final_step_noise and t_idx == steps - 1)
+        coef = []
+        for k, (lo, hi, two) in enumerate(((sg.tr_sigma_min, sg.tr_sigma_max, True), (sg.rot_sigma_min, sg.rot_sigma_max, False),
+                                           (sg.tor_sigma_min, sg.tor_sigma_max, True),
+                                           (sg.sidechain_tor_sigma_min, sg.sidechain_tor_sigma_max, True))):
+            sigma = lo ** (1 - t) * hi ** t
+            g = sigma * math.sqrt(2 * math.log(hi / lo)) if two else 2 * sigma * math.sqrt(math.log(hi / lo))
+            if cfg.ode:
+                a, b = 0.5 * g ** 2 * dt, 0.0
+            elif cfg.temp_sampling[k] != 1.0:
+                sigma_data = math.exp(cfg.temp_sigma_data * math.log(hi) + (1 - cfg.temp_sigma_data) * math.log(lo))
+                lam = (sigma_data + sigma) / (sigma_data + sigma / cfg.temp_sampling[k])
+                a, b = g ** 2 * dt * (lam + cfg.temp_sampling[k] * cfg.temp_psi[k] / 2), g * math.sqrt(dt * (1 + cfg.temp_psi[k]))
+            else:
+                a, b = g ** 2 * dt, g * math.sqrt(dt)
+            coef += [a, b]
+        return t, coef, noise_off
+
+    def _upload_step(self, t_idx, schedule):
+        """Time, coefficients and noise of the step -> the device buffer: one asynchronous copy from a fresh pinned block (the
+        pinned allocator does not hand the block out again before the copy has run; a copy from pageable memory would make the
+        host wait for the stream to drain).  Noise is drawn for ALL samples of the job from the seeded generator - in the
+        reference loop's order tr, rot, tor, side chains - and sliced to this shard."""
+        cfg, N, sl, n = self.cfg, self.n_total, self.slice, self.n
+        t, coef, noise_off = self._step_coefficients(t_idx, schedule)
+        host = torch.empty(self._n_par, pin_memory=True)
+        host[0] = t
+        host[1:8] = 0.0
+        host[8:16] = torch.tensor(coef, dtype=torch.float64).float()
+        o = self._off
+
+        def z(shape, key, cols):
+            full = torch.zeros(shape) if noise_off else torch.randn(shape, generator=self.gen)
+            host[o[key]:o[key] + n * cols] = full[sl].reshape(-1)
+
+        z((N, 3), "z_tr", 3)
+        z((N, 3), "z_rot", 3)
+        if self.z_tor is not None:
+            z((N, self.T), "z_tor", self.T)
+        if self.z_sc is not None:
+            z((N, self.S), "z_sc", self.S)
+        self.params.copy_(host, non_blocking=True)
+
+    def _step_body(self):
+        """Everything of a step that runs on the device: score model, SDE step, side-chain and ligand pose update (in place)."""
+        from . import _lib as L
+        import ctypes as C
+        lib = L.load()
+        cfg = self.cfg
+        tr_score, rot_score, tor_score, sc_score = self._call_model(self.model, self.batch)
+        a = L.SdeArgs()
+        use_tor = self.z_tor is not None
+        comps = [(tr_score, self.z_tr, self.upd["tr"]), (rot_score, self.z_rot, self.upd["rot"]),
+                 (tor_score if use_tor else None, self.z_tor, self.upd["tor"]), (sc_score if self.has_flex else None, self.z_sc, self.upd["sc"])]
+        keep = []
+        for k, (sc, zz, out) in enumerate(comps):
+            if sc is None or out is None or out.numel() == 0:
+                a.n[k] = 0
+                continue
+            sc = sc.contiguous()
+            keep.append(sc)
+            a.score[k], a.z[k], a.out[k], a.n[k] = sc.data_ptr(), (0 if cfg.ode else zz.data_ptr()), out.data_ptr(), out.numel()
+        st = torch._C._cuda_getCurrentRawStream(self.lig_pos.device.index)
+        L.check(lib.ddp_sde_update(self.coef.data_ptr(), C.byref(a), st), "ddp_sde_update")
+        if self.has_flex:
+            L.check(lib.ddp_sidechain_update(self.atom_pos.data_ptr(), self.n, self.n_a, self.upd["sc"].data_ptr(), self.S,
+                                             self.sc_edge_i32.data_ptr(), self.sc_sub_i32.data_ptr(), self.sc_map_i32.data_ptr(),
+                                             self.atom_pos.data_ptr(), st), "ddp_sidechain_update")
+            torch.autograd.graph.increment_version(self.atom_pos)     # moved in place: the model's static-graph cache keys on it
+        L.check(lib.ddp_pose_update(self.lig_pos.data_ptr(), self.n, self.n_l, self.upd["tr"].data_ptr(), self.upd["rot"].data_ptr(),
+                                    self.upd["tor"].data_ptr() if use_tor else None, self.T if use_tor else 0,
+                                    self.bonds_i32.data_ptr() if use_tor else None, self.mask_u8.data_ptr() if use_tor else None,
+                                    self.lig_pos.data_ptr(), st), "ddp_pose_update")
+        torch.autograd.graph.increment_version(self.lig_pos)
+
+    def _step_hip(self, t_idx, schedule):
+        with torch.cuda.device(self.device):
+            self._bind_batch()
+            self._upload_step(t_idx, schedule)
+            if self._graph and self.graph_enabled:
+                self._graph.replay()
+            elif self.cfg.hip_graph and self.graph_enabled and self._steps_run >= 2 and self._graph is None:
+                self._capture()
+            else:
+                self._step_body()
+            self._steps_run += 1
+
+    def _capture(self):
+        """Capture one step in a hipGraph (the step being captured is also executed: capture records, then the graph is
+        replayed once).  Anything that cannot be captured makes the sampler fall back to ordinary launches for good."""
+        g = torch.cuda.CUDAGraph()
+        try:
+            torch.cuda.synchronize(self.device)
+            with torch.cuda.graph(g):
+                self._step_body()
+        except Exception as e:     # noqa: BLE001
+            import warnings
+            warnings.warn(f"hipGraph capture of the denoising step failed ({type(e).__name__}: {e}); running it launch by launch",
+                          RuntimeWarning)
+            self._graph = False
+            torch.cuda.synchronize(self.device)
+            self._step_body()
+            return
+        self._graph = g
+        g.replay()
 
     # -- randomize_position (reference utils/sampling.py:16-60), pocket_knowledge=False -----------------------
     def randomize(self):
         cfg, N, sl = self.cfg, self.n_total, self.slice
         if not cfg.no_torsion and self.T > 0:
             ang = (torch.rand((N, self.T), generator=self.gen) * 2 - 1) * math.pi
-            self.lig_pos = apply_torsions(self.lig_pos, self.bonds, self.rot_idx, ang[sl].to(self.device))
+            self._set_pos("lig_pos", apply_torsions(self.lig_pos, self.bonds, self.rot_idx, ang[sl].to(self.device)))
         if self.has_flex:
             ang = (torch.rand((N, self.S), generator=self.gen) * 2 - 1) * math.pi
-            self.atom_pos = apply_sidechain_torsions(self.atom_pos, self.sc_edge_idx, self.sc_sub, self.sc_map,
-                                                     ang[sl].to(self.device))
+            self._set_pos("atom_pos", apply_sidechain_torsions(self.atom_pos, self.sc_edge_idx, self.sc_sub, self.sc_map,
+                                                               ang[sl].to(self.device)))
         # uniform random rotations from normalised gaussian quaternions (scipy Rotation.random)
         q = torch.randn((N, 4), generator=self.gen)
         q = (q / q.norm(dim=1, keepdim=True))[sl].to(self.device)
@@ -204,13 +387,24 @@ class Sampler:
                          2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
                          2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
         center = self.lig_pos.mean(1, keepdim=True)
-        self.lig_pos = (self.lig_pos - center) @ R.transpose(1, 2)
+        new = (self.lig_pos - center) @ R.transpose(1, 2)
         if not cfg.no_random:
             tr = torch.randn((N, 1, 3), generator=self.gen) * cfg.sigma.tr_sigma_max
-            self.lig_pos = self.lig_pos + tr[sl].to(self.device)
+            new = new + tr[sl].to(self.device)
+        self._set_pos("lig_pos", new)
+
+    def _set_pos(self, name, value):
+        """Poses are replaced on the CPU path and written IN PLACE on a HIP device (the batch holds views of them and a captured
+        step their addresses)."""
+        if self.on_hip:
+            getattr(self, name).copy_(value)
+        else:
+            setattr(self, name, value)
 
     # -- one denoising step (reference utils/sampling.py:93-251) ------------------------------------------------
     def step(self, t_idx: int, schedule: np.ndarray):
+        if self.on_hip:
+            return self._step_hip(t_idx, schedule)
         cfg, sg, N, sl, dev = self.cfg, self.cfg.sigma, self.n_total, self.slice, self.device
         steps = len(schedule)
         t = float(schedule[t_idx])
@@ -294,9 +488,13 @@ class Sampler:
         returns (confidence [n] or [n, k], order) with `order` = sample indices from most to least confident (for a
         multi-output head the reference ranks by the first column, inference.py:213-216)."""
         b = self.batch
-        b["ligand"].pos = self.lig_pos.reshape(-1, 3)
-        b["atom"].pos = self.atom_pos.reshape(-1, 3)
-        set_time(b, 0.0, 0.0, 0.0, 0.0, device=self.device)
+        if self.on_hip:     # the batch's poses and times are views of the sampler's device buffers
+            self._bind_batch()
+            self.t_dev.zero_()
+        else:
+            b["ligand"].pos = self.lig_pos.reshape(-1, 3)
+            b["atom"].pos = self.atom_pos.reshape(-1, 3)
+            set_time(b, 0.0, 0.0, 0.0, 0.0, device=self.device)
         conf = self._call_model(confidence_model, b)
         key = conf[:, 0] if conf.dim() == 2 else conf
         return conf, torch.argsort(key, descending=True)
@@ -328,6 +526,8 @@ class PipelinedSampler:
         self.model, self.device = model, device
         lo, hi, _ = (sample_slice or slice(0, n_total)).indices(n_total)
         ways = max(1, min(ways, hi - lo))
+        import dataclasses
+        cfg = dataclasses.replace(cfg, hip_graph=False)      # (the groups switch streams inside a step: launched one by one)
         cuts = [lo + (hi - lo) * w // ways for w in range(ways + 1)]
         self.streams = [torch.cuda.Stream(device=device, priority=-1) for _ in range(ways)]       # fronts: high priority
         self.layer_streams = [torch.cuda.Stream(device=device, priority=0) for _ in range(ways)]

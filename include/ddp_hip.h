@@ -209,6 +209,18 @@ int ddp_sidechain_update(const float* pos_in, int n_samples, int n_atoms, const 
                          const int32_t* edge_idx, const int32_t* subcomponents, const int32_t* mapping, float* pos_out,
                          void* stream);
 
+/* Scores -> pose updates of one denoising step (utils/sampling.py:146-193, the SDE with low-temperature sampling or the ODE):
+ *   out[k][i] = coef[2k] * score[k][i] + coef[2k+1] * z[k][i]      k = tr, rot, tor, sc_tor;  i < n[k];  z[k] == NULL: no noise
+ * coef (8 floats) lives in DEVICE memory: the host writes the step's coefficients next to the noise, so a captured step (hipGraph)
+ * has no kernel argument that changes from step to step. */
+typedef struct {
+  const float* score[4];
+  const float* z[4];
+  float* out[4];
+  int32_t n[4];
+} ddp_sde_args_t;
+int ddp_sde_update(const float* coef, const ddp_sde_args_t* args, void* stream);
+
 /* Neighbour search of the forward (torch_cluster radius / radius_graph / knn_graph, models/all_atom_score_model.py:457,
  * 524,545-564,607,627).  Graphs are contiguous node ranges x_ptr[g] .. x_ptr[g+1]; y_batch[q] is the graph of query q.
  *  radius: every x of the query's graph with |x - y|^2 < r^2 (strict).  More than max_neighbors matches: by default the

@@ -22,16 +22,20 @@ def _lines(out):
 
 
 def test_parent_starts_one_process_per_gpu_weak_and_strong():
-    r = _run(["--gpus", "4"])
+    r = _run(["--gpus", "4", "--scaling", "weak"])
     assert r.returncode == 0, r.stderr
     ranks = _lines(r.stdout)
     assert [d["rank"] for d in ranks] == [0, 1, 2, 3] and all(d["world"] == 4 and d["local_rank"] == d["rank"] for d in ranks)
     assert len({d["port"] for d in ranks}) == 1 and all(d["master"] == "127.0.0.1" for d in ranks)
     assert [d["slice"] for d in ranks] == [[0, 40], [40, 80], [80, 120], [120, 160]] and ranks[0]["samples_total"] == 160
-    r = _run(["--gpus", "8", "--scaling", "strong"])
+    # the default for several ranks: the STRONG split of one complex's 40 samples (BASELINE configs[3]) is the headline
+    r = _run(["--gpus", "8"])
     assert r.returncode == 0, r.stderr
     ranks = _lines(r.stdout)
-    assert [d["slice"] for d in ranks] == [[5 * i, 5 * i + 5] for i in range(8)] and ranks[0]["samples_total"] == 40   # configs[3]
+    assert [d["slice"] for d in ranks] == [[5 * i, 5 * i + 5] for i in range(8)] and ranks[0]["samples_total"] == 40
+    assert all(d["scaling"] == "strong" for d in ranks)
+    r = _run(["--gpus", "1"])
+    assert _lines(r.stdout)[0]["slice"] == [0, 40] and _lines(r.stdout)[0]["scaling"] == "weak"      # the N = 1 line is unchanged
     r = _run(["--gpus", "3", "--scaling", "strong"])                  # uneven split: [0,13) [13,26) [26,40)
     assert [d["slice"] for d in _lines(r.stdout)] == [[0, 13], [13, 26], [26, 40]]
 
@@ -44,6 +48,7 @@ def test_a_failing_rank_fails_the_parent():
 def test_rank_of_an_external_launcher_and_world_size_mismatch():
     r = _run(["--gpus", "2"], {"WORLD_SIZE": "2", "RANK": "1", "LOCAL_RANK": "1"}, drop=())      # as under torch.distributed.run
     assert r.returncode == 0 and _lines(r.stdout) == [{"rank": 1, "local_rank": 1, "world": 2, "master": os.environ.get("MASTER_ADDR"),
-                                                       "port": os.environ.get("MASTER_PORT"), "samples_total": 80, "slice": [40, 80]}]
+                                                       "port": os.environ.get("MASTER_PORT"), "samples_total": 40, "slice": [20, 40],
+                                                       "scaling": "strong"}]
     r = _run(["--gpus", "4"], {"WORLD_SIZE": "2", "RANK": "0"}, drop=())
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)

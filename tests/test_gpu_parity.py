@@ -116,10 +116,7 @@ def test_bench_batch_samples_match_oracle(flex):
             smp.step(getattr(smp, "_steps_done", 0), sched)
             smp._steps_done = getattr(smp, "_steps_done", 0) + 1
         t = float(sched[t_idx])
-        b = smp.batch
-        b["ligand"].pos, b["atom"].pos = smp.lig_pos.reshape(-1, 3), smp.atom_pos.reshape(-1, 3)
-        set_time(b, t, t, t, t, device=dev)
-        got = [o.float().cpu() for o in model(b)]
+        got = [o.float().cpu() for o in smp.scores(t)]
         assert got[0].shape == (40, 3) and model.last_stats["B"] == 40
         graphs = []
         for i in picks:
@@ -512,13 +509,15 @@ def test_sidechain_update_kernel_matches_pytorch_form():
     assert float((got - pos.double()).abs().max()) > 0.1          # something moved
 
 
-def test_layer0_sharing_across_identical_receptors():
+@pytest.mark.parametrize("name", ["cfg2_noflex", "cfg2_small"])
+def test_layer0_sharing_across_identical_receptors(name):
     """A sampling batch = N poses of one complex at one diffusion time: the layer-0 receptor-side convs are computed for
-    graph 0 only (score_model.share_layer0).  Same result as the general path (up to the changed summation order of the
-    residual update) and as the CPU oracle; a batch with different times or moved atoms must not take the shortcut."""
+    graph 0 only (score_model.share_layer0): all four of them for a rigid receptor, receptor<-receptor alone when side chains
+    are flexible (they move per sample).  Same result as the general path (up to the changed summation order of the residual
+    update) and as the CPU oracle; a batch with different times must not take the shortcut."""
     from diffdock_pocket_amd.batch import collate, set_time
     from diffdock_pocket_amd.synthetic import make_3dpf_complex
-    case, gold, batch, sd = case_inputs("cfg2_small")
+    case, gold, batch, sd = case_inputs(name)
     dev = _dev()
     model = _model_for(case, sd)
     gs = []
@@ -532,7 +531,10 @@ def test_layer0_sharing_across_identical_receptors():
     bd = b.to(dev)
     model.share_layer0 = True
     fast = [t.clone() for t in model(bd)]
-    assert {3, 5, 6, 8} <= {k for k, v in model._static_cache["shared0"][3].items() if v is not None}
+    if case.flexible_sidechains:
+        assert {6} == {k for k, v in model._static_cache["shared0_rec"][3].items() if v is not None}
+    else:
+        assert {3, 5, 6, 8} <= {k for k, v in model._static_cache["shared0"][3].items() if v is not None}
     model.share_layer0 = False
     slow = [t.clone() for t in model(bd)]
     want = OracleScoreModel(case.oracle_config(), sd)(b)

@@ -29,11 +29,8 @@ def run_job(cfg, flex, n, device, sampler_kwargs=None):
     out = {}
     for t_idx in STEPS:
         # scores of the step's forward on the poses the sampler holds, then the step itself
-        b = smp.batch
-        b["ligand"].pos, b["atom"].pos = smp.lig_pos.reshape(-1, 3), smp.atom_pos.reshape(-1, 3)
         t = float(sched[t_idx])
-        set_time(b, t, t, t, t, device=device)
-        scores = [o.float().cpu().clone() for o in model(b)]
+        scores = [o.float().cpu().clone() for o in smp.scores(t)]
         smp.step(t_idx, sched)
         torch.cuda.synchronize()
         out[t_idx] = {"scores": scores, "lig_pos": smp.lig_pos.cpu().clone(), "atom_pos": smp.atom_pos.cpu().clone(),
