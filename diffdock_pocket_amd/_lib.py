@@ -86,7 +86,7 @@ class SelectJob(C.Structure):
 class RadiusJob(C.Structure):
     _fields_ = [("x", _P), ("x_ptr", _P), ("y", _P), ("y_batch", _P), ("ny", _I), ("r", C.c_float), ("max_neighbors", _I),
                 ("flags", _I), ("graph_div", _P), ("counts", _P), ("offsets", _P), ("base", _I), ("total", _P), ("out_query", _P),
-                ("out_x", _P), ("capacity", _I)]
+                ("out_x", _P), ("capacity", _I), ("overflow", _P)]
 
 
 class SdeArgs(C.Structure):

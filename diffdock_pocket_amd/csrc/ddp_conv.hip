@@ -1284,8 +1284,8 @@ static int launch_conv(K kernel, ConvLaunch& L, const ddp_conv_task_t* tasks, in
   if (const char* pad = (ET == 32) ? getenv("DDP_STAMP_LDS_PAD_KB") : nullptr) lds_bytes += (size_t)atoi(pad) * 1024;
 #endif
   if (lds_bytes > 160 * 1024 - 4096) return ddp_fail(DDP_ELIMIT, "ddp_conv_messages: LDS budget exceeded");
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds_bytes);
+  static int lds_have = 0;     // (one instance per kernel: launch_conv is a template over it)
+  hipError_t err = ddp_need_lds(reinterpret_cast<const void*>(kernel), (int)lds_bytes, &lds_have);
   if (err != hipSuccess) return ddp_fail_hip(err, "hipFuncSetAttribute(conv)");
   hipLaunchKernelGGL(kernel, dim3(tiles), dim3(ET * 8), lds_bytes, (hipStream_t)stream, L);
   err = hipGetLastError();

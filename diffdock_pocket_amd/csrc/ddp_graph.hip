@@ -150,6 +150,8 @@ __global__ __launch_bounds__(256) void ddp_radius_kernel(const RadiusLaunch L) {
       if (o < J.capacity) {
         J.out_query[o] = q;
         J.out_x[o] = j;
+      } else if (J.overflow) {
+        *J.overflow = 1;
       }
     }
     kept += __popcll(mk);

@@ -312,8 +312,8 @@ extern "C" int ddp_edge_featurize(const float* pos_a, const int32_t* ia, const f
   if (k_rbf < 2 || k_rbf > 256) return ddp_fail(DDP_ELIMIT, "ddp_edge_featurize: k_rbf");
   if ((k_rbf & 7) == 0 && k_rbf <= 64) {   // both Linears on the matrix cores
     const size_t lds_m = (size_t)(k_rbf * EF_NS + EF_NS * EF_NS + EF_NS + 64 + 4 * 32 * EF_HS) * sizeof(float);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(ddp_edge_featurize_mfma_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+    static int lds_have_m = 0;
+    hipError_t e2 = ddp_need_lds(reinterpret_cast<const void*>(ddp_edge_featurize_mfma_kernel), (int)lds_m, &lds_have_m);
     if (e2 != hipSuccess) return ddp_fail_hip(e2, "hipFuncSetAttribute(edge_featurize_mfma)");
     int blocks_m = (n_edges + 127) / 128;
     if (blocks_m > 1024) blocks_m = 1024;
@@ -324,8 +324,8 @@ extern "C" int ddp_edge_featurize(const float* pos_a, const int32_t* ia, const f
     return 0;
   }
   const size_t lds = (size_t)(k_rbf * EF_NS + EF_NS * EF_NS + EF_NS + ((k_rbf + 3) & ~3) + 4 * 64 * 65) * sizeof(float);
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(ddp_edge_featurize_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static int lds_have = 0;
+  hipError_t err = ddp_need_lds(reinterpret_cast<const void*>(ddp_edge_featurize_kernel), (int)lds, &lds_have);
   if (err != hipSuccess) return ddp_fail_hip(err, "hipFuncSetAttribute(edge_featurize)");
   int blocks = (n_edges + 255) / 256;
   if (blocks > 2048) blocks = 2048;

@@ -72,12 +72,15 @@ __global__ __launch_bounds__(256) void ddp_node_linear_kernel(const NodeLaunch L
   for (int c0 = 0; c0 < K; c0 += ND_KC) {
     const int kc = min(ND_KC, K - c0);
     const int kc2 = (kc + 1) & ~1;
-    // A chunk: element (row, c0 + c)
-    for (int i = tid; i < ND_ROWS * kc2; i += 256) {
+    // A chunk: element (row, c0 + c); a thread's 16 elements are fetched together (independent loads in flight), then stored
+    float av[ND_ROWS * ND_KC / 256];
+#pragma unroll
+    for (int u = 0; u < ND_ROWS * ND_KC / 256; ++u) {
+      const int i = tid + 256 * u;
       const int rr = i / kc2, c = i - rr * kc2, k = c0 + c;
-      const int row = row0 + min(rr, nvalid - 1);
       float v = 0.f;
-      if (c < kc) {
+      if (i < ND_ROWS * kc2 && c < kc) {
+        const int row = row0 + min(rr, nvalid - 1);
         if (k < k_emb) v = nd_emb_sum(J, cat_lds[rr], k);
         else if (k < k_d0) v = J.dense[0][(size_t)row * J.ld_dense[0] + (k - k_emb)];
         else if (k < k_d1) v = J.dense[1][(size_t)row * J.ld_dense[1] + (k - k_d0)];
@@ -89,7 +92,12 @@ __global__ __launch_bounds__(256) void ddp_node_linear_kernel(const NodeLaunch L
           if (J.sig_out && rr < nvalid) J.sig_out[(size_t)row * J.ld_sig_out + s] = v;   // data[node type].node_sigma_emb
         }
       }
-      a_lds[rr * ND_LD + c] = v;
+      av[u] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < ND_ROWS * ND_KC / 256; ++u) {
+      const int i = tid + 256 * u;
+      if (i < ND_ROWS * kc2) a_lds[(i / kc2) * ND_LD + (i % kc2)] = av[u];
     }
     __syncthreads();
 #pragma unroll
@@ -99,11 +107,23 @@ __global__ __launch_bounds__(256) void ddp_node_linear_kernel(const NodeLaunch L
         const int col = tile * 32 + r;
         const bool cok = col < J.ncols;
         const float* wcol = J.w + (size_t)c0 * J.ncols + (cok ? col : 0);
-        for (int kk = 0; kk < kc2; kk += 2) {
-          const int k = kk + hh;
-          const float a = a_lds[r * ND_LD + k];
-          const float b = (cok && k < kc) ? wcol[(size_t)k * J.ncols] : 0.f;
-          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q], 0, 0, 0);
+        // eight k-steps at a time: their eight weight loads are issued together (one memory round trip per group instead of
+        // one per MFMA - a lone workgroup of the 1404-row receptor Linear is a latency chain otherwise)
+        for (int kk = 0; kk < kc2; kk += 16) {
+          float a[8], b[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int k = kk + 2 * u + hh;
+            b[u] = (cok && k < kc) ? wcol[(size_t)k * J.ncols] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int k = kk + 2 * u + hh;
+            a[u] = (k < kc2) ? a_lds[r * ND_LD + k] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (kk + 2 * u < kc2) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc[q], 0, 0, 0);
         }
       }
     }

@@ -87,6 +87,7 @@ class ForwardEngine:
         lig, rec, atom = data["ligand"], data["receptor"], data["atom"]
         dev = lig.pos.device
         m._refresh_weight_caches()
+        m.check_overflow()
         mark = m.section_timer.mark if m.section_timer is not None else (lambda name: None)
         mark("start")
         if m.no_aminoacid_identities:
@@ -138,7 +139,7 @@ class ForwardEngine:
         # worst-case sizes of the pose-dependent edge lists (per graph: every query x every point of its graph, or the cap)
         S.cap_ll = S.E_bond + sum(n * min(max(n - 1, 0), 32) for n in nl)
         S.cap_lr = sum(a * min(b, 10000) for a, b in zip(nl, nr))
-        S.cap_la = sum(a * min(b, 10000) for a, b in zip(nl, na))
+        S.cap_la = sum(a * min(b, 10000, max(int(m.la_capacity_per_atom), 1)) for a, b in zip(nl, na))
         S.stats = {"E_rr": int(rr.shape[1]), "E_ar": int(ar.shape[1]), "N_l": S.Nl, "N_r": S.Nr, "N_a": S.Na, "B": B}
         S.tor = S.sc = None
         if not m.confidence_mode:
@@ -172,6 +173,8 @@ class ForwardEngine:
         """Do all receptor-side nodes sit at ONE diffusion time (the sampling batch)?  `batch.set_time` says so for the time
         tensors it made; for any others the device is asked (one host synchronisation)."""
         ts = (rec.node_t["tr"], atom.node_t["tr"])
+        if all(t.numel() > 0 and (t.numel() == 1 or t.stride(0) == 0) for t in ts) and ts[0].data_ptr() == ts[1].data_ptr():
+            return True      # stride-0 views of ONE device scalar (sampler.Sampler): one time by construction
         hint = getattr(data, "ddp_time_hint", None)
         if hint is not None and hint[0] == tuple(id(t) for t in ts) and hint[1] == tuple(t._version for t in ts):
             return bool(hint[2])
@@ -234,7 +237,7 @@ class ForwardEngine:
             jobs.append(K.radius_job(rpos, ptr_r, lpos, b32_l, m.cross_max_distance, 10000, 0, i32e(Nl), i32e(Nl + 1), total=cnt["lr"],
                                      out_query=lr0, out_x=lr1, capacity=S.cap_lr))
         jobs.append(K.radius_job(apos, ptr_a, lpos, b32_l, m.lig_max_radius, 10000, 0, i32e(Nl), i32e(Nl + 1), total=cnt["la"],
-                                 out_query=la0, out_x=la1, capacity=S.cap_la))
+                                 out_query=la0, out_x=la1, capacity=S.cap_la, overflow=m.overflow_flag(dev)))
         # atoms with a ligand atom of their graph within the radius = the sources of ligand<-atom edges = the atoms an
         # atom<-ligand message reaches ("touched"): the same search with the roles swapped, count pass only
         F.touched = i32e(Na)

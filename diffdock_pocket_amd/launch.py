@@ -367,13 +367,13 @@ def select_jobs(jobs: Sequence[L.SelectJob]):
 
 
 def radius_job(x, x_ptr, y, y_batch, r, cap, flags, counts, offsets=None, base=0, total=None, out_query=None, out_x=None,
-               capacity=0, graph_div=None) -> L.RadiusJob:
+               capacity=0, graph_div=None, overflow=None) -> L.RadiusJob:
     j = L.RadiusJob()
     j.x, j.x_ptr, j.y, j.y_batch, j.ny = x.data_ptr(), x_ptr.data_ptr(), y.data_ptr(), y_batch.data_ptr(), int(y.shape[0])
     j.r, j.max_neighbors, j.flags, j.graph_div = float(r), int(cap), int(flags), _p(graph_div)
     j.counts, j.offsets, j.base, j.total = _p(counts), _p(offsets), int(base), _p(total)
-    j.out_query, j.out_x, j.capacity = _p(out_query), _p(out_x), int(capacity)
-    return _hold(j, x, x_ptr, y, y_batch, graph_div, counts, offsets, total, out_query, out_x)
+    j.out_query, j.out_x, j.capacity, j.overflow = _p(out_query), _p(out_x), int(capacity), _p(overflow)
+    return _hold(j, x, x_ptr, y, y_batch, graph_div, counts, offsets, total, out_query, out_x, overflow)
 
 
 def radius_search_jobs(jobs: Sequence[L.RadiusJob]):

@@ -364,6 +364,10 @@ class Sampler:
                           RuntimeWarning)
             self._graph = False
             torch.cuda.synchronize(self.device)
+            # what the aborted capture left in the model's static-graph cache was never computed
+            for mdl in (self.model,):
+                if hasattr(mdl, "_static_cache"):
+                    mdl._static_cache = {}
             self._step_body()
             return
         self._graph = g
@@ -504,6 +508,9 @@ class Sampler:
         self.__dict__["_weights_checked"] = set()      # a run re-checks the weights' values once
         for i in range(len(schedule)):
             self.step(i, schedule)
+        if self.on_hip and hasattr(self.model, "check_overflow"):
+            torch.cuda.synchronize(self.device)
+            self.model.check_overflow()
         return self.lig_pos, self.atom_pos
 
 

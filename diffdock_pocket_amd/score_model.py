@@ -397,6 +397,12 @@ class TensorProductScoreModel(nn.Module):
         self._stage_a_stacks = {}      # (layer, conv ids) -> stacked stage-A right-hand sides, see _stage_a()
         self.section_timer = None      # optional SectionTimer (tools/time_sections.py): per-section GPU + host time
         self.check_weight_values = True  # see _refresh_weight_caches
+        # Capacity of the ligand<-atom edge list: pocket atoms within lig_max_radius of a ligand atom, per ligand atom (its
+        # worst case, every atom of the pocket, is ~80 x what occurs: the grids of every consumer are sized for the capacity).
+        # 128 is ~3 x the densest packing of protein heavy atoms inside 5 A; a search that finds more sets a flag in pinned host
+        # memory and the NEXT forward (or Sampler.run's end) raises - results are never silently truncated.
+        self.la_capacity_per_atom = 128
+        self._overflow_flag = None
         self.exact_sizes = False       # test mode: device-side list sizes are read back and every list is cut to its length
         self.debug_conv_outputs = None  # set to a dict: forward then stores the output [n_out, d_out] of every conv call in it
                                         # (conv_layers.<9l+k>, final_conv, tor_bond_conv, sc_tor_bond_conv: the tensors the
@@ -536,6 +542,18 @@ class TensorProductScoreModel(nn.Module):
             self.invalidate_packed()
             self._weights_seen = wv
             self._weights_seen_fp = fp if self.check_weight_values else self._weights_fingerprint()
+
+    def overflow_flag(self, dev):
+        """int32 [1] in pinned host memory (device-writable, host-readable without a synchronisation)."""
+        if self._overflow_flag is None:
+            self._overflow_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+        return self._overflow_flag
+
+    def check_overflow(self):
+        if self._overflow_flag is not None and int(self._overflow_flag[0]) != 0:
+            self._overflow_flag.zero_()
+            raise L.DdpError(f"a ligand atom had more than la_capacity_per_atom = {self.la_capacity_per_atom} pocket atoms within "
+                             f"lig_max_radius: the ligand<-atom edge list of an earlier forward was truncated; raise the capacity")
 
     def invalidate_packed(self):
         self._weights_seen = None

@@ -348,6 +348,8 @@ typedef struct {
   int32_t* out_query;
   int32_t* out_x;
   int32_t capacity;
+  int32_t* overflow;   /* optional: set to 1 when a pair had to be dropped because it lay at or behind `capacity` (may point to
+                          pinned host memory: the host can then notice it without synchronising) */
 } ddp_radius_job_t;
 int ddp_radius_search_jobs(const ddp_radius_job_t* jobs, int njobs, void* stream);
 

@@ -218,6 +218,26 @@ def test_results_do_not_depend_on_list_capacities(name):
         assert torch.equal(x, y)
 
 
+def test_a_truncated_ligand_atom_edge_list_is_reported():
+    """The ligand<-atom edge list has a capacity per ligand atom (model.la_capacity_per_atom) instead of its worst case.  A
+    search that finds more pairs drops them AND raises a flag in pinned host memory: the next forward refuses to go on."""
+    from diffdock_pocket_amd import _lib as L
+    case, gold, batch, sd = case_inputs("cfg2_small")
+    model = _model_for(case, sd)
+    b = case.make_batch().to(_dev())
+    want = [t.clone() for t in model(b)]
+    model.la_capacity_per_atom = 2
+    model._static_cache = {}
+    model(b)
+    torch.cuda.synchronize()
+    with pytest.raises(L.DdpError, match="la_capacity_per_atom"):
+        model(b)
+    model.la_capacity_per_atom = 128
+    model._static_cache = {}
+    for x, y in zip(model(b), want):        # (the flag was cleared by the report)
+        assert torch.equal(x, y)
+
+
 def test_device_driven_step_equals_the_host_driven_one():
     """tests/golden/step_outputs_r02_host_path.pt holds the scores and poses of the first denoising steps of bench.py's jobs as
     the round-2 forward produced them (exact-size lists, ~10 host synchronisations and ~700 PyTorch launches per step; written
