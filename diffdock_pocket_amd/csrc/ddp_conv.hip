@@ -54,6 +54,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #include "ddp_conv_diag.h"   // STAMP / GSTAMP / DDP_ABL_* : no-ops in the product build
 
+// Size classes: the conv kernels are instantiated per scalar multiplicity ns of the released architectures, with the k-group
+// counts of their loops as compile-time constants (fully unrolled tile loops, static register rings: section 4.3 of DESIGN.md).
+// One instantiation per class keeps every kernel's register allocation to ITS loops (with all variants inside one kernel the
+// allocator spills in the ns = 60 path).  SZ = ns when f_in = hid = 3 ns for ns in {60, 32, 24, 16}; SZ = 0: any shape (runtime loops).
+template <int SZ> struct SizeClass { static constexpr int NM = 0; static constexpr bool TAIL = false; };
+template <> struct SizeClass<60> { static constexpr int NM = 23; static constexpr bool TAIL = true; };   // hp = 184 = 8 x 23, hid = 180
+template <> struct SizeClass<32> { static constexpr int NM = 12; static constexpr bool TAIL = false; };  // README small score model
+template <> struct SizeClass<24> { static constexpr int NM = 9; static constexpr bool TAIL = false; };   // confidence model
+template <> struct SizeClass<16> { static constexpr int NM = 6; static constexpr bool TAIL = false; };   // BASELINE configs[0]
+
 struct ConvLaunch {
   ddp_conv_shape_t shape;
   int tv_off;   // 32-edge kernels: row stride (floats) of the LDS message tile; unused by the 64-edge kernel
@@ -234,7 +244,7 @@ __device__ __forceinline__ void g_main_static(const ddp_conv_shape_t& S, const f
   }
 }
 
-template <int ET, int NW = ET / 8, int KC = 16, int RD = 5>
+template <int SZ, int ET, int NW = ET / 8, int KC = 16, int RD = 5>
 __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, const ddp_conv_task_t& T, const float* hbuf,
                                         float* outb, int os, const int* gmap, const TileAux<ET>& aux, int wave, int lane) {
   // One pass per G slot; a wave takes units wave, wave + NW, ...  For a unit (<= 8 edges of one source node)
@@ -287,10 +297,10 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
     const int cb = 64 * pass;
     const bool act0 = lane < (pass ? nx : nmain);
     const int c0 = cb + (act0 ? lane : 0);
-    if (nq == 45 || nq == 18) {   // hid = 180 (ns = 60), hid = 72 (ns = 24): steps of a unit unrolled (g_main_static)
+    if constexpr (SZ != 0) {   // hid = 3 SZ = 180 / 96 / 72 / 48: the steps of a unit unrolled (g_main_static), nq = 3 x NM steps of 3 k-quads
+      constexpr int GNM = (3 * SZ / 4) / 3, GRING = (SZ == 60) ? 5 : (SZ == 24) ? 6 : 4;
       const int gmv = gmap[cb + (act0 ? lane : 0)];
-      if (nq == 45) g_main_static<ET, 3, 15, 5>(S, Gb, G4, gstride, gc, gmv, act0, c0, nmine, my_e0, my_len, my_node, hbuf, outb, os, aux, lane);
-      else g_main_static<ET, 3, 6, 6>(S, Gb, G4, gstride, gc, gmv, act0, c0, nmine, my_e0, my_len, my_node, hbuf, outb, os, aux, lane);
+      g_main_static<ET, 3, GNM, GRING>(S, Gb, G4, gstride, gc, gmv, act0, c0, nmine, my_e0, my_len, my_node, hbuf, outb, os, aux, lane);
       continue;
     }
     f32x4 ring[RD][KC / 4];   // (indices are compile-time constants after unrolling: registers)
@@ -740,16 +750,15 @@ __device__ __forceinline__ void seg_tiles(const ddp_conv_shape_t& S, const ddp_b
   }
 }
 
-// the k-group counts with an unrolled tile loop: hp = 184 (ns = 60: the README score model); everything else runs the generic loop
-template <int C, int FS = 36>
+// the tile loop of the kernel's size class (SizeClass): unrolled for ns = 60 / 32 / 24 / 16, runtime loop otherwise
+template <int SZ, int C, int FS = 36>
 __device__ __forceinline__ void seg_tiles_any(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
                                               const float* hbuf, const float* fblk, const ddp_role_seg_t& R, int lane, f32x16* out,
                                               int rt = 0) {
-  if (S.hp == 184 && S.hid == 180) seg_tiles<C, 23, FS, true>(S, B, T, hbuf, fblk, R, lane, rt, out);   // ns = 60: the README score model
-  else seg_tiles<C, 0, FS>(S, B, T, hbuf, fblk, R, lane, rt, out);
+  seg_tiles<C, SizeClass<SZ>::NM, FS, SizeClass<SZ>::TAIL>(S, B, T, hbuf, fblk, R, lane, rt, out);
 }
 
-template <int ET, int C>
+template <int SZ, int ET, int C>
 __device__ __forceinline__ void run_block_rows(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
                                           const float* hbuf, float* fbuf, int tid,
                                           const TileAux<ET>& aux, int nvalid, int sbase) {
@@ -767,7 +776,7 @@ __device__ __forceinline__ void run_block_rows(const ddp_conv_shape_t& S, const 
     seg.tstride = 4;
     seg.count = (ngroups > wq) ? (ngroups - wq + 3) >> 2 : 0;
     seg.round = 0;
-    seg_tiles_any<C, FS>(S, B, T, hbuf, fbuf, seg, lane, out, rt);
+    seg_tiles_any<SZ, C, FS>(S, B, T, hbuf, fbuf, seg, lane, out, rt);
   }
 
   // ---- phase 4: deterministic cross-wave / cross-lane reduction.  Every wave parks a 32-row partial tile in its own
@@ -1019,15 +1028,15 @@ __device__ __forceinline__ void fc1_tiles(const ddp_conv_shape_t& S, const ddp_c
   }
 }
 
-template <int ET, int NW = ET / 8>
+template <int SZ, int ET, int NW = ET / 8>
 __device__ __forceinline__ void fc1_to_lds(const ddp_conv_shape_t& S, const ddp_conv_task_t& T, const float* xa, float* hbuf, int tid) {
-  if (S.kp1 == 184 && S.f_in == 180) fc1_tiles<ET, NW, 23, true>(S, T, xa, hbuf, tid);     // ns = 60 (the README score model): unrolled
-  else fc1_tiles<ET, NW, 0>(S, T, xa, hbuf, tid);
+  fc1_tiles<ET, NW, SizeClass<SZ>::NM, SizeClass<SZ>::TAIL>(S, T, xa, hbuf, tid);
   __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------ kernel, 64-edge form
 // (direct shapes: every block's features on the per-edge MFMA path)
+template <int SZ>
 __global__ __launch_bounds__(512, 2) void ddp_conv_messages_kernel(const ConvLaunch L) {
   constexpr int ET = 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1045,7 +1054,7 @@ __global__ __launch_bounds__(512, 2) void ddp_conv_messages_kernel(const ConvLau
   STAMP(22);  // s_memrealtime (100 MHz) at entry
   stage_edge_attr<ET>(S, T, aux, xa, p0, nvalid, tid);
   STAMP(1);
-  fc1_to_lds<ET>(S, T, xa, hbuf, tid);
+  fc1_to_lds<SZ, ET>(S, T, xa, hbuf, tid);
   STAMP(2);
 
   // ---- per weight block
@@ -1059,9 +1068,9 @@ __global__ __launch_bounds__(512, 2) void ddp_conv_messages_kernel(const ConvLau
     if (B.C == 1 && B.ntiles >= 64)
       run_block_full<1>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
     else if (B.C == 1)
-      run_block_rows<ET, 1>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
+      run_block_rows<SZ, ET, 1>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
     else
-      run_block_rows<ET, 3>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
+      run_block_rows<SZ, ET, 3>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
   }
   STAMP(23);  // s_memrealtime at exit
 #ifdef DDP_STAMPS
@@ -1129,6 +1138,7 @@ __device__ __forceinline__ void seg_park(const ddp_block_t& B, const ddp_role_se
   }
 }
 
+template <int SZ>
 __global__ __launch_bounds__(256, 3) void ddp_conv32_kernel(const ConvLaunch L) {
   constexpr int ET = 32, NT = 256, FS = 36;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1157,7 +1167,7 @@ __global__ __launch_bounds__(256, 3) void ddp_conv32_kernel(const ConvLaunch L) 
   }
   stage_edge_attr<ET>(S, T, aux, rb, p0, nvalid, tid);
   STAMP(1);
-  fc1_to_lds<ET>(S, T, rb, hbuf, tid);
+  fc1_to_lds<SZ, ET>(S, T, rb, hbuf, tid);
   STAMP(2);
 
   // ---- phase 2: basis features of every block
@@ -1183,15 +1193,15 @@ __global__ __launch_bounds__(256, 3) void ddp_conv32_kernel(const ConvLaunch L) 
     const ddp_role_seg_t& R0 = S.role[wave][0];
     c0 = S.blk[R0.block].C;
     for (int bi = 0; bi < R0.block; ++bi) f0 += S.blk[bi].U * S.blk[bi].C;
-    if (c0 == 1) seg_tiles_any<1>(S, S.blk[R0.block], T, hbuf, rb + f0 * FS, R0, lane, res);
-    else seg_tiles_any<3>(S, S.blk[R0.block], T, hbuf, rb + f0 * FS, R0, lane, res + 1);
+    if (c0 == 1) seg_tiles_any<SZ, 1>(S, S.blk[R0.block], T, hbuf, rb + f0 * FS, R0, lane, res);
+    else seg_tiles_any<SZ, 3>(S, S.blk[R0.block], T, hbuf, rb + f0 * FS, R0, lane, res + 1);
   }
   if (nseg > 1) {
     const ddp_role_seg_t& R1 = S.role[wave][1];
     c1 = S.blk[R1.block].C;
     for (int bi = 0; bi < R1.block; ++bi) f1 += S.blk[bi].U * S.blk[bi].C;
-    if (c1 == 1) seg_tiles_any<1>(S, S.blk[R1.block], T, hbuf, rb + f1 * FS, R1, lane, res + 1);
-    else seg_tiles_any<3>(S, S.blk[R1.block], T, hbuf, rb + f1 * FS, R1, lane, res + 1);
+    if (c1 == 1) seg_tiles_any<SZ, 1>(S, S.blk[R1.block], T, hbuf, rb + f1 * FS, R1, lane, res + 1);
+    else seg_tiles_any<SZ, 3>(S, S.blk[R1.block], T, hbuf, rb + f1 * FS, R1, lane, res + 1);
   }
   STAMP(4);
   __syncthreads();   // every wave is done with F: region B becomes the message tile
@@ -1226,7 +1236,7 @@ __global__ __launch_bounds__(256, 3) void ddp_conv32_kernel(const ConvLaunch L) 
   // ---- phase 5: factorised features (one pass per G slot)
   __builtin_amdgcn_s_setprio(DDP_GPRIO);
   for (int slot = 0; slot < 2; ++slot)
-    if (S.g_cols[slot] > 0) g_stage<ET>(S, slot, T, hbuf, rb, os, gmap[slot], aux, wave, lane);
+    if (S.g_cols[slot] > 0) g_stage<SZ, ET>(S, slot, T, hbuf, rb, os, gmap[slot], aux, wave, lane);
   __builtin_amdgcn_s_setprio(0);
   STAMP(7);
   __syncthreads();
@@ -1259,6 +1269,18 @@ __global__ __launch_bounds__(256, 3) void ddp_conv32_kernel(const ConvLaunch L) 
 }
 
 // ------------------------------------------------------------------------------------------------ host
+// size class of a shape (SizeClass): f_in = hid = 3 ns with ns one of the released architectures' multiplicities
+static int size_class(const ddp_conv_shape_t* S) {
+  if (S->f_in != S->hid || S->kp1 != S->hp) return 0;
+  switch (S->hid) {
+    case 180: return S->hp == 184 ? 60 : 0;
+    case 96: return 32;
+    case 72: return 24;
+    case 48: return 16;
+    default: return 0;
+  }
+}
+
 template <int ET, typename K>
 static int launch_conv(K kernel, ConvLaunch& L, const ddp_conv_task_t* tasks, int ntasks, size_t lds_bytes, void* stream) {
   const ddp_conv_shape_t* shape = &L.shape;
@@ -1284,8 +1306,13 @@ static int launch_conv(K kernel, ConvLaunch& L, const ddp_conv_task_t* tasks, in
   if (const char* pad = (ET == 32) ? getenv("DDP_STAMP_LDS_PAD_KB") : nullptr) lds_bytes += (size_t)atoi(pad) * 1024;
 #endif
   if (lds_bytes > 160 * 1024 - 4096) return ddp_fail(DDP_ELIMIT, "ddp_conv_messages: LDS budget exceeded");
-  static int lds_have = 0;     // (one instance per kernel: launch_conv is a template over it)
-  hipError_t err = ddp_need_lds(reinterpret_cast<const void*>(kernel), (int)lds_bytes, &lds_have);
+  // (the limit is per kernel FUNCTION: a small table keyed on the function pointer; ten instantiations at most)
+  static const void* lds_fn[16];
+  static int lds_have_tab[16];
+  int slot = 0;
+  while (slot < 15 && lds_fn[slot] && lds_fn[slot] != reinterpret_cast<const void*>(kernel)) ++slot;
+  lds_fn[slot] = reinterpret_cast<const void*>(kernel);
+  hipError_t err = ddp_need_lds(reinterpret_cast<const void*>(kernel), (int)lds_bytes, &lds_have_tab[slot]);
   if (err != hipSuccess) return ddp_fail_hip(err, "hipFuncSetAttribute(conv)");
   hipLaunchKernelGGL(kernel, dim3(tiles), dim3(ET * 8), lds_bytes, (hipStream_t)stream, L);
   err = hipGetLastError();
@@ -1344,7 +1371,14 @@ extern "C" int ddp_conv_messages(const ddp_conv_shape_t* shape, const ddp_conv_t
     if (rbf < frows * (ET + 4)) rbf = frows * (ET + 4);   // features of all blocks
     if (rbf < ET * os) rbf = ET * os;               // message tile
     L.tv_off = os;
-    return launch_conv<32>(ddp_conv32_kernel, L, tasks, ntasks, (size_t)(ET * shape->hs + rbf) * sizeof(float), stream);
+    const size_t lds32 = (size_t)(ET * shape->hs + rbf) * sizeof(float);
+    switch (size_class(shape)) {
+      case 60: return launch_conv<32>(ddp_conv32_kernel<60>, L, tasks, ntasks, lds32, stream);
+      case 32: return launch_conv<32>(ddp_conv32_kernel<32>, L, tasks, ntasks, lds32, stream);
+      case 24: return launch_conv<32>(ddp_conv32_kernel<24>, L, tasks, ntasks, lds32, stream);
+      case 16: return launch_conv<32>(ddp_conv32_kernel<16>, L, tasks, ntasks, lds32, stream);
+      default: return launch_conv<32>(ddp_conv32_kernel<0>, L, tasks, ntasks, lds32, stream);
+    }
   }
   // 64-edge workgroups: the host-provided fbuf_floats covers features, the 5 x 4096 partial regions of the 2x2 variant
   // and (never used on this path, kept for shapes built by older hosts) a tv region behind them
@@ -1353,5 +1387,12 @@ extern "C" int ddp_conv_messages(const ddp_conv_shape_t* shape, const ddp_conv_t
       return ddp_fail(DDP_EINVAL, "ddp_conv_messages: fbuf_floats too small");
   if (64 * shape->hs > shape->fbuf_floats) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: fbuf_floats < staging tile");
   L.tv_off = 0;
-  return launch_conv<64>(ddp_conv_messages_kernel, L, tasks, ntasks, (size_t)(64 * shape->hs + shape->fbuf_floats) * sizeof(float), stream);
+  const size_t lds64 = (size_t)(64 * shape->hs + shape->fbuf_floats) * sizeof(float);
+  switch (size_class(shape)) {
+    case 60: return launch_conv<64>(ddp_conv_messages_kernel<60>, L, tasks, ntasks, lds64, stream);
+    case 32: return launch_conv<64>(ddp_conv_messages_kernel<32>, L, tasks, ntasks, lds64, stream);
+    case 24: return launch_conv<64>(ddp_conv_messages_kernel<24>, L, tasks, ntasks, lds64, stream);
+    case 16: return launch_conv<64>(ddp_conv_messages_kernel<16>, L, tasks, ntasks, lds64, stream);
+    default: return launch_conv<64>(ddp_conv_messages_kernel<0>, L, tasks, ntasks, lds64, stream);
+  }
 }

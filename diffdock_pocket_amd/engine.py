@@ -70,9 +70,44 @@ def _i32(t):
     return t.to(torch.int32).contiguous()
 
 
+class _Fork:
+    """Independent launches of one layer on side streams (fork / join with events; inside a captured step they become
+    parallel branches of the hipGraph).  Used for SMALL batches only: a layer's direct-conv launch (receptor<-atom: one 64-edge
+    workgroup per 64 atoms, ~0.3 ms each whatever the batch) and its stage-A products then overlap with the 32-edge conv
+    kernel instead of running behind it - at 5 samples of 3dpf the kernels of a layer do not fill the chip one by one; at
+    40 samples they do, and sharing the CUs was measured without gain."""
+
+    def __init__(self, dev, n):
+        self.main = torch.cuda.current_stream(dev)
+        self.side = [torch.cuda.Stream(device=dev) for _ in range(n)]
+        self.used = []
+
+    def run(self, i, fn):
+        st = self.side[i % len(self.side)]
+        if st not in self.used:
+            st.wait_stream(self.main)     # fork: after everything queued so far
+            self.used.append(st)
+        with torch.cuda.stream(st):
+            return fn()
+
+    def join(self):
+        for st in self.used:
+            self.main.wait_stream(st)
+        self.used = []
+
+
 class ForwardEngine:
     def __init__(self, model):
         self.m = model
+        self._forks = {}
+
+    def _fork(self, dev):
+        """Side streams of the current stream (None: launches stay in order on one stream)."""
+        f = self._forks.get(dev)     # (created by the first ordinary step: no stream is created while a step is being captured)
+        if f is None:
+            f = self._forks[dev] = _Fork(dev, 3)
+        f.main = torch.cuda.current_stream(dev)
+        return f
 
     # ================================================================================================ entry
     @torch.no_grad()
@@ -555,6 +590,8 @@ class ForwardEngine:
         nodes = {"l": (xl, Nl), "a": (xa, Na), "r": (xr, Nr)}
         dbg = m.debug_conv_outputs
         exact = getattr(F, "exact", None)
+        # small batches: independent launches of a layer side by side (see _Fork); decided by the batch's size, not its content
+        fork = self._fork(dev) if (m.concurrent_small_batches and Na <= m.concurrent_max_atoms and m.before_layers is None) else None
         for l in range(L_):
             spec, spec_g = m._layer_specs[l], m._layer_specs_g[l]
             do_atom = m.flexible_sidechains or l != L_ - 1
@@ -597,8 +634,13 @@ class ForwardEngine:
                     groups.setdefault((st_, rows[0]), (x_src, rows, []))[2].append((k, m.conv_layers[9 * l + k]))
             # ---- stage A: one batched product per (source-node array, row set)
             gmap = {}
-            for (st_, gid), (x_src, rows, convs) in groups.items():
-                gmap.update(self._stage_a(l, convs, x_src, rows[3], rows=rows[1], rows_cnt=rows[2]))
+            for gi, ((st_, gid), (x_src, rows, convs)) in enumerate(groups.items()):
+                if fork is not None and gi > 0:
+                    gmap.update(fork.run(gi - 1, lambda: self._stage_a(l, convs, x_src, rows[3], rows=rows[1], rows_cnt=rows[2])))
+                else:
+                    gmap.update(self._stage_a(l, convs, x_src, rows[3], rows=rows[1], rows_cnt=rows[2]))
+            if fork is not None:
+                fork.join()
             x_clean = None
             if c1 is not None:      # atom<-atom at layer 1: touched edges per sample + the clean pairs once
                 conv3 = m.conv_layers[9 * l + 3]
@@ -652,8 +694,13 @@ class ForwardEngine:
                     segs = [(e_base, csr.eid, ns, ns), (x_recv, csr.recv, ldx, ns), (x_src, csr.src, ldx, ns)]
                     tasks.append(K.make_task(pkc, x_src, ldx, csr, sh_k, segs, msg))
             mark("conv_prep")
-            K.launch_convs(spec_g, tasks_g, flops_spec=spec, node_bytes=nb_g)
-            K.launch_convs(spec, tasks, node_bytes=nb_d)
+            if fork is not None and tasks and tasks_g:
+                fork.run(0, lambda: K.launch_convs(spec, tasks, node_bytes=nb_d))     # the direct convs beside the factorised ones
+                K.launch_convs(spec_g, tasks_g, flops_spec=spec, node_bytes=nb_g)
+                fork.join()
+            else:
+                K.launch_convs(spec_g, tasks_g, flops_spec=spec, node_bytes=nb_g)
+                K.launch_convs(spec, tasks, node_bytes=nb_d)
             mark("conv_launch")
             if dbg is not None:   # every conv's own output = segmented mean + BatchNorm of its messages alone
                 for k, ent in msgs.items():

@@ -344,6 +344,10 @@ class Sampler:
             self._upload_step(t_idx, schedule)
             if self._graph and self.graph_enabled:
                 self._graph.replay()
+                # (the replay moved the poses in place behind Python's back: the model's static-graph cache keys on the versions)
+                torch.autograd.graph.increment_version(self.lig_pos)
+                if self.has_flex:
+                    torch.autograd.graph.increment_version(self.atom_pos)
             elif self.cfg.hip_graph and self.graph_enabled and self._steps_run >= 2 and self._graph is None:
                 self._capture()
             else:
@@ -371,6 +375,14 @@ class Sampler:
             self._step_body()
             return
         self._graph = g
+        # Everything the capture left in the model's static-graph cache lives in the graph's memory pool and is read and
+        # written by its replays: those tensors must not be freed while the graph is alive, whatever later forwards put in
+        # the cache's slots
+        b = self.batch
+        self._graph_keep = [[dict(c) for c in self.model.__dict__.get("_static_caches", {}).values()],
+                            getattr(self.model, "last_stats", None), getattr(b, "graph_sigma_emb", None),
+                            [getattr(b[nt], "node_sigma_emb", None) for nt in ("ligand", "receptor", "atom")],
+                            getattr(b["atom", "atom"], "edge_index", None)]     # (what the captured forward left on model and batch)
         g.replay()
 
     # -- randomize_position (reference utils/sampling.py:16-60), pocket_knowledge=False -----------------------

@@ -402,6 +402,10 @@ class TensorProductScoreModel(nn.Module):
         # 128 is ~3 x the densest packing of protein heavy atoms inside 5 A; a search that finds more sets a flag in pinned host
         # memory and the NEXT forward (or Sampler.run's end) raises - results are never silently truncated.
         self.la_capacity_per_atom = 128
+        # Small batches (a strong-scaling shard: 5 of 40 samples per GPU): a layer's independent launches run side by side on
+        # forked streams (engine._Fork); above this many pocket atoms in the batch every kernel fills the chip on its own
+        self.concurrent_small_batches = True
+        self.concurrent_max_atoms = 16000
         self._overflow_flag = None
         self.exact_sizes = False       # test mode: device-side list sizes are read back and every list is cut to its length
         self.debug_conv_outputs = None  # set to a dict: forward then stores the output [n_out, d_out] of every conv call in it
