@@ -117,10 +117,12 @@ template <int KT>
 __global__ __launch_bounds__(DDP_GEMM_THREADS, DDP_SA_WPE) void ddp_stage_a_mfma_kernel(const float* __restrict__ x, int ldx, int nrows,
                                                                                 const int32_t* __restrict__ rows,
                                                                                 const int32_t* __restrict__ nrows_dev, int out_rows,
-                                                                                const GemmOffs offs, const float* __restrict__ w,
+                                                                                int mrows, const GemmOffs offs, const float* __restrict__ w,
                                                                                 int ncols, float* __restrict__ out, int ldo) {
+  // mrows: rows per workgroup (a multiple of 32).  DDP_GEMM_MROWS for large products - the weight registers of a workgroup are
+  // loaded once per 512 rows - and 128 for small ones (a strong-scaling shard has 185 ligand rows: more, shorter workgroups)
   if (nrows_dev) nrows = min(nrows, *nrows_dev);              // device-side length of the row list (nrows = its capacity)
-  if ((int)blockIdx.y * DDP_GEMM_MROWS >= nrows) return;
+  if ((int)blockIdx.y * mrows >= nrows) return;
   constexpr int KH = KT / 2, CT = DDP_SA_CT;
   constexpr bool LAG = (4 + 3 * (KH / 4) <= KH - 1);   // room for the lagged stores between a block's MFMAs
   constexpr int XS = KT + 1;                                    // odd LDS row stride: conflict-free ds_read_b32 down a column
@@ -140,8 +142,8 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, DDP_SA_WPE) void ddp_stage_a_mfma
 #pragma unroll
     for (int s2 = 0; s2 < KH; ++s2) wr[t][s2] = W[(size_t)(hh * KH + s2) * ncols + c];
   }
-  const int R0 = (int)blockIdx.y * DDP_GEMM_MROWS;
-  const int R1 = min(nrows, R0 + DDP_GEMM_MROWS);
+  const int R0 = (int)blockIdx.y * mrows;
+  const int R1 = min(nrows, R0 + mrows);
   const float* __restrict__ xb = x + offs.off[z];
   const bool al4 = ((ldx | offs.off[z]) & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0;
 
@@ -292,8 +294,9 @@ extern "C" int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* ro
                      dim3(DDP_GEMM_THREADS), 0, s, x, ldx, nrows, rows, nrows_dev, out_rows, O, w, k, ncols, out, ldo)
   const bool wide = ((ncols | ldo) & 3) == 0 && ncols >= 4 * DDP_GEMM_THREADS && (reinterpret_cast<size_t>(out) & 15) == 0;
 #define DDP_GEMM_MFMA(KT)                                                                                        \
-  hipLaunchKernelGGL((ddp_stage_a_mfma_kernel<KT>), dim3((ncols + 128 * DDP_SA_CT - 1) / (128 * DDP_SA_CT), (nrows + DDP_GEMM_MROWS - 1) / DDP_GEMM_MROWS, nbatch), \
-                     dim3(DDP_GEMM_THREADS), 0, s, x, ldx, nrows, rows, nrows_dev, out_rows, O, w, ncols, out, ldo)
+  hipLaunchKernelGGL((ddp_stage_a_mfma_kernel<KT>), dim3((ncols + 128 * DDP_SA_CT - 1) / (128 * DDP_SA_CT), (nrows + mrows - 1) / mrows, nbatch), \
+                     dim3(DDP_GEMM_THREADS), 0, s, x, ldx, nrows, rows, nrows_dev, out_rows, mrows, O, w, ncols, out, ldo)
+  const int mrows = (nrows >= 8192) ? DDP_GEMM_MROWS : 128;
   static const bool no_mfma = getenv("DDP_STAGE_A_VALU") != nullptr;   // diagnostic: force the VALU form
   if (ncols >= 512 && !no_mfma && (k == 60 || k == 64 || k == 32 || k == 24 || k == 16)) {
     switch (k) {

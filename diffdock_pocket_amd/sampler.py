@@ -358,6 +358,10 @@ class Sampler:
         """Capture one step in a hipGraph (the step being captured is also executed: capture records, then the graph is
         replayed once).  Anything that cannot be captured makes the sampler fall back to ordinary launches for good."""
         g = torch.cuda.CUDAGraph()
+        # Whatever the model's static-graph cache holds for the CURRENT poses (a forward on them may just have run: Sampler.scores)
+        # must be recomputed INSIDE the graph, not referenced by it: the cache keys on the pose tensors' version counters
+        torch.autograd.graph.increment_version(self.lig_pos)
+        torch.autograd.graph.increment_version(self.atom_pos)
         try:
             torch.cuda.synchronize(self.device)
             with torch.cuda.graph(g):
