@@ -361,7 +361,8 @@ class Sampler:
         # Whatever the model's static-graph cache holds for the CURRENT poses (a forward on them may just have run: Sampler.scores)
         # must be recomputed INSIDE the graph, not referenced by it: the cache keys on the pose tensors' version counters
         torch.autograd.graph.increment_version(self.lig_pos)
-        torch.autograd.graph.increment_version(self.atom_pos)
+        if self.has_flex:     # (a rigid receptor's entries are genuinely static - and some of them synchronise when they are built)
+            torch.autograd.graph.increment_version(self.atom_pos)
         try:
             torch.cuda.synchronize(self.device)
             with torch.cuda.graph(g):
