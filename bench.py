@@ -60,7 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
                     help="auto: one rank -> the 40-sample job; several ranks -> the STRONG split of the 40 samples is the headline "
                          "(BASELINE configs[3]) and the weak run (40 samples per rank) is measured in the same invocation as a sub-record")
-    ap.add_argument("--cfg", default="cfg2", choices=["cfg1", "cfg2"])
+    ap.add_argument("--cfg", default="cfg2", choices=["cfg1", "cfg2", "small32"])
     ap.add_argument("--flex", action="store_true", help="flexible side chains (BASELINE configs[2])")
     ap.add_argument("--ways", type=int, default=1,
                     help="resident sample groups per GPU (sampler.PipelinedSampler); measured slower than one batch on MI355X "
@@ -77,9 +77,13 @@ def parse_args(argv=None):
                     help="launcher test (no GPU needed): every rank prints its RANK / WORLD_SIZE / sample slice as one JSON line and "
                          "exits, rank DDP_BENCH_FAIL_RANK (if set) with code 3")
     ap.add_argument("--cpu-samples", type=int, default=40, help="sample graphs per CPU-baseline step (40 = the full workload)")
-    ap.add_argument("--cpu-batch", type=int, default=10, help="graphs per oracle forward (the reference's default --batch_size, inference.py)")
+    ap.add_argument("--cpu-batch", type=int, default=4, help="graphs per oracle forward (memory: ~1 GB of per-edge weights per graph and conv)")
+    ap.add_argument("--cpu-budget-s", type=float, default=60.0, help="wall-clock budget of the CPU baseline (a bounded sample)")
+    ap.add_argument("--cpu-full", action="store_true", help="no budget: two FULL 40-sample steps and three full cfg1 loops")
     ap.add_argument("--cpu-steps", type=int, default=2)
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = os.cpu_count()")
+    ap.add_argument("--cpu-threads", type=int, default=32,
+                    help="threads of the CPU baseline (capped at os.cpu_count(); 0 = all cores - on the GPU boxes' many-core hosts the "
+                         "oracle's small ops get SLOWER beyond ~32 threads)")
     ap.add_argument("--no-roofline-pass", action="store_true", help="skip the instrumented steps behind the timed region")
     return ap.parse_args(argv)
 
@@ -145,9 +149,11 @@ def load_pmc(workload_key):
 
 
 def model_kwargs(cfg, flex):
-    if cfg == "cfg2":
+    if cfg == "cfg2":          # the README's large score model (reference README.md:72)
         ns, nv, L, emb = 60, 10, 6, 64
-    else:
+    elif cfg == "small32":     # the README's small score model (reference README.md:82: --ns 32 --nv 6 --num_conv_layers 5)
+        ns, nv, L, emb = 32, 6, 5, 32
+    else:                      # cfg1 = BASELINE configs[0]
         ns, nv, L, emb = 16, 4, 2, 32
     return dict(sh_lmax=1, ns=ns, nv=nv, num_conv_layers=L, sigma_embed_dim=emb, distance_embed_dim=emb,
                 cross_distance_embed_dim=emb, lig_max_radius=5.0, cross_max_distance=80.0, dynamic_max_cross=True,
@@ -174,19 +180,24 @@ def build_model(cfg, flex, device):
 
 
 def cpu_baseline(args, model, kw, complex_graph):
-    """Reference-equivalent CPU restatement (oracle/) timed as SURVEY section 8(d) asks: cfg2 = two FULL steps of the 40-sample
-    job (first and mid schedule position; the reference's loop feeds the score model `batch_size` = 10 graphs at a time,
-    inference.py / utils/sampling.py:112-120), extrapolated x10 to the 20-step job; cfg1 = the whole 4-sample x 20-step loop,
-    median of 3.  All host cores (count stated)."""
+    """Reference-equivalent CPU restatement (oracle/) on a BOUNDED sample of the same workload, all host cores (count stated).
+    cfg2: forwards of `--cpu-batch` sample graphs at t = 1.0 and t = 0.5 (first and mid schedule position) until each step's
+    share of `--cpu-budget-s` is used or the 40 graphs of the step are done (`--cpu-full`: always all 40: SURVEY section 8(d)'s
+    two full steps, ~10 minutes on the GPU box's host; profiles/r03_cpu_baseline_full.json is such a run); the per-batch times
+    are listed - they are what "linear in the graph count" rests on.  cfg1 (BASELINE configs[0]): the whole 4-sample loop,
+    as many of its 20 steps as the remaining budget allows (three full loops with --cpu-full: median of 3)."""
     import statistics
     import numpy as np
     import torch
     from oracle.ref_model import OracleConfig, OracleScoreModel
     from diffdock_pocket_amd.batch import collate, set_time
+    from diffdock_pocket_amd.diffusion import get_t_schedule
     from diffdock_pocket_amd.sampler import Sampler, SamplerConfig
     from diffdock_pocket_amd.synthetic import make_3dpf_complex
     n, bs = args.cpu_samples, max(1, args.cpu_batch)
-    torch.set_num_threads(args.cpu_threads or (os.cpu_count() or 1))
+    budget = float("inf") if args.cpu_full else float(args.cpu_budget_s)
+    torch.set_num_threads(min(args.cpu_threads or (os.cpu_count() or 1), os.cpu_count() or 1))
+    t_begin = time.perf_counter()
 
     def oracle_for(m, k):
         ocfg = OracleConfig(ns=k["ns"], nv=k["nv"], num_conv_layers=k["num_conv_layers"], sigma_embed_dim=k["sigma_embed_dim"],
@@ -201,39 +212,54 @@ def cpu_baseline(args, model, kw, complex_graph):
         c = complex_graph.clone()
         c["ligand"].pos = c["ligand"].pos + torch.randn(1, 3, generator=g) * 2.0
         gs.append(c)
-    with torch.no_grad():     # warm-up: one small forward (thread pool, allocator)
-        b = collate(gs[:2])
+    with torch.no_grad():     # warm-up: one single-graph forward (thread pool, allocator)
+        b = collate(gs[:1])
         set_time(b, 1.0, 1.0, 1.0, 1.0)
         oracle(b)
-    times = []
-    for t in (1.0, 0.5)[: args.cpu_steps]:
-        t0 = time.perf_counter()
+    steps_t = (1.0, 0.5)[: args.cpu_steps]
+    batches = []
+    for si, t in enumerate(steps_t):
+        share = 0.7 * budget * (si + 1) / len(steps_t)      # 70 % of the budget for cfg2, split over the steps
+        times = []
         for i in range(0, n, bs):
+            t0 = time.perf_counter()
             b = collate(gs[i:i + bs])
             set_time(b, t, t, t, t)
             with torch.no_grad():
                 oracle(b)
-        times.append(time.perf_counter() - t0)
-    s_per_step = float(np.mean(times))
+            times.append((len(gs[i:i + bs]), time.perf_counter() - t0))
+            if time.perf_counter() - t_begin > share:
+                break
+        batches.append(times)
+    per_graph = [sum(x[1] for x in bt) / sum(x[0] for x in bt) for bt in batches]
+    s_per_step = float(np.mean(per_graph)) * n
     out = {"value": n / (s_per_step * 20.0), "unit": "poses/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": f"{len(times)} full denoising step(s) (t = 1.0, 0.5) of {n} sample graphs, {bs} graphs per forward (the reference's "
-                     f"batch_size), through oracle/ref_model.py (fp32 PyTorch-CPU, per-edge weights materialised): "
-                     f"{', '.join(f'{x:.1f}' for x in times)} s per step, extrapolated x{20 // max(len(times), 1)} to the 20-step job",
-           "seconds_per_step": times}
-    # BASELINE configs[0] in full: cfg1, 4 samples x 20 steps, the whole sampling loop on the CPU, median of 3
+           "sample": f"oracle/ref_model.py (fp32 PyTorch-CPU, per-edge weights materialised) on {bs}-graph batches of the workload's {n} "
+                     f"sample graphs at t = {', '.join(str(t) for t in steps_t)}: {', '.join(str(sum(x[0] for x in bt)) for bt in batches)} "
+                     f"graphs timed per step ({', '.join(f'{p:.2f}' for p in per_graph)} s per graph), scaled to {n} graphs x 20 steps",
+           "seconds_per_batch": [[round(x[1], 3) for x in bt] for bt in batches], "graphs_per_batch": bs,
+           "seconds_per_40_sample_step": s_per_step}
+    # BASELINE configs[0]: cfg1, 4 samples x 20 steps, the whole sampling loop on the CPU
     m1, kw1 = build_model("cfg1", True, torch.device("cpu"))
     o1 = oracle_for(m1, kw1)
     g1 = make_3dpf_complex(seed=0, flexible_sidechains=True)
+    sched = get_t_schedule(20)
     runs = []
-    for _ in range(3):
+    for rep in range(3 if args.cpu_full else 1):
         smp = Sampler(lambda bb: o1(bb), g1, 4, torch.device("cpu"), SamplerConfig(inference_steps=20, flexible_sidechains=True), seed=0)
         smp.randomize()
-        t0 = time.perf_counter()
+        t0, done = time.perf_counter(), 0
         with torch.no_grad():
-            smp.run()
-        runs.append(time.perf_counter() - t0)
-    out["configs[0] cfg1 4 samples x 20 steps (whole loop, median of 3)"] = {
-        "value": 4.0 / statistics.median(runs), "unit": "poses/s", "seconds": runs, "cores": torch.get_num_threads()}
+            for i in range(20):
+                smp.step(i, sched)
+                done += 1
+                if time.perf_counter() - t_begin > budget and done >= 2:
+                    break
+        runs.append((time.perf_counter() - t0) * 20.0 / done)
+    out["configs[0] cfg1 4 samples x 20 steps (whole CPU loop)"] = {
+        "value": 4.0 / statistics.median(runs), "unit": "poses/s", "seconds_per_20_step_loop": runs, "cores": torch.get_num_threads(),
+        "note": "median of 3 full loops" if args.cpu_full else "one loop, scaled from the steps that fit the time budget"}
+    out["seconds_spent"] = time.perf_counter() - t_begin
     return out
 
 
@@ -486,24 +512,43 @@ def main(argv=None):
         if world == 1 and default_workload and not args.no_other_workloads:
             # BASELINE configs[2] and configs[0] in the same driver-run line (short runs: 20 and 20 steps)
             others = {}
-            m2, kw2 = build_model("cfg2", True, device)
-            g2 = make_3dpf_complex(seed=0, flexible_sidechains=True)
-            el2, s2, fp2, _, _, _ = timed_job(m2, g2, 40, slice(0, 40), device, True, 20, 3)
-            assert torch.isfinite(fp2).all() and torch.isfinite(s2.atom_pos).all()
-            others["configs[2] 3dpf flexible side chains, 40 samples, cfg2"] = {
-                "value": 40.0 / el2, "unit": "poses/s", "ms_per_step": el2 / 20 * 1e3, "steps": 20, "edges_last_step": dict(m2.last_stats)}
-            del m2, s2
-            m0, kw0 = build_model("cfg1", True, device)
-            el0, s0, fp0, _, _, _ = timed_job(m0, g2, 4, slice(0, 4), device, True, 20, 3)
-            assert torch.isfinite(fp0).all()
-            others["configs[0] 3dpf 4 samples, cfg1 (ns=16 nv=4 L=2), flexible side chains"] = {
-                "value": 4.0 / el0, "unit": "poses/s", "ms_per_step": el0 / 20 * 1e3, "steps": 20, "edges_last_step": dict(m0.last_stats)}
+
+            def conv_fracs(pr):   # per conv kernel: useful fp32-MFMA TFLOP/s of the instrumented pass against the peak
+                out = {}
+                for kname in sorted({k for k in pr.kernel}):
+                    n_, _, ms_ = pr.summary(kname)
+                    tf = pr.useful_flops(kname) / (ms_ * 1e-3) / 1e12
+                    out[kname] = {"launches": n_, "avg_launch_ms": ms_ / n_, "achieved_tflops": tf, "frac": tf / FP32_MFMA_PEAK_TFLOPS}
+                return out
+
+            def sub_job(cfg_, flex_, n_):   # a timed job + its instrumented pass
+                m_, kw_ = build_model(cfg_, flex_, device)
+                g_ = make_3dpf_complex(seed=0, flexible_sidechains=flex_)
+                pr = sm.ConvProfiler()
+
+                def inst(smp_, snap_, sched_):
+                    smp_.restore(snap_)
+                    smp_.graph_enabled = False
+                    sm.set_conv_profiler(pr)
+                    for i in range(20):
+                        smp_.step(i, sched_)
+                    torch.cuda.synchronize()
+                    sm.set_conv_profiler(None)
+                    smp_.graph_enabled = True
+
+                el_, s_, fp_, _, _, _ = timed_job(m_, g_, n_, slice(0, n_), device, flex_, 20, 3, on_timed=inst)
+                assert torch.isfinite(fp_).all() and torch.isfinite(s_.atom_pos).all()
+                return {"value": n_ / el_, "unit": "poses/s", "ms_per_step": el_ / 20 * 1e3, "steps": 20,
+                        "edges_last_step": dict(m_.last_stats), "conv_kernels": conv_fracs(pr)}
+
+            others["configs[2] 3dpf flexible side chains, 40 samples, cfg2"] = sub_job("cfg2", True, 40)
+            others["configs[0] 3dpf 4 samples, cfg1 (ns=16 nv=4 L=2), flexible side chains"] = sub_job("cfg1", True, 4)
+            others["README small score model (ns=32 nv=6 L=5), 40 samples, rigid receptor"] = sub_job("small32", False, 40)
             # BASELINE configs[3]'s shard: 5 of the 40 samples on this GPU (what one of 8 ranks runs under the strong split)
             el5, s5, fp5, _, _, _ = timed_job(model, complex_graph, 40, slice(0, 5), device, False, 20, 3)
             others["configs[3] shard: samples [0, 5) of the 40 on one GPU, cfg2"] = {
                 "value": 5.0 / el5, "unit": "poses/s per GPU", "ms_per_step": el5 / 20 * 1e3, "steps": 20}
             del s5
-            del m0, s0
             line["other_workloads"] = others
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (the other ranks must not wait for it)
             line["cpu_baseline"] = cpu_baseline(args, model, kw, complex_graph)

@@ -859,26 +859,33 @@ __device__ __forceinline__ bool conv_tile(const ConvLaunch& L, int& t, int& p0, 
     nvalid = min(ET, L.task[t].n_edges - p0);
     return true;
   }
-  int total = 0;
-  for (int i = 0; i < L.ntasks; ++i) {
-    const ddp_conv_task_t& T = L.task[i];
-    const int n = T.n_edges_dev ? max(0, min(*T.n_edges_dev, T.n_edges)) : T.n_edges;
-    total += (n + ET - 1) / ET;
+  // all counts first (independent scalar loads, one round trip), then the prefix arithmetic in registers
+  int cnt[DDP_MAX_TASKS];
+#pragma unroll
+  for (int i = 0; i < DDP_MAX_TASKS; ++i) {
+    int n = 0;
+    if (i < L.ntasks) {
+      const ddp_conv_task_t& T = L.task[i];
+      n = T.n_edges_dev ? max(0, min(*T.n_edges_dev, T.n_edges)) : T.n_edges;
+    }
+    cnt[i] = n;
   }
+  int total = 0;
+#pragma unroll
+  for (int i = 0; i < DDP_MAX_TASKS; ++i) total += (cnt[i] + ET - 1) / ET;
   if ((int)blockIdx.x >= total) return false;
   const int tile = xcd_tile(total);
   int base = 0;
   t = 0;
   p0 = 0;
   nvalid = 0;
-  for (int i = 0; i < L.ntasks; ++i) {
-    const ddp_conv_task_t& T = L.task[i];
-    const int n = T.n_edges_dev ? max(0, min(*T.n_edges_dev, T.n_edges)) : T.n_edges;
-    const int nt = (n + ET - 1) / ET;
+#pragma unroll
+  for (int i = 0; i < DDP_MAX_TASKS; ++i) {
+    const int nt = (cnt[i] + ET - 1) / ET;
     if (tile >= base && tile < base + nt) {
       t = i;
       p0 = (tile - base) * ET;
-      nvalid = min(ET, n - p0);
+      nvalid = min(ET, cnt[i] - p0);
     }
     base += nt;
   }

@@ -48,17 +48,25 @@ __device__ __forceinline__ int scan_value(const ddp_scan_job_t& J, int i) {
   return v;
 }
 
+// EPL consecutive items per lane and iteration: the lane's loads are independent (one round trip), its items are summed in
+// registers, the lane totals are scanned with shuffles; a wave walks its segment 64 * EPL items at a time.
+#define DDP_SCAN_EPL 8
 __global__ __launch_bounds__(1024) void ddp_scan_jobs_kernel(const ListLaunch<ddp_scan_job_t> L) {
   __shared__ int seg_total[16];
+  constexpr int EPL = DDP_SCAN_EPL, CH = 64 * EPL;
   const ddp_scan_job_t& J = L.job[blockIdx.x];
   const int n = dev_count(J.n, J.n_dev);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int S = (((n + 15) / 16) + 63) & ~63;      // contiguous segment per wave, a multiple of 64
+  const int S = (((n + 15) / 16) + CH - 1) / CH * CH;      // contiguous segment per wave, a multiple of the chunk
   const int lo = min(wave * S, n), hi = min(lo + S, n);
   int run = 0;
-  for (int base = lo; base < hi; base += 64) {
-    const int i = base + lane;
-    int v = (i < hi) ? scan_value(J, i) : 0;
+  for (int base = lo; base < hi; base += CH) {
+    int v = 0;
+#pragma unroll
+    for (int u = 0; u < EPL; ++u) {
+      const int i = base + lane * EPL + u;
+      v += (i < hi) ? scan_value(J, i) : 0;
+    }
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
     run += v;
@@ -68,20 +76,31 @@ __global__ __launch_bounds__(1024) void ddp_scan_jobs_kernel(const ListLaunch<dd
   int offset = J.base;
   for (int w = 0; w < wave; ++w) offset += seg_total[w];
   run = offset;
-  for (int base = lo; base < hi; base += 64) {
-    const int i = base + lane;
-    const int v = (i < hi) ? scan_value(J, i) : 0;
-    int incl = v;
+  for (int base = lo; base < hi; base += CH) {
+    int val[EPL];
+    int mine = 0;
+#pragma unroll
+    for (int u = 0; u < EPL; ++u) {
+      const int i = base + lane * EPL + u;
+      val[u] = (i < hi) ? scan_value(J, i) : 0;
+      mine += val[u];
+    }
+    int incl = mine;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const int u = __shfl_up(incl, off);
       if (lane >= off) incl += u;
     }
-    const int ex = run + incl - v;
-    if (i < hi) {
-      if (J.excl) J.excl[i] = ex;
-      if (J.excl2) J.excl2[i] = ex;
-      if (J.list && v != 0) J.list[ex] = i;        // (weights are 0 / 1 when a list is asked for)
+    int ex = run + incl - mine;                      // exclusive prefix of the lane's first item
+#pragma unroll
+    for (int u = 0; u < EPL; ++u) {
+      const int i = base + lane * EPL + u;
+      if (i < hi) {
+        if (J.excl) J.excl[i] = ex;
+        if (J.excl2) J.excl2[i] = ex;
+        if (J.list && val[u] != 0) J.list[ex] = i;   // (weights are 0 / 1 when a list is asked for)
+      }
+      ex += val[u];
     }
     run += __shfl(incl, 63);
   }
