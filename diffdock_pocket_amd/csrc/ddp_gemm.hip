@@ -142,9 +142,12 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, DDP_SA_WPE) void ddp_stage_a_mfma
 #pragma unroll
     for (int s2 = 0; s2 < KH; ++s2) wr[t][s2] = W[(size_t)(hh * KH + s2) * ncols + c];
   }
-  const int R0 = (int)blockIdx.y * mrows;
-  const int R1 = min(nrows, R0 + mrows);
   const float* __restrict__ xb = x + offs.off[z];
+  // Row tiles of this workgroup: blockIdx.y, + gridDim.y, ...  Dense products get one tile per workgroup; a ROW LIST (whose grid
+  // is sized for the list's capacity, ~10 x its usual length) is launched with a bounded gridDim.y and walks its tiles, keeping
+  // the weight registers: far fewer workgroups that only find out they have nothing to do
+  for (int R0 = (int)blockIdx.y * mrows; R0 < nrows; R0 += (int)gridDim.y * mrows) {
+  const int R1 = min(nrows, R0 + mrows);
   const bool al4 = ((ldx | offs.off[z]) & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0;
 
   // The 32 x K tile of x rows is fetched ONCE per workgroup with coalesced 16-byte loads (each wave fetching its own A
@@ -272,6 +275,8 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, DDP_SA_WPE) void ddp_stage_a_mfma
       drain_store(p);
     }
   }
+  __syncthreads();   // the next row tile reuses the LDS tiles
+  }
 }
 
 extern "C" int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows,
@@ -294,9 +299,11 @@ extern "C" int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* ro
                      dim3(DDP_GEMM_THREADS), 0, s, x, ldx, nrows, rows, nrows_dev, out_rows, O, w, k, ncols, out, ldo)
   const bool wide = ((ncols | ldo) & 3) == 0 && ncols >= 4 * DDP_GEMM_THREADS && (reinterpret_cast<size_t>(out) & 15) == 0;
 #define DDP_GEMM_MFMA(KT)                                                                                        \
-  hipLaunchKernelGGL((ddp_stage_a_mfma_kernel<KT>), dim3((ncols + 128 * DDP_SA_CT - 1) / (128 * DDP_SA_CT), (nrows + mrows - 1) / mrows, nbatch), \
+  hipLaunchKernelGGL((ddp_stage_a_mfma_kernel<KT>), dim3((ncols + 128 * DDP_SA_CT - 1) / (128 * DDP_SA_CT), gy, nbatch), \
                      dim3(DDP_GEMM_THREADS), 0, s, x, ldx, nrows, rows, nrows_dev, out_rows, mrows, O, w, ncols, out, ldo)
   const int mrows = (nrows >= 8192) ? DDP_GEMM_MROWS : 128;
+  int gy = (nrows + mrows - 1) / mrows;
+  if (rows && nrows_dev && gy > 24) gy = 24;       // a row list with a device-side length: bounded grid, the kernel walks its tiles
   static const bool no_mfma = getenv("DDP_STAGE_A_VALU") != nullptr;   // diagnostic: force the VALU form
   if (ncols >= 512 && !no_mfma && (k == 60 || k == 64 || k == 32 || k == 24 || k == 16)) {
     switch (k) {
