@@ -301,9 +301,12 @@ extern "C" int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* ro
 #define DDP_GEMM_MFMA(KT)                                                                                        \
   hipLaunchKernelGGL((ddp_stage_a_mfma_kernel<KT>), dim3((ncols + 128 * DDP_SA_CT - 1) / (128 * DDP_SA_CT), gy, nbatch), \
                      dim3(DDP_GEMM_THREADS), 0, s, x, ldx, nrows, rows, nrows_dev, out_rows, mrows, O, w, ncols, out, ldo)
-  const int mrows = (nrows >= 8192) ? DDP_GEMM_MROWS : 128;
+  // a row list with a device-side length is usually a small part of its capacity: 128-row tiles (as many workgroups as an
+  // exactly-sized launch of the actual list would get), a bounded grid, the kernel walks its tiles
+  const bool listed = rows && nrows_dev;
+  const int mrows = (nrows >= 8192 && !listed) ? DDP_GEMM_MROWS : 128;
   int gy = (nrows + mrows - 1) / mrows;
-  if (rows && nrows_dev && gy > 24) gy = 24;       // a row list with a device-side length: bounded grid, the kernel walks its tiles
+  if (listed && gy > 96) gy = 96;
   static const bool no_mfma = getenv("DDP_STAGE_A_VALU") != nullptr;   // diagnostic: force the VALU form
   if (ncols >= 512 && !no_mfma && (k == 60 || k == 64 || k == 32 || k == 24 || k == 16)) {
     switch (k) {
