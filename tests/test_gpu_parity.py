@@ -218,6 +218,35 @@ def test_results_do_not_depend_on_list_capacities(name):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("flex", [False, True])
+def test_graph_replay_equals_launch_by_launch(flex):
+    """sampler.Sampler captures its third step in a hipGraph and replays it.  Poses must be bit for bit those of the same job
+    launched kernel by kernel - also when ordinary forwards on the current poses (Sampler.scores: the model's static-graph
+    cache then holds entries for exactly these poses) run between the steps, before and after the capture."""
+    import bench
+    from diffdock_pocket_amd.diffusion import get_t_schedule
+    from diffdock_pocket_amd.sampler import Sampler, SamplerConfig
+    from diffdock_pocket_amd.synthetic import make_3dpf_complex
+    dev = _dev()
+    sched = get_t_schedule(20)
+    g = make_3dpf_complex(seed=0, flexible_sidechains=flex)
+    out = {}
+    for graph in (False, True):
+        model, kw = bench.build_model("cfg2", flex, dev)
+        smp = Sampler(model, g, 6, dev, SamplerConfig(inference_steps=20, flexible_sidechains=flex, hip_graph=graph), seed=0)
+        smp.randomize()
+        poses = []
+        for j, i in enumerate((0, 1, 2, 10, 11, 12)):
+            if j != 4:
+                smp.scores(float(sched[i]))
+            smp.step(i, sched)
+            poses.append((smp.lig_pos.clone(), smp.atom_pos.clone()))
+        assert bool(smp._graph) == graph
+        out[graph] = poses
+    for (l0, a0), (l1, a1) in zip(out[False], out[True]):
+        assert torch.equal(l0, l1) and torch.equal(a0, a1)
+
+
 def test_a_truncated_ligand_atom_edge_list_is_reported():
     """The ligand<-atom edge list has a capacity per ligand atom (model.la_capacity_per_atom) instead of its worst case.  A
     search that finds more pairs drops them AND raises a flag in pinned host memory: the next forward refuses to go on."""
@@ -410,6 +439,74 @@ def test_stage_a_gemm(k, ncols, nrows, ldx, offs):
     for b in range(nb):
         want = x[:, offs[b]:offs[b] + k].double() @ w[b].double()
         assert float((got[b] - want).abs().max()) < 2e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("n_list,cap", [(37, 300), (300, 300), (0, 64), (9000, 20000)])
+def test_stage_a_row_list_with_a_device_side_length(n_list, cap):
+    """ddp_stage_a on a ROW LIST whose length lives in device memory: exactly the listed rows of out are written (in place, at
+    their own row index), bit for bit what the dense product gives for them; the rest of out is untouched."""
+    import ctypes as C
+    from diffdock_pocket_amd import _lib as L
+    from diffdock_pocket_amd.score_model import _stream
+    torch.manual_seed(n_list + cap)
+    dev = _dev()
+    lib = L.load()
+    k, ncols, nrows, ldx = 60, 12600, max(cap, 1), 180
+    nb, offs = 2, (120, 0)
+    ldo = (ncols + 31) // 32 * 32
+    x, w = torch.randn(nrows, ldx, device=dev), torch.randn(nb, k, ncols, device=dev)
+    dense = torch.zeros((nb, nrows, ldo), device=dev)
+    offs_c = (C.c_int32 * nb)(*offs)
+    L.check(lib.ddp_stage_a(x.data_ptr(), ldx, nrows, None, None, nrows, offs_c, nb, w.data_ptr(), k, ncols, dense.data_ptr(), ldo,
+                            _stream()), "ddp_stage_a")
+    rows = torch.randperm(nrows, device=dev)[:cap].to(torch.int32).sort().values.contiguous()
+    n_dev = torch.tensor([n_list], dtype=torch.int32, device=dev)
+    out = torch.full((nb, nrows, ldo), -7.0, device=dev)
+    L.check(lib.ddp_stage_a(x.data_ptr(), ldx, cap, rows.data_ptr(), n_dev.data_ptr(), nrows, offs_c, nb, w.data_ptr(), k, ncols,
+                            out.data_ptr(), ldo, _stream()), "ddp_stage_a")
+    torch.cuda.synchronize()
+    listed = rows[:n_list].long()
+    mask = torch.zeros(nrows, dtype=torch.bool, device=dev)
+    mask[listed] = True
+    assert torch.equal(out[:, mask, :ncols], dense[:, mask, :ncols])
+    assert bool((out[:, ~mask] == -7.0).all()) and bool((out[:, :, ncols:] == -7.0).all())
+
+
+def test_sde_update_and_replicated_reduce():
+    """ddp_sde_update against the PyTorch expression `a * score + b * z` (separate roundings) and ddp_segment_reduce's
+    replicated add (n_rep) against reduce-then-add."""
+    import ctypes as C
+    from diffdock_pocket_amd import _lib as L
+    from diffdock_pocket_amd import graph as G
+    from diffdock_pocket_amd import launch as K
+    from diffdock_pocket_amd.score_model import _stream
+    torch.manual_seed(0)
+    dev = _dev()
+    lib = L.load()
+    coef = torch.randn(8, device=dev)
+    shapes = [(40, 3), (40, 3), (40, 7), (40, 18)]
+    sc = [torch.randn(sh, device=dev) for sh in shapes]
+    zz = [torch.randn(sh, device=dev) for sh in shapes]
+    out = [torch.empty(sh, device=dev) for sh in shapes]
+    a = L.SdeArgs()
+    for k in range(4):
+        a.score[k], a.z[k], a.out[k], a.n[k] = sc[k].data_ptr(), zz[k].data_ptr(), out[k].data_ptr(), sc[k].numel()
+    L.check(lib.ddp_sde_update(coef.data_ptr(), C.byref(a), _stream()), "ddp_sde_update")
+    for k in range(4):
+        assert torch.equal(out[k], float(coef[2 * k]) * sc[k] + float(coef[2 * k + 1]) * zz[k])
+    # replicated reduce: the update of n0 nodes (computed from 0) added to the rows of B graphs
+    B, n0, d, E = 5, 30, 36, 400
+    recv = torch.sort(torch.randint(0, n0, (E,))).values
+    csr = G.build_csr(recv.to(dev), torch.zeros(E, dtype=torch.long, device=dev), n0, presorted=True)
+    msg = torch.randn(E, d, device=dev)
+    pk = type("PK", (), {"bn_scale": torch.rand(d, device=dev) + 0.5, "bn_shift": torch.randn(d, device=dev)})()
+    x = torch.randn(B * n0, 40, device=dev)
+    want = x.clone()
+    u0 = torch.zeros(n0, d, device=dev)
+    K.launch_reduce(u0, d, n0, d, [(msg, csr, pk)], accumulate=False)
+    want.view(B, n0, 40)[:, :, :d].add_(u0)
+    K.launch_reduce(x, 40, n0, d, [(msg, csr, pk)], accumulate=True, n_rep=B, rep_stride=n0)
+    assert torch.equal(x, want)
 
 
 def test_static_graph_cache_is_invalidated_by_in_place_updates():
