@@ -19,7 +19,7 @@ FS = 68  # feature-buffer row stride of ddp_conv.hip
 DDP_MAX_GEMM_BATCH = 16
 EXPORTS = ["ddp_conv_messages", "ddp_segment_reduce", "ddp_edge_featurize", "ddp_torsion_sh", "ddp_stage_a",
            "ddp_pose_update", "ddp_sidechain_update", "ddp_sde_update", "ddp_radius_count", "ddp_radius_fill", "ddp_knn", "ddp_group_by_key", "ddp_node_linear", "ddp_scan_jobs", "ddp_mark_jobs", "ddp_rowcopy_jobs", "ddp_select_jobs",
-           "ddp_gather_rows", "ddp_clean_pair_maps", "ddp_radius_search_jobs", "ddp_group_by_key_jobs", "ddp_abi_version", "ddp_last_error", "ddp_source_hash"]
+           "ddp_gather_rows", "ddp_clean_pair_maps", "ddp_step_prologue", "ddp_trrot_head", "ddp_tor_head", "ddp_radius_search_jobs", "ddp_group_by_key_jobs", "ddp_abi_version", "ddp_last_error", "ddp_source_hash"]
 
 
 class Seg(C.Structure):
@@ -99,6 +99,35 @@ class GroupJob(C.Structure):
 
 
 
+class _BondJob(C.Structure):
+    _fields_ = [("pos", _P), ("b0", _P), ("b1", _P), ("n", _I), ("mid", _P), ("vec", _P)]
+
+
+class _CopyJob(C.Structure):
+    _fields_ = [("src", _P), ("dst", _P), ("n", _I)]
+
+
+class PrologueArgs(C.Structure):
+    """ddp_prologue_args_t of include/ddp_hip.h."""
+    _fields_ = [("t", _P * 4), ("t_stride", _I * 4), ("sig_min", C.c_float * 4), ("sig_max", C.c_float * 4), ("sigma", _P * 4),
+                ("n_graphs", _I), ("cut", _P), ("cut_mul", C.c_float), ("cut_add", C.c_float), ("graph_emb", _P), ("sd", _I),
+                ("emb_scale", C.c_float), ("freq", _P), ("lig_pos", _P), ("graph_ptr", _P), ("center", _P),
+                ("bonds", _BondJob * 2), ("copy", _CopyJob * 2)]
+
+
+class TrRotArgs(C.Structure):
+    """ddp_trrot_args_t of include/ddp_hip.h."""
+    _fields_ = [("gp", _P), ("ld_gp", _I), ("n_graphs", _I), ("ns", _I), ("sd", _I), ("graph_emb", _P), ("w1", _P * 2), ("b1", _P * 2),
+                ("w2", _P * 2), ("b2", _P * 2), ("sigma", _P * 2), ("so3_table", _P), ("so3_n", _I), ("so3_lo", C.c_float),
+                ("so3_span", C.c_float), ("out", _P * 2)]
+
+
+class TorArgs(C.Structure):
+    """ddp_tor_args_t of include/ddp_hip.h."""
+    _fields_ = [("h", _P), ("ld_h", _I), ("n_bonds", _I), ("ns", _I), ("w1", _P), ("w2", _P), ("sigma", _P), ("graph_of_bond", _P),
+                ("torus_table", _P), ("torus_n", _I), ("torus_lo", C.c_float), ("torus_span", C.c_float), ("out", _P)]
+
+
 class NodeJob(C.Structure):
     """ddp_node_job_t of include/ddp_hip.h."""
     _fields_ = [("n_rows", C.c_int32), ("cat", C.c_void_p), ("ld_cat", C.c_int32), ("n_cat", C.c_int32), ("table", C.c_void_p),
@@ -145,7 +174,8 @@ def load():
                                        C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ddp_edge_featurize.restype = C.c_int
-    lib.ddp_torsion_sh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ddp_torsion_sh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.ddp_torsion_sh.restype = C.c_int
     lib.ddp_stage_a.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_int,
                                 C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
@@ -177,9 +207,12 @@ def load():
     lib.ddp_clean_pair_maps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_void_p]
     lib.ddp_clean_pair_maps.restype = C.c_int
+    for name, st in (("ddp_step_prologue", PrologueArgs), ("ddp_trrot_head", TrRotArgs), ("ddp_tor_head", TorArgs)):
+        getattr(lib, name).argtypes = [C.POINTER(st), C.c_void_p]
+        getattr(lib, name).restype = C.c_int
     lib.ddp_node_linear.argtypes = [C.POINTER(NodeJob), C.c_int, C.c_void_p]
     lib.ddp_node_linear.restype = C.c_int
-    if lib.ddp_abi_version() != 7:
+    if lib.ddp_abi_version() != 8:
         raise DdpError("libddp_hip.so ABI version mismatch")
     lib.ddp_source_hash.restype = C.c_char_p
     if "DDP_HIP_LIB" not in os.environ:   # (diagnostic builds loaded through DDP_HIP_LIB carry extra -D flags, same sources)

@@ -30,11 +30,12 @@ __global__ __launch_bounds__(DDP_HEAD_THREADS) void ddp_step_prologue_kernel(Pro
     float s0 = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (!A.t[k] || !A.sigma[k]) continue;
-      const float t = A.t[k][(size_t)g * A.t_stride[k]];
-      const float s = powf(A.sig_min[k], 1.0f - t) * powf(A.sig_max[k], t);   // sigma_min^(1-t) * sigma_max^t
-      A.sigma[k][g] = s;
-      if (k == 0) s0 = s;
+      if (!A.sigma[k]) continue;
+      if (A.t[k] && A.sig_max[k] > 0.f) {   // (sig_max <= 0: sigma[k] is an INPUT - the caller's own t_to_sigma made it)
+        const float t = A.t[k][(size_t)g * A.t_stride[k]];
+        A.sigma[k][g] = powf(A.sig_min[k], 1.0f - t) * powf(A.sig_max[k], t);   // sigma_min^(1-t) * sigma_max^t
+      }
+      if (k == 0) s0 = A.sigma[0][g];
     }
     if (A.cut) A.cut[g] = s0 * A.cut_mul + A.cut_add;
     if (A.graph_emb) {   // [sin(scale t w) | cos(scale t w) | 0]  (utils/diffusion_utils.py:73-84), t = the tr time
@@ -95,7 +96,7 @@ extern "C" int ddp_step_prologue(const ddp_prologue_args_t* args, void* stream) 
   if (!args) return ddp_fail(DDP_EINVAL, "ddp_step_prologue: null argument");
   const ddp_prologue_args_t& A = *args;
   if (A.n_graphs < 0) return ddp_fail(DDP_EINVAL, "ddp_step_prologue: n_graphs");
-  if (A.cut && !(A.t[0] && A.sigma[0])) return ddp_fail(DDP_EINVAL, "ddp_step_prologue: cut needs the tr sigma");
+  if (A.cut && !A.sigma[0]) return ddp_fail(DDP_EINVAL, "ddp_step_prologue: cut needs the tr sigma");
   if (A.graph_emb && (!A.t[0] || !A.freq || A.sd < 2)) return ddp_fail(DDP_EINVAL, "ddp_step_prologue: graph_emb");
   if (A.center && (!A.lig_pos || !A.graph_ptr)) return ddp_fail(DDP_EINVAL, "ddp_step_prologue: center");
   PrologueLaunch L;
@@ -157,9 +158,7 @@ __global__ __launch_bounds__(DDP_HEAD_THREADS) void ddp_trrot_head_kernel(ddp_tr
     float scale = 1.0f;
     if (A.sigma[h]) {
       const float s = A.sigma[h][g];
-      if (h == 0) {
-        scale = __fdiv_rn(1.0f, s);
-      } else {   // so3.score_norm (utils/so3.py:85-89): table over log10(sigma), fp32 index arithmetic
+      if (h == 1) {   // so3.score_norm (utils/so3.py:85-89): table over log10(sigma), fp32 index arithmetic
         float idx = __fdiv_rn(log10f(s) - A.so3_lo, A.so3_span) * (float)A.so3_n;
         int i = (int)rintf(idx);
         i = min(max(i, 0), A.so3_n - 1);
@@ -167,7 +166,8 @@ __global__ __launch_bounds__(DDP_HEAD_THREADS) void ddp_trrot_head_kernel(ddp_tr
       }
     }
     if (j < 3) {
-      float o = __fdiv_rn(v[h][j], norm) * mlp;
+      const float vj = j == 0 ? v[h][0] : (j == 1 ? v[h][1] : v[h][2]);
+      float o = __fdiv_rn(vj, norm) * mlp;
       if (A.sigma[h]) o = (h == 0) ? __fdiv_rn(o, A.sigma[h][g]) : o * scale;
       A.out[h][3 * (size_t)g + j] = o;
     }

@@ -341,7 +341,16 @@ extern "C" int ddp_edge_featurize(const float* pos_a, const int32_t* ia, const f
 // (sh(edge), Y2(bond)) (reference models/all_atom_score_model.py:394-395,418-419).
 __global__ void ddp_torsion_sh_kernel(const float* __restrict__ sh_edge, const float* __restrict__ bond_vec,
                                       const int* __restrict__ bond_of_edge, int n_edges, const int* __restrict__ n_edges_dev,
-                                      float* __restrict__ out) {
+                                      float* __restrict__ out, int edge_blocks, const float* __restrict__ x, int ldx, int ns,
+                                      const int* __restrict__ b0, const int* __restrict__ b1, int n_bonds,
+                                      float* __restrict__ bond_attr) {
+  if ((int)blockIdx.x >= edge_blocks) {   // bond_attr = x[b0, :ns] + x[b1, :ns]
+    const int i = (blockIdx.x - edge_blocks) * blockDim.x + threadIdx.x;
+    if (i >= n_bonds * ns) return;
+    const int b = i / ns, c = i - b * ns;
+    bond_attr[i] = x[(size_t)b0[b] * ldx + c] + x[(size_t)b1[b] * ldx + c];
+    return;
+  }
   if (n_edges_dev) n_edges = min(n_edges, *n_edges_dev);
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_edges) return;
@@ -358,11 +367,19 @@ __global__ void ddp_torsion_sh_kernel(const float* __restrict__ sh_edge, const f
 }
 
 extern "C" int ddp_torsion_sh(const float* sh_edge, const float* bond_vec, const int32_t* bond_of_edge, int n_edges,
-                              const int32_t* n_edges_dev, float* out, void* stream) {
-  if (n_edges <= 0) return 0;
-  if (!sh_edge || !bond_vec || !bond_of_edge || !out) return ddp_fail(DDP_EINVAL, "ddp_torsion_sh: null argument");
-  hipLaunchKernelGGL(ddp_torsion_sh_kernel, dim3((n_edges + 255) / 256), dim3(256), 0, (hipStream_t)stream, sh_edge,
-                     bond_vec, bond_of_edge, n_edges, n_edges_dev, out);
+                              const int32_t* n_edges_dev, float* out, const float* x, int ldx, int ns, const int32_t* b0,
+                              const int32_t* b1, int n_bonds, float* bond_attr, void* stream) {
+  if (n_edges < 0) n_edges = 0;
+  if (n_edges > 0 && (!sh_edge || !bond_vec || !bond_of_edge || !out)) return ddp_fail(DDP_EINVAL, "ddp_torsion_sh: null argument");
+  int attr = 0;
+  if (bond_attr && n_bonds > 0) {
+    if (!x || !b0 || !b1 || ns < 1 || ldx < ns) return ddp_fail(DDP_EINVAL, "ddp_torsion_sh: bond_attr arguments");
+    attr = n_bonds * ns;
+  }
+  const int eb = (n_edges + 255) / 256, ab = (attr + 255) / 256;
+  if (eb + ab == 0) return 0;
+  hipLaunchKernelGGL(ddp_torsion_sh_kernel, dim3(eb + ab), dim3(256), 0, (hipStream_t)stream, sh_edge, bond_vec, bond_of_edge,
+                     n_edges, n_edges_dev, out, eb, x, ldx, ns, b0, b1, n_bonds, bond_attr);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return ddp_fail_hip(err, "ddp_torsion_sh launch");
   return 0;

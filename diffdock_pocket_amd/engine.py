@@ -186,7 +186,8 @@ class ForwardEngine:
                     bnd = bond_ei[:, idx].long()
                     bb = lbatch[bnd[0]]
                     lay = G.DenseLayout.build(bb, B) if idx.shape[0] > 0 else None
-                    return SimpleNamespace(idx=idx, bonds=bnd, batch=bb, lay=lay, T=int(idx.shape[0]))
+                    return SimpleNamespace(idx=idx, bonds=bnd, batch=bb, lay=lay, T=int(idx.shape[0]), flat32=_i32(bnd.reshape(-1)),
+                                           batch32=_i32(bb))
                 tor = m._cached("tor_static", (lig.edge_mask, bond_ei, lig.batch), tor_static)
                 if tor.T > 0:
                     G._ptr(tor.lay)
@@ -199,7 +200,7 @@ class ForwardEngine:
                     sb = fr.batch.long()
                     bonds = S.lay_a.starts[sb] + fr.edge_idx.t().long()     # get_sc_tor_bonds (:638-652)
                     return SimpleNamespace(bonds=bonds, batch=sb, lay=G.DenseLayout.build(sb, B), T=int(sb.shape[0]),
-                                           flat32=_i32(bonds.reshape(-1)))
+                                           flat32=_i32(bonds.reshape(-1)), batch32=_i32(sb))
                 sc = m._cached("sc_static", (fr.batch, fr.edge_idx, atom.batch), sc_static)
                 G._ptr(sc.lay)
                 sc.cap = sum(t * min(n, 32) for t, n in zip(sc.lay.counts_host, na))
@@ -218,21 +219,75 @@ class ForwardEngine:
         t_nodes = torch.cat([t.reshape(-1) for t in ts])
         return bool((t_nodes == t_nodes[0]).all().item()) if t_nodes.numel() else True
 
+    # ================================================================================================ prologue
+    def _prologue(self, data, S, F, lig, dev, ll0, ll1):
+        """Everything that depends on the times and the poses only, in ONE launch (ddp_step_prologue): t -> sigma (:244-245),
+        the dynamic cross cutoff (:548-550), the graphs' sigma embedding (:371) and ligand centres (:571-576), the bond
+        centres / directions of the torsion heads (:589-592,613-616,392,416), the bond rows of the ligand edge list (:462-468)."""
+        m = self.m
+        B = S.B
+        a = L.PrologueArgs()
+        ts = [data.complex_t[k] for k in ("tr", "rot", "tor", "sc_tor")]
+        ts = [t if t.dtype == torch.float32 else t.float() for t in ts]
+        keep = [ts]
+        a.n_graphs = B
+        for k, t in enumerate(ts):
+            a.t[k], a.t_stride[k] = K._p(t), (t.stride(0) if t.numel() > 1 else 0)
+        rng = None if m.confidence_mode else m._sigma_ranges()
+        if m.confidence_mode:       # (:245) the times are used as they are
+            F.sig = [t.expand(B).contiguous() for t in ts]
+        elif rng is None:           # a foreign t_to_sigma: called as the reference calls it
+            F.sig = [s.float().expand(B).contiguous() for s in m.t_to_sigma(*ts)]
+        else:
+            sig = torch.empty((4, B), device=dev)
+            F.sig = [sig[k] for k in range(4)]
+            for k in range(4):
+                a.sig_min[k], a.sig_max[k] = rng[k]
+        for k in range(4):
+            a.sigma[k] = K._p(F.sig[k])
+        F.cut = None
+        if m.dynamic_max_cross:
+            F.cut = torch.empty(B, device=dev)
+            a.cut, a.cut_mul, a.cut_add = K._p(F.cut), 3.0, 20.0
+        F.center = F.graph_emb = None
+        if not m.confidence_mode:
+            spec = m._sigma_spec(ts[0], dev)
+            if spec[0] == "t":
+                F.graph_emb = torch.empty((B, spec[4]), device=dev)
+                a.graph_emb, a.sd, a.emb_scale, a.freq = K._p(F.graph_emb), spec[4], spec[2], K._p(spec[3])
+            else:
+                F.graph_emb = spec[1]
+            keep.append(spec)
+            F.center = torch.empty((B, 3), device=dev)
+            a.lig_pos, a.graph_ptr, a.center = K._p(F.lpos), K._p(S.lay_l._ptr32), K._p(F.center)
+        F.tor = F.sc = None
+        for i, (name, st, pos) in enumerate((("tor", S.tor, F.lpos), ("sc", S.sc, F.apos))):
+            if st is None:
+                continue
+            h = SimpleNamespace(st=st, bond_pos=torch.empty((st.T, 3), device=dev), bond_vec=torch.empty((st.T, 3), device=dev))
+            b = a.bonds[i]
+            b.pos, b.b0, b.b1, b.n = K._p(pos), K._p(st.flat32[:st.T]), K._p(st.flat32[st.T:]), st.T
+            b.mid, b.vec = K._p(h.bond_pos), K._p(h.bond_vec)
+            setattr(F, name, h)
+        for i, (src, dst) in enumerate(((S.bond32[0], ll0), (S.bond32[1], ll1))):
+            a.copy[i].src, a.copy[i].dst, a.copy[i].n = K._p(src), K._p(dst), S.E_bond
+        L.check(L.load().ddp_step_prologue(C.byref(a), K.stream()), "ddp_step_prologue")
+        F.keep_pro = (keep, a)
+
     # ================================================================================================ front
     def _front(self, data, S, lig, rec, atom, dev, mark):
         m = self.m
         ns, B = m.ns, S.B
         F = SimpleNamespace()
         cnt = F.cnt = K.CountBlock(dev)
-        if m.confidence_mode:   # (:245) the times are used as they are
-            F.sig = [data.complex_t[k] for k in ("tr", "rot", "tor", "sc_tor")]
-        else:
-            F.sig = m.t_to_sigma(*[data.complex_t[k] for k in ("tr", "rot", "tor", "sc_tor")])
         lpos, rpos, apos = lig.pos.float().contiguous(), rec.pos.float().contiguous(), atom.pos.float().contiguous()
         F.lpos, F.rpos, F.apos = lpos, rpos, apos
         Nl, Nr, Na = S.Nl, S.Nr, S.Na
         lay_l, lay_r, lay_a = S.lay_l, S.lay_r, S.lay_a
         i32e = lambda n: torch.empty(n, dtype=torch.int32, device=dev)      # noqa: E731
+        Eb = S.E_bond
+        ll0, ll1 = i32e(S.cap_ll), i32e(S.cap_ll)     # ligand edges = bonds (first) + radius graph (:462-468)
+        self._prologue(data, S, F, lig, dev, ll0, ll1)
 
         # node encoders, sigma embeddings and the per-node part of the edge-embedding MLPs' first Linear: one HIP launch
         F.xl, F.xr, F.xa, pre = m._node_tables(lig, rec, atom, dev)
@@ -258,16 +313,12 @@ class ForwardEngine:
         data["atom", "atom"].edge_index = aa
         F.aa = aa
         S.stats["E_aa"] = int(aa.shape[1])
-        Eb = S.E_bond
-        ll0, ll1 = i32e(S.cap_ll), i32e(S.cap_ll)     # ligand edges = bonds (first) + radius graph (:462-468)
-        ll0[:Eb].copy_(S.bond32[0])
-        ll1[:Eb].copy_(S.bond32[1])
         lr0, lr1, la0, la1 = i32e(S.cap_lr), i32e(S.cap_lr), i32e(S.cap_la), i32e(S.cap_la)
         jobs = [K.radius_job(lpos, ptr_l, lpos, b32_l, m.lig_max_radius, 33, _DROP_SELF, i32e(Nl), i32e(Nl + 1), base=Eb,
                              total=cnt["ll"], out_query=ll1, out_x=ll0, capacity=S.cap_ll)]
         cut = None
         if m.dynamic_max_cross:     # (:548-556) both point sets divided by 3 sigma_tr + 20, searched with r = 1
-            cut = (F.sig[0] * 3 + 20).float().contiguous()
+            cut = F.cut
             jobs.append(K.radius_job(rpos, ptr_r, lpos, b32_l, 1.0, 10000, 0, i32e(Nl), i32e(Nl + 1), total=cnt["lr"],
                                      out_query=lr0, out_x=lr1, capacity=S.cap_lr, graph_div=cut))
         else:
@@ -279,13 +330,11 @@ class ForwardEngine:
         # atom<-ligand message reaches ("touched"): the same search with the roles swapped, count pass only
         F.touched = i32e(Na)
         jobs.append(K.radius_job(lpos, ptr_l, apos, b32_a, m.lig_max_radius, 10000, 0, F.touched))
-        F.tor = F.sc = None
         for name, st, pos, ptr_x in (("tor", S.tor, lpos, ptr_l), ("sc", S.sc, apos, ptr_a)):
             if st is None:
                 continue
             # build_bond_conv_graph / build_sidechain_conv_graph (:586-636): atoms around the bond centres, default cap 32
-            h = SimpleNamespace(st=st)
-            h.bond_pos = ((pos[st.bonds[0]] + pos[st.bonds[1]]) / 2).contiguous()
+            h = getattr(F, name)      # (bond centres and directions: ddp_step_prologue)
             h.q, h.x = i32e(st.cap), i32e(st.cap)
             jobs.append(K.radius_job(pos, ptr_x, h.bond_pos, G._batch32(st.lay, st.T), m.lig_max_radius, 32, 0, i32e(st.T),
                                      i32e(st.T + 1), total=cnt[name], out_query=h.q, out_x=h.x, capacity=st.cap))
@@ -399,7 +448,15 @@ class ForwardEngine:
         Nl, Nr, Na = S.Nl, S.Nr, S.Na
         cnt, c, so = F.cnt, F.c, F.so
         i32e = lambda n: torch.empty(n, dtype=torch.int32, device=dev)      # noqa: E731
-        i32z = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)      # noqa: E731
+        # (every zero-initialised mask of this function is a slice of ONE zero-filled block: one launch)
+        zpool = [torch.zeros(4 * (Na + Nr) + Na + 64, dtype=torch.int32, device=dev), 0]
+
+        def i32z(n):
+            if zpool[1] + n > zpool[0].numel():
+                return torch.zeros(n, dtype=torch.int32, device=dev)
+            v = zpool[0][zpool[1]:zpool[1] + n]
+            zpool[1] += (n + 3) & ~3
+            return v
         F.pruned, F.pruned_so, F.rows_a = {}, {}, {}
         F.clean1 = None
         n_of = {"l": Nl, "a": Na, "r": Nr}
@@ -752,12 +809,13 @@ class ForwardEngine:
             return m.confidence_predictor(conf_in).squeeze(dim=-1)
 
         dd = m.distance_embed_dim
-        # ---- translation / rotation head (:357-384): ligand atoms -> their graph's centre
+        lib = L.load()
+        # ---- translation / rotation head (:357-384): ligand atoms -> their graph's centre (ddp_step_prologue: summed in index
+        # order - index_add_'s float atomics land in an order that depends on what else the device is doing, and one ulp in
+        # the centre is one ulp in tr / rot)
         ar_l = G.iota32(Nl, dev)
         b32_l = G._batch32(lay_l, Nl)
-        # (a dense sum, not index_add_: float atomics land in an order that depends on what else the device is doing, and
-        # one ulp in the centre is one ulp in tr / rot - seen as run-to-run differences at the full size)
-        center = (lay_l.dense(lpos, 0.0).sum(1) / lay_l.counts.unsqueeze(1)).contiguous()
+        center = F.center
         pk = m._edge_pack("center_edge_embedding", slice(0, dd), dev)
         e_c, sh_c = K.edge_featurize(pk, m.center_distance_expansion, center, b32_l, lpos, ar_l, F.pre["center"], ar_l)
         c_c = m._cached("c_c", (lig.batch,), lambda: G.build_csr(b32_l, ar_l, B, presorted=True))
@@ -766,64 +824,73 @@ class ForwardEngine:
         msg = torch.empty((Nl, fspec.d_out), device=dev)
         seg_idx = c_c.src if m.fixed_center_conv else c_c.recv
         K.launch_convs(fspec, [K.make_task(pkc, xl, ldx, c_c, sh_c, [(e_c, c_c.eid, ns, ns), (xl, seg_idx, ldx, ns)], msg)])
-        gp = torch.zeros((B, fspec.d_out), device=dev)
+        gp = torch.empty((B, fspec.d_out), device=dev)      # (every row is written: accumulate = False)
         K.launch_reduce(gp, fspec.d_out, B, fspec.d_out, [(msg, c_c, pkc)], accumulate=False)
         if m.debug_conv_outputs is not None:
             m.debug_conv_outputs["final_conv"] = gp
-        tr_pred = gp[:, :3] + gp[:, 6:9]
-        rot_pred = gp[:, 3:6] + gp[:, 9:]
-        data.graph_sigma_emb = m.timestep_emb_func(data.complex_t["tr"])
-        tr_norm = torch.linalg.vector_norm(tr_pred, dim=1).unsqueeze(1)
-        tr_pred = tr_pred / tr_norm * m.tr_final_layer(torch.cat([tr_norm, data.graph_sigma_emb], dim=1))
-        rot_norm = torch.linalg.vector_norm(rot_pred, dim=1).unsqueeze(1)
-        rot_pred = rot_pred / rot_norm * m.rot_final_layer(torch.cat([rot_norm, data.graph_sigma_emb], dim=1))
+        data.graph_sigma_emb = F.graph_emb
+        # read-out MLPs on [|v|, sigma embedding], score norms (:362-384): one launch
+        a = L.TrRotArgs()
+        a.gp, a.ld_gp, a.n_graphs, a.ns, a.sd, a.graph_emb = K._p(gp), fspec.d_out, B, ns, F.graph_emb.shape[1], K._p(F.graph_emb)
+        tr_pred, rot_pred = torch.empty((B, 3), device=dev), torch.empty((B, 3), device=dev)
+        hw = m._head_weights(dev)
+        for i, name in enumerate(("tr_final_layer", "rot_final_layer")):
+            a.w1[i], a.b1[i], a.w2[i], a.b2[i] = (K._p(t) for t in hw[name])
+        a.out[0], a.out[1] = K._p(tr_pred), K._p(rot_pred)
         if m.scale_by_sigma:
-            tr_pred = tr_pred / tr_sigma.unsqueeze(1)
-            rot_pred = rot_pred * m._so3_score_norm(rot_sigma).unsqueeze(1)
+            a.sigma[0], a.sigma[1] = K._p(tr_sigma), K._p(rot_sigma)
+            a.so3_table, a.so3_n = K._p(hw["so3"]), hw["so3"].shape[0]
+            a.so3_lo, a.so3_span = hw["so3_lo"], hw["so3_span"]
+        L.check(lib.ddp_trrot_head(C.byref(a), K.stream()), "ddp_trrot_head")
         mark("center_head")
         # ---- torsion heads (:386-434)
         tor_pred = torch.empty(0, device=dev)
         if F.tor is not None:
-            tor_pred = self._torsion_head(F.tor, "final_edge_embedding", m.tor_bond_conv, m.tor_final_layer, xl, lpos, dev, "tor_bond_conv")
-            if m.scale_by_sigma:
-                edge_sigma = tor_sigma[lbatch][S.bond_ei[0].long()][S.tor.idx]
-                tor_pred = tor_pred * torch.sqrt(m._torus_score_norm(edge_sigma))
+            tor_pred = self._torsion_head(F.tor, "final_edge_embedding", m.tor_bond_conv, "tor_final_layer", xl, lpos, dev, "tor_bond_conv",
+                                          tor_sigma)
         sc_pred = torch.empty(0, device=dev)
         if F.sc is not None:
-            sc_pred = self._torsion_head(F.sc, "sidechain_final_edge_embedding", m.sc_tor_bond_conv, m.sc_tor_final_layer, xa, F.apos,
-                                         dev, "sc_tor_bond_conv")
-            if m.scale_by_sigma:
-                sc_pred = sc_pred * torch.sqrt(m._torus_score_norm(sc_sigma[data["flexResidues"].batch.long()]))
+            sc_pred = self._torsion_head(F.sc, "sidechain_final_edge_embedding", m.sc_tor_bond_conv, "sc_tor_final_layer", xa, F.apos,
+                                         dev, "sc_tor_bond_conv", sc_sigma)
         mark("tor_heads")
-        F.keep.append((center, e_c, sh_c, msg, gp))
+        F.keep.append((center, e_c, sh_c, msg, gp, a, hw))
         return tr_pred, rot_pred, tor_pred, sc_pred
 
-    def _torsion_head(self, h, mlp_name, conv, final_layer, x, pos, dev, name):
+    def _torsion_head(self, h, mlp_name, conv, final_name, x, pos, dev, name, sigma):
         """build_bond_conv_graph / build_sidechain_conv_graph (:586-636) on the searched bond-centre graph + FullTensorProduct
-        + tor_bond_conv + final layer (:386-434).  An empty graph gives zero scores (the reference fails there)."""
+        + tor_bond_conv + final layer + torus score norm (:386-434).  An empty graph gives zero scores (the reference fails
+        there).  Launches: edge embedding, edge harmonics + bond attributes, conv, segmented mean, read-out."""
         m = self.m
         lib = L.load()
         ns, ldx = m.ns, m._ldx
         st, csr = h.st, h.csr
-        E, T, bonds = csr.n_edges, st.T, st.bonds
+        E, T = csr.n_edges, st.T
         pk = m._edge_pack(mlp_name, slice(0, m.distance_embed_dim), dev)
         pre = pk.b1.reshape(1, -1).contiguous()
         zero_idx = m._cached("zeros_" + name, (st.bonds,), lambda: torch.zeros(st.cap, device=dev, dtype=torch.int32))
         e_t, sh_e = K.edge_featurize(pk, m.lig_distance_expansion, h.bond_pos, csr.recv, pos, csr.src, pre, zero_idx[:E], n_edges=E, cnt=csr.cnt)
-        bond_vec = (pos[bonds[1]] - pos[bonds[0]]).contiguous()
         tor_sh = torch.empty((E, 4), device=dev)
-        if E > 0:
-            L.check(lib.ddp_torsion_sh(K.ptr(sh_e), K.ptr(bond_vec), K.ptr(csr.recv), E, K.ptr(csr.cnt), K.ptr(tor_sh), K.stream()),
-                    "ddp_torsion_sh")
-        bond_attr = (x[bonds[0], :ns] + x[bonds[1], :ns]).contiguous()
+        bond_attr = torch.empty((T, ns), device=dev)      # (:399,423) x[b0, :ns] + x[b1, :ns]
+        L.check(lib.ddp_torsion_sh(K._p(sh_e), K._p(h.bond_vec), K._p(csr.recv), E, K._p(csr.cnt), K._p(tor_sh), K._p(x), ldx, ns,
+                                   K._p(st.flat32[:T]), K._p(st.flat32[T:]), T, K._p(bond_attr), K.stream()), "ddp_torsion_sh")
         spec, pkc = conv.spec, conv.packed(dev)
         msg = torch.empty((E, spec.d_out), device=dev)
         segs = [(e_t, csr.eid, ns, ns), (x, csr.src, ldx, ns), (bond_attr, csr.recv, ns, ns)]
         if E > 0:
             K.launch_convs(spec, [K.make_task(pkc, x, ldx, csr, tor_sh, segs, msg)])
-        hsum = torch.zeros((T, spec.d_out), device=dev)
-        K.launch_reduce(hsum, spec.d_out, T, spec.d_out, [(msg, csr, pkc)], accumulate=False)
+        hsum = torch.empty((T, spec.d_out), device=dev)      # (every row is written: accumulate = False)
+        K.launch_reduce(hsum, spec.d_out, T, spec.d_out, [(msg, csr, pkc)] if E > 0 else [], accumulate=False)
         if m.debug_conv_outputs is not None:
             m.debug_conv_outputs[name] = hsum
-        h.keep = (e_t, sh_e, bond_vec, tor_sh, bond_attr, msg)
-        return final_layer(hsum).squeeze(1)
+        hw = m._head_weights(dev)
+        out = torch.empty(T, device=dev)
+        a = L.TorArgs()
+        a.h, a.ld_h, a.n_bonds, a.ns = K._p(hsum), spec.d_out, T, ns
+        a.w1, a.w2 = (K._p(t) for t in hw[final_name])
+        a.out = K._p(out)
+        if m.scale_by_sigma:
+            a.sigma, a.graph_of_bond = K._p(sigma), K._p(st.batch32)
+            a.torus_table, a.torus_n, a.torus_lo, a.torus_span = K._p(hw["torus"]), hw["torus"].shape[0] - 1, hw["torus_lo"], hw["torus_span"]
+        L.check(lib.ddp_tor_head(C.byref(a), K.stream()), "ddp_tor_head")
+        h.keep = (e_t, sh_e, tor_sh, bond_attr, msg, hsum, a, hw)
+        return out

@@ -665,6 +665,45 @@ class TensorProductScoreModel(nn.Module):
         self._keep_alive = keep      # raw pointers were handed to the launches above
         return xs[0], xs[1], xs[2], pre
 
+    def _sigma_ranges(self):
+        """((sigma_min, sigma_max) x 4) when `t_to_sigma` is this package's schedule bound to its ranges (the reference's
+        functools.partial(t_to_sigma_compl, args=args), utils/utils.py / inference.py) - ddp_step_prologue then evaluates it; any
+        other callable is called as it is (None)."""
+        from .diffusion import t_to_sigma
+        f = self.t_to_sigma
+        kw = getattr(f, "keywords", None) or {}
+        if getattr(f, "func", None) is not t_to_sigma or getattr(f, "args", ()) or set(kw) != {"args"}:
+            return None
+        r = kw["args"]
+        try:
+            out = tuple((float(getattr(r, p + "_sigma_min")), float(getattr(r, p + "_sigma_max"))) for p in ("tr", "rot", "tor", "sidechain_tor"))
+        except (AttributeError, TypeError, ValueError):
+            return None
+        return out if all(lo > 0 and hi > 0 for lo, hi in out) else None
+
+    def _head_weights(self, dev):
+        """fp32 device tensors of the read-out MLPs and score-norm tables as ddp_trrot_head / ddp_tor_head take them (kept with
+        the packed weights: rebuilt when a parameter changes)."""
+        hw = self._edge_packs.get("heads")
+        if hw is None or hw["dev"] != dev:
+            f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()      # noqa: E731
+            hw = {"dev": dev}
+            for name in ("tr_final_layer", "rot_final_layer"):
+                seq = getattr(self, name)
+                hw[name] = (f(seq[0].weight), f(seq[0].bias), f(seq[3].weight.reshape(-1)), f(seq[3].bias))
+            for name in ("tor_final_layer", "sc_tor_final_layer"):
+                seq = getattr(self, name, None)
+                if seq is not None:
+                    hw[name] = (f(seq[0].weight), f(seq[3].weight.reshape(-1)))
+            # utils/so3.py:85-89 and utils/torus.py:78-82: index arithmetic in float32 like numpy on a float32 array
+            hw["so3"], hw["torus"] = f(self._so3_table), f(self._torus_table)
+            lo, hi = math.log10(0.01), math.log10(2.0)
+            hw["so3_lo"], hw["so3_span"] = float(np.float32(lo)), float(np.float32(hi - lo))
+            lo, hi = math.log(3e-3), math.log(2.0)
+            hw["torus_lo"], hw["torus_span"] = float(np.float32(lo)), float(np.float32(hi - lo))
+            self._edge_packs["heads"] = hw
+        return hw
+
     def _so3_score_norm(self, sigma):
         """reference utils/so3.py:85-89 (float32 arithmetic like numpy on a float32 array)."""
         lo, hi, n = math.log10(0.01), math.log10(2.0), 1000

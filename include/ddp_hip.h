@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DDP_ABI_VERSION 7
+#define DDP_ABI_VERSION 8
 #define DDP_EINVAL (-1)   /* bad argument (shape not supported, null pointer, ...) */
 #define DDP_ELIMIT (-2)   /* exceeds a compiled-in limit (see DDP_MAX_*) */
 
@@ -172,8 +172,97 @@ int ddp_edge_featurize(const float* pos_a, const int32_t* ia, const float* pos_b
  *   t[e] = sqrt(3/2) * (3 (n.v) v - n),  n = unit(sh edge vector), v = unit(bond vector of bond ib[e])
  * written as [0, t] so the conv kernel reads it like an edge_sh row.
  * Replaces all_atom_score_model.py:394-395,418-419 (o3.spherical_harmonics("2e") + o3.FullTensorProduct). */
+/* The same launch also writes the bonds' node attributes (optional, bond_attr == NULL skips it):
+ *   bond_attr[b, 0..ns) = x[b0[b], 0..ns) + x[b1[b], 0..ns)       (all_atom_score_model.py:399,423: the scalar features of
+ *   the bond's two atoms, gathered per edge by the conv kernel). */
 int ddp_torsion_sh(const float* sh_edge, const float* bond_vec, const int32_t* bond_of_edge, int n_edges,
-                   const int32_t* n_edges_dev, float* out, void* stream);
+                   const int32_t* n_edges_dev, float* out, const float* x, int ldx, int ns, const int32_t* b0,
+                   const int32_t* b1, int n_bonds, float* bond_attr, void* stream);
+
+/* ---- Per-graph / per-bond scalar work of a forward (csrc/ddp_heads.hip).  In PyTorch these are 15 - 30 launches of a few
+ * hundred bytes each; a dependent launch of a replayed hipGraph costs ~5 us whatever it does, so for small batches they were
+ * the step.  All sums run in a fixed order (bitwise repeatable).
+ *
+ * ddp_step_prologue: everything that depends on the times and the poses only, ONE launch at the top of a forward.
+ *   t[k], t_stride[k]     diffusion time of graph g for component k (tr, rot, tor, sc_tor): t[k][g * t_stride[k]] (stride 0: one time)
+ *   sigma[k][g]           = sig_min[k]^(1-t) * sig_max[k]^t     (utils/diffusion_utils.py:22-34 t_to_sigma; NULL: skipped;
+ *                         sig_max[k] <= 0 or t[k] == NULL: sigma[k] is an INPUT, made by the caller's own t_to_sigma)
+ *   cut[g]                = sigma[0][g] * cut_mul + cut_add     (dynamic cross cutoff 3 sigma_tr + 20, all_atom_score_model.py:548-550)
+ *   graph_emb[g, 0..sd)   sinusoidal embedding of t[0][g] (utils/diffusion_utils.py:73-84: [sin | cos] of emb_scale * t * freq[s]);
+ *                         the read-out MLPs' input (:371)
+ *   center[g]             mean of lig_pos over graph_ptr[g] .. graph_ptr[g+1] (:571-576)
+ *   bonds[h]              h = 0 ligand torsion head, 1 side-chain head: mid[i] = (pos[b0[i]] + pos[b1[i]]) / 2 (:589-592,613-616),
+ *                         vec[i] = pos[b1[i]] - pos[b0[i]] (:392,416)
+ *   copy[h]               dst[0..n) = src[0..n) (int32): the bond rows in front of the ligand edge list (:462-468) */
+typedef struct {
+  const float* t[4];
+  int32_t t_stride[4];
+  float sig_min[4], sig_max[4];
+  float* sigma[4];
+  int32_t n_graphs;
+  float* cut;
+  float cut_mul, cut_add;
+  float* graph_emb;
+  int32_t sd;
+  float emb_scale;
+  const float* freq;
+  const float* lig_pos;
+  const int32_t* graph_ptr;
+  float* center;
+  struct {
+    const float* pos;
+    const int32_t* b0;
+    const int32_t* b1;
+    int32_t n;
+    float* mid;
+    float* vec;
+  } bonds[2];
+  struct {
+    const int32_t* src;
+    int32_t* dst;
+    int32_t n;
+  } copy[2];
+} ddp_prologue_args_t;
+int ddp_step_prologue(const ddp_prologue_args_t* args, void* stream);
+
+/* ddp_trrot_head: translation / rotation read-out (all_atom_score_model.py:362-384) from the reduced final conv gp[B, >= 12]
+ * = [tr 1o | rot 1o | tr 1e | rot 1e]:  v = 1o + 1e halves,  out = v / |v| * MLP([|v|, graph_emb]),  MLP = Linear(1 + sd, ns) ->
+ * ReLU -> Linear(ns, 1) (index 0: tr_final_layer, 1: rot_final_layer; w1 [ns, 1 + sd] and w2 [ns] as nn.Linear stores them).
+ * sigma[0] != NULL: tr / sigma_tr;  sigma[1] != NULL: rot * so3_table[clamp(round((log10(sigma_rot) - so3_lo) / so3_span * so3_n),
+ * 0, so3_n - 1)] (utils/so3.py:85-89 score_norm). */
+typedef struct {
+  const float* gp;
+  int32_t ld_gp, n_graphs, ns, sd;
+  const float* graph_emb;
+  const float* w1[2];
+  const float* b1[2];
+  const float* w2[2];
+  const float* b2[2];
+  const float* sigma[2];
+  const float* so3_table;
+  int32_t so3_n;
+  float so3_lo, so3_span;
+  float* out[2];
+} ddp_trrot_args_t;
+int ddp_trrot_head(const ddp_trrot_args_t* args, void* stream);
+
+/* ddp_tor_head: torsion read-out (all_atom_score_model.py:400-410,424-434) per rotatable bond from the reduced bond conv
+ * h[T, >= 2 ns]:  out[b] = Linear(ns, 1, no bias)(tanh(Linear(2 ns, ns, no bias)(h[b]))), and with sigma != NULL
+ * * sqrt(torus_table[round(clamp((ln(sigma[graph_of_bond[b]] / pi) - torus_lo) / torus_span * torus_n, 0, torus_n))])
+ * (utils/torus.py:78-82 score_norm; the table has torus_n + 1 entries). */
+typedef struct {
+  const float* h;
+  int32_t ld_h, n_bonds, ns;
+  const float* w1;
+  const float* w2;
+  const float* sigma;
+  const int32_t* graph_of_bond;
+  const float* torus_table;
+  int32_t torus_n;
+  float torus_lo, torus_span;
+  float* out;
+} ddp_tor_args_t;
+int ddp_tor_head(const ddp_tor_args_t* args, void* stream);
 
 /* Stage A of the source-node factorisation (ddp_block_t::g_slot): the per-source-node tensors consumed through
  * ddp_conv_task_t::g, for all (conv, G slot) pairs that read one node-feature array x:
