@@ -136,7 +136,8 @@ class NodeJob(C.Structure):
                 ("t", C.c_void_p), ("t_stride", C.c_int32), ("scale", C.c_float), ("freq", C.c_void_p),
                 ("sig_emb", C.c_void_p), ("ld_sig", C.c_int32), ("sd", C.c_int32), ("sig_out", C.c_void_p), ("ld_sig_out", C.c_int32),
                 ("w", C.c_void_p), ("bias", C.c_void_p),
-                ("out", C.c_void_p), ("ld_out", C.c_int32), ("ncols", C.c_int32), ("zero_to", C.c_int32)]
+                ("out", C.c_void_p), ("ld_out", C.c_int32), ("ncols", C.c_int32), ("zero_to", C.c_int32),
+                ("add", C.c_void_p), ("ld_add", C.c_int32)]
 
 
 def g_ld(hid: int, gcols: int) -> int:
@@ -178,7 +179,7 @@ def load():
                                    C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.ddp_torsion_sh.restype = C.c_int
     lib.ddp_stage_a.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_int,
-                                C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+                                C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     lib.ddp_stage_a.restype = C.c_int
     lib.ddp_pose_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]
@@ -212,7 +213,7 @@ def load():
         getattr(lib, name).restype = C.c_int
     lib.ddp_node_linear.argtypes = [C.POINTER(NodeJob), C.c_int, C.c_void_p]
     lib.ddp_node_linear.restype = C.c_int
-    if lib.ddp_abi_version() != 8:
+    if lib.ddp_abi_version() != 9:
         raise DdpError("libddp_hip.so ABI version mismatch")
     lib.ddp_source_hash.restype = C.c_char_p
     if "DDP_HIP_LIB" not in os.environ:   # (diagnostic builds loaded through DDP_HIP_LIB carry extra -D flags, same sources)

@@ -279,8 +279,166 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, DDP_SA_WPE) void ddp_stage_a_mfma
   }
 }
 
+// ---- bf16x3 form of the MFMA kernel: the same product on v_mfma_f32_32x32x16_bf16 (16 x the fp32 rate) with BOTH operands
+// split into three bfloat16 terms, v = hi + mid + lo (hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid): 24 significant
+// bits, every residual exact in fp32), and the six products whose weight is >= 2^-16 of the leading one accumulated in fp32:
+//   x w ~ xh wh + (xh wm + xm wh) + (xm wm + xh wl + xl wh)            dropped: xm wl, xl wm, xl wl  (<= 2^-24 |x w| each)
+// i.e. fp32-class accuracy (measured against an fp64 product: tests/test_gpu_parity.py::test_stage_a_bf16x3_error) at 6 MFMAs
+// of 32 cycles per 16 k instead of 8 of 64: the matrix side of the product shrinks 2.7 x and the kernel is left with the HBM
+// write of G.  Not bitwise the fp32 form (different rounding points), deterministic like it (a row's result does not depend
+// on the tile it sits in).  Weights arrive pre-split from the host (packing.split_bf16x3): [batch][plane][k/16][k/8 % 2][col][8].
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#define DDP_SA3_CT 2   // column tiles per wave: 3 planes x 4 k-steps x 4 registers each = 96 weight registers (3 tiles: 256 + spills)
+
+template <int KT>
+__global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_x3_kernel(const float* __restrict__ x, int ldx, int nrows,
+                                                                              const int32_t* __restrict__ rows,
+                                                                              const int32_t* __restrict__ nrows_dev, int out_rows,
+                                                                              int mrows, const GemmOffs offs,
+                                                                              const __bf16* __restrict__ w3, int ncols,
+                                                                              float* __restrict__ out, int ldo) {
+  if (nrows_dev) nrows = min(nrows, *nrows_dev);
+  if ((int)blockIdx.y * mrows >= nrows) return;
+  constexpr int KP = (KT + 15) / 16 * 16, NS = KP / 16, CT = DDP_SA3_CT;
+  constexpr int XS = KP + 8;                                   // bf16 per LDS row of an x plane (16-byte aligned rows)
+  constexpr int NV = (32 * KT / 4 + DDP_GEMM_THREADS - 1) / DDP_GEMM_THREADS;
+  constexpr int TS = 36;
+  constexpr int NM = NS * 6;                                    // MFMAs per block
+  __shared__ __attribute__((aligned(16))) __bf16 xt[2][3][32 * XS];
+  __shared__ __attribute__((aligned(16))) float st[4][2][32 * TS];
+  const int z = (int)blockIdx.z, tid = (int)threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int col0 = ((int)blockIdx.x * 4 + wave) * (32 * CT);
+  bf16x8 wr[CT][3][NS];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) {
+    const int c = min(col0 + 32 * t + r, ncols - 1);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2)
+        wr[t][p][s2] = *reinterpret_cast<const bf16x8*>(w3 + (((((size_t)z * 3 + p) * NS + s2) * 2 + hh) * ncols + c) * 8);
+  }
+  // the k padding [KT, KP) of both x buffers is zero for good
+  if constexpr (KP > KT) {
+    for (int i = tid; i < 2 * 3 * 32 * (KP - KT); i += DDP_GEMM_THREADS) {
+      const int kk = i % (KP - KT), rr = (i / (KP - KT)) % 32, bp = i / ((KP - KT) * 32);
+      xt[bp / 3][bp % 3][rr * XS + KT + kk] = (__bf16)0.f;
+    }
+  }
+  const float* __restrict__ xb = x + offs.off[z];
+  for (int R0 = (int)blockIdx.y * mrows; R0 < nrows; R0 += (int)gridDim.y * mrows) {
+  const int R1 = min(nrows, R0 + mrows);
+  const bool al4 = ((ldx | offs.off[z]) & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0;
+  f32x4 xv[NV];
+  auto fetch = [&](int row0) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int i = tid + v * DDP_GEMM_THREADS;
+      const int rr = min(i / (KT / 4), 31), q = i % (KT / 4);
+      const int ri = min(row0 + rr, nrows - 1);
+      const float* __restrict__ p = xb + (size_t)(rows ? rows[ri] : ri) * ldx + 4 * q;
+      if (al4)
+        xv[v] = *reinterpret_cast<const f32x4*>(p);
+      else
+        xv[v] = f32x4{p[0], p[1], p[2], p[3]};
+    }
+  };
+  auto park = [&](int buf) {   // split into the three bf16 planes on the way into LDS (once per workgroup, not per wave)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int i = tid + v * DDP_GEMM_THREADS;
+      if (i < 32 * (KT / 4)) {
+        const int rr = i / (KT / 4), q = i % (KT / 4);
+        bf16x4 h, m, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float f = xv[v][e];
+          h[e] = (__bf16)f;
+          const float r1 = f - (float)h[e];
+          m[e] = (__bf16)r1;
+          l[e] = (__bf16)(r1 - (float)m[e]);
+        }
+        *reinterpret_cast<bf16x4*>(&xt[buf][0][rr * XS + 4 * q]) = h;
+        *reinterpret_cast<bf16x4*>(&xt[buf][1][rr * XS + 4 * q]) = m;
+        *reinterpret_cast<bf16x4*>(&xt[buf][2][rr * XS + 4 * q]) = l;
+      }
+    }
+  };
+  float* pend_ob = nullptr;
+  int pend_c0 = 0, pend_rows = 0, pend_buf = 0, pbuf = 0;
+  int pend_ri[4] = {0, 0, 0, 0};
+  f32x4 dv = {0.f, 0.f, 0.f, 0.f};
+  auto drain_read = [&](int p) {
+    if (pend_ob) dv = *reinterpret_cast<const f32x4*>(&st[wave][pend_buf][(8 * p + (lane >> 3)) * TS + 4 * (lane & 7)]);
+  };
+  auto drain_store = [&](int p) {
+    if (pend_ob) {
+      const int rr = 8 * p + (lane >> 3), c = pend_c0 + 4 * (lane & 7);
+      if (rr < pend_rows && c < ncols) *reinterpret_cast<f32x4*>(&pend_ob[(size_t)pend_ri[p] * ldo + c]) = dv;
+    }
+  };
+  fetch(R0);
+  park(0);
+  __syncthreads();
+  int buf = 0;
+  for (int row0 = R0; row0 < R1; row0 += 32, buf ^= 1) {
+    const bool more = row0 + 32 < R1;
+    if (more) fetch(row0 + 32);
+    bf16x8 a[3][NS];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) a[p][s2] = *reinterpret_cast<const bf16x8*>(&xt[buf][p][r * XS + 16 * s2 + 8 * hh]);
+    float* __restrict__ ob = out + (size_t)z * out_rows * ldo;
+    int blk_ri[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ri = min(row0 + 8 * p + (lane >> 3), R1 - 1);
+      blk_ri[p] = rows ? rows[ri] : ri;
+    }
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      // smallest terms first; quarter q of the pending block leaves between the MFMAs (LDS read at MFMA q NM/4, store 2 later)
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // (xl wh) (xh wl) (xm wm) (xm wh) (xh wm) (xh wh)
+        const int pr = m / NS, s2 = m % NS;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[pr]][s2], wr[t][PB[pr]][s2], acc, 0, 0, 0);
+        static_assert(NM / 4 >= 3 && NM % 4 == 0, "quarter schedule");
+        if (m % (NM / 4) == 0) drain_read(m / (NM / 4));
+        if (m % (NM / 4) == 2) drain_store(m / (NM / 4));
+      }
+      float* tl = st[wave][pbuf];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) tl[((i & 3) + 8 * (i >> 2) + 4 * hh) * TS + r] = acc[i];
+      pend_ob = ob;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) pend_ri[p] = blk_ri[p];
+      pend_c0 = col0 + 32 * t;
+      pend_rows = R1 - row0;
+      pend_buf = pbuf;
+      pbuf ^= 1;
+    }
+    if (more) park(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {   // the last block
+    drain_read(p);
+    drain_store(p);
+  }
+  __syncthreads();
+  }
+}
+
 extern "C" int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows,
-                           const int32_t* offs, int nbatch, const float* w, int k, int ncols, float* out, int ldo, void* stream) {
+                           const int32_t* offs, int nbatch, const float* w, const void* w_bf16x3, int k, int ncols, float* out, int ldo,
+                           void* stream) {
   if (!rows) out_rows = nrows;                       // dense: out[b] has one row per x row
   if (out_rows < 1 && nrows > 0) return ddp_fail(DDP_EINVAL, "ddp_stage_a: out_rows");
   if (nbatch < 0 || nbatch > DDP_MAX_GEMM_BATCH) return ddp_fail(DDP_ELIMIT, "ddp_stage_a: nbatch > DDP_MAX_GEMM_BATCH");
@@ -308,6 +466,19 @@ extern "C" int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* ro
   int gy = (nrows + mrows - 1) / mrows;
   if (listed && gy > 96) gy = 96;
   static const bool no_mfma = getenv("DDP_STAGE_A_VALU") != nullptr;   // diagnostic: force the VALU form
+  // bf16x3 form: wide, 16-byte aligned outputs only (its blocks always leave through the LDS transpose)
+  if (w_bf16x3 && wide && (k == 60 || k == 32) && !no_mfma && (reinterpret_cast<size_t>(w_bf16x3) & 15) == 0) {
+    const dim3 grid((ncols + 128 * DDP_SA3_CT - 1) / (128 * DDP_SA3_CT), gy, nbatch);
+    if (k == 60)
+      hipLaunchKernelGGL((ddp_stage_a_x3_kernel<60>), grid, dim3(DDP_GEMM_THREADS), 0, s, x, ldx, nrows, rows, nrows_dev, out_rows, mrows, O,
+                         reinterpret_cast<const __bf16*>(w_bf16x3), ncols, out, ldo);
+    else
+      hipLaunchKernelGGL((ddp_stage_a_x3_kernel<32>), grid, dim3(DDP_GEMM_THREADS), 0, s, x, ldx, nrows, rows, nrows_dev, out_rows, mrows, O,
+                         reinterpret_cast<const __bf16*>(w_bf16x3), ncols, out, ldo);
+    const hipError_t e3 = hipGetLastError();
+    if (e3 != hipSuccess) return ddp_fail_hip(e3, "ddp_stage_a (bf16x3) launch");
+    return 0;
+  }
   if (ncols >= 512 && !no_mfma && (k == 60 || k == 64 || k == 32 || k == 24 || k == 16)) {
     switch (k) {
       case 60: DDP_GEMM_MFMA(60); break;

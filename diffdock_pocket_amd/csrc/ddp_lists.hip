@@ -48,28 +48,92 @@ __device__ __forceinline__ int scan_value(const ddp_scan_job_t& J, int i) {
   return v;
 }
 
-// EPL consecutive items per lane and iteration: the lane's loads are independent (one round trip), its items are summed in
-// registers, the lane totals are scanned with shuffles; a wave walks its segment 64 * EPL items at a time.
-#define DDP_SCAN_EPL 8
+// A lane owns EPL = 4 CONSECUTIVE items per chunk and moves them with 16-byte accesses: a wave instruction then covers 1 KiB of
+// contiguous memory.  (One workgroup does a whole job, so everything goes through ONE CU's memory pipe: with 8 items per lane
+// fetched as 8 separate dwords - every instruction touching 16 cache lines for 256 useful bytes - a 44 K-item scan took
+// 46 - 74 us; the arithmetic is nothing.)  `vec`: every array of the job is 16-byte aligned (the usual case).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+#define DDP_SCAN_EPL 4
+#define DDP_SCAN_NCH 12   // chunks of 64 * EPL items a wave keeps in registers (small form: n <= 16 * NCH * 256 = 48 K)
+
+__device__ __forceinline__ void scan_load4(const ddp_scan_job_t& J, int i, int hi, bool vec, int v[4]) {
+  if (i + 4 <= hi && vec) {
+    if (J.val) {
+      const i32x4 a = *reinterpret_cast<const i32x4*>(J.val + i);
+      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    } else if (J.rowptr) {
+      const i32x4 a = *reinterpret_cast<const i32x4*>(J.rowptr + i);
+      const int nx = J.rowptr[i + 4];
+      v[0] = a[1] - a[0]; v[1] = a[2] - a[1]; v[2] = a[3] - a[2]; v[3] = nx - a[3];
+    } else {
+      v[0] = v[1] = v[2] = v[3] = 1;
+    }
+    if (J.flag) {
+      const i32x4 f = *reinterpret_cast<const i32x4*>(J.flag + i);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (f[u] == 0) v[u] = 0;
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = (i + u < hi) ? scan_value(J, i + u) : 0;
+  }
+}
+
+// writes the exclusive prefixes ex, ex + v0, ... of the lane's four items (and the compacted indices)
+__device__ __forceinline__ void scan_store4(const ddp_scan_job_t& J, int i, int hi, bool vec, const int v[4], int ex) {
+  const int e[4] = {ex, ex + v[0], ex + v[0] + v[1], ex + v[0] + v[1] + v[2]};
+  if (i + 4 <= hi && vec) {
+    const i32x4 o = {e[0], e[1], e[2], e[3]};
+    if (J.excl) *reinterpret_cast<i32x4*>(J.excl + i) = o;
+    if (J.excl2) *reinterpret_cast<i32x4*>(J.excl2 + i) = o;
+  } else {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + u < hi) {
+        if (J.excl) J.excl[i + u] = e[u];
+        if (J.excl2) J.excl2[i + u] = e[u];
+      }
+  }
+  if (J.list) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + u < hi && v[u] != 0) J.list[e[u]] = i + u;   // (weights are 0 / 1 when a list is asked for)
+  }
+}
+
+__device__ __forceinline__ bool scan_aligned(const ddp_scan_job_t& J) {
+  return ((reinterpret_cast<size_t>(J.val) | reinterpret_cast<size_t>(J.rowptr) | reinterpret_cast<size_t>(J.flag) |
+           reinterpret_cast<size_t>(J.excl) | reinterpret_cast<size_t>(J.excl2)) & 15) == 0;
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int up = __shfl_up(v, off);
+    if (lane >= off) v += up;
+  }
+  return v;
+}
+
+// General form, any n: one workgroup of 1024 threads per job, a contiguous segment per wave, two passes over it.
 __global__ __launch_bounds__(1024) void ddp_scan_jobs_kernel(const ListLaunch<ddp_scan_job_t> L) {
   __shared__ int seg_total[16];
   constexpr int EPL = DDP_SCAN_EPL, CH = 64 * EPL;
   const ddp_scan_job_t& J = L.job[blockIdx.x];
   const int n = dev_count(J.n, J.n_dev);
+  const bool vec = scan_aligned(J);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int S = (((n + 15) / 16) + CH - 1) / CH * CH;      // contiguous segment per wave, a multiple of the chunk
   const int lo = min(wave * S, n), hi = min(lo + S, n);
   int run = 0;
   for (int base = lo; base < hi; base += CH) {
-    int v = 0;
+    int v[4];
+    scan_load4(J, base + lane * EPL, hi, vec, v);
+    int t = v[0] + v[1] + v[2] + v[3];
 #pragma unroll
-    for (int u = 0; u < EPL; ++u) {
-      const int i = base + lane * EPL + u;
-      v += (i < hi) ? scan_value(J, i) : 0;
-    }
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
-    run += v;
+    for (int m = 32; m > 0; m >>= 1) t += __shfl_xor(t, m);
+    run += t;
   }
   if (lane == 0) seg_total[wave] = run;
   __syncthreads();
@@ -77,33 +141,59 @@ __global__ __launch_bounds__(1024) void ddp_scan_jobs_kernel(const ListLaunch<dd
   for (int w = 0; w < wave; ++w) offset += seg_total[w];
   run = offset;
   for (int base = lo; base < hi; base += CH) {
-    int val[EPL];
-    int mine = 0;
-#pragma unroll
-    for (int u = 0; u < EPL; ++u) {
-      const int i = base + lane * EPL + u;
-      val[u] = (i < hi) ? scan_value(J, i) : 0;
-      mine += val[u];
-    }
-    int incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int u = __shfl_up(incl, off);
-      if (lane >= off) incl += u;
-    }
-    int ex = run + incl - mine;                      // exclusive prefix of the lane's first item
-#pragma unroll
-    for (int u = 0; u < EPL; ++u) {
-      const int i = base + lane * EPL + u;
-      if (i < hi) {
-        if (J.excl) J.excl[i] = ex;
-        if (J.excl2) J.excl2[i] = ex;
-        if (J.list && val[u] != 0) J.list[ex] = i;   // (weights are 0 / 1 when a list is asked for)
-      }
-      ex += val[u];
-    }
+    int v[4];
+    scan_load4(J, base + lane * EPL, hi, vec, v);
+    const int mine = v[0] + v[1] + v[2] + v[3];
+    const int incl = wave_incl_scan(mine, lane);
+    scan_store4(J, base + lane * EPL, hi, vec, v, run + incl - mine);
     run += __shfl(incl, 63);
   }
+  if (threadIdx.x == 0) {
+    int total = J.base;
+    for (int w = 0; w < 16; ++w) total += seg_total[w];
+    if (J.excl) J.excl[n] = total;
+    if (J.total) *J.total = total;
+  }
+}
+
+// Small form (host-chosen by the jobs' capacities: every job <= 48 K items, i.e. every per-node scan of a 40-sample batch): a
+// wave's whole segment is fetched at once - NCH independent 16-byte loads per lane and array, ONE memory round trip - and stays
+// in registers for the second pass.
+__global__ __launch_bounds__(1024) void ddp_scan_jobs_small_kernel(const ListLaunch<ddp_scan_job_t> L) {
+  __shared__ int seg_total[16];
+  constexpr int EPL = DDP_SCAN_EPL, CH = 64 * EPL, NCH = DDP_SCAN_NCH;
+  const ddp_scan_job_t& J = L.job[blockIdx.x];
+  const int n = dev_count(J.n, J.n_dev);
+  const bool vec = scan_aligned(J);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int S = (((n + 15) / 16) + CH - 1) / CH * CH;
+  const int lo = min(wave * S, n), hi = min(lo + S, n);
+  const int nch = S / CH;
+  int val[NCH][4];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (c < nch) {
+      scan_load4(J, lo + c * CH + lane * EPL, hi, vec, val[c]);
+    } else {
+      val[c][0] = val[c][1] = val[c][2] = val[c][3] = 0;
+    }
+  }
+  int run = 0;
+  int excl[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int mine = val[c][0] + val[c][1] + val[c][2] + val[c][3];
+    const int incl = wave_incl_scan(mine, lane);
+    excl[c] = run + incl - mine;           // exclusive prefix of the lane's first item inside the wave's segment
+    run += __shfl(incl, 63);
+  }
+  if (lane == 0) seg_total[wave] = run;
+  __syncthreads();
+  int offset = J.base;
+  for (int w = 0; w < wave; ++w) offset += seg_total[w];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+    if (c < nch) scan_store4(J, lo + c * CH + lane * EPL, hi, vec, val[c], offset + excl[c]);
   if (threadIdx.x == 0) {
     int total = J.base;
     for (int w = 0; w < 16; ++w) total += seg_total[w];
@@ -133,7 +223,12 @@ extern "C" int ddp_scan_jobs(const ddp_scan_job_t* jobs, int njobs, void* stream
       return ddp_fail(DDP_EINVAL, "ddp_scan_jobs: n < 0, or a list asked for with weights other than 0 / 1");
     L.job[i] = jobs[i];
   }
-  hipLaunchKernelGGL(ddp_scan_jobs_kernel, dim3(njobs), dim3(1024), 0, (hipStream_t)stream, L);
+  bool small = true;
+  for (int i = 0; i < njobs; ++i) small = small && jobs[i].n <= 16 * DDP_SCAN_NCH * 64 * DDP_SCAN_EPL;
+  if (small)
+    hipLaunchKernelGGL(ddp_scan_jobs_small_kernel, dim3(njobs), dim3(1024), 0, (hipStream_t)stream, L);
+  else
+    hipLaunchKernelGGL(ddp_scan_jobs_kernel, dim3(njobs), dim3(1024), 0, (hipStream_t)stream, L);
   return launch_ok("ddp_scan_jobs launch");
 }
 

@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void ddp_node_linear_kernel(const NodeLaunch L
         if (rr < nvalid) {
           float v = acc[q][i] + b;                                  // Linear: x W^T + b
           if (J.emb_mode == 2) v = nd_emb_sum(J, cat_lds[rr], col) + v;   // x_embedding += linear(...) (score_model.py:47)
+          if (J.add) v = J.add[(size_t)(row0 + rr) * J.ld_add + col] + v;
           J.out[(size_t)(row0 + rr) * J.ld_out + col] = v;
         }
       }

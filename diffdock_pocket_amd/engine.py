@@ -612,9 +612,10 @@ class ForwardEngine:
                     if pk.wg[slot] is not None:
                         Ws.append(pk.wg[slot])
                         meta.append((k, slot, pk.g_in_off[slot]))
-            ent = (torch.stack(Ws).contiguous(), meta, (C.c_int32 * len(meta))(*[mm[2] for mm in meta]))
+            Wst = torch.stack(Ws).contiguous()
+            ent = (Wst, meta, (C.c_int32 * len(meta))(*[mm[2] for mm in meta]), P.split_bf16x3(Wst))
             m._stage_a_stacks[key] = ent
-        Wst, meta, offs = ent
+        Wst, meta, offs, W3 = ent
         nb = len(meta)
         if nb > L.DDP_MAX_GEMM_BATCH:
             raise L.DdpError("more (conv, slot) pairs per source array than DDP_MAX_GEMM_BATCH")
@@ -624,7 +625,7 @@ class ForwardEngine:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         n_list = n_rows if rows is None else int(rows.shape[0])
-        K.stage_a(x, n_list, offs, nb, Wst, Gall, rows=rows, rows_cnt=rows_cnt, out_rows=n_rows)
+        K.stage_a(x, n_list, offs, nb, Wst, Gall, rows=rows, rows_cnt=rows_cnt, out_rows=n_rows, W3=W3 if m.stage_a_bf16x3 else None)
         if prof is not None:
             e1.record()
             # algorithmic bytes: the G rows written once + the scalar columns of x read once per product + the weights

@@ -290,14 +290,15 @@ def edge_featurize(pack: EdgeMLPPack, dist, pos_a, ia, pos_b, ib, pre, pre_idx, 
     return out, sh
 
 
-def stage_a(x, n_rows, offs, nb, W, out, rows=None, rows_cnt=None, out_rows=None):
-    """ddp_stage_a: out[b][row] = x[row, offs[b]:offs[b]+k] @ W[b] for the listed rows (all n_rows rows if rows is None)."""
+def stage_a(x, n_rows, offs, nb, W, out, rows=None, rows_cnt=None, out_rows=None, W3=None):
+    """ddp_stage_a: out[b][row] = x[row, offs[b]:offs[b]+k] @ W[b] for the listed rows (all n_rows rows if rows is None).
+    W3: the weights pre-split for the bf16x3 form (packing.split_bf16x3), None: exact fp32 MFMA."""
     lib = L.load()
     n_in, ncols = W.shape[1], W.shape[2]
     if n_rows == 0:
         return
     L.check(lib.ddp_stage_a(x.data_ptr(), x.stride(0), n_rows, ptr(rows), ptr(rows_cnt), out_rows if out_rows is not None else n_rows,
-                            offs, nb, W.data_ptr(), n_in, ncols, out.data_ptr(), ncols, stream()), "ddp_stage_a")
+                            offs, nb, W.data_ptr(), ptr(W3), n_in, ncols, out.data_ptr(), ncols, stream()), "ddp_stage_a")
 
 
 # ------------------------------------------------------------------------------------------------ list primitives

@@ -328,6 +328,23 @@ def factor_weights(spec: ConvSpec, weight: torch.Tensor, bias: torch.Tensor):
     return Wg, Bg, offs
 
 
+def split_bf16x3(W: torch.Tensor) -> torch.Tensor:
+    """Stage-A weights [nb, K, ncols] fp32 as three bfloat16 terms w = hi + mid + lo (hi = bf16(w), mid = bf16(w - hi),
+    lo = bf16(w - hi - mid): 24 significant bits, the residuals are exact in fp32), in the operand order of
+    v_mfma_f32_32x32x16_bf16: [nb][plane][k/16][k/8 % 2][ncols][8] (include/ddp_hip.h, ddp_stage_a `w_bf16x3`), K zero-padded
+    to a multiple of 16."""
+    nb, K, ncols = W.shape
+    KP = (K + 15) // 16 * 16
+    Wf = torch.zeros((nb, KP, ncols), dtype=torch.float32, device=W.device)
+    Wf[:, :K] = W.float()
+    hi = Wf.to(torch.bfloat16)
+    r1 = Wf - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    planes = torch.stack([hi, mid, lo], dim=1)                                  # [nb, 3, KP, ncols]
+    return planes.reshape(nb, 3, KP // 16, 2, 8, ncols).permute(0, 1, 2, 3, 5, 4).contiguous()
+
+
 def torsion_tp_spec(in_mul: Sequence[int], ns: int, n_edge_features: int) -> ConvSpec:
     """The two non-empty paths of o3.FullyConnectedTensorProduct(in, FullTensorProduct(sh,"2e").irreps_out,
     "ns x0o + ns x0e") (reference models/all_atom_score_model.py:194-202):

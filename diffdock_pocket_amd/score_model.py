@@ -191,7 +191,7 @@ class TensorProductConvLayer(nn.Module):
             w = pk.wg[slot]
             g[slot] = torch.empty((N, w.shape[1]), device=x_src.device, dtype=torch.float32)
             offs = (C.c_int32 * 1)(pk.g_in_off[slot])
-            L.check(lib.ddp_stage_a(x_src.data_ptr(), x_src.shape[1], N, None, None, N, offs, 1, w.data_ptr(), w.shape[0], w.shape[1],
+            L.check(lib.ddp_stage_a(x_src.data_ptr(), x_src.shape[1], N, None, None, N, offs, 1, w.data_ptr(), None, w.shape[0], w.shape[1],
                                     g[slot].data_ptr(), w.shape[1], _stream()), "ddp_stage_a")
         return g
 
@@ -281,7 +281,7 @@ class _EncoderPack:
                 self.w, self.b = lin.weight.detach().float().t().contiguous().to(dev), lin.bias.detach().float().to(dev)
 
 
-def _node_job(n_rows, out, ncols, w, bias, zero_to=0, cat=None, pack=None, emb_mode=0, dense=(), sigma=None, sig_out=None):
+def _node_job(n_rows, out, ncols, w, bias, zero_to=0, cat=None, pack=None, emb_mode=0, dense=(), sigma=None, sig_out=None, add=None):
     """One ddp_node_job_t.  dense: [(tensor [n, ld] float32 with unit column stride, first column, width)]; sigma:
     None | ("t", t [n] (any stride), scale, freq [sd/2], sd) | ("emb", tensor [n, sd])."""
     j = L.NodeJob()
@@ -300,6 +300,8 @@ def _node_job(n_rows, out, ncols, w, bias, zero_to=0, cat=None, pack=None, emb_m
         j.sig_emb, j.ld_sig, j.sd = sigma[1].data_ptr(), sigma[1].stride(0), sigma[1].shape[1]
     if sig_out is not None:
         j.sig_out, j.ld_sig_out = sig_out.data_ptr(), sig_out.stride(0)
+    if add is not None:
+        j.add, j.ld_add = add.data_ptr(), add.stride(0)
     return j
 
 
@@ -406,6 +408,10 @@ class TensorProductScoreModel(nn.Module):
         # forked streams (engine._Fork); above this many pocket atoms in the batch every kernel fills the chip on its own
         self.concurrent_small_batches = True
         self.concurrent_max_atoms = 16000
+        # Stage A on the bf16 matrix cores with both operands split into three bfloat16 terms (csrc/ddp_gemm.hip,
+        # ddp_stage_a_x3_kernel): fp32-class accuracy (error <= ~2^-22 sum |x w|, measured against fp64 in
+        # tests/test_gpu_parity.py::test_stage_a_bf16x3_error), 1/2.7 of the matrix time.  False: exact fp32 MFMA (an fmaf chain).
+        self.stage_a_bf16x3 = True
         self._overflow_flag = None
         self.exact_sizes = False       # test mode: device-side list sizes are read back and every list is cut to its length
         self.debug_conv_outputs = None  # set to a dict: forward then stores the output [n_out, d_out] of every conv call in it
@@ -639,8 +645,19 @@ class TensorProductScoreModel(nn.Module):
                     raise NotImplementedError("AtomEncoder without additional features (sigma_embed_dim = 0, no ESM)")
                 if pk.w.shape[0] != pk.emb_dim + n_lm + sd:
                     raise ValueError(f"{name}.x has {st.x.shape[1]} columns, the encoder expects {pk.w.shape[0] - pk.emb_dim - sd + ncat}")
-                jobs.append(_node_job(N, x, ns, pk.w, pk.b, zero_to=ldx, cat=cat, pack=pk, emb_mode=1,
-                                      dense=[(xf, ncat, n_lm)] if n_lm else [], sigma=sigma, sig_out=sig_out))
+                # out = [emb | ESM | sigma] @ W + b: everything but the sigma columns is the same at every denoising step of a
+                # batch (the ESM block is 1280 of the receptor's 1340 input columns) - computed once per batch by a job of its
+                # own, kept while `x` and the weights are unchanged, and ADDED by the per-step job (K = sigma_embed_dim)
+                k_st = pk.emb_dim + n_lm
+
+                def static_part(N=N, pk=pk, cat=cat, xf=xf, ncat=ncat, n_lm=n_lm):
+                    out = torch.empty((N, ns), device=dev)
+                    _launch_node_jobs([_node_job(N, out, ns, pk.w, pk.b, cat=cat, pack=pk, emb_mode=1,
+                                                 dense=[(xf, ncat, n_lm)] if n_lm else [])])
+                    return out
+                static = self._cached("enc_static_" + name, (st.x,), static_part)
+                keep.append(static)
+                jobs.append(_node_job(N, x, ns, pk.w[k_st:], None, zero_to=ldx, sigma=sigma, sig_out=sig_out, add=static))
             elif not pk.has_lm:
                 jobs.append(_node_job(N, x, ns, pk.w1, pk.b1, zero_to=ldx, cat=cat, pack=pk, emb_mode=2, sigma=sigma, sig_out=sig_out))
             else:   # scalars = the first n_scalar columns behind the categorical ones, "ESM" = the last 1280 of [ESM | sigma]

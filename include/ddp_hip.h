@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DDP_ABI_VERSION 8
+#define DDP_ABI_VERSION 9
 #define DDP_EINVAL (-1)   /* bad argument (shape not supported, null pointer, ...) */
 #define DDP_ELIMIT (-2)   /* exceeds a compiled-in limit (see DDP_MAX_*) */
 
@@ -277,9 +277,15 @@ int ddp_tor_head(const ddp_tor_args_t* args, void* stream);
 #define DDP_G_LD(hid, gcols) ((((((hid) + 3) / 4) * 4 + 1) * (gcols) + 31) / 32 * 32)   /* floats per node of a G array */
 /* rows (optional, device int32 [nrows]): only the listed node rows are computed - x row rows[i] -> row rows[i] of out[b], which
  * has out_rows rows per batch slice; the other rows of out are left as they are - and nrows_dev (optional, device) holds the
- * length of the list (nrows = its capacity).  rows == NULL: out_rows is ignored (= nrows). */
+ * length of the list (nrows = its capacity).  rows == NULL: out_rows is ignored (= nrows).
+ * w_bf16x3 (optional): the same weights split into three bfloat16 terms w = hi + mid + lo (hi = bf16(w), mid = bf16(w - hi),
+ * lo = bf16(w - hi - mid)), laid out [nbatch][3 planes][kp / 16][2][ncols][8] with element (b, p, s, h, c, j) = plane p of
+ * w[b][16 s + 8 h + j, c] (zero for k >= the product's k; kp = k rounded up to 16), 16-byte aligned.  When given (and k is 60 or
+ * 32, ncols >= 1024, out 16-byte aligned with ldo % 4 == 0) the product runs on v_mfma_f32_32x32x16_bf16 with x split the
+ * same way in the kernel and the six largest cross terms accumulated in fp32: error <= ~2^-22 sum_u |x w|, i.e. fp32 class,
+ * not bitwise the fp32-MFMA form, at 1/2.7 of its matrix time (csrc/ddp_gemm.hip). */
 int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows, const int32_t* offs,
-                int nbatch, const float* w, int k, int ncols, float* out, int ldo, void* stream);
+                int nbatch, const float* w, const void* w_bf16x3, int k, int ncols, float* out, int ldo, void* stream);
 
 /* The pose update between two score-model calls, for all samples of a batch in one launch:
  * modify_conformer(pos, tr_update, rot_update, torsion_updates) of utils/diffusion_utils.py:37-60 = rigid move about the
@@ -497,6 +503,8 @@ typedef struct {
   const float* bias;
   float* out;
   int32_t ld_out, ncols, zero_to;
+  const float* add;     /* optional [n_rows, ld_add]: added to the result, out = add + (bias + [..] @ w) - the part of a Linear that */
+  int32_t ld_add;       /* does not change between denoising steps (embedding tables, ESM block), computed once by another job   */
 } ddp_node_job_t;
 int ddp_node_linear(const ddp_node_job_t* jobs, int njobs, void* stream);
 

@@ -273,9 +273,11 @@ def test_device_driven_step_equals_the_host_driven_one():
     by tools/dump_step_outputs.py at commit 'Node encoders ... as one HIP launch').  Up to the commit that moved the read-out
     MLPs into ddp_trrot_head / ddp_tor_head the device-driven step reproduced them BIT FOR BIT (same kernels, same per-element
     arithmetic, same summation orders - only who knows the list sizes had changed; profiles/r03_v2_pytest_gpu.txt).  Since then
-    the read-out MLPs sum their 33 / 120 products in index order instead of hipBLASLt's order and the ligand centre is summed
-    in index order instead of torch.sum's: the edge counts are still identical, scores and poses agree to a few ulp."""
-    STEP_TOL = 5e-6
+    the read-out MLPs sum their 33 / 120 products in index order instead of hipBLASLt's order, the ligand centre is summed in
+    index order instead of torch.sum's, the node encoders add the step-independent part of their Linear as one term, and
+    stage A runs as bf16x3 products with fp32 accumulation: the edge counts are still identical, scores and poses agree to
+    2e-5 of the largest component (the parity tolerance of the path is 1e-4)."""
+    STEP_TOL = 2e-5
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -544,7 +546,7 @@ def test_stage_a_gemm(k, ncols, nrows, ldx, offs):
     xd, wd = x.to(dev), w.to(dev)
     ldo = (ncols + 31) // 32 * 32 if ncols > 100 else ncols        # padded rows (the G layout) and dense rows (Gb)
     od = torch.full((nb, nrows, ldo), float("nan"), device=dev)
-    L.check(lib.ddp_stage_a(xd.data_ptr(), ldx, nrows, None, None, nrows, (C.c_int32 * nb)(*offs), nb, wd.data_ptr(), k, ncols,
+    L.check(lib.ddp_stage_a(xd.data_ptr(), ldx, nrows, None, None, nrows, (C.c_int32 * nb)(*offs), nb, wd.data_ptr(), None, k, ncols,
                             od.data_ptr(), ldo, _stream()), "ddp_stage_a")
     torch.cuda.synchronize()
     assert torch.isnan(od[:, :, ncols:]).all()                     # the padding columns are not written
@@ -553,6 +555,48 @@ def test_stage_a_gemm(k, ncols, nrows, ldx, offs):
     for b in range(nb):
         want = x[:, offs[b]:offs[b] + k].double() @ w[b].double()
         assert float((got[b] - want).abs().max()) < 2e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("k,ncols,nrows,nb", [(60, 12672, 1111, 2), (60, 2560, 37, 3), (32, 3104, 500, 2), (60, 12672, 4500, 1)])
+def test_stage_a_bf16x3_error(k, ncols, nrows, nb):
+    """The bf16x3 form of stage A (both operands as three bfloat16 terms, six cross products accumulated in fp32 on
+    v_mfma_f32_32x32x16_bf16) against an fp64 product: the error of an element stays below 2^-21 of sum_u |x w| - the class of an
+    fp32 dot product of this length (the exact-fp32 MFMA form is measured beside it) - on rows with a device-side list, in place."""
+    import ctypes as C
+    from diffdock_pocket_amd import _lib as L
+    from diffdock_pocket_amd.packing import split_bf16x3
+    from diffdock_pocket_amd.score_model import _stream
+    torch.manual_seed(k + nrows)
+    dev = _dev()
+    lib = L.load()
+    ldx, ldo = 184, ncols
+    x = (torch.randn(nrows, ldx) * torch.exp(torch.randn(nrows, 1))).to(dev)       # rows of very different magnitude
+    w = (torch.randn(nb, k, ncols) * 0.1 * torch.exp(2 * torch.randn(nb, 1, ncols))).to(dev)
+    offs = [0, 120, 60][:nb]
+    offs_c = (C.c_int32 * nb)(*offs)
+    w3 = split_bf16x3(w)
+    assert w3.dtype == torch.bfloat16 and w3.shape == (nb, 3, (k + 15) // 16, 2, ncols, 8)
+    exact = torch.stack([x[:, o:o + k].double() @ w[b].double() for b, o in enumerate(offs)])
+    scale = torch.stack([x[:, o:o + k].double().abs() @ w[b].double().abs() for b, o in enumerate(offs)])
+    out32, out3 = torch.empty(nb, nrows, ldo, device=dev), torch.full((nb, nrows, ldo), float("nan"), device=dev)
+    L.check(lib.ddp_stage_a(x.data_ptr(), ldx, nrows, None, None, nrows, offs_c, nb, w.data_ptr(), None, k, ncols, out32.data_ptr(), ldo,
+                            _stream()), "ddp_stage_a")
+    L.check(lib.ddp_stage_a(x.data_ptr(), ldx, nrows, None, None, nrows, offs_c, nb, w.data_ptr(), w3.data_ptr(), k, ncols, out3.data_ptr(),
+                            ldo, _stream()), "ddp_stage_a")
+    e32 = float(((out32.double() - exact).abs() / scale).max())
+    e3 = float(((out3.double() - exact).abs() / scale).max())
+    assert e32 < 2.0 ** -21 and e3 < 2.0 ** -21, (e32, e3)
+    # a row list with a device-side length: the listed rows only, bitwise the dense launch's rows
+    rows = torch.randperm(nrows, device=dev)[:max(nrows // 3, 1)].int().contiguous()
+    n_dev = torch.tensor([rows.numel() - 1], dtype=torch.int32, device=dev)
+    part = torch.full((nb, nrows, ldo), -7.0, device=dev)
+    L.check(lib.ddp_stage_a(x.data_ptr(), ldx, rows.numel(), rows.data_ptr(), n_dev.data_ptr(), nrows, offs_c, nb, w.data_ptr(), w3.data_ptr(),
+                            k, ncols, part.data_ptr(), ldo, _stream()), "ddp_stage_a")
+    sel = rows[:-1].long()
+    assert torch.equal(part[:, sel], out3[:, sel])
+    rest = torch.ones(nrows, dtype=torch.bool, device=dev)
+    rest[sel] = False
+    assert bool((part[:, rest] == -7.0).all())
 
 
 @pytest.mark.parametrize("n_list,cap", [(37, 300), (300, 300), (0, 64), (9000, 20000)])
@@ -571,12 +615,12 @@ def test_stage_a_row_list_with_a_device_side_length(n_list, cap):
     x, w = torch.randn(nrows, ldx, device=dev), torch.randn(nb, k, ncols, device=dev)
     dense = torch.zeros((nb, nrows, ldo), device=dev)
     offs_c = (C.c_int32 * nb)(*offs)
-    L.check(lib.ddp_stage_a(x.data_ptr(), ldx, nrows, None, None, nrows, offs_c, nb, w.data_ptr(), k, ncols, dense.data_ptr(), ldo,
+    L.check(lib.ddp_stage_a(x.data_ptr(), ldx, nrows, None, None, nrows, offs_c, nb, w.data_ptr(), None, k, ncols, dense.data_ptr(), ldo,
                             _stream()), "ddp_stage_a")
     rows = torch.randperm(nrows, device=dev)[:cap].to(torch.int32).sort().values.contiguous()
     n_dev = torch.tensor([n_list], dtype=torch.int32, device=dev)
     out = torch.full((nb, nrows, ldo), -7.0, device=dev)
-    L.check(lib.ddp_stage_a(x.data_ptr(), ldx, cap, rows.data_ptr(), n_dev.data_ptr(), nrows, offs_c, nb, w.data_ptr(), k, ncols,
+    L.check(lib.ddp_stage_a(x.data_ptr(), ldx, cap, rows.data_ptr(), n_dev.data_ptr(), nrows, offs_c, nb, w.data_ptr(), None, k, ncols,
                             out.data_ptr(), ldo, _stream()), "ddp_stage_a")
     torch.cuda.synchronize()
     listed = rows[:n_list].long()

@@ -7,6 +7,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from diffdock_pocket_amd import _lib as L  # noqa: E402
+from diffdock_pocket_amd.packing import split_bf16x3  # noqa: E402
 
 
 def timeit(fn, n=10):
@@ -26,20 +27,21 @@ def main():
     dev = torch.device("cuda:0")
     lib = L.load()
     st = torch.cuda.current_stream().cuda_stream
-    for name, N, nb, ncols in (("atom", 44440, 2, 12600), ("atom-pad32", 44440, 2, 12608), ("atom-pad512", 44440, 2, 12800),
-                               ("rec", 5560, 6, 12600), ("lig", 1480, 6, 12600)):
+    for name, N, nb, ncols in (("atom", 44440, 2, 12672), ("rec", 5560, 6, 12672), ("lig", 1480, 6, 12672), ("lig5", 185, 6, 12672)):
         k, ldx = 60, 180
         x = torch.randn(N, ldx, device=dev)
         w = torch.randn(nb, k, ncols, device=dev)
         ldo = (ncols + 31) // 32 * 32
         out = torch.empty(nb, N, ldo, device=dev)
         offs = (C.c_int32 * nb)(*[120 * (i % 2) for i in range(nb)])
-        t_mine = timeit(lambda: L.check(lib.ddp_stage_a(x.data_ptr(), ldx, N, None, None, N, offs, nb, w.data_ptr(), k, ncols, out.data_ptr(), ldo, st), "a"))
+        t_mine = timeit(lambda: L.check(lib.ddp_stage_a(x.data_ptr(), ldx, N, None, None, N, offs, nb, w.data_ptr(), None, k, ncols, out.data_ptr(), ldo, st), "a"))
+        w3 = split_bf16x3(w)
+        t_x3 = timeit(lambda: L.check(lib.ddp_stage_a(x.data_ptr(), ldx, N, None, None, N, offs, nb, w.data_ptr(), w3.data_ptr(), k, ncols, out.data_ptr(), ldo, st), "a"))
         A = torch.stack([x[:, 120 * (i % 2):120 * (i % 2) + k] for i in range(nb)])
         t_bmm = timeit(lambda: torch.bmm(A, w))
         t_mm = timeit(lambda: [torch.mm(A[i], w[i]) for i in range(nb)])
         gb = nb * N * ncols * 4 / 1e9
-        print(f"{name}: N={N} nb={nb}  {gb:.2f} GB out | ddp_stage_a {t_mine:.3f} ms ({gb / t_mine:.2f} TB/s)  bmm {t_bmm:.3f} ms ({gb / t_bmm:.2f})  "
+        print(f"{name}: N={N} nb={nb}  {gb:.2f} GB out | ddp_stage_a fp32 {t_mine:.3f} ms ({gb / t_mine:.2f} TB/s)  bf16x3 {t_x3:.3f} ms ({gb / t_x3:.2f})  bmm {t_bmm:.3f} ms ({gb / t_bmm:.2f})  "
               f"mm x{nb} {t_mm:.3f} ms ({gb / t_mm:.2f})")
 
 
