@@ -90,10 +90,12 @@ class _Fork:
         with torch.cuda.stream(st):
             return fn()
 
-    def join(self):
-        for st in self.used:
-            self.main.wait_stream(st)
-        self.used = []
+    def join(self, only=None):
+        """Main waits for the forked streams (`only`: for that slot alone, the others stay forked)."""
+        for st in list(self.used):
+            if only is None or st is self.side[only % len(self.side)]:
+                self.main.wait_stream(st)
+                self.used.remove(st)
 
 
 class ForwardEngine:
@@ -105,7 +107,7 @@ class ForwardEngine:
         """Side streams of the current stream for a layer's independent launches."""
         f = self._forks.get(dev)     # (created by the first ordinary step: no stream is created during a capture)
         if f is None:
-            f = self._forks[dev] = _Fork(dev, 3)
+            f = self._forks[dev] = _Fork(dev, 4)
         f.main = torch.cuda.current_stream(dev)
         return f
 
@@ -692,15 +694,46 @@ class ForwardEngine:
                 per[k] = (csr, so_k, x_src)
                 if so_k is not None and csr.n_edges > 0 and not (k == 3 and c1 is not None):
                     groups.setdefault((st_, rows[0]), (x_src, rows, []))[2].append((k, m.conv_layers[9 * l + k]))
+            # ---- the direct convs (receptor<-atom: one edge per atom, nothing to factorise) need no stage A.  Small batches: they
+            # start FIRST, on a stream of their own, beside stage A - their few long workgroups (one per 64 atoms, 130 KB of LDS:
+            # they cannot share a CU with the 32-edge kernel's) then hold their CUs before that kernel's thousands arrive,
+            # instead of waiting for CUs it has drained (measured at 5 samples: 0.3 ms alone, 0.7 - 1.0 ms launched beside it)
+            tasks, tasks_g, msgs = [], [], {}
+            nb_g = nb_d = 0.0
+            prof_on = K.profiler() is not None
+            c1_here = c1 is not None
+
+            def node_bytes(k):     # algorithmic node bytes of a conv call (profiler only)
+                d_in = P.irreps_dim(P.irreps_muls(ns, m.nv, l))
+                return 4.0 * (nodes[SRC_TYPE[k]][1] * d_in + nodes[RECV_TYPE[k]][1] * spec.d_out)
+
+            for k, (csr, so_k, x_src) in per.items():
+                if so_k is not None or (k == 3 and c1_here):
+                    continue
+                x_recv, _, ek = arr[k]
+                pkc = m.conv_layers[9 * l + k].packed(dev)
+                msg = torch.empty((csr.n_edges, spec.d_out), device=dev)
+                msgs[k] = (msg, csr, pkc)
+                if csr.n_edges == 0:
+                    continue
+                if prof_on:
+                    nb_d += node_bytes(k)
+                segs = [(e[ek], csr.eid, ns, ns), (x_recv, csr.recv, ldx, ns), (x_src, csr.src, ldx, ns)]
+                tasks.append(K.make_task(pkc, x_src, ldx, csr, sh[ek], segs, msg))
+            direct_first = fork is not None and bool(tasks)
+            if direct_first:
+                fork.run(3, lambda: K.launch_convs(spec, tasks, node_bytes=nb_d))
             # ---- stage A: one batched product per (source-node array, row set)
             gmap = {}
             for gi, ((st_, gid), (x_src, rows, convs)) in enumerate(groups.items()):
                 if fork is not None and gi > 0:
-                    gmap.update(fork.run(gi - 1, lambda: self._stage_a(l, convs, x_src, rows[3], rows=rows[1], rows_cnt=rows[2])))
+                    # (slots 0 - 2; slot 3 is the direct conv's alone: it is joined later than these)
+                    gmap.update(fork.run((gi - 1) % 3, lambda: self._stage_a(l, convs, x_src, rows[3], rows=rows[1], rows_cnt=rows[2])))
                 else:
                     gmap.update(self._stage_a(l, convs, x_src, rows[3], rows=rows[1], rows_cnt=rows[2]))
             if fork is not None:
-                fork.join()
+                for i_ in range(3):
+                    fork.join(only=i_)
             x_clean = None
             if c1 is not None:      # atom<-atom at layer 1: touched edges per sample + the clean pairs once
                 conv3 = m.conv_layers[9 * l + 3]
@@ -713,11 +746,10 @@ class ForwardEngine:
                 g_v = self._stage_a(l, [(3, conv3)], x_clean, c1.n0)
                 keep += [g_d, g_v, x_clean]
             keep.append(gmap)
-            # ---- conv tasks
-            tasks, tasks_g, msgs = [], [], {}
-            nb_g = nb_d = 0.0
-            prof_on = K.profiler() is not None
+            # ---- the factorised convs
             for k, (csr, so_k, x_src) in per.items():
+                if k in msgs:
+                    continue
                 x_recv, _, ek = arr[k]
                 conv = m.conv_layers[9 * l + k]
                 pkc = conv.packed(dev)
@@ -740,26 +772,15 @@ class ForwardEngine:
                 msgs[k] = (msg, csr, pkc)
                 if csr.n_edges == 0:
                     continue
-                if prof_on:     # algorithmic node bytes of the conv call (profiler only)
-                    d_in = P.irreps_dim(P.irreps_muls(ns, m.nv, l))
-                    b_ = 4.0 * (nodes[SRC_TYPE[k]][1] * d_in + nodes[RECV_TYPE[k]][1] * spec.d_out)
-                    if so_k is not None:
-                        nb_g += b_
-                    else:
-                        nb_d += b_
-                if so_k is not None:
-                    segs = [(e_base, so_k.eid, ns, ns), (x_recv, so_k.recv, ldx, ns), (x_src, so_k.src, ldx, ns)]
-                    tasks_g.append(K.make_task(conv.packed_g(dev), x_src, ldx, so_k, sh_k, segs, msg, g=[gmap.get((k, s_)) for s_ in (0, 1)]))
-                else:
-                    segs = [(e_base, csr.eid, ns, ns), (x_recv, csr.recv, ldx, ns), (x_src, csr.src, ldx, ns)]
-                    tasks.append(K.make_task(pkc, x_src, ldx, csr, sh_k, segs, msg))
+                if prof_on:
+                    nb_g += node_bytes(k)
+                segs = [(e_base, so_k.eid, ns, ns), (x_recv, so_k.recv, ldx, ns), (x_src, so_k.src, ldx, ns)]
+                tasks_g.append(K.make_task(conv.packed_g(dev), x_src, ldx, so_k, sh_k, segs, msg, g=[gmap.get((k, s_)) for s_ in (0, 1)]))
             mark("conv_prep")
-            if fork is not None and tasks and tasks_g:
-                fork.run(0, lambda: K.launch_convs(spec, tasks, node_bytes=nb_d))     # the direct convs beside the factorised ones
-                K.launch_convs(spec_g, tasks_g, flops_spec=spec, node_bytes=nb_g)
+            K.launch_convs(spec_g, tasks_g, flops_spec=spec, node_bytes=nb_g)
+            if direct_first:
                 fork.join()
             else:
-                K.launch_convs(spec_g, tasks_g, flops_spec=spec, node_bytes=nb_g)
                 K.launch_convs(spec, tasks, node_bytes=nb_d)
             mark("conv_launch")
             if dbg is not None:   # every conv's own output = segmented mean + BatchNorm of its messages alone

@@ -408,10 +408,13 @@ class TensorProductScoreModel(nn.Module):
         # forked streams (engine._Fork); above this many pocket atoms in the batch every kernel fills the chip on its own
         self.concurrent_small_batches = True
         self.concurrent_max_atoms = 16000
-        # Stage A on the bf16 matrix cores with both operands split into three bfloat16 terms (csrc/ddp_gemm.hip,
-        # ddp_stage_a_x3_kernel): fp32-class accuracy (error <= ~2^-22 sum |x w|, measured against fp64 in
-        # tests/test_gpu_parity.py::test_stage_a_bf16x3_error), 1/2.7 of the matrix time.  False: exact fp32 MFMA (an fmaf chain).
-        self.stage_a_bf16x3 = True
+        # Option, OFF: stage A on the bf16 matrix cores with both operands split into three bfloat16 terms (csrc/ddp_gemm.hip,
+        # ddp_stage_a_x3_kernel): fp32-class accuracy (error <= 2^-21 sum |x w|, measured against fp64 in
+        # tests/test_gpu_parity.py::test_stage_a_bf16x3_error) at 1/2.7 of the matrix time.  Measured on one box, alternating
+        # (profiles/r03_stage_a_bf16x3_ab.txt): stage A 5.77 -> 5.54 ms per 40-sample step, but the 32-edge conv kernel that
+        # follows every stage A runs 5 - 6 % slower (3.26 -> 3.45 ms per launch: the chip holds a lower clock after the bf16
+        # bursts) and the step gets 1 ms LONGER (32.0 -> 33.0 ms); at 5 samples 5.48 -> 5.44 ms.  False = exact fp32 MFMA.
+        self.stage_a_bf16x3 = False
         self._overflow_flag = None
         self.exact_sizes = False       # test mode: device-side list sizes are read back and every list is cut to its length
         self.debug_conv_outputs = None  # set to a dict: forward then stores the output [n_out, d_out] of every conv call in it

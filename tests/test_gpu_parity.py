@@ -599,6 +599,21 @@ def test_stage_a_bf16x3_error(k, ncols, nrows, nb):
     assert bool((part[:, rest] == -7.0).all())
 
 
+def test_forward_with_bf16x3_stage_a_agrees_with_the_exact_form():
+    """model.stage_a_bf16x3 (an option, off by default): the same forward with stage A as bf16x3 products - scores within 2e-5
+    of the exact-fp32 form's (parity tolerance of the path: 1e-4)."""
+    case, gold, batch, sd = case_inputs("cfg2_noflex")
+    model = _model_for(case, sd)
+    b = batch.to(_dev())
+    out = {}
+    for flag in (False, True):
+        model.stage_a_bf16x3 = flag
+        out[flag] = [t.clone() for t in model(b)]
+    assert any(not torch.equal(a, c) for a, c in zip(out[False], out[True]))      # (the option did switch kernels)
+    for a, c in zip(out[False], out[True]):
+        assert elementwise_excess(c, a, 2e-5, 2e-5) <= 1
+
+
 @pytest.mark.parametrize("n_list,cap", [(37, 300), (300, 300), (0, 64), (9000, 20000)])
 def test_stage_a_row_list_with_a_device_side_length(n_list, cap):
     """ddp_stage_a on a ROW LIST whose length lives in device memory: exactly the listed rows of out are written (in place, at
