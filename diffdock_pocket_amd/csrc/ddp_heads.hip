@@ -15,6 +15,14 @@
 #pragma clang fp contract(off)
 
 #define DDP_HEAD_THREADS 64
+#define DDP_HEAD_MAX_SD 64   // widest sigma embedding the read-out kernel stages in LDS
+
+// wave-wide sum in a fixed order (all lanes get it)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+  return v;
+}
 
 struct PrologueLaunch {
   ddp_prologue_args_t a;
@@ -24,43 +32,48 @@ struct PrologueLaunch {
 __global__ __launch_bounds__(DDP_HEAD_THREADS) void ddp_step_prologue_kernel(PrologueLaunch L) {
   const ddp_prologue_args_t& A = L.a;
   const int b = blockIdx.x, tid = threadIdx.x;
-  if (b < L.blk_bond[0]) {   // ---- one thread per graph
-    const int g = b * DDP_HEAD_THREADS + tid;
-    if (g >= A.n_graphs) return;
-    float s0 = 0.f;
+  if (b < L.blk_bond[0]) {   // ---- one wave per graph (its loops are chains of dependent loads for a single thread)
+    const int g = b, lane = tid;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (!A.sigma[k]) continue;
-      if (A.t[k] && A.sig_max[k] > 0.f) {   // (sig_max <= 0: sigma[k] is an INPUT - the caller's own t_to_sigma made it)
-        const float t = A.t[k][(size_t)g * A.t_stride[k]];
-        A.sigma[k][g] = powf(A.sig_min[k], 1.0f - t) * powf(A.sig_max[k], t);   // sigma_min^(1-t) * sigma_max^t
+    for (int k = 0; k < 4; ++k) {   // component k on lane k
+      if (lane == k && A.sigma[k]) {
+        float s = 0.f;
+        if (A.t[k] && A.sig_max[k] > 0.f) {   // (sig_max <= 0: sigma[k] is an INPUT - the caller's own t_to_sigma made it)
+          const float t = A.t[k][(size_t)g * A.t_stride[k]];
+          s = powf(A.sig_min[k], 1.0f - t) * powf(A.sig_max[k], t);   // sigma_min^(1-t) * sigma_max^t
+          A.sigma[k][g] = s;
+        } else {
+          s = A.sigma[k][g];
+        }
+        if (k == 0 && A.cut) A.cut[g] = s * A.cut_mul + A.cut_add;
       }
-      if (k == 0) s0 = A.sigma[0][g];
     }
-    if (A.cut) A.cut[g] = s0 * A.cut_mul + A.cut_add;
     if (A.graph_emb) {   // [sin(scale t w) | cos(scale t w) | 0]  (utils/diffusion_utils.py:73-84), t = the tr time
       const float st = A.emb_scale * A.t[0][(size_t)g * A.t_stride[0]];
       const int half = A.sd / 2;
       float* o = A.graph_emb + (size_t)g * A.sd;
-      for (int s = 0; s < half; ++s) {
+      for (int s = lane; s < half; s += DDP_HEAD_THREADS) {
         const float arg = st * A.freq[s];
         o[s] = sinf(arg);
         o[half + s] = cosf(arg);
       }
-      if (A.sd & 1) o[A.sd - 1] = 0.f;
+      if ((A.sd & 1) && lane == 0) o[A.sd - 1] = 0.f;
     }
-    if (A.center) {      // mean position of the graph's ligand atoms, summed in index order
+    if (A.center) {      // mean position of the graph's ligand atoms: lane l sums atoms l, l + 64, ... in order, then a fixed tree
       const int p0 = A.graph_ptr[g], p1 = A.graph_ptr[g + 1];
       float x = 0.f, y = 0.f, z = 0.f;
-      for (int p = p0; p < p1; ++p) {
+      for (int p = p0 + lane; p < p1; p += DDP_HEAD_THREADS) {
         x += A.lig_pos[3 * p];
         y += A.lig_pos[3 * p + 1];
         z += A.lig_pos[3 * p + 2];
       }
-      const float n = (float)(p1 - p0);
-      A.center[3 * g] = __fdiv_rn(x, n);
-      A.center[3 * g + 1] = __fdiv_rn(y, n);
-      A.center[3 * g + 2] = __fdiv_rn(z, n);
+      x = wave_sum(x); y = wave_sum(y); z = wave_sum(z);
+      if (lane == 0) {
+        const float n = (float)(p1 - p0);
+        A.center[3 * g] = __fdiv_rn(x, n);
+        A.center[3 * g + 1] = __fdiv_rn(y, n);
+        A.center[3 * g + 2] = __fdiv_rn(z, n);
+      }
     }
     return;
   }
@@ -102,7 +115,7 @@ extern "C" int ddp_step_prologue(const ddp_prologue_args_t* args, void* stream) 
   PrologueLaunch L;
   L.a = A;
   auto blocks = [](int n) { return n > 0 ? (n + DDP_HEAD_THREADS - 1) / DDP_HEAD_THREADS : 0; };
-  int nb = blocks(A.n_graphs);
+  int nb = A.n_graphs;      // one wave per graph
   for (int h = 0; h < 2; ++h) {
     if (A.bonds[h].n > 0 && (!A.bonds[h].pos || !A.bonds[h].b0 || !A.bonds[h].b1))
       return ddp_fail(DDP_EINVAL, "ddp_step_prologue: bond job");
@@ -122,17 +135,17 @@ extern "C" int ddp_step_prologue(const ddp_prologue_args_t* args, void* stream) 
   return 0;
 }
 
-// wave-wide sum in a fixed order (all lanes get it)
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
-  return v;
-}
-
 // ------------------------------------------------------------------------------------------------ tr / rot read-out
 // One wave per graph; lane j = hidden unit j of both read-out MLPs Linear(1 + sd, ns) -> ReLU -> Linear(ns, 1).
 __global__ __launch_bounds__(DDP_HEAD_THREADS) void ddp_trrot_head_kernel(ddp_trrot_args_t A) {
   const int g = blockIdx.x, j = threadIdx.x;
+  // the first Linear's weights go through LDS: coalesced, independent loads (read straight from memory, lane j walks row j: one
+  // dependent 4-byte load per product, 33 memory round trips)
+  __shared__ float wl[2][DDP_HEAD_THREADS * (DDP_HEAD_MAX_SD + 1)];
+  const int k_in = 1 + A.sd;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    for (int i = j; i < A.ns * k_in; i += DDP_HEAD_THREADS) wl[h][i] = A.w1[h][i];
   const float* gp = A.gp + (size_t)g * A.ld_gp;
   // (:362-363) the 1o and 1e halves of the final conv's output are added
   float v[2][3];
@@ -142,13 +155,13 @@ __global__ __launch_bounds__(DDP_HEAD_THREADS) void ddp_trrot_head_kernel(ddp_tr
     v[1][c] = gp[3 + c] + gp[9 + c];
   }
   const float* emb = A.graph_emb + (size_t)g * A.sd;
-  const int k_in = 1 + A.sd;
+  __syncthreads();
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const float norm = sqrtf(v[h][0] * v[h][0] + v[h][1] * v[h][1] + v[h][2] * v[h][2]);
     float hid = 0.f;
     if (j < A.ns) {
-      const float* w = A.w1[h] + (size_t)j * k_in;
+      const float* w = wl[h] + j * k_in;
       float acc = w[0] * norm;
       for (int k = 0; k < A.sd; ++k) acc += w[1 + k] * emb[k];
       acc += A.b1[h][j];
@@ -178,7 +191,7 @@ extern "C" int ddp_trrot_head(const ddp_trrot_args_t* args, void* stream) {
   if (!args) return ddp_fail(DDP_EINVAL, "ddp_trrot_head: null argument");
   const ddp_trrot_args_t& A = *args;
   if (A.n_graphs <= 0) return 0;
-  if (!A.gp || !A.graph_emb || A.ld_gp < 12 || A.ns < 1 || A.ns > DDP_HEAD_THREADS || A.sd < 0)
+  if (!A.gp || !A.graph_emb || A.ld_gp < 12 || A.ns < 1 || A.ns > DDP_HEAD_THREADS || A.sd < 0 || A.sd > DDP_HEAD_MAX_SD)
     return ddp_fail(DDP_EINVAL, "ddp_trrot_head: arguments");
   for (int h = 0; h < 2; ++h)
     if (!A.w1[h] || !A.b1[h] || !A.w2[h] || !A.b2[h] || !A.out[h]) return ddp_fail(DDP_EINVAL, "ddp_trrot_head: null weights");

@@ -1,7 +1,7 @@
 # Everything the round-end evidence comes from, in one gpurun call:  gpurun --timeout 3600 -- "bash tools/gpu_round.sh <name>"
 # GPU tests, bench lines (configs[1] with sub-records + cpu_baseline, configs[2], the 5-sample shard, a 2-rank gloo run), rocprofv3
 # kernel stats (rigid, flexible, 5 samples, cfg1), the three PMC passes + tools/pmc_collect.py, device-idle analysis.
-# Outputs under gpurun_out/<name>/.   SKIP_PYTEST=1 / SKIP_CPU=1 / SKIP_PMC=1 shorten it.
+# Outputs under gpurun_out/<name>/.   SKIP_PYTEST=1 / SKIP_CPU=1 / SKIP_PMC=1 shorten it, CPU_FULL=1 adds the unbounded CPU baseline.
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-round}
 mkdir -p $O $O/pmc_fetch $O/pmc_write $O/pmc_mfma
@@ -10,6 +10,7 @@ ulimit -c 0
 if [ -z "$SKIP_PYTEST" ]; then timeout 1500 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log; fi
 CPU=""; if [ -n "$SKIP_CPU" ]; then CPU="--no-cpu-baseline"; fi
 timeout 1500 python bench.py --steps 20 --warmup 3 $CPU > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+if [ -n "$CPU_FULL" ]; then timeout 1500 python bench.py --steps 20 --warmup 3 --no-other-workloads --no-roofline-pass --cpu-full > $O/cpu_baseline_full.json 2>> $O/bench.err; echo "cpu full rc=$?"; fi
 timeout 300 python bench.py --steps 20 --warmup 3 --flex --no-cpu-baseline > $O/bench_flex.json 2>> $O/bench.err
 timeout 300 python bench.py --samples 5 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_5samples.json 2>> $O/bench.err
 timeout 300 env DDP_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 6 --warmup 3 --no-cpu-baseline 2>> $O/bench.err | grep -v "^\[Gloo\]" > $O/bench_2rank_gloo_strong.json
