@@ -832,6 +832,18 @@ class ForwardEngine:
 
         dd = m.distance_embed_dim
         lib = L.load()
+        # ---- torsion heads (:386-434).  The three read-outs are independent chains of five small launches each (embedding ->
+        # harmonics -> conv -> mean -> MLP): the torsion heads run on forked streams beside the tr / rot head (parallel branches
+        # of the captured step)
+        fork = self._fork(dev) if (m.concurrent_heads and m.before_layers is None and m.section_timer is None) else None
+        heads = []
+        if F.tor is not None:
+            heads.append(lambda: self._torsion_head(F.tor, "final_edge_embedding", m.tor_bond_conv, "tor_final_layer", xl, lpos, dev,
+                                                    "tor_bond_conv", tor_sigma))
+        if F.sc is not None:
+            heads.append(lambda: self._torsion_head(F.sc, "sidechain_final_edge_embedding", m.sc_tor_bond_conv, "sc_tor_final_layer", xa,
+                                                    F.apos, dev, "sc_tor_bond_conv", sc_sigma))
+        preds = [fork.run(i, fn) for i, fn in enumerate(heads)] if fork is not None else None
         # ---- translation / rotation head (:357-384): ligand atoms -> their graph's centre (ddp_step_prologue: summed in index
         # order - index_add_'s float atomics land in an order that depends on what else the device is doing, and one ulp in
         # the centre is one ulp in tr / rot)
@@ -865,15 +877,13 @@ class ForwardEngine:
             a.so3_lo, a.so3_span = hw["so3_lo"], hw["so3_span"]
         L.check(lib.ddp_trrot_head(C.byref(a), K.stream()), "ddp_trrot_head")
         mark("center_head")
-        # ---- torsion heads (:386-434)
-        tor_pred = torch.empty(0, device=dev)
-        if F.tor is not None:
-            tor_pred = self._torsion_head(F.tor, "final_edge_embedding", m.tor_bond_conv, "tor_final_layer", xl, lpos, dev, "tor_bond_conv",
-                                          tor_sigma)
-        sc_pred = torch.empty(0, device=dev)
-        if F.sc is not None:
-            sc_pred = self._torsion_head(F.sc, "sidechain_final_edge_embedding", m.sc_tor_bond_conv, "sc_tor_final_layer", xa, F.apos,
-                                         dev, "sc_tor_bond_conv", sc_sigma)
+        if fork is not None:
+            fork.join()
+        else:
+            preds = [fn() for fn in heads]
+        preds = list(preds)
+        tor_pred = preds.pop(0) if F.tor is not None else torch.empty(0, device=dev)
+        sc_pred = preds.pop(0) if F.sc is not None else torch.empty(0, device=dev)
         mark("tor_heads")
         F.keep.append((center, e_c, sh_c, msg, gp, a, hw))
         return tr_pred, rot_pred, tor_pred, sc_pred

@@ -408,6 +408,7 @@ class TensorProductScoreModel(nn.Module):
         # forked streams (engine._Fork); above this many pocket atoms in the batch every kernel fills the chip on its own
         self.concurrent_small_batches = True
         self.concurrent_max_atoms = 16000
+        self.concurrent_heads = True   # the torsion read-outs on forked streams beside the tr / rot read-out (any batch size)
         # Option, OFF: stage A on the bf16 matrix cores with both operands split into three bfloat16 terms (csrc/ddp_gemm.hip,
         # ddp_stage_a_x3_kernel): fp32-class accuracy (error <= 2^-21 sum |x w|, measured against fp64 in
         # tests/test_gpu_parity.py::test_stage_a_bf16x3_error) at 1/2.7 of the matrix time.  Measured on one box, alternating
