@@ -19,7 +19,7 @@ FS = 68  # feature-buffer row stride of ddp_conv.hip
 DDP_MAX_GEMM_BATCH = 16
 EXPORTS = ["ddp_conv_messages", "ddp_segment_reduce", "ddp_edge_featurize", "ddp_torsion_sh", "ddp_stage_a",
            "ddp_pose_update", "ddp_sidechain_update", "ddp_sde_update", "ddp_radius_count", "ddp_radius_fill", "ddp_knn", "ddp_group_by_key", "ddp_node_linear", "ddp_scan_jobs", "ddp_mark_jobs", "ddp_rowcopy_jobs", "ddp_select_jobs",
-           "ddp_gather_rows", "ddp_clean_pair_maps", "ddp_step_prologue", "ddp_trrot_head", "ddp_tor_head", "ddp_radius_search_jobs", "ddp_group_by_key_jobs", "ddp_abi_version", "ddp_last_error", "ddp_source_hash"]
+           "ddp_gather_rows", "ddp_clean_pair_maps", "ddp_flex_mark", "ddp_fallback_rowmap", "ddp_step_prologue", "ddp_trrot_head", "ddp_tor_head", "ddp_radius_search_jobs", "ddp_group_by_key_jobs", "ddp_abi_version", "ddp_last_error", "ddp_source_hash"]
 
 
 class Seg(C.Structure):
@@ -205,15 +205,20 @@ def load():
     lib.ddp_sde_update.restype = C.c_int
     lib.ddp_gather_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.ddp_gather_rows.restype = C.c_int
-    lib.ddp_clean_pair_maps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                        C.c_void_p]
+    lib.ddp_clean_pair_maps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]
     lib.ddp_clean_pair_maps.restype = C.c_int
+    lib.ddp_flex_mark.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_void_p]
+    lib.ddp_flex_mark.restype = C.c_int
+    lib.ddp_fallback_rowmap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.ddp_fallback_rowmap.restype = C.c_int
     for name, st in (("ddp_step_prologue", PrologueArgs), ("ddp_trrot_head", TrRotArgs), ("ddp_tor_head", TorArgs)):
         getattr(lib, name).argtypes = [C.POINTER(st), C.c_void_p]
         getattr(lib, name).restype = C.c_int
     lib.ddp_node_linear.argtypes = [C.POINTER(NodeJob), C.c_int, C.c_void_p]
     lib.ddp_node_linear.restype = C.c_int
-    if lib.ddp_abi_version() != 9:
+    if lib.ddp_abi_version() != 10:
         raise DdpError("libddp_hip.so ABI version mismatch")
     lib.ddp_source_hash.restype = C.c_char_p
     if "DDP_HIP_LIB" not in os.environ:   # (diagnostic builds loaded through DDP_HIP_LIB carry extra -D flags, same sources)

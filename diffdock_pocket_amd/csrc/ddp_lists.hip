@@ -418,10 +418,17 @@ extern "C" int ddp_gather_rows(const float* x, int ldx, const int32_t* idx, int 
 //              = E + p % e0             otherwise (the message computed once on the complex's own edge list)
 //   rows_v[a0] = g * n0 + a0 for the first sample g in which atom a0 is untouched (g = 0 if there is none: then unused)
 __global__ __launch_bounds__(256) void ddp_clean_pair_maps_kernel(const int32_t* __restrict__ touched, const int32_t* __restrict__ recv,
-                                                                  const int32_t* __restrict__ src, int E, int e0, int B, int n0,
+                                                                  const int32_t* __restrict__ src, const int32_t* __restrict__ rowptr,
+                                                                  int E, int e0, int B, int n0,
                                                                   int32_t* __restrict__ rowmap, int32_t* __restrict__ rows_v) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < E) rowmap[i] = (touched[recv[i]] | touched[src[i]]) ? i : E + i % e0;
+  if (i < E) {
+    // the same edge in the complex's own list: position i % e0 when every sample has the same list (rigid receptor); in general
+    // the receiver's row in sample 0 at the same offset (an untouched receiver's row is, entry by entry, its copy's)
+    const int r = recv[i];
+    const int ref = rowptr ? rowptr[r % n0] + (i - rowptr[r]) : i % e0;
+    rowmap[i] = (touched[r] | touched[src[i]]) ? i : E + ref;
+  }
   if (i < n0) {
     int g = 0;
     for (int b = 0; b < B; ++b)
@@ -433,13 +440,85 @@ __global__ __launch_bounds__(256) void ddp_clean_pair_maps_kernel(const int32_t*
   }
 }
 
-extern "C" int ddp_clean_pair_maps(const int32_t* touched, const int32_t* recv, const int32_t* src, int n_edges, int e0, int n_graphs,
-                                   int n0, int32_t* rowmap, int32_t* rows_v, void* stream) {
+extern "C" int ddp_clean_pair_maps(const int32_t* touched, const int32_t* recv, const int32_t* src, const int32_t* rowptr, int n_edges,
+                                   int e0, int n_graphs, int n0, int32_t* rowmap, int32_t* rows_v, void* stream) {
   if (n_edges <= 0 || e0 <= 0 || n_graphs <= 0 || n0 <= 0 || n_edges != e0 * n_graphs)
     return ddp_fail(DDP_EINVAL, "ddp_clean_pair_maps: sizes");
   if (!touched || !recv || !src || !rowmap || !rows_v) return ddp_fail(DDP_EINVAL, "ddp_clean_pair_maps: null argument");
   const int n = n_edges > n0 ? n_edges : n0;
   hipLaunchKernelGGL(ddp_clean_pair_maps_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, touched, recv, src,
-                     n_edges, e0, n_graphs, n0, rowmap, rows_v);
+                     rowptr, n_edges, e0, n_graphs, n0, rowmap, rows_v);
   return launch_ok("ddp_clean_pair_maps launch");
+}
+
+// ------------------------------------------------------------------------------------------------ partial sharing with moving atoms
+// A batch of B poses of ONE complex whose side chains move (flexible residues): node (s, i) = copy i of sample s, n nodes and e0
+// edges per sample, every sample's edge list stored sample after sample.  An atom is "off" in sample s when its position there
+// differs bitwise from its position in sample 0 (flag == NULL), or when flag[(s, i)] != 0 (a mask made by an earlier pass).
+// For an edge list (a[e], b[e]) of per-sample node ids this marks
+//   mark[a[e]] = 1  if b[e] is off - or, with a_too, a[e] itself is off                                  (edges of sample s)
+//   mark[(s, a0)] = 1  for every edge (a0, b0) of SAMPLE 0's list whose b0 is off in sample s             (ref_list)
+//   mark[(0, i)] = 1  for every node of sample 0                                                          (the reference copy)
+// engine._lists runs it twice over the atom kNN graph (first a = the query atom of an edge, b = the neighbour it found; then
+// a = the receiver, b = the query, off = the first pass's marks) and once over receptor<-atom; the proof that an unmarked
+// receiver has, edge by edge, bitwise the inputs of its copy in sample 0 is there.
+__global__ __launch_bounds__(256) void ddp_flex_mark_kernel(const float* __restrict__ pos, const int32_t* __restrict__ flag,
+                                                            int n_b_per_graph, const int32_t* __restrict__ a, const int32_t* __restrict__ b,
+                                                            int n_edges, int e0, int n_a_per_graph, int a_too, int ref_list,
+                                                            int32_t* __restrict__ mark) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < n_a_per_graph) mark[e] = 1;
+  if (e >= n_edges) return;
+  const int s = e / e0;
+  if (s == 0) return;
+  auto off = [&](int x) {   // node x = (s, j) of the b kind (atoms)
+    if (flag) return flag[x] != 0;
+    const int x0 = x - s * n_b_per_graph;
+    return pos[3 * (size_t)x] != pos[3 * (size_t)x0] || pos[3 * (size_t)x + 1] != pos[3 * (size_t)x0 + 1] ||
+           pos[3 * (size_t)x + 2] != pos[3 * (size_t)x0 + 2];
+  };
+  const int ai = a[e], bi = b[e];
+  bool m = off(bi);
+  if (a_too) m = m || off(ai);
+  if (m) mark[ai] = 1;
+  if (ref_list) {   // sample 0's edge number e - s e0, seen with sample s's flags / positions
+    const int l = e - s * e0;
+    if (off(b[l] + s * n_b_per_graph)) mark[a[l] + s * n_a_per_graph] = 1;
+  }
+}
+
+extern "C" int ddp_flex_mark(const float* pos, const int32_t* flag, int n_b_per_graph, const int32_t* a, const int32_t* b, int n_edges,
+                             int e0, int n_a_per_graph, int a_too, int ref_list, int32_t* mark, void* stream) {
+  if (n_edges <= 0 || e0 <= 0 || n_edges % e0 || n_b_per_graph <= 0 || n_a_per_graph <= 0)
+    return ddp_fail(DDP_EINVAL, "ddp_flex_mark: sizes");
+  if ((!pos && !flag) || !a || !b || !mark) return ddp_fail(DDP_EINVAL, "ddp_flex_mark: null argument");
+  if (a_too && n_a_per_graph != n_b_per_graph) return ddp_fail(DDP_EINVAL, "ddp_flex_mark: a_too needs both ends of one node kind");
+  const int n = n_edges > n_a_per_graph ? n_edges : n_a_per_graph;
+  hipLaunchKernelGGL(ddp_flex_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pos, flag, n_b_per_graph, a, b,
+                     n_edges, e0, n_a_per_graph, a_too, ref_list, mark);
+  return launch_ok("ddp_flex_mark launch");
+}
+
+// Message row of every position of the FULL receiver-CSR list when only the rows of the marked receivers were kept
+// (ddp_rowcopy_jobs: new_rowptr) and an unmarked receiver (s, i) reads the messages of its copy (0, i):
+//   rowmap[p] = new_rowptr[t] + (p - old_rowptr[r]),   r = recv[p],   t = mark[r] ? r : r % n_recv_per_graph
+__global__ __launch_bounds__(256) void ddp_fallback_rowmap_kernel(const int32_t* __restrict__ mark, const int32_t* __restrict__ recv,
+                                                                  const int32_t* __restrict__ old_rowptr,
+                                                                  const int32_t* __restrict__ new_rowptr, int n_edges,
+                                                                  int n_recv_per_graph, int32_t* __restrict__ rowmap) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n_edges) return;
+  const int r = recv[p];
+  const int t = mark[r] ? r : r % n_recv_per_graph;
+  rowmap[p] = new_rowptr[t] + (p - old_rowptr[r]);
+}
+
+extern "C" int ddp_fallback_rowmap(const int32_t* mark, const int32_t* recv, const int32_t* old_rowptr, const int32_t* new_rowptr,
+                                   int n_edges, int n_recv_per_graph, int32_t* rowmap, void* stream) {
+  if (n_edges <= 0) return 0;
+  if (n_recv_per_graph <= 0) return ddp_fail(DDP_EINVAL, "ddp_fallback_rowmap: sizes");
+  if (!mark || !recv || !old_rowptr || !new_rowptr || !rowmap) return ddp_fail(DDP_EINVAL, "ddp_fallback_rowmap: null argument");
+  hipLaunchKernelGGL(ddp_fallback_rowmap_kernel, dim3((n_edges + 255) / 256), dim3(256), 0, (hipStream_t)stream, mark, recv, old_rowptr,
+                     new_rowptr, n_edges, n_recv_per_graph, rowmap);
+  return launch_ok("ddp_fallback_rowmap launch");
 }

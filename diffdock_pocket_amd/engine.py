@@ -142,7 +142,7 @@ class ForwardEngine:
         self._layers(S, F, dev, mark)
         out = self._heads(data, S, F, lig, rec, atom, dev, mark)
         m.last_stats = LazyStats(S.stats, F.cnt, {"E_ll": "ll", "E_lr": "lr", "E_la": "la", "n_near": "near",
-                                                  "clean1_dirty_edges": "dirty"})
+                                                  "clean1_dirty_edges": "dirty", "flex0_kept_aa_edges": "fx_3"})
         prof = K.profiler()
         if prof is not None:
             prof.hold = getattr(prof, "hold", [])
@@ -352,12 +352,13 @@ class ForwardEngine:
         if m.share_layer0 and B > 1 and m.debug_conv_outputs is None and self._one_time(data, lig, rec, atom):
             ar = S.ar
             if S.num_flex > 0:      # side chains move per sample: only the receptor-receptor part can be shared
-                sh_ = m._cached("shared0_rec", (rec.x, rec.pos, rr),
-                                lambda: m._shared_receptor_side(B, rec, atom, rpos, apos, lay_r, lay_a, rr.long(), ar.long(), aa, atoms=False))
+                sh_ = m._cached("shared0_rec", (rec.x, rec.pos, rr, atom.x, ar),
+                                lambda: m._shared_receptor_side(B, rec, atom, rpos, apos, lay_r, lay_a, rr.long(), ar.long(), aa, atoms="static"))
             else:
                 sh_ = m._cached("shared0", (rec.x, rec.pos, atom.x, atom.pos, rr, ar, aa),
                                 lambda: m._shared_receptor_side(B, rec, atom, rpos, apos, lay_r, lay_a, rr.long(), ar.long(), aa))
             shared0 = {k: v for k, v in sh_.items() if v is not None}
+        F.flex_static = shared0.pop("flex", None)
         F.shared0 = shared0
 
         def rows32(name, ei, k):   # int32 rows of a step-independent edge set (kept across calls), graph 0 only when shared
@@ -451,7 +452,7 @@ class ForwardEngine:
         cnt, c, so = F.cnt, F.c, F.so
         i32e = lambda n: torch.empty(n, dtype=torch.int32, device=dev)      # noqa: E731
         # (every zero-initialised mask of this function is a slice of ONE zero-filled block: one launch)
-        zpool = [torch.zeros(4 * (Na + Nr) + Na + 64, dtype=torch.int32, device=dev), 0]
+        zpool = [torch.zeros(6 * (Na + Nr) + Na + 64, dtype=torch.int32, device=dev), 0]
 
         def i32z(n):
             if zpool[1] + n > zpool[0].numel():
@@ -549,6 +550,72 @@ class ForwardEngine:
             K.group_jobs(gj)
             F.keep.append(gj)
 
+        # ---- Layer 0 with flexible side chains (N poses of one complex, only the flexible residues' side chains differ between
+        # the samples).  The node features entering layer 0 are the same in every sample (one diffusion time), so the message
+        # of an edge is the same wherever its two ends sit where they sit in sample 0.  The atom graph is a kNN graph: the edge
+        # r <- q exists because r is one of the k nearest atoms of the QUERY q (reference :524; receivers have no fixed degree).
+        # "Moved" = position differs from sample 0's.  (1) If q and every member of q's list in sample s AND in sample 0 is
+        # unmoved in s, both lists are the k nearest unmoved atoms around q at identical distances: equal, entry by entry.
+        # (2) A receiver r none of whose incoming edges - in sample s or in sample 0 - leaves a query failing (1) therefore has
+        # the same incoming edges, in the same order (edges are listed by query), with the same geometry as its copy in sample 0
+        # (a moved r fails: every query that found it fails (1)).  Such receivers read sample 0's messages through a row map;
+        # sample 0 and the marked receivers of the other samples are computed (pruned-list machinery: stage A runs on the kept
+        # edges' source rows only).  atom<-receptor (one edge per atom) uses the same receiver marks (a superset of the moved
+        # atoms); receptor<-atom: a residue needs its own messages if one of its atoms moved.
+        # Bitwise the general path (tests/test_gpu_parity.py::test_flexible_layer0_sharing_is_exact).
+        F.flex0 = None
+        fx = getattr(F, "flex_static", None)
+        kk = m.atom_max_neighbors if m.atom_max_neighbors else 32
+        if (fx is not None and m.share_flex_layer0 and S.num_flex > 0 and not dbg and 0 not in F.pruned and L_ >= 2
+                and 3 in F.fact and 5 in F.fact and E_aa == Na * kk and E_aa % B == 0 and E_aa >= m.plan_min_edges):
+            na, e_ar, nr = fx
+            e0 = E_aa // B
+            qdirty, dirty, need_r = i32z(Na), i32z(Na), i32z(Nr)
+            # pass 1, per QUERY atom q (the source end: edge r <- q exists because r is one of q's k nearest): q's list may differ
+            # from sample 0's, or carries other geometry, if q or a member of its list - here or in sample 0 - moved
+            K.flex_mark(c[3].src, c[3].recv, E_aa, e0, na, na, qdirty, pos=F.apos, a_too=True, ref_list=True)
+            # pass 2, per RECEIVER r: its incoming edges are those of its copy in sample 0 unless one of them - here or there -
+            # leaves such a query (r moved itself: then every query that found it is marked, and r with them)
+            K.flex_mark(c[3].recv, c[3].src, E_aa, e0, na, na, dirty, flag=qdirty, a_too=True, ref_list=True)
+            K.flex_mark(c[8].recv, c[8].src, c[8].n_edges, e_ar, nr, na, need_r, pos=F.apos)
+            scans, copies, pl, rowmaps = [], [], {}, {}
+            for k, need, n in ((3, dirty, Na), (5, dirty, Na), (8, need_r, Nr)):
+                full = c[k]
+                v = EdgeView(full.n_edges, i32e(full.n_edges), i32e(full.n_edges), i32e(full.n_edges), rowptr=i32e(n + 1), cnt=cnt[f"fx_{k}"])
+                scans.append(K.scan_job(n, flag=need, rowptr=full.rowptr, excl=v.rowptr, total=cnt[f"fx_{k}"]))
+                copies.append(K.rowcopy_job(n, need, full.rowptr, v.rowptr, [full.recv, full.src, full.eid], [v.recv, v.src, v.eid]))
+                pl[k] = v
+            K.scan_jobs(scans)
+            K.rowcopy_jobs(copies)
+            for k, need, n_per in ((3, dirty, na), (5, dirty, na), (8, need_r, nr)):
+                rowmaps[k] = i32e(c[k].n_edges)
+                K.fallback_rowmap(need, c[k].recv, c[k].rowptr, pl[k].rowptr, c[k].n_edges, n_per, rowmaps[k])
+            # source rows stage A has to produce: atoms for atom<-atom, residues for atom<-receptor and ligand<-receptor
+            rows_mask = {"a": i32z(Na), "r": i32z(Nr)}
+            marks = [K.mark_job(rows_mask["a"], pl[3].src, pl[3].n_edges, pl[3].cnt),
+                     K.mark_job(rows_mask["r"], pl[5].src, pl[5].n_edges, pl[5].cnt)]
+            if 1 in F.fact and c[1].n_edges > 0:
+                marks.append(K.mark_job(rows_mask["r"], c[1].src, c[1].n_edges, c[1].cnt))
+            K.mark_jobs(marks)
+            lists, scans = {}, []
+            for t in ("a", "r"):
+                rows = i32e(n_of[t])
+                scans.append(K.scan_job(n_of[t], flag=rows_mask[t], lst=rows, total=cnt[f"rows0_{t}"]))
+                lists[t] = (rows, cnt[f"rows0_{t}"])
+            K.scan_jobs(scans)
+            gj, pso = [], {}
+            for k in (3, 5):
+                v = pl[k]
+                n_keys = n_of[SRC_TYPE[k]]
+                w = SimpleNamespace(rp=i32e(n_keys + 1), perm=i32e(v.n_edges), key=i32e(v.n_edges), o0=i32e(v.n_edges), o1=i32e(v.n_edges))
+                gj.append(K.group_job(v.src, v.n_edges, n_keys, [v.recv, v.eid], w.rp, w.perm, w.key, [w.o0, w.o1],
+                                      i32e(n_keys + v.n_edges), n_dev=v.cnt))
+                pso[k] = EdgeView(v.n_edges, w.o0, w.key, w.o1, pos=w.perm, cnt=v.cnt)
+            K.group_jobs(gj)
+            F.keep.append(gj)
+            F.pruned[0], F.pruned_so[0], F.rows_a[0] = pl, pso, lists
+            F.flex0 = SimpleNamespace(dirty=dirty, need_r=need_r, rowmaps=rowmaps, na=na, e0=e0)
+
         # ---- Layer 1, atom<-atom, sampling batches of one rigid complex (shared0 has conv 3): after the shared layer 0 an
         # atom's features differ between the samples only if an atom<-ligand message reached it ("touched", the atoms within
         # 5 A of that sample's ligand, ~15 %).  A layer-1 atom<-atom message between two untouched atoms is therefore the same
@@ -557,19 +624,25 @@ class ForwardEngine:
         # computed per sample (source-ordered sub-list, stage A on their source rows only).  Messages of a clean pair are
         # bitwise those the general path computes (same inputs, per-edge arithmetic), the mean sums the same values in the
         # same order: the result is bitwise the general path's (GPU test).  Layer 1 must not be one of the pruned layers.
-        if (m.share_clean_layer1 and 3 in F.shared0 and 3 in so and L_ >= 4 and E_aa > 0 and E_aa >= m.plan_min_edges and not dbg
-                and 1 not in F.pruned):
-            n0, e0, _ = F.shared0[3]
+        # With flexible side chains (F.flex0): the same, with "touched" widened by the receivers layer 0 computed per sample.
+        if (m.share_clean_layer1 and (3 in F.shared0 or F.flex0 is not None) and 3 in so and L_ >= 4 and E_aa > 0
+                and E_aa >= m.plan_min_edges and not dbg and 1 not in F.pruned):
+            if F.flex0 is not None:
+                n0, e0 = F.flex0.na, F.flex0.e0
+                F.touched_l1 = F.touched + F.flex0.dirty
+            else:
+                n0, e0, _ = F.shared0[3]
+                F.touched_l1 = F.touched
             so3 = so[3]
             d = SimpleNamespace(recv=i32e(E_aa), src=i32e(E_aa), eid=i32e(E_aa), pos=i32e(E_aa))
-            K.select_jobs([K.select_job(E_aa, F.touched, so3.recv, F.touched, so3.src, [so3.recv, so3.src, so3.eid, so3.pos],
+            K.select_jobs([K.select_job(E_aa, F.touched_l1, so3.recv, F.touched_l1, so3.src, [so3.recv, so3.src, so3.eid, so3.pos],
                                         [d.recv, d.src, d.eid, d.pos], cnt["dirty"], i32e(2 * ((E_aa + 2047) // 2048) + 1))])
             so_d = EdgeView(E_aa, d.recv, d.src, d.eid, pos=d.pos, cnt=cnt["dirty"])
             mask, rows_d = i32z(Na), i32e(Na)
             K.mark_jobs([K.mark_job(mask, d.src, E_aa, cnt["dirty"])])
             K.scan_jobs([K.scan_job(Na, flag=mask, lst=rows_d, total=cnt["rows_dirty"])])
             rowmap, rows_v = i32e(E_aa), i32e(n0)
-            K.clean_pair_maps(F.touched, c[3].recv, c[3].src, E_aa, e0, B, n0, rowmap, rows_v)
+            K.clean_pair_maps(F.touched_l1, c[3].recv, c[3].src, E_aa, e0, B, n0, rowmap, rows_v, rowptr=c[3].rowptr if F.flex0 is not None else None)
             so_v = m._cached(f"so_v{e0}", (so3.pos,), lambda: G.SourceOrder(e0, so3.recv[:e0], so3.src[:e0], so3.eid[:e0], (so3.pos[:e0] + E_aa).contiguous()))
             F.clean1 = SimpleNamespace(so_d=so_d, rows_d=rows_d, rows_d_cnt=cnt["rows_dirty"], rowmap=rowmap, so_v=so_v, rows_v=rows_v,
                                        E=E_aa, e0=e0, n0=n0)
@@ -783,6 +856,12 @@ class ForwardEngine:
             else:
                 K.launch_convs(spec, tasks, node_bytes=nb_d)
             mark("conv_launch")
+            if l == 0 and F.flex0 is not None:
+                # flexible side chains: the kept receivers' messages were computed on the pruned lists; the segmented mean walks
+                # the FULL lists and reads an unmarked receiver's messages from its copy in sample 0 (row map)
+                for k, rm in F.flex0.rowmaps.items():
+                    if k in msgs:
+                        msgs[k] = (msgs[k][0], c[k], msgs[k][2], rm)
             if dbg is not None:   # every conv's own output = segmented mean + BatchNorm of its messages alone
                 for k, ent in msgs.items():
                     n_k = nodes[RECV_TYPE[k]][1]

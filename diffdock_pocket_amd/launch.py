@@ -404,7 +404,18 @@ def gather_rows(x, idx, n, out, ncols, n_dev=None):
                                     stream()), "ddp_gather_rows")
 
 
-def clean_pair_maps(touched, recv, src, n_edges, e0, n_graphs, n0, rowmap, rows_v):
+def flex_mark(a, b, n_edges, e0, n_a_per_graph, n_b_per_graph, mark, pos=None, flag=None, a_too=False, ref_list=False):
+    """ddp_flex_mark: mark[a[e]] = 1 where b[e] (a_too: or a[e]) is "off" in its sample - by position (pos) or by an earlier mask (flag)."""
+    L.check(L.load().ddp_flex_mark(ptr(pos), ptr(flag), n_b_per_graph, ptr(a), ptr(b), n_edges, e0, n_a_per_graph, int(a_too), int(ref_list),
+                                   ptr(mark), stream()), "ddp_flex_mark")
+
+
+def fallback_rowmap(mark, recv, old_rowptr, new_rowptr, n_edges, n_recv_per_graph, rowmap):
+    L.check(L.load().ddp_fallback_rowmap(ptr(mark), ptr(recv), ptr(old_rowptr), ptr(new_rowptr), n_edges, n_recv_per_graph, ptr(rowmap),
+                                         stream()), "ddp_fallback_rowmap")
+
+
+def clean_pair_maps(touched, recv, src, n_edges, e0, n_graphs, n0, rowmap, rows_v, rowptr=None):
     lib = L.load()
-    L.check(lib.ddp_clean_pair_maps(touched.data_ptr(), recv.data_ptr(), src.data_ptr(), n_edges, e0, n_graphs, n0, rowmap.data_ptr(),
-                                    rows_v.data_ptr(), stream()), "ddp_clean_pair_maps")
+    L.check(lib.ddp_clean_pair_maps(touched.data_ptr(), recv.data_ptr(), src.data_ptr(), ptr(rowptr), n_edges, e0, n_graphs, n0,
+                                    rowmap.data_ptr(), rows_v.data_ptr(), stream()), "ddp_clean_pair_maps")

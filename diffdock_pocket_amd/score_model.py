@@ -387,6 +387,7 @@ class TensorProductScoreModel(nn.Module):
         self.prune_last_receptor_layer = True   # layer L-2 receptor-side convs only where the final layer reads them
         self.share_layer0 = True       # layer-0 receptor-side convs once per batch of identical receptors (forward)
         self.share_clean_layer1 = True  # layer-1 atom<-atom messages between atoms no ligand message has reached: once (forward)
+        self.share_flex_layer0 = True   # flexible side chains: layer-0 atom-side convs per sample only where an atom moved nearby
         # The index lists of these eliminations are built on the device (engine._lists: ~25 small launches, no host
         # synchronisation); below this many atom-atom edges they are skipped (0: always on)
         self.plan_min_edges = 0
@@ -487,7 +488,8 @@ class TensorProductScoreModel(nn.Module):
         or (receiver nodes per graph, edges per graph, source nodes per graph).  Exact comparison of node features,
         positions and per-graph edge lists; depends only on step-independent tensors, so it is evaluated once (`_cached`).
         atoms=False: the atom side is not examined (flexible side chains move per sample and per step: its comparison
-        would fail anyway, after a handful of host synchronisations on every call)."""
+        would fail anyway, after a handful of host synchronisations on every call); atoms="static": only what does not move
+        is examined (features, atom-receptor edges) and reported under the key "flex"."""
         out = {3: None, 5: None, 6: None, 8: None}
         if B < 2 or not (lay_r.uniform and lay_a.uniform):
             return out
@@ -508,10 +510,15 @@ class TensorProductScoreModel(nn.Module):
             return e if bool(ok) else 0
 
         rec_same = same_rows(rec.x, nr) and same_rows(rpos, nr)
-        atom_same = atoms and same_rows(atom.x, na) and same_rows(apos, na)
+        atom_same = atoms is True and same_rows(atom.x, na) and same_rows(apos, na)
         if rec_same:
             e = same_edges(rr, nr, nr)
             out[6] = (nr, e, nr) if e else None
+        if atoms == "static" and rec_same and same_rows(atom.x, na):
+            # flexible side chains: the atoms' FEATURES and the atom-receptor edges repeat across the samples, their positions
+            # (and with them the atom kNN graph) do not - what can still be shared is decided per step (engine._lists)
+            e = same_edges(ar, na, nr)
+            out["flex"] = (na, e, nr) if e else None
         if atom_same:
             e = same_edges(aa, na, na)
             out[3] = (na, e, na) if e else None

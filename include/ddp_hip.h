@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DDP_ABI_VERSION 9
+#define DDP_ABI_VERSION 10
 #define DDP_EINVAL (-1)   /* bad argument (shape not supported, null pointer, ...) */
 #define DDP_ELIMIT (-2)   /* exceeds a compiled-in limit (see DDP_MAX_*) */
 
@@ -418,8 +418,22 @@ int ddp_gather_rows(const float* x, int ldx, const int32_t* idx, int n, const in
                     void* stream);
 
 /* The two index maps of the layer-1 clean-pair sharing (see csrc/ddp_lists.hip); n_edges = e0 * n_graphs. */
-int ddp_clean_pair_maps(const int32_t* touched, const int32_t* recv, const int32_t* src, int n_edges, int e0, int n_graphs, int n0,
-                        int32_t* rowmap, int32_t* rows_v, void* stream);
+int ddp_clean_pair_maps(const int32_t* touched, const int32_t* recv, const int32_t* src, const int32_t* rowptr, int n_edges, int e0,
+                        int n_graphs, int n0, int32_t* rowmap, int32_t* rows_v, void* stream);
+
+/* Partial sharing across the poses of ONE complex whose side chains move (csrc/ddp_lists.hip): node (s, i) = copy i of sample s,
+ * the samples' edge lists stored sample after sample with e0 edges each.  An atom is "off" in sample s when its position there
+ * differs bitwise from its position in sample 0 (flag == NULL) or when flag[(s, i)] != 0.
+ * ddp_flex_mark over an edge list (a[e], b[e]): mark[a[e]] = 1 if b[e] is off (a_too: or a[e] is); ref_list: mark[(s, a0)] = 1
+ *   for every edge (a0, b0) of SAMPLE 0's list whose b0 is off in sample s; mark[(0, i)] = 1 for all i.  (rowptr in
+ *   ddp_clean_pair_maps, optional: the receiver CSR's row pointers, for lists whose rows do not sit at the same positions in
+ *   every sample.)
+ * ddp_fallback_rowmap: rowmap[p] = new_rowptr[t] + (p - old_rowptr[recv[p]]), t = mark[recv[p]] ? recv[p] : recv[p] % n_recv_per_graph:
+ *   the message row of position p of the full list when only the marked receivers' rows were kept (ddp_rowcopy_jobs). */
+int ddp_flex_mark(const float* pos, const int32_t* flag, int n_b_per_graph, const int32_t* a, const int32_t* b, int n_edges, int e0,
+                  int n_a_per_graph, int a_too, int ref_list, int32_t* mark, void* stream);
+int ddp_fallback_rowmap(const int32_t* mark, const int32_t* recv, const int32_t* old_rowptr, const int32_t* new_rowptr, int n_edges,
+                        int n_recv_per_graph, int32_t* rowmap, void* stream);
 
 /* One neighbour search of ddp_radius_search_jobs = ddp_radius_count + prefix sum + ddp_radius_fill without the host in between:
  * counts[ny] and offsets[ny + 1] are outputs (offsets[q] = base + pairs of the queries before q), *total = base + all pairs,

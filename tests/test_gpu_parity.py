@@ -822,7 +822,10 @@ def test_layer0_sharing_across_identical_receptors(name):
     model.share_layer0 = True
     fast = [t.clone() for t in model(bd)]
     if case.flexible_sidechains:
-        assert {6} == {k for k, v in model._static_cache["shared0_rec"][3].items() if v is not None}
+        # (+ "flex": features and atom-receptor edges repeat, so layer 0's atom side is shared wherever no atom moved - here
+        # every copy has the same side-chain pose: samples 1, 2 read everything from sample 0, test_flexible_layer0_sharing_is_exact)
+        assert {6, "flex"} == {k for k, v in model._static_cache["shared0_rec"][3].items() if v is not None}
+        assert model.last_stats["flex0_kept_aa_edges"] == model.last_stats["E_aa"] // 3
     else:
         assert {3, 5, 6, 8} <= {k for k, v in model._static_cache["shared0"][3].items() if v is not None}
     model.share_layer0 = False
@@ -885,6 +888,39 @@ def test_layer1_clean_pair_sharing_is_exact():
     model.share_clean_layer1 = False
     for f, s_ in zip(far, model(b2.to(dev))):
         assert torch.equal(f, s_)
+
+
+@pytest.mark.parametrize("n", [6, 40])
+def test_flexible_layer0_sharing_is_exact(n):
+    """score_model.share_flex_layer0 (flexible side chains: N poses of one complex whose side chains differ): layer 0's
+    atom<-atom / atom<-receptor / receptor<-atom messages are computed for sample 0 and, in the other samples, only for the
+    receivers with a moved atom on an incoming edge or in reach of their kNN list; everyone else reads sample 0's messages through
+    the segmented mean's row map, and layer 1's clean-pair sharing works on top with those receivers counted as touched.
+    Bitwise the general path - at the first step (every side chain freshly randomised) and after two denoising steps."""
+    import bench
+    from diffdock_pocket_amd.diffusion import get_t_schedule
+    from diffdock_pocket_amd.sampler import Sampler, SamplerConfig
+    from diffdock_pocket_amd.synthetic import make_3dpf_complex
+    dev = _dev()
+    sched = get_t_schedule(20)
+    g = make_3dpf_complex(seed=0, flexible_sidechains=True)
+    model, kw = bench.build_model("cfg2", True, dev)
+    smp = Sampler(model, g, n, dev, SamplerConfig(inference_steps=20, flexible_sidechains=True, hip_graph=False), seed=0)
+    smp.randomize()
+    for rnd in range(2):
+        model.share_flex_layer0 = True
+        fast = [t.clone() for t in smp.scores(float(sched[2 * rnd]))]
+        st = dict(model.last_stats)
+        assert 0 < st["flex0_kept_aa_edges"] < 0.7 * st["E_aa"], st      # sample 0 + the dirty receivers of the others
+        assert "clean1_dirty_edges" in st and st["clean1_dirty_edges"] < st["E_aa"], st
+        model.share_flex_layer0 = False
+        slow = [t.clone() for t in smp.scores(float(sched[2 * rnd]))]
+        assert "flex0_kept_aa_edges" not in model.last_stats and "clean1_dirty_edges" not in model.last_stats
+        for f, s_ in zip(fast, slow):
+            assert torch.equal(f, s_), rel_err(f, s_)
+        model.share_flex_layer0 = True
+        smp.step(2 * rnd, sched)
+        smp.step(2 * rnd + 1, sched)
 
 
 @pytest.mark.parametrize("name", ["cfg2_noflex", "cfg2_small", "cfg1_full", "ns24_l3"])
