@@ -85,6 +85,8 @@ def parse_args(argv=None):
                     help="threads of the CPU baseline (capped at os.cpu_count(); 0 = all cores - on the GPU boxes' many-core hosts the "
                          "oracle's small ops get SLOWER beyond ~32 threads)")
     ap.add_argument("--no-roofline-pass", action="store_true", help="skip the instrumented steps behind the timed region")
+    ap.add_argument("--no-flex-sharing", action="store_true",
+                    help="diagnostic: flexible side chains without the partial sharing of layers 0 / 1 (model.share_flex_layer0 = False)")
     ap.add_argument("--stage-a-fp32", action="store_true",
                     help="diagnostic: stage A as exact fp32 MFMA products instead of the bf16x3 form (model.stage_a_bf16x3 = False)")
     return ap.parse_args(argv)
@@ -374,6 +376,8 @@ def main(argv=None):
     model, kw = build_model(args.cfg, args.flex, device)
     if args.stage_a_fp32:
         model.stage_a_bf16x3 = False
+    if args.no_flex_sharing:
+        model.share_flex_layer0 = False
     complex_graph = make_3dpf_complex(seed=0, flexible_sidechains=args.flex)
     n_total = args.samples * world if scaling == "weak" else args.samples
     if n_total < world:

@@ -567,7 +567,8 @@ class ForwardEngine:
         fx = getattr(F, "flex_static", None)
         kk = m.atom_max_neighbors if m.atom_max_neighbors else 32
         if (fx is not None and m.share_flex_layer0 and S.num_flex > 0 and not dbg and 0 not in F.pruned and L_ >= 2
-                and 3 in F.fact and 5 in F.fact and E_aa == Na * kk and E_aa % B == 0 and E_aa >= m.plan_min_edges):
+                and 3 in F.fact and 5 in F.fact and E_aa == Na * kk and E_aa % B == 0 and E_aa >= m.plan_min_edges
+                and E_aa * m.ns >= m.flex_share_min_work):
             na, e_ar, nr = fx
             e0 = E_aa // B
             qdirty, dirty, need_r = i32z(Na), i32z(Na), i32z(Nr)

@@ -388,6 +388,9 @@ class TensorProductScoreModel(nn.Module):
         self.share_layer0 = True       # layer-0 receptor-side convs once per batch of identical receptors (forward)
         self.share_clean_layer1 = True  # layer-1 atom<-atom messages between atoms no ligand message has reached: once (forward)
         self.share_flex_layer0 = True   # flexible side chains: layer-0 atom-side convs per sample only where an atom moved nearby
+        # ... when there is enough to save: its lists cost ~20 launches (atom-atom edges x ns; cfg1 x 4 samples = 0.57 M: 1.10 ms
+        # per step without, 1.20 with; cfg2 x 5 samples = 2.7 M: 6.29 -> 6.14 ms; x 40: 39.4 -> 37.2 ms)
+        self.flex_share_min_work = 2_000_000
         # The index lists of these eliminations are built on the device (engine._lists: ~25 small launches, no host
         # synchronisation); below this many atom-atom edges they are skipped (0: always on)
         self.plan_min_edges = 0

@@ -820,6 +820,7 @@ def test_layer0_sharing_across_identical_receptors(name):
     set_time(b, 0.4, 0.4, 0.4, 0.4)
     bd = b.to(dev)
     model.share_layer0 = True
+    model.flex_share_min_work = 0
     fast = [t.clone() for t in model(bd)]
     if case.flexible_sidechains:
         # (+ "flex": features and atom-receptor edges repeat, so layer 0's atom side is shared wherever no atom moved - here
