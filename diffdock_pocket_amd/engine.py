@@ -395,11 +395,17 @@ class ForwardEngine:
             return m._cached(name, (ei,), lambda: G.build_csr(recv, src, n))
 
         c = {}
-        c[3] = static_csr("c_aa", 3, aa, aa[0], aa[1], Na)
+        g1 = []
+        aa_per_step = S.num_flex > 0 and aa.shape[1] > 0     # the atom kNN graph is rebuilt every step: its views join the batched calls
+        if aa_per_step:
+            v = SimpleNamespace(rp=i32e(Na + 1), perm=i32e(aa.shape[1]), key=i32e(aa.shape[1]), o0=i32e(aa.shape[1]))
+            g1.append(K.group_job(aa32[0], aa.shape[1], Na, [aa32[1]], v.rp, v.perm, v.key, [v.o0], i32e(Na + aa.shape[1])))
+            c[3] = G.CSR(int(aa.shape[1]), v.key, v.o0, v.perm, v.rp)
+        else:
+            c[3] = static_csr("c_aa", 3, aa, aa[0], aa[1], Na)
         c[5] = static_csr("c_ar", 5, S.ar, S.ar[0], S.ar[1], Na)
         c[6] = static_csr("c_rr", 6, rr, rr[0], rr[1], Nr)
         c[8] = static_csr("c_ra", 8, S.ar, S.ar[1], S.ar[0], Nr)
-        g1 = []
         v = SimpleNamespace(rp=i32e(Nl + 1), perm=i32e(S.cap_ll), key=i32e(S.cap_ll), o0=i32e(S.cap_ll))
         g1.append(K.group_job(ll0, S.cap_ll, Nl, [ll1], v.rp, v.perm, v.key, [v.o0], i32e(Nl + S.cap_ll), n_dev=cnt["ll"]))
         c[0] = EdgeView(S.cap_ll, v.key, v.o0, v.perm, rowptr=v.rp, cnt=cnt["ll"])
@@ -427,11 +433,18 @@ class ForwardEngine:
             # edges per source node - all but receptor<-atom (one edge per atom).  Their edges are listed in source order.
             F.fact = {0, 1, 2, 3, 4, 5, 6, 7}
             for k in (3, 5, 6):
+                if k == 3 and aa_per_step:
+                    continue
                 so[k] = m._cached(f"so_{k}", (c[k].src, c[k].eid), lambda k=k: G.source_order(c[k], n_src[SRC_TYPE[k]]))
             # ligand<-receptor / ligand<-atom in source order = the receptor<-ligand / atom<-ligand CSR views read the other way
             so[1] = EdgeView(S.cap_lr, c[7].src, c[7].recv, c[7].eid, pos=c[7].eid, cnt=cnt["lr"])
             so[2] = EdgeView(S.cap_la, c[4].src, c[4].recv, c[4].eid, pos=c[4].eid, cnt=cnt["la"])
             g2 = []
+            if aa_per_step:
+                E3 = c[3].n_edges
+                v = SimpleNamespace(rp=i32e(Na + 1), perm=i32e(E3), key=i32e(E3), o0=i32e(E3), o1=i32e(E3))
+                g2.append(K.group_job(c[3].src, E3, Na, [c[3].recv, c[3].eid], v.rp, v.perm, v.key, [v.o0, v.o1], i32e(Na + E3)))
+                so[3] = G.SourceOrder(E3, v.o0, v.key, v.o1, v.perm)
             for k, cap, name in ((0, S.cap_ll, "ll"), (4, S.cap_la, "la"), (7, S.cap_lr, "lr")):
                 v = SimpleNamespace(rp=i32e(Nl + 1), perm=i32e(cap), key=i32e(cap), o0=i32e(cap), o1=i32e(cap))
                 g2.append(K.group_job(c[k].src, cap, Nl, [c[k].recv, c[k].eid], v.rp, v.perm, v.key, [v.o0, v.o1], i32e(Nl + cap),

@@ -217,3 +217,50 @@ def test_clean_pair_maps():
     clean = (touched.view(B, n0) == 0)
     first = clean.to(torch.uint8).argmax(0)
     assert torch.equal(rows_v.cpu().long(), first * n0 + torch.arange(n0))
+
+
+@pytest.mark.parametrize("a_too,ref_list,by_flag", [(True, True, False), (False, False, False), (True, True, True), (False, True, True)])
+def test_flex_mark_and_fallback_rowmap(a_too, ref_list, by_flag):
+    """ddp_flex_mark / ddp_fallback_rowmap (partial sharing with moving atoms) against their definitions: B samples of n nodes,
+    e0 edges each stored sample after sample; "off" = position differs from sample 0's, or a given flag."""
+    dev = _dev()
+    torch.manual_seed(3 + a_too + 2 * by_flag)
+    B, n, deg = 5, 57, 4
+    e0 = n * deg
+    pos0 = torch.randn(n, 3)
+    pos = pos0.repeat(B, 1, 1)
+    moved = torch.rand(B, n) < 0.1
+    moved[0] = False
+    pos[moved] += 0.25
+    flag = (torch.rand(B, n) < 0.15).int()
+    off = (flag != 0) if by_flag else moved
+    a_loc = torch.stack([torch.randint(0, n, (e0,)).sort().values for _ in range(B)])       # per-sample lists, node-major
+    b_loc = torch.randint(0, n, (B, e0))
+    offs = (torch.arange(B) * n).unsqueeze(1)
+    a, b = (a_loc + offs).reshape(-1).int(), (b_loc + offs).reshape(-1).int()
+    want = torch.zeros(B, n, dtype=torch.int32)
+    want[0] = 1
+    for s in range(1, B):
+        hit = off[s][b_loc[s]] | (off[s][a_loc[s]] if a_too else False)
+        want[s][a_loc[s][hit]] = 1
+        if ref_list:
+            want[s][a_loc[0][off[s][b_loc[0]]]] = 1
+    mark = torch.zeros(B * n, dtype=torch.int32, device=dev)
+    K.flex_mark(a.to(dev), b.to(dev), B * e0, e0, n, n, mark, pos=None if by_flag else pos.reshape(-1, 3).to(dev),
+                flag=flag.reshape(-1).to(dev) if by_flag else None, a_too=a_too, ref_list=ref_list)
+    assert torch.equal(mark.cpu().reshape(B, n), want)
+    # fallback row map: kept rows = marked receivers; an unmarked receiver reads its copy's rows in sample 0 (equal row lengths there)
+    a_same = (a_loc[0].unsqueeze(0) + offs).reshape(-1)                                        # every sample with sample 0's rows
+    rowptr = torch.zeros(B * n + 1, dtype=torch.long)
+    rowptr[1:] = torch.bincount(a_same, minlength=B * n).cumsum(0)
+    keep = want.reshape(-1).bool()
+    lens = (rowptr[1:] - rowptr[:-1]) * keep
+    new_rowptr = torch.zeros(B * n + 1, dtype=torch.long)
+    new_rowptr[1:] = lens.cumsum(0)
+    p = torch.arange(B * e0)
+    r = a_same
+    t = torch.where(keep[r], r, r % n)
+    want_map = new_rowptr[t] + (p - rowptr[r])
+    rowmap = torch.empty(B * e0, dtype=torch.int32, device=dev)
+    K.fallback_rowmap(want.reshape(-1).to(dev), a_same.int().to(dev), rowptr.int().to(dev), new_rowptr.int().to(dev), B * e0, n, rowmap)
+    assert torch.equal(rowmap.cpu().long(), want_map)
