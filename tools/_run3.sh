@@ -1,3 +1,4 @@
 ulimit -c 0
-O=gpurun_out/r03_f3; mkdir -p $O
-for a in "--flex" "--flex --no-flex-sharing" "--flex" "--flex --no-flex-sharing" "--flex --samples 5" "--flex --samples 5 --no-flex-sharing" "--flex --samples 4 --cfg cfg1" "--flex --samples 4 --cfg cfg1 --no-flex-sharing"; do timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline-pass --no-other-workloads $a 2>>$O/bench.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$a |', round(d['ms_per_step'],3), '|', round(d['value'],2))"; done 2>&1 | tee $O/ab.txt
+O=gpurun_out/r03_f4; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_lists.py tests/test_gpu_parity.py -m gpu -q -x -k "flex_mark or clean_pair or flexible_layer0 or graph_replay or layer0_sharing or sampler_end or forward_matches or capacities" > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -8 $O/pytest.log
+for a in "--flex --samples 4 --cfg cfg1" "--flex" "--flex --samples 5"; do timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline-pass --no-other-workloads $a 2>>$O/bench.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$a |', round(d['ms_per_step'],3), '|', round(d['value'],2))"; done
