@@ -284,6 +284,38 @@ def test_shared_receptor_side_detection():
     assert out[6] is None and out[3] is not None and out[5] is not None
     assert model._shared_receptor_side(1, rec, atom, rec.pos.float(), atom.pos.float(), lay_r, lay_a, rr, ar, aa) \
         == {3: None, 5: None, 6: None, 8: None}
+    # atoms="static" (flexible side chains): positions are not examined, features and atom-receptor edges are
+    atom.pos[na + 5] += 0.25
+    out = model._shared_receptor_side(B, rec, atom, rec.pos.float(), atom.pos.float(), lay_r, lay_a, rr, ar, aa, atoms="static")
+    assert out[6] is not None and out[3] is None and out["flex"] == (na, ar.shape[1] // B, nr)
+    atom.x[na + 5, 0] += 1
+    out = model._shared_receptor_side(B, rec, atom, rec.pos.float(), atom.pos.float(), lay_r, lay_a, rr, ar, aa, atoms="static")
+    assert out[6] is not None and "flex" not in out
+
+
+def test_split_bf16x3_and_sigma_range_detection():
+    """packing.split_bf16x3: the three bfloat16 planes add up to the fp32 weights (to 2^-24 relative) in the operand layout of
+    include/ddp_hip.h; score_model._sigma_ranges: only the package's own schedule bound to its ranges is evaluated in the kernel."""
+    from diffdock_pocket_amd.diffusion import SigmaRanges, t_to_sigma
+    torch.manual_seed(0)
+    W = torch.randn(2, 60, 96) * torch.exp(torch.randn(2, 1, 96))
+    W3 = P.split_bf16x3(W)
+    assert W3.dtype == torch.bfloat16 and W3.shape == (2, 3, 4, 2, 96, 8)
+    back = W3.float().permute(0, 1, 2, 3, 5, 4).reshape(2, 3, 64, 96).sum(1)
+    assert torch.equal(back[:, 60:], torch.zeros(2, 4, 96))
+    assert float(((back[:, :60] - W).abs() / W.abs().clamp_min(1e-30)).max()) < 2.0 ** -22
+    case = CASES["cfg1_edge"]
+    kw = dict(case.model_kwargs())
+    kw.update(case.ctor_extras())
+    model = TensorProductScoreModel(**kw)
+    rng = SigmaRanges()
+    model.t_to_sigma = functools.partial(t_to_sigma, args=rng)
+    assert model._sigma_ranges() == ((rng.tr_sigma_min, rng.tr_sigma_max), (rng.rot_sigma_min, rng.rot_sigma_max),
+                                     (rng.tor_sigma_min, rng.tor_sigma_max), (rng.sidechain_tor_sigma_min, rng.sidechain_tor_sigma_max))
+    model.t_to_sigma = lambda *ts: tuple(t * 2 for t in ts)
+    assert model._sigma_ranges() is None
+    model.t_to_sigma = functools.partial(t_to_sigma, args=object())
+    assert model._sigma_ranges() is None
 
 
 @pytest.mark.parametrize("key", ["score_README_72", "confidence_README_88", "confidence_two_cutoffs", "score_old_yml"])
