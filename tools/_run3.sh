@@ -1,4 +1,6 @@
 ulimit -c 0
-O=gpurun_out/r03_f4; mkdir -p $O
-timeout 1500 python -m pytest tests/test_gpu_lists.py tests/test_gpu_parity.py -m gpu -q -x -k "flex_mark or clean_pair or flexible_layer0 or graph_replay or layer0_sharing or sampler_end or forward_matches or capacities" > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -8 $O/pytest.log
-for a in "--flex --samples 4 --cfg cfg1" "--flex" "--flex --samples 5"; do timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline-pass --no-other-workloads $a 2>>$O/bench.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$a |', round(d['ms_per_step'],3), '|', round(d['value'],2))"; done
+O=gpurun_out/r03_final; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest.log
+timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
+timeout 600 python bench.py > $O/bench_default.json 2> $O/bench.err; echo "bench rc=$?"; python -c "
+import json; d=json.load(open('$O/bench_default.json')); r=d['roofline']; print(d['value'], d['ms_per_step'], r['frac'], r['traffic'], r.get('mfma_busy_pmc'), r.get('padding_frac_pmc'), d['cpu_baseline']['value'])"
