@@ -17,7 +17,7 @@ F_SCALAR_S0, F_DOT, F_SCALAR_S1, F_VEC_S0, F_CROSS = range(5)
 FS = 68  # feature-buffer row stride of ddp_conv.hip
 
 DDP_MAX_GEMM_BATCH = 16
-EXPORTS = ["ddp_conv_messages", "ddp_segment_reduce", "ddp_edge_featurize", "ddp_torsion_sh", "ddp_stage_a",
+EXPORTS = ["ddp_conv_messages", "ddp_segment_reduce", "ddp_edge_featurize", "ddp_edge_featurize_jobs", "ddp_torsion_sh", "ddp_stage_a",
            "ddp_pose_update", "ddp_sidechain_update", "ddp_sde_update", "ddp_radius_count", "ddp_radius_fill", "ddp_knn", "ddp_group_by_key", "ddp_node_linear", "ddp_scan_jobs", "ddp_mark_jobs", "ddp_rowcopy_jobs", "ddp_select_jobs",
            "ddp_gather_rows", "ddp_clean_pair_maps", "ddp_flex_mark", "ddp_fallback_rowmap", "ddp_step_prologue", "ddp_trrot_head", "ddp_tor_head", "ddp_radius_search_jobs", "ddp_group_by_key_jobs", "ddp_abi_version", "ddp_last_error", "ddp_source_hash"]
 
@@ -99,6 +99,16 @@ class GroupJob(C.Structure):
 
 
 
+DDP_MAX_FEATURIZE_JOBS = 8
+
+
+class FeaturizeJob(C.Structure):
+    """ddp_featurize_job_t of include/ddp_hip.h."""
+    _fields_ = [("pos_a", _P), ("ia", _P), ("pos_b", _P), ("ib", _P), ("n_edges", _I), ("n_edges_dev", _P), ("offset", _P), ("k_rbf", _I),
+                ("coeff", C.c_float), ("pre", _P), ("pre_idx", _P), ("ld_pre", _I), ("pre2", _P), ("n_pre2", _I), ("ld_pre2", _I),
+                ("w1d", _P), ("w2", _P), ("b2", _P), ("ns", _I), ("out", _P), ("sh", _P)]
+
+
 class _BondJob(C.Structure):
     _fields_ = [("pos", _P), ("b0", _P), ("b1", _P), ("n", _I), ("mid", _P), ("vec", _P)]
 
@@ -175,6 +185,8 @@ def load():
                                        C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ddp_edge_featurize.restype = C.c_int
+    lib.ddp_edge_featurize_jobs.argtypes = [C.POINTER(FeaturizeJob), C.c_int, C.c_void_p]
+    lib.ddp_edge_featurize_jobs.restype = C.c_int
     lib.ddp_torsion_sh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.ddp_torsion_sh.restype = C.c_int
@@ -218,7 +230,7 @@ def load():
         getattr(lib, name).restype = C.c_int
     lib.ddp_node_linear.argtypes = [C.POINTER(NodeJob), C.c_int, C.c_void_p]
     lib.ddp_node_linear.restype = C.c_int
-    if lib.ddp_abi_version() != 10:
+    if lib.ddp_abi_version() != 11:
         raise DdpError("libddp_hip.so ABI version mismatch")
     lib.ddp_source_hash.restype = C.c_char_p
     if "DDP_HIP_LIB" not in os.environ:   # (diagnostic builds loaded through DDP_HIP_LIB carry extra -D flags, same sources)

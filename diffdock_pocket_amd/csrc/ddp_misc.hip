@@ -196,13 +196,37 @@ __global__ __launch_bounds__(256) void ddp_edge_featurize_kernel(
 // goes through LDS once to turn the C/D layout into the A layout of the second layer.
 typedef float ef_f32x16 __attribute__((ext_vector_type(16)));
 #define EF_HS 68   // LDS row stride of the hidden tile
-__global__ __launch_bounds__(256) void ddp_edge_featurize_mfma_kernel(
-    const float* __restrict__ pos_a, const int* __restrict__ ia, const float* __restrict__ pos_b,
-    const int* __restrict__ ib, int n_edges, const int* __restrict__ n_edges_dev, const float* __restrict__ offset, int k_rbf,
-    float coeff, const float* __restrict__ pre, const int* __restrict__ pre_idx, int ld_pre, const float* __restrict__ pre2,
-    int n_pre2, int ld_pre2, const float* __restrict__ w1d, const float* __restrict__ w2, const float* __restrict__ b2, int ns,
-    float* __restrict__ out, float* __restrict__ sh) {
-  if (n_edges_dev) n_edges = min(n_edges, *n_edges_dev);   // device-side edge count: n_edges is then the capacity
+struct FeatLaunch {
+  int njobs;
+  int blk_start[DDP_MAX_FEATURIZE_JOBS + 1];
+  ddp_featurize_job_t job[DDP_MAX_FEATURIZE_JOBS];
+};
+
+// One launch for several edge sets (ddp_edge_featurize_jobs): a workgroup belongs to one job - the block ranges of
+// FeatLaunch::blk_start - stages that job's weights and walks that job's edges.
+__global__ __launch_bounds__(256) void ddp_edge_featurize_mfma_kernel(const FeatLaunch L) {
+  int j = 0;
+  while (j + 1 < L.njobs && (int)blockIdx.x >= L.blk_start[j + 1]) ++j;
+  const ddp_featurize_job_t& J = L.job[j];
+  const int blk = (int)blockIdx.x - L.blk_start[j], nblk = L.blk_start[j + 1] - L.blk_start[j];
+  const float* __restrict__ pos_a = J.pos_a;
+  const int* __restrict__ ia = J.ia;
+  const float* __restrict__ pos_b = J.pos_b;
+  const int* __restrict__ ib = J.ib;
+  const float* __restrict__ offset = J.offset;
+  const float* __restrict__ pre = J.pre;
+  const int* __restrict__ pre_idx = J.pre_idx;
+  const float* __restrict__ pre2 = J.pre2;
+  const float* __restrict__ w1d = J.w1d;
+  const float* __restrict__ w2 = J.w2;
+  const float* __restrict__ b2 = J.b2;
+  float* __restrict__ out = J.out;
+  float* __restrict__ sh = J.sh;
+  const int k_rbf = J.k_rbf, ld_pre = J.ld_pre, n_pre2 = J.n_pre2, ld_pre2 = J.ld_pre2, ns = J.ns;
+  const float coeff = J.coeff;
+  int n_edges = J.n_edges;
+  if (J.n_edges_dev) n_edges = min(n_edges, *J.n_edges_dev);   // device-side edge count: n_edges is then the capacity
+  if (blk * 128 >= n_edges) return;                              // (a capacity-sized grid: nothing to do behind the count)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_w1 = smem;                         // packed [k_rbf/8][2 hh][64 cols][4]
   float* s_w2 = s_w1 + k_rbf * EF_NS;         // packed [8][2][64][4]
@@ -227,7 +251,7 @@ __global__ __launch_bounds__(256) void ddp_edge_featurize_mfma_kernel(
   const f32x4* w1q = reinterpret_cast<const f32x4*>(s_w1);
   const f32x4* w2q = reinterpret_cast<const f32x4*>(s_w2);
   const int nm1 = k_rbf >> 3;
-  for (int base = (blockIdx.x * 4 + wave) * 32; base < n_edges; base += gridDim.x * 128) {
+  for (int base = (blk * 4 + wave) * 32; base < n_edges; base += nblk * 128) {
     const int e = base + r;
     const int ec = min(e, n_edges - 1);
     const int a = ia[ec], b = ib[ec];
@@ -311,17 +335,9 @@ extern "C" int ddp_edge_featurize(const float* pos_a, const int32_t* ia, const f
   if (ns < 1 || ns > EF_NS) return ddp_fail(DDP_ELIMIT, "ddp_edge_featurize: ns > 64");
   if (k_rbf < 2 || k_rbf > 256) return ddp_fail(DDP_ELIMIT, "ddp_edge_featurize: k_rbf");
   if ((k_rbf & 7) == 0 && k_rbf <= 64) {   // both Linears on the matrix cores
-    const size_t lds_m = (size_t)(k_rbf * EF_NS + EF_NS * EF_NS + EF_NS + 64 + 4 * 32 * EF_HS) * sizeof(float);
-    static int lds_have_m = 0;
-    hipError_t e2 = ddp_need_lds(reinterpret_cast<const void*>(ddp_edge_featurize_mfma_kernel), (int)lds_m, &lds_have_m);
-    if (e2 != hipSuccess) return ddp_fail_hip(e2, "hipFuncSetAttribute(edge_featurize_mfma)");
-    int blocks_m = (n_edges + 127) / 128;
-    if (blocks_m > 1024) blocks_m = 1024;
-    hipLaunchKernelGGL(ddp_edge_featurize_mfma_kernel, dim3(blocks_m), dim3(256), lds_m, (hipStream_t)stream, pos_a, ia, pos_b,
-                       ib, n_edges, n_edges_dev, offset, k_rbf, coeff, pre, pre_idx, ld_pre, pre2, n_pre2, ld_pre2, w1d, w2, b2, ns, out, sh);
-    e2 = hipGetLastError();
-    if (e2 != hipSuccess) return ddp_fail_hip(e2, "ddp_edge_featurize (mfma) launch");
-    return 0;
+    ddp_featurize_job_t J = {pos_a, ia, pos_b, ib, n_edges, n_edges_dev, offset, k_rbf, coeff, pre, pre_idx, ld_pre, pre2, n_pre2, ld_pre2,
+                             w1d, w2, b2, ns, out, sh};
+    return ddp_edge_featurize_jobs(&J, 1, stream);
   }
   const size_t lds = (size_t)(k_rbf * EF_NS + EF_NS * EF_NS + EF_NS + ((k_rbf + 3) & ~3) + 4 * 64 * 65) * sizeof(float);
   static int lds_have = 0;
@@ -333,6 +349,42 @@ extern "C" int ddp_edge_featurize(const float* pos_a, const int32_t* ia, const f
                      n_edges, n_edges_dev, offset, k_rbf, coeff, pre, pre_idx, ld_pre, pre2, n_pre2, ld_pre2, w1d, w2, b2, ns, out, sh);
   err = hipGetLastError();
   if (err != hipSuccess) return ddp_fail_hip(err, "ddp_edge_featurize launch");
+  return 0;
+}
+
+extern "C" int ddp_edge_featurize_jobs(const ddp_featurize_job_t* jobs, int njobs, void* stream) {
+  if (njobs < 0 || njobs > DDP_MAX_FEATURIZE_JOBS) return ddp_fail(DDP_ELIMIT, "ddp_edge_featurize_jobs: njobs");
+  if (njobs == 0) return 0;
+  if (!jobs) return ddp_fail(DDP_EINVAL, "ddp_edge_featurize_jobs: null jobs");
+  FeatLaunch L;
+  L.njobs = 0;
+  int blocks = 0, kmax = 0;
+  for (int i = 0; i < njobs; ++i) {
+    ddp_featurize_job_t J = jobs[i];
+    if (J.n_edges <= 0) continue;
+    if (J.n_pre2 > 0 && !J.pre2) return ddp_fail(DDP_EINVAL, "ddp_edge_featurize: n_pre2 > 0 but pre2 is null");
+    if (!J.pre2) J.n_pre2 = 0;
+    if (!J.pos_a || !J.ia || !J.pos_b || !J.ib || !J.offset || !J.pre || !J.pre_idx || !J.w1d || !J.w2 || !J.b2 || !J.out || !J.sh)
+      return ddp_fail(DDP_EINVAL, "ddp_edge_featurize: null argument");
+    if (J.ns < 1 || J.ns > EF_NS) return ddp_fail(DDP_ELIMIT, "ddp_edge_featurize: ns > 64");
+    if (J.k_rbf < 8 || J.k_rbf > 64 || (J.k_rbf & 7))
+      return ddp_fail(DDP_ELIMIT, "ddp_edge_featurize_jobs: k_rbf must be a multiple of 8 in [8, 64] (ddp_edge_featurize takes any)");
+    int nb = (J.n_edges + 127) / 128;
+    if (nb > 1024) nb = 1024;
+    L.blk_start[L.njobs] = blocks;
+    L.job[L.njobs++] = J;
+    blocks += nb;
+    if (J.k_rbf > kmax) kmax = J.k_rbf;
+  }
+  L.blk_start[L.njobs] = blocks;
+  if (blocks == 0) return 0;
+  const size_t lds_m = (size_t)(kmax * EF_NS + EF_NS * EF_NS + EF_NS + 64 + 4 * 32 * EF_HS) * sizeof(float);
+  static int lds_have_m = 0;
+  hipError_t e2 = ddp_need_lds(reinterpret_cast<const void*>(ddp_edge_featurize_mfma_kernel), (int)lds_m, &lds_have_m);
+  if (e2 != hipSuccess) return ddp_fail_hip(e2, "hipFuncSetAttribute(edge_featurize_mfma)");
+  hipLaunchKernelGGL(ddp_edge_featurize_mfma_kernel, dim3(blocks), dim3(256), lds_m, (hipStream_t)stream, L);
+  e2 = hipGetLastError();
+  if (e2 != hipSuccess) return ddp_fail_hip(e2, "ddp_edge_featurize (mfma) launch");
   return 0;
 }
 

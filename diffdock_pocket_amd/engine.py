@@ -369,15 +369,16 @@ class ForwardEngine:
         rr32, aa32, ar32 = rows32("rr32", rr, 6), rows32("aa32", aa, 3), rows32("ar32", S.ar, 5)
 
         # ---- edge embeddings + harmonics (the per-node `pre` tables came with the node encoders)
-        EF = K.edge_featurize
         F.e, F.sh = {}, {}
-        F.e["ll"], F.sh["ll"] = EF(epk["ll"], m.lig_distance_expansion, lpos, ll0, lpos, ll1, pre["ll"], ll0, pre2=bond_pre,
-                                   n_edges=S.cap_ll, cnt=cnt["ll"])
-        F.e["rr"], F.sh["rr"] = EF(epk["rr"], m.rec_distance_expansion, rpos, rr32[0], rpos, rr32[1], pre["rr"], rr32[0])
-        F.e["aa"], F.sh["aa"] = EF(epk["aa"], m.lig_distance_expansion, apos, aa32[0], apos, aa32[1], pre["aa"], aa32[0])
-        F.e["lr"], F.sh["lr"] = EF(epk["lr"], m.cross_distance_expansion, lpos, lr0, rpos, lr1, pre["lr"], lr0, n_edges=S.cap_lr, cnt=cnt["lr"])
-        F.e["la"], F.sh["la"] = EF(epk["la"], m.cross_distance_expansion, lpos, la0, apos, la1, pre["la"], la0, n_edges=S.cap_la, cnt=cnt["la"])
-        F.e["ar"], F.sh["ar"] = EF(epk["ar"], m.rec_distance_expansion, apos, ar32[0], rpos, ar32[1], pre["ar"], ar32[0])
+        calls = {   # one launch for the six edge sets (ddp_edge_featurize_jobs)
+            "ll": ((epk["ll"], m.lig_distance_expansion, lpos, ll0, lpos, ll1, pre["ll"], ll0), dict(pre2=bond_pre, n_edges=S.cap_ll, cnt=cnt["ll"])),
+            "rr": ((epk["rr"], m.rec_distance_expansion, rpos, rr32[0], rpos, rr32[1], pre["rr"], rr32[0]), {}),
+            "aa": ((epk["aa"], m.lig_distance_expansion, apos, aa32[0], apos, aa32[1], pre["aa"], aa32[0]), {}),
+            "lr": ((epk["lr"], m.cross_distance_expansion, lpos, lr0, rpos, lr1, pre["lr"], lr0), dict(n_edges=S.cap_lr, cnt=cnt["lr"])),
+            "la": ((epk["la"], m.cross_distance_expansion, lpos, la0, apos, la1, pre["la"], la0), dict(n_edges=S.cap_la, cnt=cnt["la"])),
+            "ar": ((epk["ar"], m.rec_distance_expansion, apos, ar32[0], rpos, ar32[1], pre["ar"], ar32[0]), {})}
+        for key, (o_, s_) in zip(calls, K.edge_featurize_jobs(list(calls.values()))):
+            F.e[key], F.sh[key] = o_, s_
         mark("edge_featurize")
 
         # ---- CSR views per conv direction (receiver = edge_index[0] of the conv call) and source-ordered views of the

@@ -290,6 +290,37 @@ def edge_featurize(pack: EdgeMLPPack, dist, pos_a, ia, pos_b, ib, pre, pre_idx, 
     return out, sh
 
 
+def edge_featurize_jobs(calls):
+    """Several edge_featurize calls as ONE launch (ddp_edge_featurize_jobs).  calls: [(args, kwargs)] of `edge_featurize`;
+    returns [(out, sh)].  Falls back to one launch per call when an MLP is outside the batched kernel's shape range."""
+    if any(a[0].k % 8 or not 8 <= a[0].k <= 64 for a, _ in calls) or len(calls) > L.DDP_MAX_FEATURIZE_JOBS:
+        return [edge_featurize(*a, **kw) for a, kw in calls]
+    jobs, outs, keep = [], [], []
+    for (pack, dist, pos_a, ia, pos_b, ib, pre, pre_idx), kw in calls:
+        pre2, n_edges, cnt = kw.get("pre2"), kw.get("n_edges"), kw.get("cnt")
+        E = int(ia.shape[0]) if n_edges is None else int(n_edges)
+        out = torch.empty((E, pack.ns), device=pos_a.device, dtype=torch.float32)
+        sh = torch.empty((E, 4), device=pos_a.device, dtype=torch.float32)
+        outs.append((out, sh))
+        if E == 0:
+            continue
+        if pre.stride(1) != 1:
+            pre = pre.contiguous()
+        n2 = 0 if pre2 is None else int(pre2.shape[0])
+        j = L.FeaturizeJob()
+        j.pos_a, j.ia, j.pos_b, j.ib, j.n_edges, j.n_edges_dev = _p(pos_a), _p(ia), _p(pos_b), _p(ib), E, _p(cnt)
+        j.offset, j.k_rbf, j.coeff = _p(dist.offset), pack.k, float(dist.coeff)
+        j.pre, j.pre_idx, j.ld_pre = _p(pre), _p(pre_idx), pre.stride(0)
+        j.pre2, j.n_pre2, j.ld_pre2 = (_p(pre2) if n2 else 0), n2, (pre2.stride(0) if n2 else 0)
+        j.w1d, j.w2, j.b2, j.ns, j.out, j.sh = _p(pack.w1d), _p(pack.w2), _p(pack.b2), pack.ns, _p(out), _p(sh)
+        jobs.append(j)
+        keep.append((pre, pre2, ia, ib, pre_idx))
+    if jobs:
+        arr = (L.FeaturizeJob * len(jobs))(*jobs)
+        L.check(L.load().ddp_edge_featurize_jobs(arr, len(jobs), stream()), "ddp_edge_featurize_jobs")
+    return outs
+
+
 def stage_a(x, n_rows, offs, nb, W, out, rows=None, rows_cnt=None, out_rows=None, W3=None):
     """ddp_stage_a: out[b][row] = x[row, offs[b]:offs[b]+k] @ W[b] for the listed rows (all n_rows rows if rows is None).
     W3: the weights pre-split for the bf16x3 form (packing.split_bf16x3), None: exact fp32 MFMA."""

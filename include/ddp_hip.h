@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DDP_ABI_VERSION 10
+#define DDP_ABI_VERSION 11
 #define DDP_EINVAL (-1)   /* bad argument (shape not supported, null pointer, ...) */
 #define DDP_ELIMIT (-2)   /* exceeds a compiled-in limit (see DDP_MAX_*) */
 
@@ -167,6 +167,34 @@ int ddp_edge_featurize(const float* pos_a, const int32_t* ia, const float* pos_b
                        const int32_t* n_edges_dev, const float* offset, int k_rbf, float coeff, const float* pre,
                        const int32_t* pre_idx, int ld_pre, const float* pre2, int n_pre2, int ld_pre2, const float* w1d,
                        const float* w2, const float* b2, int ns, float* out, float* sh, void* stream);
+
+/* The same for several edge sets in ONE launch (a forward has six: ligand, receptor, atom, ligand-receptor, ligand-atom,
+ * atom-receptor; for small batches each is a handful of workgroups and a launch of its own ~5 - 14 us of latency).  Fields as
+ * the arguments above; k_rbf a multiple of 8 in [8, 64] (the matrix-core form). */
+#define DDP_MAX_FEATURIZE_JOBS 8
+typedef struct {
+  const float* pos_a;
+  const int32_t* ia;
+  const float* pos_b;
+  const int32_t* ib;
+  int32_t n_edges;
+  const int32_t* n_edges_dev;
+  const float* offset;
+  int32_t k_rbf;
+  float coeff;
+  const float* pre;
+  const int32_t* pre_idx;
+  int32_t ld_pre;
+  const float* pre2;
+  int32_t n_pre2, ld_pre2;
+  const float* w1d;
+  const float* w2;
+  const float* b2;
+  int32_t ns;
+  float* out;
+  float* sh;
+} ddp_featurize_job_t;
+int ddp_edge_featurize_jobs(const ddp_featurize_job_t* jobs, int njobs, void* stream);
 
 /* Torsion-head edge harmonics: the 1o block of FullTensorProduct(sh(edge), Y2(bond)) in closed form,
  *   t[e] = sqrt(3/2) * (3 (n.v) v - n),  n = unit(sh edge vector), v = unit(bond vector of bond ib[e])

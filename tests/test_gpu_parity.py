@@ -427,6 +427,33 @@ def test_edge_featurize_and_torsion_sh():
     assert torch.equal(battr, x[b0.long(), :ns] + x[b1.long(), :ns])
 
 
+def test_edge_featurize_jobs_equal_single_launches():
+    """ddp_edge_featurize_jobs: several edge sets in one launch - different MLPs, sizes from 1 edge to several workgroups, a
+    device-side count below the capacity, an empty set - bitwise the single-set launches."""
+    from diffdock_pocket_amd import launch as K
+    from diffdock_pocket_amd.score_model import GaussianSmearing, _EdgeMLPPack
+    torch.manual_seed(1)
+    dev = _dev()
+    calls = []
+    for ns, k, E, n_dev in ((60, 32, 5000, None), (60, 64, 1, None), (16, 32, 700, 333), (24, 32, 0, None), (60, 32, 129, 129)):
+        seq = torch.nn.Sequential(torch.nn.Linear(7 + k, ns), torch.nn.ReLU(), torch.nn.Dropout(0.0), torch.nn.Linear(ns, ns)).to(dev)
+        dist = GaussianSmearing(0.0, 5.0, k).to(dev)
+        Na, Nb = 50, 70
+        pa, pb = torch.randn(Na, 3, device=dev) * 3, torch.randn(Nb, 3, device=dev) * 3
+        ia, ib = torch.randint(0, Na, (E,), device=dev).int(), torch.randint(0, Nb, (E,), device=dev).int()
+        pk = _EdgeMLPPack(seq, slice(7, 7 + k), dev)
+        pre = torch.randn(Na, ns, device=dev)
+        kw = {}
+        if n_dev is not None:
+            kw = dict(n_edges=E, cnt=torch.tensor([n_dev], dtype=torch.int32, device=dev))
+        calls.append(((pk, dist, pa, ia, pb, ib, pre, ia), kw))
+    got = K.edge_featurize_jobs(calls)
+    for (a, kw), (o, s_) in zip(calls, got):
+        wo, ws = K.edge_featurize(*a, **kw)
+        n = int(kw["cnt"][0]) if kw else o.shape[0]
+        assert o.shape == wo.shape and torch.equal(o[:n], wo[:n]) and torch.equal(s_[:n], ws[:n])
+
+
 @pytest.mark.parametrize("B,stride0", [(1, False), (40, True), (130, False)])
 def test_prologue_and_read_out_kernels_match_their_pytorch_definitions(B, stride0):
     """ddp_step_prologue / ddp_trrot_head / ddp_tor_head (csrc/ddp_heads.hip) against the PyTorch expressions they replace
