@@ -28,7 +28,7 @@ The JSON line also carries
                 launch's edge count) / mean launch time from HIP events on the launch stream inside the timed region;
                 `frac` = achieved / 157.3 TFLOP/s <= 1.  The reference formulation's FLOPs, most of
                 which the source-node factorisation removes, are reported separately as `algorithmic_vs_fp32_peak`.
-                PMC-derived fields (traffic, issued MFMA FLOPs, padding, pipe-busy) come from profiles/r02_pmc.json and are
+                PMC-derived fields (traffic, issued MFMA FLOPs, padding, pipe-busy) come from profiles/r04_pmc.json (collected on the builder's box, see `pmc_source`) and are
                 dropped when that file was taken from other kernel sources than the ones loaded (source hash).
   cpu_baseline  the CPU oracle (reference-equivalent restatement, kind "port") on a bounded sample of the same workload
   other_workloads  BASELINE configs[2] (flexible side chains) and configs[0] (cfg1, 4 samples) measured in the same run.
@@ -48,7 +48,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 HBM_PEAK_GBS = 8000.0           # same guide: HBM3E ~8 TB/s
-PMC_FILE = os.path.join("profiles", "r03_pmc.json")
+PMC_FILE = os.path.join("profiles", "r04_pmc.json")
 
 
 def parse_args(argv=None):
@@ -87,8 +87,6 @@ def parse_args(argv=None):
     ap.add_argument("--no-roofline-pass", action="store_true", help="skip the instrumented steps behind the timed region")
     ap.add_argument("--no-flex-sharing", action="store_true",
                     help="diagnostic: flexible side chains without the partial sharing of layers 0 / 1 (model.share_flex_layer0 = False)")
-    ap.add_argument("--stage-a-fp32", action="store_true",
-                    help="diagnostic: stage A as exact fp32 MFMA products instead of the bf16x3 form (model.stage_a_bf16x3 = False)")
     return ap.parse_args(argv)
 
 
@@ -136,14 +134,15 @@ def loaded_hash():
 
 
 def load_pmc(workload_key):
-    """PMC-derived per-launch figures (tools/pmc_collect.py -> profiles/r02_pmc.json).  Returned only if they were collected
+    """PMC-derived per-launch figures (tools/pmc_collect.py -> PMC_FILE).  Returned only if they were collected
     on the kernel sources that are loaded now AND on this workload; otherwise {} (the fields are then null in the line)."""
     try:
         with open(os.path.join(ROOT, PMC_FILE)) as f:
             pmc = json.load(f)
     except OSError:
         return {}, None
-    src = {"file": PMC_FILE, "src_sha16": pmc.get("src_sha16"), "workload": pmc.get("workload")}
+    src = {"file": PMC_FILE, "src_sha16": pmc.get("src_sha16"), "workload": pmc.get("workload"),
+           "measured_on": pmc.get("measured_on", "builder's gpurun box (one MI355X), rocprofv3 --pmc passes of tools/gpu_round.sh; NOT this run")}
     if pmc.get("src_sha16") != loaded_hash() or pmc.get("workload") != workload_key:
         src["stale"] = True
         return {}, src
@@ -155,14 +154,20 @@ def load_pmc(workload_key):
 def model_kwargs(cfg, flex):
     if cfg == "cfg2":          # the README's large score model (reference README.md:72)
         ns, nv, L, emb = 60, 10, 6, 64
-    elif cfg == "small32":     # the README's small score model (reference README.md:82: --ns 32 --nv 6 --num_conv_layers 5)
-        ns, nv, L, emb = 32, 6, 5, 32
+    elif cfg == "small32":     # the README's small score model AS THE README DEFINES IT (reference README.md:82: --ns 32 --nv 6
+        ns, nv, L, emb = 32, 6, 5, 32   # --num_conv_layers 5 --atom_max_neighbors 12 --tr_sigma_max 15, embedding widths at the parser's 32)
     else:                      # cfg1 = BASELINE configs[0]
         ns, nv, L, emb = 16, 4, 2, 32
     return dict(sh_lmax=1, ns=ns, nv=nv, num_conv_layers=L, sigma_embed_dim=emb, distance_embed_dim=emb,
                 cross_distance_embed_dim=emb, lig_max_radius=5.0, cross_max_distance=80.0, dynamic_max_cross=True,
                 scale_by_sigma=True, batch_norm=True, dropout=0.0, lm_embedding_type="esm", fixed_center_conv=True,
-                atom_max_neighbors=8, flexible_sidechains=flex, use_old_atom_encoder=False), emb
+                atom_max_neighbors=12 if cfg == "small32" else 8, flexible_sidechains=flex, use_old_atom_encoder=False), emb
+
+
+def sigma_ranges(cfg):
+    """Noise ranges the model was trained with: README.md:72 (tr_sigma_max 5) / README.md:82 (the small model: 15)."""
+    from diffdock_pocket_amd.diffusion import SigmaRanges
+    return SigmaRanges(tr_sigma_max=15.0) if cfg == "small32" else SigmaRanges()
 
 
 def build_model(cfg, flex, device):
@@ -171,7 +176,7 @@ def build_model(cfg, flex, device):
     from diffdock_pocket_amd.score_model import TensorProductScoreModel
     kw, emb = model_kwargs(cfg, flex)
     torch.manual_seed(0)
-    model = TensorProductScoreModel(t_to_sigma=functools.partial(t_to_sigma, args=SigmaRanges()), device=device,
+    model = TensorProductScoreModel(t_to_sigma=functools.partial(t_to_sigma, args=sigma_ranges(cfg)), device=device,
                                     timestep_emb_func=get_timestep_embedding("sinusoidal", emb, 1000.0), **kw)
     # non-trivial BatchNorm statistics (identity BN would be unrepresentative)
     g = torch.Generator().manual_seed(1)
@@ -184,12 +189,12 @@ def build_model(cfg, flex, device):
 
 
 def cpu_baseline(args, model, kw, complex_graph):
-    """Reference-equivalent CPU restatement (oracle/) on a BOUNDED sample of the same workload, all host cores (count stated).
-    cfg2: forwards of `--cpu-batch` sample graphs at t = 1.0 and t = 0.5 (first and mid schedule position) until each step's
-    share of `--cpu-budget-s` is used or the 40 graphs of the step are done (`--cpu-full`: always all 40: SURVEY section 8(d)'s
-    two full steps, ~10 minutes on the GPU box's host; profiles/r03_cpu_baseline_full.json is such a run); the per-batch times
-    are listed - they are what "linear in the graph count" rests on.  cfg1 (BASELINE configs[0]): the whole 4-sample loop,
-    as many of its 20 steps as the remaining budget allows (three full loops with --cpu-full: median of 3)."""
+    """Reference-equivalent CPU restatement (oracle/) on a BOUNDED sample of the same workload, `--cpu-threads` host cores (count
+    stated).  cfg1 (BASELINE configs[0]) first: the whole 4-sample x 20-step loop three times, median (nothing extrapolated).
+    cfg2: forwards of `--cpu-batch` sample graphs at t = 1.0 and t = 0.5 (first and mid schedule position), as many rounds as
+    the rest of `--cpu-budget-s` allows or until the 40 graphs of the step are done (`--cpu-full`: always all 40: SURVEY section
+    8(d)'s two full steps, ~10 minutes on the GPU box's host; profiles/r03_cpu_baseline_full.json is such a run); the graphs
+    timed (`extrapolated_from_graphs`) and the per-batch times are listed - they are what "linear in the graph count" rests on."""
     import statistics
     import numpy as np
     import torch
@@ -209,6 +214,24 @@ def cpu_baseline(args, model, kw, complex_graph):
                             flexible_sidechains=k["flexible_sidechains"], embedding_scale=1000.0)
         return OracleScoreModel(ocfg, {kk: v.detach().cpu() for kk, v in m.state_dict().items()})
 
+    # BASELINE configs[0] first: cfg1, 4 samples x 20 steps, the WHOLE sampling loop on the CPU, three times (median; ~3.5 s each)
+    m1, kw1 = build_model("cfg1", True, torch.device("cpu"))
+    o1 = oracle_for(m1, kw1)
+    g1 = make_3dpf_complex(seed=0, flexible_sidechains=True)
+    sched = get_t_schedule(20)
+    runs = []
+    for rep in range(3):
+        smp = Sampler(lambda bb: o1(bb), g1, 4, torch.device("cpu"), SamplerConfig(inference_steps=20, flexible_sidechains=True), seed=0)
+        smp.randomize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for i in range(20):
+                smp.step(i, sched)
+        runs.append(time.perf_counter() - t0)
+    cfg1 = {"value": 4.0 / statistics.median(runs), "unit": "poses/s", "seconds_per_20_step_loop": runs, "cores": torch.get_num_threads(),
+            "note": "median of 3 full 20-step loops (nothing extrapolated)"}
+
+    # the headline workload: as many `--cpu-batch`-graph forwards as the remaining budget allows, alternating over the steps
     oracle = oracle_for(model, kw)
     gs = []
     g = torch.Generator().manual_seed(7)
@@ -221,54 +244,37 @@ def cpu_baseline(args, model, kw, complex_graph):
         set_time(b, 1.0, 1.0, 1.0, 1.0)
         oracle(b)
     steps_t = (1.0, 0.5)[: args.cpu_steps]
-    batches = []
-    for si, t in enumerate(steps_t):
-        share = 0.7 * budget * (si + 1) / len(steps_t)      # 70 % of the budget for cfg2, split over the steps
-        times = []
-        for i in range(0, n, bs):
+    batches = [[] for _ in steps_t]
+    for i in range(0, n, bs):
+        for si, t in enumerate(steps_t):
             t0 = time.perf_counter()
             b = collate(gs[i:i + bs])
             set_time(b, t, t, t, t)
             with torch.no_grad():
                 oracle(b)
-            times.append((len(gs[i:i + bs]), time.perf_counter() - t0))
-            if time.perf_counter() - t_begin > share:
-                break
-        batches.append(times)
+            batches[si].append((len(gs[i:i + bs]), time.perf_counter() - t0))
+        # (every step position has the same number of batches; at least one round is always timed)
+        spent = time.perf_counter() - t_begin
+        per_round = sum(bt[-1][1] for bt in batches)
+        if spent + per_round > budget:
+            break
     per_graph = [sum(x[1] for x in bt) / sum(x[0] for x in bt) for bt in batches]
     s_per_step = float(np.mean(per_graph)) * n
+    n_timed = [sum(x[0] for x in bt) for bt in batches]
     out = {"value": n / (s_per_step * 20.0), "unit": "poses/s", "cores": torch.get_num_threads(), "kind": "port",
            "sample": f"oracle/ref_model.py (fp32 PyTorch-CPU, per-edge weights materialised) on {bs}-graph batches of the workload's {n} "
-                     f"sample graphs at t = {', '.join(str(t) for t in steps_t)}: {', '.join(str(sum(x[0] for x in bt)) for bt in batches)} "
+                     f"sample graphs at t = {', '.join(str(t) for t in steps_t)}: {', '.join(str(k) for k in n_timed)} "
                      f"graphs timed per step ({', '.join(f'{p:.2f}' for p in per_graph)} s per graph), scaled to {n} graphs x 20 steps",
+           "extrapolated_from_graphs": n_timed, "graphs_per_step_of_the_workload": n,
            "seconds_per_batch": [[round(x[1], 3) for x in bt] for bt in batches], "graphs_per_batch": bs,
            "seconds_per_40_sample_step": s_per_step}
-    # BASELINE configs[0]: cfg1, 4 samples x 20 steps, the whole sampling loop on the CPU
-    m1, kw1 = build_model("cfg1", True, torch.device("cpu"))
-    o1 = oracle_for(m1, kw1)
-    g1 = make_3dpf_complex(seed=0, flexible_sidechains=True)
-    sched = get_t_schedule(20)
-    runs = []
-    for rep in range(3 if args.cpu_full else 1):
-        smp = Sampler(lambda bb: o1(bb), g1, 4, torch.device("cpu"), SamplerConfig(inference_steps=20, flexible_sidechains=True), seed=0)
-        smp.randomize()
-        t0, done = time.perf_counter(), 0
-        with torch.no_grad():
-            for i in range(20):
-                smp.step(i, sched)
-                done += 1
-                if time.perf_counter() - t_begin > budget and done >= 2:
-                    break
-        runs.append((time.perf_counter() - t0) * 20.0 / done)
-    out["configs[0] cfg1 4 samples x 20 steps (whole CPU loop)"] = {
-        "value": 4.0 / statistics.median(runs), "unit": "poses/s", "seconds_per_20_step_loop": runs, "cores": torch.get_num_threads(),
-        "note": "median of 3 full loops" if args.cpu_full else "one loop, scaled from the steps that fit the time budget"}
+    out["configs[0] cfg1 4 samples x 20 steps (whole CPU loop)"] = cfg1
     out["seconds_spent"] = time.perf_counter() - t_begin
     return out
 
 
 def timed_job(model, complex_graph, n_total, sl, device, flex, steps, warmup, ways=1, sync=lambda: None, dist=None, world=1,
-              on_timed=None):
+              on_timed=None, cfg="cfg2"):
     """`warmup` (at least 3) untimed steps on the sampler that is then timed - they fill the model's static caches and the
     allocator and capture the step's hipGraph - then the job restarts from its first step (poses and noise stream restored)
     and exactly `steps` steps are timed, bracketed by barrier + synchronize.  on_timed(sampler, snapshot, schedule) runs after
@@ -276,7 +282,7 @@ def timed_job(model, complex_graph, n_total, sl, device, flex, steps, warmup, wa
     import torch
     from diffdock_pocket_amd.diffusion import get_t_schedule
     from diffdock_pocket_amd.sampler import PipelinedSampler, Sampler, SamplerConfig
-    scfg = SamplerConfig(inference_steps=20, flexible_sidechains=flex)
+    scfg = SamplerConfig(inference_steps=20, flexible_sidechains=flex, sigma=sigma_ranges(cfg))
     if ways > 1:
         sampler = PipelinedSampler(model, complex_graph, n_total, device, scfg, seed=0, sample_slice=sl, ways=ways)
     else:
@@ -315,6 +321,9 @@ def timed_job(model, complex_graph, n_total, sl, device, flex, steps, warmup, wa
     sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if hasattr(sampler, "check_overflow"):
+        sampler.check_overflow()      # replayed steps never enter the model's Python forward: a truncated edge list is reported here
+    info["edges_last_step"] = dict(getattr(sampler, "last_stats", None) or model.last_stats)     # (of THIS job: read before any other runs)
     if on_timed is not None:
         on_timed(sampler, snap, schedule)
     return elapsed, sampler, final_pos.clone(), gathered, schedule, info
@@ -374,8 +383,6 @@ def main(argv=None):
     from diffdock_pocket_amd import score_model as sm
 
     model, kw = build_model(args.cfg, args.flex, device)
-    if args.stage_a_fp32:
-        model.stage_a_bf16x3 = False
     if args.no_flex_sharing:
         model.share_flex_layer0 = False
     complex_graph = make_3dpf_complex(seed=0, flexible_sidechains=args.flex)
@@ -413,7 +420,7 @@ def main(argv=None):
 
     elapsed, sampler, final_pos, gathered, schedule, info = timed_job(model, complex_graph, n_total, sl, device, args.flex, args.steps,
                                                                       args.warmup, ways=args.ways, sync=sync, dist=dist, world=world,
-                                                                      on_timed=roofline_pass)
+                                                                      on_timed=roofline_pass, cfg=args.cfg)
     rank_ms = [elapsed / args.steps * 1e3]
     if dist is not None:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -428,7 +435,7 @@ def main(argv=None):
         nw = args.samples * world
         slw = shard_slice(rank, world, nw, None)
         elw, _, fpw, gw, _, infow = timed_job(model, complex_graph, nw, slw, device, args.flex, args.steps, args.warmup, sync=sync,
-                                              dist=dist, world=world)
+                                              dist=dist, world=world, cfg=args.cfg)
         tt = torch.tensor([elw], device=device, dtype=torch.float64)
         allt = [torch.empty_like(tt) for _ in range(world)]
         dist.all_gather(allt, tt)
@@ -465,7 +472,10 @@ def main(argv=None):
                      "tile_padded_mfma_gflop_per_launch": issued_model / 1e9,
                      "algorithmic_gflop_per_launch": fl_ / n_ / 1e9,
                      "algorithmic_vs_fp32_peak": fl_ / n_ / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                     "share_of_wall": ms_ * 1e-3 / elapsed,
+                     "share_of_wall": ms_ * 1e-3 / elapsed, "ms_per_step": ms_ / args.steps,
+                     "by_layer": {str(tag): {"launches": n_t, "avg_launch_ms": ms_t / n_t, "edges_per_launch": ne_t / n_t,
+                                             "achieved": u_t / (ms_t * 1e-3) / 1e12, "frac": u_t / (ms_t * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+                                  for tag, (n_t, u_t, ms_t, ne_t) in sorted(prof.by_tag(kname).items(), key=lambda kv: str(kv[0]))},
                      "traffic": p.get("hbm_bytes_per_launch"), "issued_mfma_gflop_per_launch_pmc": p.get("issued_mfma_gflop_per_launch"),
                      "padding_frac_pmc": p.get("padding_frac"), "mfma_busy_pmc": p.get("mfma_busy_frac")}
                 return e
@@ -508,7 +518,7 @@ def main(argv=None):
                            "ways": args.ways, "ms_per_step_by_rank": rank_ms, "src_sha16": loaded_hash(),
                            "hip_graph_replay": info.get("hip_graph"), "rccl_ranks_seen": ranks_seen, "backend": backend,
                            "all_gather_ms": info.get("all_gather_ms"),
-                           "edges_last_step": dict(getattr(sampler, "last_stats", None) or model.last_stats)},
+                           "edges_last_step": info.get("edges_last_step")},
                 "roofline": roof}
         if weak is not None:
             line["weak_scaling"] = weak
@@ -544,16 +554,17 @@ def main(argv=None):
                     sm.set_conv_profiler(None)
                     smp_.graph_enabled = True
 
-                el_, s_, fp_, _, _, _ = timed_job(m_, g_, n_, slice(0, n_), device, flex_, 20, 3, on_timed=inst)
+                el_, s_, fp_, _, _, _ = timed_job(m_, g_, n_, slice(0, n_), device, flex_, 20, 3, on_timed=inst, cfg=cfg_)
                 assert torch.isfinite(fp_).all() and torch.isfinite(s_.atom_pos).all()
                 return {"value": n_ / el_, "unit": "poses/s", "ms_per_step": el_ / 20 * 1e3, "steps": 20,
                         "edges_last_step": dict(m_.last_stats), "conv_kernels": conv_fracs(pr)}
 
             others["configs[2] 3dpf flexible side chains, 40 samples, cfg2"] = sub_job("cfg2", True, 40)
             others["configs[0] 3dpf 4 samples, cfg1 (ns=16 nv=4 L=2), flexible side chains"] = sub_job("cfg1", True, 4)
-            others["README small score model (ns=32 nv=6 L=5), 40 samples, rigid receptor"] = sub_job("small32", False, 40)
+            others["README small score model (README.md:82: ns=32 nv=6 L=5, atom_max_neighbors=12, tr_sigma_max=15), 40 samples, rigid receptor"] = \
+                sub_job("small32", False, 40)
             # BASELINE configs[3]'s shard: 5 of the 40 samples on this GPU (what one of 8 ranks runs under the strong split)
-            el5, s5, fp5, _, _, _ = timed_job(model, complex_graph, 40, slice(0, 5), device, False, 20, 3)
+            el5, s5, fp5, _, _, _ = timed_job(model, complex_graph, 40, slice(0, 5), device, False, 20, 3, cfg=args.cfg)
             others["configs[3] shard: samples [0, 5) of the 40 on one GPU, cfg2"] = {
                 "value": 5.0 / el5, "unit": "poses/s per GPU", "ms_per_step": el5 / 20 * 1e3, "steps": 20}
             del s5

@@ -56,6 +56,11 @@ class LazyStats(Mapping):
             self._vals = vals
         return self._vals
 
+    def fresh(self):
+        """A new, unread view over the same count block.  The block of a CAPTURED forward is rewritten by every replay of the
+        step's hipGraph, while this object memoises its first read: sampler.Sampler installs a fresh view after each replay."""
+        return LazyStats(self._static, self._counts, self._names)
+
     def __getitem__(self, k):
         return self._resolve()[k]
 
@@ -176,7 +181,9 @@ class ForwardEngine:
             S.num_flex = int(data["flexResidues"].edge_idx.shape[0])
         nl, nr, na = S.lay_l.counts_host, S.lay_r.counts_host, S.lay_a.counts_host
         # worst-case sizes of the pose-dependent edge lists (per graph: every query x every point of its graph, or the cap)
-        S.cap_ll = S.E_bond + sum(n * min(max(n - 1, 0), 32) for n in nl)
+        # (ligand radius graph: searched with 33 matches per query, then self is dropped - a query whose first 33 in-radius
+        # matches in index order all precede it keeps 33 of them)
+        S.cap_ll = S.E_bond + sum(n * min(max(n - 1, 0), 33) for n in nl)
         S.cap_lr = sum(a * min(b, 10000) for a, b in zip(nl, nr))
         S.cap_la = sum(a * min(b, 10000, max(int(m.la_capacity_per_atom), 1)) for a, b in zip(nl, na))
         S.stats = {"E_rr": int(rr.shape[1]), "E_ar": int(ar.shape[1]), "N_l": S.Nl, "N_r": S.Nr, "N_a": S.Na, "B": B}
@@ -810,7 +817,7 @@ class ForwardEngine:
                 tasks.append(K.make_task(pkc, x_src, ldx, csr, sh[ek], segs, msg))
             direct_first = fork is not None and bool(tasks)
             if direct_first:
-                fork.run(3, lambda: K.launch_convs(spec, tasks, node_bytes=nb_d))
+                fork.run(3, lambda: K.launch_convs(spec, tasks, node_bytes=nb_d, tag=f"layer{l}"))
             # ---- stage A: one batched product per (source-node array, row set)
             gmap = {}
             for gi, ((st_, gid), (x_src, rows, convs)) in enumerate(groups.items()):
@@ -865,11 +872,11 @@ class ForwardEngine:
                 segs = [(e_base, so_k.eid, ns, ns), (x_recv, so_k.recv, ldx, ns), (x_src, so_k.src, ldx, ns)]
                 tasks_g.append(K.make_task(conv.packed_g(dev), x_src, ldx, so_k, sh_k, segs, msg, g=[gmap.get((k, s_)) for s_ in (0, 1)]))
             mark("conv_prep")
-            K.launch_convs(spec_g, tasks_g, flops_spec=spec, node_bytes=nb_g)
+            K.launch_convs(spec_g, tasks_g, flops_spec=spec, node_bytes=nb_g, tag=f"layer{l}")
             if direct_first:
                 fork.join()
             else:
-                K.launch_convs(spec, tasks, node_bytes=nb_d)
+                K.launch_convs(spec, tasks, node_bytes=nb_d, tag=f"layer{l}")
             mark("conv_launch")
             if l == 0 and F.flex0 is not None:
                 # flexible side chains: the kept receivers' messages were computed on the pruned lists; the segmented mean walks
@@ -951,7 +958,7 @@ class ForwardEngine:
         pkc = m.final_conv.packed(dev)
         msg = torch.empty((Nl, fspec.d_out), device=dev)
         seg_idx = c_c.src if m.fixed_center_conv else c_c.recv
-        K.launch_convs(fspec, [K.make_task(pkc, xl, ldx, c_c, sh_c, [(e_c, c_c.eid, ns, ns), (xl, seg_idx, ldx, ns)], msg)])
+        K.launch_convs(fspec, [K.make_task(pkc, xl, ldx, c_c, sh_c, [(e_c, c_c.eid, ns, ns), (xl, seg_idx, ldx, ns)], msg)], tag="head")
         gp = torch.empty((B, fspec.d_out), device=dev)      # (every row is written: accumulate = False)
         K.launch_reduce(gp, fspec.d_out, B, fspec.d_out, [(msg, c_c, pkc)], accumulate=False)
         if m.debug_conv_outputs is not None:
@@ -1003,7 +1010,7 @@ class ForwardEngine:
         msg = torch.empty((E, spec.d_out), device=dev)
         segs = [(e_t, csr.eid, ns, ns), (x, csr.src, ldx, ns), (bond_attr, csr.recv, ns, ns)]
         if E > 0:
-            K.launch_convs(spec, [K.make_task(pkc, x, ldx, csr, tor_sh, segs, msg)])
+            K.launch_convs(spec, [K.make_task(pkc, x, ldx, csr, tor_sh, segs, msg)], tag="head")
         hsum = torch.empty((T, spec.d_out), device=dev)      # (every row is written: accumulate = False)
         K.launch_reduce(hsum, spec.d_out, T, spec.d_out, [(msg, csr, pkc)] if E > 0 else [], accumulate=False)
         if m.debug_conv_outputs is not None:

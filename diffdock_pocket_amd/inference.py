@@ -110,7 +110,8 @@ def run_csv(csv_path: str, model, device, *, confidence_model=None, samples_per_
     A row that fails on ANY rank (unreadable file, unsupported ligand format, missing ESM embedding, a parsing error: every
     Exception, like the reference's per-complex try / except, inference.py:282-287) is skipped on ALL ranks: with sample
     sharding the ranks agree on the outcome (one all_reduce of an ok flag per row) before anyone enters the sampling loop and
-    its final all_gather, so a rank-local failure cannot leave the others waiting in a collective."""
+    its final all_gather, and once more after sampling and the confidence pass (a sampling-time failure is rank-local: every rank
+    holds different poses), so a rank-local failure cannot leave the others waiting in a collective."""
     dev = torch.device(device)
     if dev.type == "cuda":      # kernels are queued on the CURRENT device's stream: make `device` current for the whole run
         with torch.cuda.device(dev):
@@ -158,13 +159,25 @@ def _run_csv(csv_path, model, device, confidence_model, samples_per_complex, inf
         cfg = sampler_cfg or SamplerConfig(inference_steps=inference_steps, flexible_sidechains=flex)
         n = samples_per_complex
         sl = slice(rank * n // world, (rank + 1) * n // world) if split else slice(0, n)
-        smp = Sampler(model, g, n, device, cfg, seed=seed + i, sample_slice=sl)
-        smp.randomize()
-        smp.run(schedule)
-        lig = smp.lig_pos
-        conf = None
-        if confidence_model is not None:
-            conf, _ = smp.confidence(confidence_model)
+        # Sampling can fail on ONE rank only (each rank holds other poses: a truncated ligand<-atom list - DdpError after the run's
+        # final synchronisation -, DDP_ELIMIT, out of memory): like the reference (inference.py:282-287) the complex is then
+        # skipped - on EVERY rank, agreed before anyone enters the gathers below
+        lig = conf = None
+        try:
+            smp = Sampler(model, g, n, device, cfg, seed=seed + i, sample_slice=sl)
+            smp.randomize()
+            smp.run(schedule)
+            lig = smp.lig_pos
+            if confidence_model is not None:
+                conf, _ = smp.confidence(confidence_model)
+        except Exception as e:      # noqa: BLE001
+            res.skipped = f"{type(e).__name__}: {e}"
+            lig = None
+        if split and not _all_ok(dist, lig is not None, device):
+            res.skipped = res.skipped or "skipped: sampling failed on another rank"
+            continue
+        if lig is None:
+            continue
         if split:
             sizes = [(r + 1) * n // world - r * n // world for r in range(world)]
             lig = _gather_rows(dist, lig, sizes)

@@ -75,15 +75,17 @@ class ConvProfiler:
     that live in device memory are resolved when a summary is asked for (after the timed region)."""
 
     def __init__(self):
-        self.events, self.kernel, self.specs, self.counts, self.node_bytes = [], [], [], [], []
+        self.events, self.kernel, self.specs, self.counts, self.node_bytes, self.tags = [], [], [], [], [], []
         self.hbm = {}   # HBM-bound kernels: name -> [(event0, event1, bytes or callable)]
         self.hbm_on = False   # their ~45 extra event pairs per step cost wall time: bench.py times them in extra steps
         self._resolved = None
 
     # -- recording (called by the launch wrappers) -------------------------------------------------------------
-    def record_conv(self, e0, e1, spec, flops_spec, tasks_counts, node_bytes):
-        """tasks_counts: [(capacity, cnt tensor or None)] of the launch's tasks."""
+    def record_conv(self, e0, e1, spec, flops_spec, tasks_counts, node_bytes, tag=None):
+        """tasks_counts: [(capacity, cnt tensor or None)] of the launch's tasks; tag: where in the forward the launch sits
+        ("layer3", "head")."""
         self.events.append((e0, e1))
+        self.tags.append(tag)
         self.kernel.append("ddp_conv32_kernel" if spec.factorized else "ddp_conv_messages_kernel")
         self.specs.append((spec, flops_spec or spec))
         self.counts.append(tasks_counts)
@@ -125,6 +127,17 @@ class ConvProfiler:
         sel = [i for i, k in enumerate(self.kernel) if kernel is None or k == kernel]
         ms = sum(self.events[i][0].elapsed_time(self.events[i][1]) for i in sel)
         return len(sel), float(sum(self.flops[i] for i in sel)), float(ms)
+
+    def by_tag(self, kernel):
+        """{tag: (launches, useful FLOPs, ms, edges)} of one kernel instantiation, e.g. per conv layer."""
+        self._resolve()
+        out = {}
+        for i, k in enumerate(self.kernel):
+            if k != kernel:
+                continue
+            n, u, ms, ne = out.get(self.tags[i], (0, 0.0, 0.0, 0))
+            out[self.tags[i]] = (n + 1, u + self.useful[i], ms + self.events[i][0].elapsed_time(self.events[i][1]), ne + self.edges[i])
+        return out
 
     def executed_flops(self, kernel=None):
         """FLOPs of the padded MFMA tiles + the G pass of factorised convs (a model of what is issued; the PMC pass counts it)."""
@@ -204,8 +217,9 @@ def make_task(pk, x_src, ldx_src, view: EdgeView, sh, segs, msg, g=None) -> L.Co
     return t
 
 
-def launch_convs(spec: P.ConvSpec, tasks: List[L.ConvTask], flops_spec: Optional[P.ConvSpec] = None, node_bytes: float = 0.0):
-    """node_bytes: 4 (N_in D_in + N_out D_out) summed over the launch's conv calls (only used by the profiler)."""
+def launch_convs(spec: P.ConvSpec, tasks: List[L.ConvTask], flops_spec: Optional[P.ConvSpec] = None, node_bytes: float = 0.0, tag=None):
+    """node_bytes: 4 (N_in D_in + N_out D_out) summed over the launch's conv calls; tag: position in the forward (both only used
+    by the profiler)."""
     lib = L.load()
     if not tasks:
         return
@@ -218,7 +232,7 @@ def launch_convs(spec: P.ConvSpec, tasks: List[L.ConvTask], flops_spec: Optional
     L.check(lib.ddp_conv_messages(C.byref(shape), arr, len(tasks), stream()), "ddp_conv_messages")
     if prof is not None:
         e1.record()
-        prof.record_conv(e0, e1, spec, flops_spec, [t._count for t in tasks], node_bytes)
+        prof.record_conv(e0, e1, spec, flops_spec, [t._count for t in tasks], node_bytes, tag)
 
 
 def launch_reduce(x, ldx, n_nodes, d_out, sources, accumulate=True, n_rep=1, rep_stride=0):

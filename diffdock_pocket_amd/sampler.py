@@ -189,6 +189,7 @@ class Sampler:
         self.atom_pos = self.batch["atom"].pos.reshape(self.n, self.n_a, 3).clone()
         self.on_hip = torch.device(device).type == "cuda"
         self._graph = None
+        self._graph_epoch, self._graph_stats, self._graph_keep = 0, None, None
         self.graph_enabled = True      # False: the step is launched kernel by kernel even if a graph has been captured
         self._steps_run = 0
         if self.on_hip:
@@ -342,8 +343,14 @@ class Sampler:
         with torch.cuda.device(self.device):
             self._bind_batch()
             self._upload_step(t_idx, schedule)
+            if self._graph and self._graph_epoch != getattr(self.model, "_packed_epoch", 0):
+                # the model dropped its packed weights / static caches (model.to(), load_state_dict, changed weights found by
+                # _refresh_weight_caches): the captured launches read memory that is no longer held - recapture from new state
+                self._graph, self._graph_keep, self._steps_run = None, None, 0
             if self._graph and self.graph_enabled:
                 self._graph.replay()
+                if self._graph_stats is not None:     # (the replay rewrote the count block the captured forward's stats read)
+                    self.model.last_stats = self._graph_stats.fresh()
                 # (the replay moved the poses in place behind Python's back: the model's static-graph cache keys on the versions)
                 torch.autograd.graph.increment_version(self.lig_pos)
                 if self.has_flex:
@@ -380,6 +387,9 @@ class Sampler:
             self._step_body()
             return
         self._graph = g
+        self._graph_epoch = getattr(self.model, "_packed_epoch", 0)
+        st = getattr(self.model, "last_stats", None)
+        self._graph_stats = st if hasattr(st, "fresh") else None
         # Everything the capture left in the model's static-graph cache lives in the graph's memory pool and is read and
         # written by its replays: those tensors must not be freed while the graph is alive, whatever later forwards put in
         # the cache's slots
@@ -387,8 +397,19 @@ class Sampler:
         self._graph_keep = [[dict(c) for c in self.model.__dict__.get("_static_caches", {}).values()],
                             getattr(self.model, "last_stats", None), getattr(b, "graph_sigma_emb", None),
                             [getattr(b[nt], "node_sigma_emb", None) for nt in ("ligand", "receptor", "atom")],
-                            getattr(b["atom", "atom"], "edge_index", None)]     # (what the captured forward left on model and batch)
+                            getattr(b["atom", "atom"], "edge_index", None),     # (what the captured forward left on model and batch)
+                            self._packed_refs()]
         g.replay()
+
+    def _packed_refs(self):
+        """Packed weights, edge-MLP packs and stage-A stacks built by the steps before the capture live OUTSIDE the graph's memory
+        pool while the captured launches carry their addresses: the graph holds them, so that `model.invalidate_packed()` (which
+        only drops the model's references) can never hand that memory to someone else under a graph that is still replayed."""
+        m = self.model
+        refs = [dict(getattr(m, "_edge_packs", {}) or {}), dict(getattr(m, "_stage_a_stacks", {}) or {})]
+        if hasattr(m, "modules"):
+            refs += [(getattr(c, "_packed", None), getattr(c, "_packed_g", None)) for c in m.modules() if hasattr(c, "_packed")]
+        return refs
 
     # -- randomize_position (reference utils/sampling.py:16-60), pocket_knowledge=False -----------------------
     def randomize(self):
@@ -517,18 +538,33 @@ class Sampler:
             b["atom"].pos = self.atom_pos.reshape(-1, 3)
             set_time(b, 0.0, 0.0, 0.0, 0.0, device=self.device)
         conf = self._call_model(confidence_model, b)
+        if self.on_hip and hasattr(confidence_model, "check_overflow"):
+            # a truncated ligand<-atom list is reported for THIS complex, before its scores are ranked (the flag is written by the
+            # search kernel: visible once the forward has run)
+            torch.cuda.synchronize(self.device)
+            confidence_model.check_overflow()
         key = conf[:, 0] if conf.dim() == 2 else conf
         return conf, torch.argsort(key, descending=True)
 
     def run(self, schedule: Optional[np.ndarray] = None):
         schedule = get_t_schedule(self.cfg.inference_steps) if schedule is None else schedule
         self.__dict__["_weights_checked"] = set()      # a run re-checks the weights' values once
+        if self.on_hip and self._graph and hasattr(self.model, "_refresh_weight_caches"):
+            # replays never enter the model's Python forward: the value check (param.data.copy_, EMA) is made here, and a change
+            # drops the packed weights -> the epoch test in _step_hip recaptures
+            self.model._refresh_weight_caches()
         for i in range(len(schedule)):
             self.step(i, schedule)
+        self.check_overflow()
+        return self.lig_pos, self.atom_pos
+
+    def check_overflow(self):
+        """Raises if the ligand<-atom list of a step queued so far was truncated (model.la_capacity_per_atom).  Inside a replayed
+        step the model's Python forward - which checks at its top - is never entered: callers that drive `step` themselves
+        (bench.py, tools) call this after their last step; `run` and `confidence` do."""
         if self.on_hip and hasattr(self.model, "check_overflow"):
             torch.cuda.synchronize(self.device)
             self.model.check_overflow()
-        return self.lig_pos, self.atom_pos
 
 
 class PipelinedSampler:
@@ -632,4 +668,11 @@ class PipelinedSampler:
         schedule = get_t_schedule(self.parts[0].cfg.inference_steps) if schedule is None else schedule
         for i in range(len(schedule)):
             self.step(i, schedule)
+        self.check_overflow()
         return self.lig_pos, self.atom_pos
+
+    def check_overflow(self):
+        """Raises if a ligand<-atom list of any group's steps was truncated (see Sampler.check_overflow)."""
+        if hasattr(self.model, "check_overflow"):
+            torch.cuda.synchronize(self.device)
+            self.model.check_overflow()

@@ -580,6 +580,8 @@ class TensorProductScoreModel(nn.Module):
                              f"lig_max_radius: the ligand<-atom edge list of an earlier forward was truncated; raise the capacity")
 
     def invalidate_packed(self):
+        # (a captured step holds the ADDRESSES of what is dropped here: sampler.Sampler compares this counter before a replay)
+        self.__dict__["_packed_epoch"] = self.__dict__.get("_packed_epoch", 0) + 1
         self._weights_seen = None
         self._weights_seen_fp = None
         self.__dict__["_weight_tensors_"] = None

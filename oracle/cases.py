@@ -48,6 +48,11 @@ class Case:
     drop_rotatable: bool = False          # edge_mask all False -> tor_pred empty
     weight_seed: int = 0
     data_seed: int = 0
+    tr_sigma_max: float = 5.0             # README.md:72 (large score model); the small score model of README.md:82 trains with 15
+    # heterogeneous batch: per-graph truncations [{n_lig, n_rec, n_atom}, ...] (overrides n_graphs / n_lig / n_rec / n_atom) -
+    # graphs of different ligand / pocket sizes and flexible-residue sets, as the reference's validation and confidence-data
+    # loaders batch them
+    hetero: Optional[List[Dict]] = None
 
     def model_kwargs(self) -> Dict:
         """kwargs for TensorProductScoreModel (reference ctor signature, README.md:72 settings)."""
@@ -68,10 +73,10 @@ class Case:
                             dynamic_max_cross=self.dynamic_max_cross, cross_max_distance=self.cross_max_distance,
                             scale_by_sigma=self.scale_by_sigma, batch_norm=self.batch_norm,
                             atom_max_neighbors=self.atom_max_neighbors,
-                            confidence_mode=self.confidence_mode, embedding_scale=1000.0)
+                            confidence_mode=self.confidence_mode, embedding_scale=1000.0, tr_sigma_max=self.tr_sigma_max)
 
     def ctor_extras(self):
-        sig = SigmaRanges()
+        sig = SigmaRanges(tr_sigma_max=self.tr_sigma_max)
         return dict(t_to_sigma=functools.partial(t_to_sigma, args=sig), device=torch.device("cpu"),
                     timestep_emb_func=get_timestep_embedding("sinusoidal", self.embed, 1000.0))
 
@@ -80,9 +85,10 @@ class Case:
         side-chain perturbations, per-graph times `t`."""
         g = torch.Generator().manual_seed(1000 + self.data_seed)
         graphs = []
-        for i in range(self.n_graphs):
-            c = make_3dpf_complex(seed=self.data_seed, flexible_sidechains=self.flexible_sidechains, n_lig=self.n_lig,
-                                  n_rec=self.n_rec, n_atom=self.n_atom)
+        cuts = self.hetero if self.hetero is not None else [dict(n_lig=self.n_lig, n_rec=self.n_rec, n_atom=self.n_atom)] * self.n_graphs
+        for i, cut in enumerate(cuts):
+            c = make_3dpf_complex(seed=self.data_seed + (i if self.hetero is not None else 0), flexible_sidechains=self.flexible_sidechains,
+                                  n_lig=cut.get("n_lig"), n_rec=cut.get("n_rec"), n_atom=cut.get("n_atom"))
             pos = c["ligand"].pos
             ctr = pos.mean(0, keepdim=True)
             axis = torch.randn(3, generator=g)
@@ -97,7 +103,7 @@ class Case:
             graphs.append(c)
         batch = collate(graphs)
         set_time(batch, 0.0, 0.0, 0.0, 0.0)
-        tt = torch.tensor(self.t[:self.n_graphs], dtype=torch.float32)
+        tt = torch.tensor(self.t[:len(cuts)], dtype=torch.float32)
         for nt in ("ligand", "receptor", "atom"):
             b = batch[nt].batch
             batch[nt].node_t = {k: tt[b].clone() for k in ("tr", "rot", "tor", "sc_tor")}
@@ -137,6 +143,20 @@ CASES: Dict[str, Case] = {c.name: c for c in [
          t=[0.85, 0.3], weight_seed=11, data_seed=5),
     Case("cfg2_full_flex", ns=60, nv=10, num_conv_layers=6, embed=64, flexible_sidechains=True, n_graphs=2,
          t=[0.6, 0.15], weight_seed=12, data_seed=6),
+    # HETEROGENEOUS batches (round 4): graphs of different ligand size, pocket size and flexible-residue set in one batch, each
+    # at its own time - per-graph offsets of get_sc_tor_bonds (all_atom_score_model.py:638-652), the CSR views, the bond-centre
+    # graphs and every per-graph reduction see unequal graphs (no receptor-side sharing applies: the general path)
+    Case("hetero_cfg1", ns=16, nv=4, num_conv_layers=3, embed=32, t=[0.8, 0.45, 0.1], weight_seed=13, data_seed=7,
+         hetero=[dict(n_rec=30), dict(n_lig=21, n_rec=18), dict(n_lig=27, n_rec=24, n_atom=150)]),
+    Case("hetero_cfg2", ns=60, nv=10, num_conv_layers=6, embed=64, t=[0.75, 0.25], weight_seed=14, data_seed=8,
+         hetero=[dict(n_rec=26), dict(n_lig=22, n_rec=16)]),
+    Case("hetero_conf", ns=24, nv=6, num_conv_layers=5, embed=32, t=[0.0, 0.0, 0.0], confidence_mode=True, num_confidence_outputs=2,
+         weight_seed=15, data_seed=9, hetero=[dict(n_rec=22), dict(n_lig=19, n_rec=28), dict(n_lig=25, n_rec=14)]),
+    # The README's SMALL score model as the README defines it (README.md:82: --ns 32 --nv 6 --num_conv_layers 5
+    # --atom_max_neighbors 12 --tr_sigma_max 15, embedding widths at the parser defaults 32): 12 atom neighbours and the
+    # 3 * sigma_tr + 20 <= 65 A cross cutoff
+    Case("small32_readme", ns=32, nv=6, num_conv_layers=5, embed=32, n_graphs=2, n_rec=40, t=[0.9, 0.3], atom_max_neighbors=12,
+         tr_sigma_max=15.0, weight_seed=16, data_seed=10),
 ]}
 
 

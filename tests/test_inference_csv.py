@@ -143,6 +143,62 @@ def test_two_rank_sample_sharding_equals_the_single_process_run(tmp_path):
             assert torch.equal(lig, ref.ligand_pos) and torch.equal(conf, ref.confidence)
 
 
+class FailingStub(Stub):
+    """Raises on rank `bad_rank` while sampling the complex with `bad_T` rotatable bonds per graph (a stand-in for a rank-local
+    DdpError: each rank holds other poses, so e.g. a truncated ligand<-atom list is seen by one rank only)."""
+
+    def __init__(self, rank, bad_rank, fail_flex):
+        self.rank, self.bad_rank, self.fail_flex = rank, bad_rank, fail_flex
+
+    def __call__(self, b):
+        has_flex = len(b["flexResidues"]) > 0
+        if self.rank == self.bad_rank and has_flex == self.fail_flex:
+            raise RuntimeError("injected sampling failure")
+        return super().__call__(b)
+
+
+def _worker_failing(rank, world, csv_path, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = INF.run_csv(csv_path, FailingStub(rank, 1, True), torch.device("cpu"), confidence_model=StubConfidence(), samples_per_complex=5,
+                      inference_steps=3, root=GOLDEN, seed=2, rank=rank, world=world, dist=dist, allow_zero_esm=True)
+    q.put((rank, [(r.name, r.skipped, r.ligand_pos, r.confidence) for r in res]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_sampling_failure_on_one_rank_skips_the_complex_on_all_ranks(tmp_path):
+    """a sampling-time exception is rank-local under sample sharding.  The complex is skipped on EVERY rank (the
+    reference skips a failing complex, inference.py:282-287), nobody is left waiting in the gathers, and the next complex still
+    comes out bitwise as in the single-process run."""
+    csv_path = _write_csv(tmp_path)
+    full = _run(csv_path)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [ctx.Process(target=_worker_failing, args=(r, 2, csv_path, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        by_name = {name: (skipped, lig, conf) for name, skipped, lig, conf in got[rank]}
+        assert by_name["3dpf_flex"][0] is not None and by_name["3dpf_flex"][1] is None
+        assert ("injected" in by_name["3dpf_flex"][0]) == (rank == 1) and ("another rank" in by_name["3dpf_flex"][0]) == (rank == 0)
+        ref = [r for r in full if r.name == "3dpf_rigid"][0]
+        assert by_name["3dpf_rigid"][0] is None and torch.equal(by_name["3dpf_rigid"][1], ref.ligand_pos)
+        assert torch.equal(by_name["3dpf_rigid"][2], ref.confidence)
+    # single process: the failing complex is reported, the run goes on
+    res = INF.run_csv(csv_path, FailingStub(0, 0, True), torch.device("cpu"), samples_per_complex=2, inference_steps=1, root=GOLDEN, seed=2,
+                      allow_zero_esm=True)
+    assert "injected" in res[0].skipped and res[2].skipped is None and res[2].ligand_pos is not None
+
+
 def test_complex_sharding_follows_array_split(tmp_path):
     csv_path = _write_csv(tmp_path)
     r0, r1 = _run(csv_path, 0, 2, shard="complexes"), _run(csv_path, 1, 2, shard="complexes")
