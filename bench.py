@@ -85,6 +85,8 @@ def parse_args(argv=None):
                     help="threads of the CPU baseline (capped at os.cpu_count(); 0 = all cores - on the GPU boxes' many-core hosts the "
                          "oracle's small ops get SLOWER beyond ~32 threads)")
     ap.add_argument("--no-roofline-pass", action="store_true", help="skip the instrumented steps behind the timed region")
+    ap.add_argument("--no-overlap-direct", action="store_true",
+                    help="diagnostic: the serial launch order of the conv layers (model.overlap_direct_conv = False) for same-box A/B runs")
     ap.add_argument("--no-flex-sharing", action="store_true",
                     help="diagnostic: flexible side chains without the partial sharing of layers 0 / 1 (model.share_flex_layer0 = False)")
     return ap.parse_args(argv)
@@ -329,6 +331,29 @@ def timed_job(model, complex_graph, n_total, sl, device, flex, steps, warmup, wa
     return elapsed, sampler, final_pos.clone(), gathered, schedule, info
 
 
+def shard_hbm_plan(cfg, n_local):
+    """HBM a rank's shard of `n_local` sample graphs needs for the two big per-layer arrays of the forward - sized PER SHARD, never
+    per job: G (stage A's output, read once by the 32-edge conv kernel: one row of DDP_G_LD floats per source node, conv and G slot)
+    and the messages.  Host arithmetic only (packing specs + the 3dpf geometry file): no GPU, no model."""
+    import numpy as np
+    from diffdock_pocket_amd import packing as P
+    kw, _ = model_kwargs(cfg, False)
+    ns, nv, L = kw["ns"], kw["nv"], kw["num_conv_layers"]
+    with np.load(os.path.join(ROOT, "diffdock_pocket_amd", "assets", "3dpf_geometry.npz")) as z:
+        n_l, n_r, n_a = int(z["lig_pos"].shape[0]), int(z["rec_pos"].shape[0]), int(z["atom_pos"].shape[0])
+        e_rr = int(z["rec_edge_index"].shape[1])
+    k = kw["atom_max_neighbors"]
+    worst = 0
+    for l in range(L):
+        sg = P.faster_tp_spec(P.irreps_muls(ns, nv, l), P.irreps_muls(ns, nv, l + 1), 3 * ns, factorized=True)
+        hg = (sg.hid + 3) // 4 * 4
+        row = sum(((hg + 1) * gc + 31) // 32 * 32 for gc in sg.g_cols if gc > 0) * 4       # bytes per source node and conv
+        g = n_local * row * (n_a + 3 * n_l + 3 * n_r)        # atom<-atom | three ligand-source convs | three receptor-source convs
+        msgs = n_local * 4 * sg.d_out * (n_a * k + 2 * n_a + e_rr + 3 * n_l * 64)          # (ligand edge sets: a generous 64 per atom)
+        worst = max(worst, g + msgs)
+    return {"samples": n_local, "g_and_messages_bytes_largest_layer": int(worst), "hbm_bytes_per_gpu": 288 * 10 ** 9}
+
+
 def shard_slice(rank, world, n_total, _):
     """Rank r of R owns samples [r*N/R, (r+1)*N/R) of the job."""
     return slice(rank * n_total // world, (rank + 1) * n_total // world)
@@ -352,9 +377,11 @@ def main(argv=None):
     if args.dry_run_ranks:
         n_total = args.samples * world if scaling == "weak" else args.samples
         sl = shard_slice(rank, world, n_total, None)
+        # (device: what the rank WOULD bind - torch.cuda.set_device(LOCAL_RANK) below; hbm_plan: the shard's big arrays)
         print(json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "master": os.environ.get("MASTER_ADDR"),
                           "port": os.environ.get("MASTER_PORT"), "samples_total": n_total, "slice": [sl.start, sl.stop],
-                          "scaling": scaling}), flush=True)
+                          "scaling": scaling, "device": f"cuda:{local_rank}",
+                          "hbm_plan": shard_hbm_plan(args.cfg, len(range(*sl.indices(n_total))))}), flush=True)
         sys.exit(3 if os.environ.get("DDP_BENCH_FAIL_RANK") == str(rank) else 0)
 
     import torch
@@ -385,6 +412,8 @@ def main(argv=None):
     model, kw = build_model(args.cfg, args.flex, device)
     if args.no_flex_sharing:
         model.share_flex_layer0 = False
+    if args.no_overlap_direct:
+        model.overlap_direct_conv = False
     complex_graph = make_3dpf_complex(seed=0, flexible_sidechains=args.flex)
     n_total = args.samples * world if scaling == "weak" else args.samples
     if n_total < world:
@@ -515,7 +544,8 @@ def main(argv=None):
                                        f"{args.cfg} (ns={kw['ns']} nv={kw['nv']} L={kw['num_conv_layers']}), "
                                        f"flexible_sidechains={args.flex}", "samples_total": n_total, "samples_rank0": n_local,
                            "parallelism": f"samples sharded over {world} rank(s), one final all_gather of poses",
-                           "ways": args.ways, "ms_per_step_by_rank": rank_ms, "src_sha16": loaded_hash(),
+                           "ways": args.ways, "ms_per_step_by_rank": rank_ms, "src_sha16": loaded_hash(), "device": str(device),
+                           "hbm_plan_rank0": shard_hbm_plan(args.cfg, n_local),
                            "hip_graph_replay": info.get("hip_graph"), "rccl_ranks_seen": ranks_seen, "backend": backend,
                            "all_gather_ms": info.get("all_gather_ms"),
                            "edges_last_step": info.get("edges_last_step")},

@@ -709,6 +709,24 @@ __device__ __forceinline__ void seg_tiles(const ddp_conv_shape_t& S, const ddp_b
 #if defined(DDP_ABLATE) && DDP_ABLATE == 9   // half of the tile loops' MFMAs, everything else unchanged: is the launch bound by the matrix pipe?
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0] + a[1], bcur[0] + bcur[1], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2] + a[3], bcur[2] + bcur[3], acc, 0, 0, 0);
+#elif defined(DDP_ABLATE) && DDP_ABLATE == 10
+          // timing only: the matrix work of an fp16 hi/lo split of both operands (3 x v_mfma_f32_32x32x16_f16 per 16 k, i.e. per
+          // TWO k-groups) on the loop's own loads - same bytes from L2 and LDS, 1/5 of the matrix-pipe time.  Operand bits are
+          // forced into halves of the smallest normal exponent with the loaded signs and mantissas (data-like toggling; their
+          // products are ~1e-8, so the run's poses and edge sets stay those of a bounded model)
+          {
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 au = (__builtin_bit_cast(u32x4, a) & 0x83FF83FFu) | 0x04000400u;
+            const u32x4 bu = (__builtin_bit_cast(u32x4, bcur) & 0x83FF83FFu) | 0x04000400u;
+            const h8 ah = __builtin_bit_cast(h8, au), bh = __builtin_bit_cast(h8, bu);
+            if (m & 1) {
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+            } else {
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc, 0, 0, 0);
+            }
+          }
 #else
 #pragma unroll
           for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[i], acc, 0, 0, 0);
@@ -1145,8 +1163,11 @@ __device__ __forceinline__ void seg_park(const ddp_block_t& B, const ddp_role_se
   }
 }
 
+#ifndef DDP_C32_WPE
+#define DDP_C32_WPE 3   // workgroups per CU the register budget of the 32-edge kernel is set for
+#endif
 template <int SZ>
-__global__ __launch_bounds__(256, 3) void ddp_conv32_kernel(const ConvLaunch L) {
+__global__ __launch_bounds__(256, DDP_C32_WPE) void ddp_conv32_kernel(const ConvLaunch L) {
   constexpr int ET = 32, NT = 256, FS = 36;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ TileAux<ET> aux;
@@ -1378,7 +1399,10 @@ extern "C" int ddp_conv_messages(const ddp_conv_shape_t* shape, const ddp_conv_t
     if (rbf < frows * (ET + 4)) rbf = frows * (ET + 4);   // features of all blocks
     if (rbf < ET * os) rbf = ET * os;               // message tile
     L.tv_off = os;
-    const size_t lds32 = (size_t)(ET * shape->hs + rbf) * sizeof(float);
+    size_t lds32 = (size_t)(ET * shape->hs + rbf) * sizeof(float);
+#ifdef DDP_C32_LDS_PAD
+    lds32 += DDP_C32_LDS_PAD;   // diagnostic builds: unused LDS on top (fewer workgroups per CU)
+#endif
     switch (size_class(shape)) {
       case 60: return launch_conv<32>(ddp_conv32_kernel<60>, L, tasks, ntasks, lds32, stream);
       case 32: return launch_conv<32>(ddp_conv32_kernel<32>, L, tasks, ntasks, lds32, stream);

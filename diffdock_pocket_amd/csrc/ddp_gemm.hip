@@ -3,13 +3,15 @@
 // i.e. G = x_scalar @ Wg per conv and G slot, [n_src, ncols] with ncols = hg * g_cols (12600 at
 // ns = 60): 120 FLOPs and 4 bytes written per output element, so the product is bound by the HBM write of G.
 //
-// Weight-stationary on the VECTOR ALU, on purpose: a lane owns two output columns and keeps their K weights in
-// registers (2 x K VGPRs, loaded once per workgroup); the x row of the current node is wave-uniform, so it arrives
-// through the SCALAR cache (s_load_dwordx16) and enters v_pk_fma_f32 as an SGPR pair: no LDS, no per-lane x traffic, one
-// 8-byte store per lane and row (512 contiguous bytes per wave).  Per row and wave: K v_pk_fma_f32 = 4K cycles for 512
-// bytes, i.e. 8.5 B/clk/CU = 5.2 TB/s over the chip at ns = 60 - the same as an fp32-MFMA formulation would reach (both
-// 64 FLOP/clk/SIMD) and above what HBM takes in writes, but it leaves the matrix pipe to the conv kernels and needs only
-// 128 registers and no LDS, so its workgroups fit beside theirs.
+// Three forms, chosen by ddp_stage_a() from the shape:
+//  * ddp_stage_a_mfma_kernel (what the score model's products run: ncols >= 512, K in {60, 64, 32, 24, 16}): weight-stationary
+//    on v_mfma_f32_32x32x2_f32, exact fp32; details above the kernel;
+//  * ddp_stage_a_kernel (narrow or odd shapes): weight-stationary on the VECTOR ALU - a lane owns two (four) output columns and
+//    keeps their K weights in registers, the x row of the current node is wave-uniform and arrives through the SCALAR cache
+//    (s_load_dwordx16) as an SGPR pair of v_pk_fma_f32: no LDS, no per-lane x traffic, one 8 / 16-byte store per lane and row;
+//    measured at ~1/3 of its nominal rate on the wide products, hence the MFMA form there;
+//  * ddp_stage_a_x3_kernel (an option that stays off, model.stage_a_bf16x3): the MFMA form on bf16 with both operands split in
+//    three terms.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

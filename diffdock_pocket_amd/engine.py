@@ -28,6 +28,7 @@ from . import _lib as L
 from . import graph as G
 from . import launch as K
 from . import packing as P
+from . import packing as P_
 from .graph import EdgeView
 
 SRC_TYPE = {0: "l", 1: "r", 2: "a", 3: "a", 4: "l", 5: "r", 6: "r", 7: "l", 8: "a"}
@@ -710,8 +711,11 @@ class ForwardEngine:
                         Ws.append(pk.wg[slot])
                         meta.append((k, slot, pk.g_in_off[slot]))
             Wst = torch.stack(Ws).contiguous()
-            ent = (Wst, meta, (C.c_int32 * len(meta))(*[mm[2] for mm in meta]), P.split_bf16x3(Wst))
+            # (the bf16x3 split of the weights - 1.5 x their size and three copy kernels - only when that option is on)
+            ent = (Wst, meta, (C.c_int32 * len(meta))(*[mm[2] for mm in meta]), P.split_bf16x3(Wst) if m.stage_a_bf16x3 else None)
             m._stage_a_stacks[key] = ent
+        if m.stage_a_bf16x3 and ent[3] is None:
+            ent = m._stage_a_stacks[key] = ent[:3] + (P.split_bf16x3(ent[0]),)
         Wst, meta, offs, W3 = ent
         nb = len(meta)
         if nb > L.DDP_MAX_GEMM_BATCH:
@@ -735,6 +739,17 @@ class ForwardEngine:
         return {(k, slot): Gall[i] for i, (k, slot, _) in enumerate(meta)}
 
     def _layers(self, S, F, dev, mark):
+        """The conv layers (reference :271-324).  Per layer: stage A of the factorised convs, the 32-edge conv launch (all
+        factorised convs), the direct conv launch (receptor<-atom), the segmented means in the reference's summation order.
+
+        Three launch orders over the same kernels with the same arguments (same bits):
+          serial     stage A(l) -> conv32(l) -> direct(l) -> means(l)                      (debug hooks, section timer, resident groups)
+          forked     small batches: direct(l) | stage-A groups side by side, then conv32(l) (see _Fork)
+          pipelined  large batches (round 4): the direct conv of layer l - receptor<-atom, one 130-KB workgroup per CU, matrix-pipe
+                     bound - runs on a side stream BESIDE stage A of layer l + 1 for the atom- and ligand-source rows (bound by
+                     the HBM write of G): conv32(l) -> means{lig, atom}(l) -> [direct(l) | stage A(l+1){atom, lig sources}] ->
+                     mean{rec}(l) -> stage A(l+1){rec sources} -> conv32(l+1).  The direct conv reads x_atom(l) as its source
+                     while the atom mean of layer l updates x_atom in place: it is given a snapshot (one 32-MB copy per layer)."""
         m = self.m
         ns, L_, B, ldx = m.ns, m.num_conv_layers, S.B, m._ldx
         Nl, Nr, Na = S.Nl, S.Nr, S.Na
@@ -747,18 +762,23 @@ class ForwardEngine:
         nodes = {"l": (xl, Nl), "a": (xa, Na), "r": (xr, Nr)}
         dbg = m.debug_conv_outputs
         exact = getattr(F, "exact", None)
+        prof_on = K.profiler() is not None
         # small batches: independent launches of a layer side by side (see _Fork); decided by the batch's size, not its content
-        fork = self._fork(dev) if (m.concurrent_small_batches and Na <= m.concurrent_max_atoms and m.before_layers is None) else None
-        for l in range(L_):
-            spec, spec_g = m._layer_specs[l], m._layer_specs_g[l]
+        plain = m.before_layers is not None
+        fork = self._fork(dev) if (m.concurrent_small_batches and Na <= m.concurrent_max_atoms and not plain) else None
+        pipelined = (fork is None and m.overlap_direct_conv and not plain and dbg is None and m.section_timer is None and L_ >= 2)
+        side = self._fork(dev) if pipelined else None
+
+        def plan(l):
+            """Host side of layer l: per conv its CSR view (mean / direct conv), its source-ordered view and the rows stage A has
+            to produce, grouped by (source-node array, row set)."""
+            P = SimpleNamespace(l=l, spec=m._layer_specs[l], spec_g=m._layer_specs_g[l], gmap={}, keep=[], msgs={})
             do_atom = m.flexible_sidechains or l != L_ - 1
-            active = {"l": True, "a": do_atom, "r": do_atom and l != L_ - 1}
-            shared = F.shared0 if l == 0 else {}
+            P.active = active = {"l": True, "a": do_atom, "r": do_atom and l != L_ - 1}
+            P.shared = shared = F.shared0 if l == 0 else {}
             pl, pl_so = F.pruned.get(l, {}), F.pruned_so.get(l, {})
-            c1 = F.clean1 if (l == 1 and F.clean1 is not None and active["a"]) else None
-            keep = []
-            # ---- per conv: its CSR view (reduce / direct conv), its source-ordered view and the rows stage A has to produce
-            per, groups = {}, {}
+            P.c1 = c1 = F.clean1 if (l == 1 and F.clean1 is not None and active["a"]) else None
+            P.per, P.groups = per, groups = {}, {}
             for k in range(9):
                 rt, st_ = RECV_TYPE[k], SRC_TYPE[k]
                 if not active[rt]:
@@ -789,61 +809,70 @@ class ForwardEngine:
                 per[k] = (csr, so_k, x_src)
                 if so_k is not None and csr.n_edges > 0 and not (k == 3 and c1 is not None):
                     groups.setdefault((st_, rows[0]), (x_src, rows, []))[2].append((k, m.conv_layers[9 * l + k]))
-            # ---- the direct convs (receptor<-atom: one edge per atom, nothing to factorise) need no stage A.  Small batches: they
-            # start FIRST, on a stream of their own, beside stage A - their few long workgroups (one per 64 atoms, 130 KB of LDS:
-            # they cannot share a CU with the 32-edge kernel's) then hold their CUs before that kernel's thousands arrive,
-            # instead of waiting for CUs it has drained (measured at 5 samples: 0.3 ms alone, 0.7 - 1.0 ms launched beside it)
-            tasks, tasks_g, msgs = [], [], {}
-            nb_g = nb_d = 0.0
-            prof_on = K.profiler() is not None
-            c1_here = c1 is not None
+            return P
 
-            def node_bytes(k):     # algorithmic node bytes of a conv call (profiler only)
-                d_in = P.irreps_dim(P.irreps_muls(ns, m.nv, l))
-                return 4.0 * (nodes[SRC_TYPE[k]][1] * d_in + nodes[RECV_TYPE[k]][1] * spec.d_out)
+        def node_bytes(l, k):     # algorithmic node bytes of a conv call (profiler only)
+            d_in = P_.irreps_dim(P_.irreps_muls(ns, m.nv, l))
+            return 4.0 * (nodes[SRC_TYPE[k]][1] * d_in + nodes[RECV_TYPE[k]][1] * m._layer_specs[l].d_out)
 
-            for k, (csr, so_k, x_src) in per.items():
-                if so_k is not None or (k == 3 and c1_here):
+        def stage_a(P, which, forked=None):
+            """Stage A of the groups whose source-node type is in `which`: one batched product per (source-node array, row set);
+            then, for atom sources at layer 1, the two products of the clean-pair split."""
+            l = P.l
+            for gi, ((st_, gid), (x_src, rows, convs)) in enumerate(P.groups.items()):
+                if st_ not in which:
                     continue
-                x_recv, _, ek = arr[k]
-                pkc = m.conv_layers[9 * l + k].packed(dev)
-                msg = torch.empty((csr.n_edges, spec.d_out), device=dev)
-                msgs[k] = (msg, csr, pkc)
-                if csr.n_edges == 0:
-                    continue
-                if prof_on:
-                    nb_d += node_bytes(k)
-                segs = [(e[ek], csr.eid, ns, ns), (x_recv, csr.recv, ldx, ns), (x_src, csr.src, ldx, ns)]
-                tasks.append(K.make_task(pkc, x_src, ldx, csr, sh[ek], segs, msg))
-            direct_first = fork is not None and bool(tasks)
-            if direct_first:
-                fork.run(3, lambda: K.launch_convs(spec, tasks, node_bytes=nb_d, tag=f"layer{l}"))
-            # ---- stage A: one batched product per (source-node array, row set)
-            gmap = {}
-            for gi, ((st_, gid), (x_src, rows, convs)) in enumerate(groups.items()):
-                if fork is not None and gi > 0:
+                if forked is not None and gi > 0:
                     # (slots 0 - 2; slot 3 is the direct conv's alone: it is joined later than these)
-                    gmap.update(fork.run((gi - 1) % 3, lambda: self._stage_a(l, convs, x_src, rows[3], rows=rows[1], rows_cnt=rows[2])))
+                    P.gmap.update(forked.run((gi - 1) % 3, lambda: self._stage_a(l, convs, x_src, rows[3], rows=rows[1], rows_cnt=rows[2])))
                 else:
-                    gmap.update(self._stage_a(l, convs, x_src, rows[3], rows=rows[1], rows_cnt=rows[2]))
-            if fork is not None:
+                    P.gmap.update(self._stage_a(l, convs, x_src, rows[3], rows=rows[1], rows_cnt=rows[2]))
+            if forked is not None:
                 for i_ in range(3):
-                    fork.join(only=i_)
-            x_clean = None
-            if c1 is not None:      # atom<-atom at layer 1: touched edges per sample + the clean pairs once
+                    forked.join(only=i_)
+            c1 = P.c1
+            if c1 is not None and "a" in which:      # atom<-atom at layer 1: touched edges per sample + the clean pairs once
                 conv3 = m.conv_layers[9 * l + 3]
                 rows_d, rows_dc = c1.rows_d, c1.rows_d_cnt
                 if exact is not None:
                     rows_d, rows_dc = rows_d[:exact[rows_dc.data_ptr()]], None
-                g_d = self._stage_a(l, [(3, conv3)], xa, Na, rows=rows_d, rows_cnt=rows_dc)
-                x_clean = torch.empty((c1.n0, ldx), device=dev)
-                K.gather_rows(xa, c1.rows_v, c1.n0, x_clean, ldx)
-                g_v = self._stage_a(l, [(3, conv3)], x_clean, c1.n0)
-                keep += [g_d, g_v, x_clean]
-            keep.append(gmap)
-            # ---- the factorised convs
-            for k, (csr, so_k, x_src) in per.items():
-                if k in msgs:
+                P.g_d = self._stage_a(l, [(3, conv3)], xa, Na, rows=rows_d, rows_cnt=rows_dc)
+                P.x_clean = torch.empty((c1.n0, ldx), device=dev)
+                K.gather_rows(xa, c1.rows_v, c1.n0, P.x_clean, ldx)
+                P.g_v = self._stage_a(l, [(3, conv3)], P.x_clean, c1.n0)
+                P.keep += [P.g_d, P.g_v, P.x_clean]
+
+        def direct_tasks(P, x_atom_src=None):
+            """The direct convs (receptor<-atom: one edge per atom, nothing to factorise): no stage A.  x_atom_src: the array the
+            atom-source rows are read from instead of x_atom (the pipelined order's snapshot)."""
+            l, spec = P.l, P.spec
+            tasks, nb_d = [], 0.0
+            for k, (csr, so_k, x_src) in P.per.items():
+                if so_k is not None or (k == 3 and P.c1 is not None):
+                    continue
+                x_recv, _, ek = arr[k]
+                pkc = m.conv_layers[9 * l + k].packed(dev)
+                msg = torch.empty((csr.n_edges, spec.d_out), device=dev)
+                P.msgs[k] = (msg, csr, pkc)
+                if csr.n_edges == 0:
+                    continue
+                if prof_on:
+                    nb_d += node_bytes(l, k)
+                if x_atom_src is not None and SRC_TYPE[k] == "a":
+                    x_src = x_atom_src[:x_src.shape[0]]
+                segs = [(e[ek], csr.eid, ns, ns), (x_recv, csr.recv, ldx, ns), (x_src, csr.src, ldx, ns)]
+                tasks.append(K.make_task(pkc, x_src, ldx, csr, sh[ek], segs, msg))
+            P.tasks, P.nb_d = tasks, nb_d
+            return tasks
+
+        def launch_direct(P):
+            K.launch_convs(P.spec, P.tasks, node_bytes=P.nb_d, tag=f"layer{P.l}")
+
+        def launch_factorised(P):
+            l, spec, c1 = P.l, P.spec, P.c1
+            tasks_g, nb_g = [], 0.0
+            for k, (csr, so_k, x_src) in P.per.items():
+                if k in P.msgs:
                     continue
                 x_recv, _, ek = arr[k]
                 conv = m.conv_layers[9 * l + k]
@@ -853,56 +882,108 @@ class ForwardEngine:
                     # rows [0, E): per-sample messages at their CSR positions (only the touched edges are written and read),
                     # rows [E, E + e0): the messages of the complex's own edge list between clean atoms
                     msg = torch.empty((c1.E + c1.e0, spec.d_out), device=dev)
-                    msgs[k] = (msg, csr, pkc, c1.rowmap)
+                    P.msgs[k] = (msg, csr, pkc, c1.rowmap)
                     pkg = conv.packed_g(dev)
                     sd_ = c1.so_d
                     if sd_.n_edges > 0:
                         segs = [(e_base, sd_.eid, ns, ns), (x_recv, sd_.recv, ldx, ns), (xa, sd_.src, ldx, ns)]
-                        tasks_g.append(K.make_task(pkg, xa, ldx, sd_, sh_k, segs, msg, g=[g_d.get((3, s_)) for s_ in (0, 1)]))
+                        tasks_g.append(K.make_task(pkg, xa, ldx, sd_, sh_k, segs, msg, g=[P.g_d.get((3, s_)) for s_ in (0, 1)]))
                     sv = c1.so_v
-                    segs = [(e_base, sv.eid, ns, ns), (x_clean, sv.recv, ldx, ns), (x_clean, sv.src, ldx, ns)]
-                    tasks_g.append(K.make_task(pkg, x_clean, ldx, sv, sh_k, segs, msg, g=[g_v.get((3, s_)) for s_ in (0, 1)]))
+                    segs = [(e_base, sv.eid, ns, ns), (P.x_clean, sv.recv, ldx, ns), (P.x_clean, sv.src, ldx, ns)]
+                    tasks_g.append(K.make_task(pkg, P.x_clean, ldx, sv, sh_k, segs, msg, g=[P.g_v.get((3, s_)) for s_ in (0, 1)]))
                     continue
                 msg = torch.empty((csr.n_edges, spec.d_out), device=dev)
-                msgs[k] = (msg, csr, pkc)
+                P.msgs[k] = (msg, csr, pkc)
                 if csr.n_edges == 0:
                     continue
                 if prof_on:
-                    nb_g += node_bytes(k)
+                    nb_g += node_bytes(l, k)
                 segs = [(e_base, so_k.eid, ns, ns), (x_recv, so_k.recv, ldx, ns), (x_src, so_k.src, ldx, ns)]
-                tasks_g.append(K.make_task(conv.packed_g(dev), x_src, ldx, so_k, sh_k, segs, msg, g=[gmap.get((k, s_)) for s_ in (0, 1)]))
-            mark("conv_prep")
-            K.launch_convs(spec_g, tasks_g, flops_spec=spec, node_bytes=nb_g, tag=f"layer{l}")
-            if direct_first:
-                fork.join()
-            else:
-                K.launch_convs(spec, tasks, node_bytes=nb_d, tag=f"layer{l}")
-            mark("conv_launch")
-            if l == 0 and F.flex0 is not None:
+                tasks_g.append(K.make_task(conv.packed_g(dev), x_src, ldx, so_k, sh_k, segs, msg, g=[P.gmap.get((k, s_)) for s_ in (0, 1)]))
+            P.tasks_g = tasks_g
+            K.launch_convs(P.spec_g, tasks_g, flops_spec=spec, node_bytes=nb_g, tag=f"layer{l}")
+
+        def fix_rowmaps(P):
+            if P.l == 0 and F.flex0 is not None:
                 # flexible side chains: the kept receivers' messages were computed on the pruned lists; the segmented mean walks
                 # the FULL lists and reads an unmarked receiver's messages from its copy in sample 0 (row map)
                 for k, rm in F.flex0.rowmaps.items():
-                    if k in msgs:
-                        msgs[k] = (msgs[k][0], c[k], msgs[k][2], rm)
-            if dbg is not None:   # every conv's own output = segmented mean + BatchNorm of its messages alone
-                for k, ent in msgs.items():
-                    n_k = nodes[RECV_TYPE[k]][1]
-                    o_k = torch.zeros((n_k, spec.d_out), device=dev)
-                    K.launch_reduce(o_k, spec.d_out, n_k, spec.d_out, [ent], accumulate=False)
-                    dbg[f"conv_layers.{9 * l + k}"] = o_k
-            for rt in ("l", "a", "r"):
-                if not active[rt]:
+                    if k in P.msgs:
+                        P.msgs[k] = (P.msgs[k][0], c[k], P.msgs[k][2], rm)
+
+        def means(P, types):
+            """Segmented mean + BatchNorm + residual (:315-324) of the node types in `types`, the reference's summation order."""
+            spec, shared = P.spec, P.shared
+            for rt in types:
+                if not P.active[rt]:
                     continue
                 x, n = nodes[rt]
-                own = [msgs[k] for k in ORDER[rt] if k not in shared]
+                own = [P.msgs[k] for k in ORDER[rt] if k not in shared]
                 if own:
                     K.launch_reduce(x, ldx, n, spec.d_out, own, accumulate=True)
-                com = [msgs[k] for k in ORDER[rt] if k in shared]
+                com = [P.msgs[k] for k in ORDER[rt] if k in shared]
                 if com:   # graph 0's update of the shared convs, added to every graph's copy of the node
                     n0 = shared[[k for k in ORDER[rt] if k in shared][0]][0]
                     K.launch_reduce(x, ldx, n0, spec.d_out, com, accumulate=True, n_rep=B, rep_stride=n0)
+
+        if pipelined:
+            P = plan(0)
+            stage_a(P, "lar")
+            for l in range(L_):
+                nxt = plan(l + 1) if l + 1 < L_ else None
+                # the direct conv's messages only enter the receptor mean: everything else of the layer goes first.  The atom mean
+                # below updates x_atom in place while the direct conv still reads x_atom(l) as its source: it gets a snapshot
+                xa_old = torch.empty_like(xa) if (P.active["a"] and 8 in P.per) else None
+                direct_tasks(P, x_atom_src=xa_old)
+                has_direct = bool(P.tasks)
+                launch_factorised(P)
+                fix_rowmaps(P)
+                if has_direct and xa_old is not None:
+                    xa_old.copy_(xa)
+                P.xa_old = xa_old
+                means(P, "la")
+                if has_direct:
+                    side.run(3, lambda: launch_direct(P))
+                if nxt is not None:
+                    stage_a(nxt, "la")
+                if has_direct:
+                    side.join()
+                means(P, "r")
+                if nxt is not None:
+                    stage_a(nxt, "r")
+                F.keep.append((P.keep, P.per, P.msgs, P.tasks, P.tasks_g, P.gmap, getattr(P, "xa_old", None)))
+                P = nxt
             mark("reduce")
-            F.keep.append((keep, per, msgs, tasks, tasks_g))
+            return
+
+        for l in range(L_):
+            P = plan(l)
+            # Small batches: the direct convs start FIRST, on a stream of their own, beside stage A - their few long workgroups (one
+            # per 64 atoms, 130 KB of LDS: they cannot share a CU with the 32-edge kernel's) then hold their CUs before that kernel's
+            # thousands arrive, instead of waiting for CUs it has drained (measured at 5 samples: 0.3 ms alone, 0.7 - 1.0 ms launched
+            # beside it)
+            direct_tasks(P)
+            direct_first = fork is not None and bool(P.tasks)
+            if direct_first:
+                fork.run(3, lambda: launch_direct(P))
+            stage_a(P, "lar", forked=fork)
+            mark("conv_prep")
+            launch_factorised(P)
+            if direct_first:
+                fork.join()
+            else:
+                launch_direct(P)
+            mark("conv_launch")
+            fix_rowmaps(P)
+            if dbg is not None:   # every conv's own output = segmented mean + BatchNorm of its messages alone
+                for k, ent in P.msgs.items():
+                    n_k = nodes[RECV_TYPE[k]][1]
+                    o_k = torch.zeros((n_k, P.spec.d_out), device=dev)
+                    K.launch_reduce(o_k, P.spec.d_out, n_k, P.spec.d_out, [ent], accumulate=False)
+                    dbg[f"conv_layers.{9 * l + k}"] = o_k
+            means(P, "lar")
+            mark("reduce")
+            F.keep.append((P.keep, P.per, P.msgs, P.tasks, P.tasks_g, P.gmap))
 
     # ================================================================================================ heads
     def _heads(self, data, S, F, lig, rec, atom, dev, mark):

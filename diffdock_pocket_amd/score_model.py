@@ -412,6 +412,9 @@ class TensorProductScoreModel(nn.Module):
         # forked streams (engine._Fork); above this many pocket atoms in the batch every kernel fills the chip on its own
         self.concurrent_small_batches = True
         self.concurrent_max_atoms = 16000
+        # Large batches (round 4): the direct conv of layer l (receptor<-atom) on a side stream beside stage A of layer l + 1 for the
+        # atom- and ligand-source rows (engine._layers, "pipelined"); same kernels, same arguments, same bits as the serial order
+        self.overlap_direct_conv = True
         self.concurrent_heads = True   # the torsion read-outs on forked streams beside the tr / rot read-out (any batch size)
         # Option, OFF: stage A on the bf16 matrix cores with both operands split into three bfloat16 terms (csrc/ddp_gemm.hip,
         # ddp_stage_a_x3_kernel): fp32-class accuracy (error <= 2^-21 sum |x w|, measured against fp64 in

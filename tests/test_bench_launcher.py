@@ -47,8 +47,28 @@ def test_a_failing_rank_fails_the_parent():
 
 def test_rank_of_an_external_launcher_and_world_size_mismatch():
     r = _run(["--gpus", "2"], {"WORLD_SIZE": "2", "RANK": "1", "LOCAL_RANK": "1"}, drop=())      # as under torch.distributed.run
-    assert r.returncode == 0 and _lines(r.stdout) == [{"rank": 1, "local_rank": 1, "world": 2, "master": os.environ.get("MASTER_ADDR"),
-                                                       "port": os.environ.get("MASTER_PORT"), "samples_total": 40, "slice": [20, 40],
-                                                       "scaling": "strong"}]
+    got = _lines(r.stdout)
+    assert r.returncode == 0 and len(got) == 1
+    plan = got[0].pop("hbm_plan")
+    assert got == [{"rank": 1, "local_rank": 1, "world": 2, "master": os.environ.get("MASTER_ADDR"), "port": os.environ.get("MASTER_PORT"),
+                    "samples_total": 40, "slice": [20, 40], "scaling": "strong", "device": "cuda:1"}] and plan["samples"] == 20
     r = _run(["--gpus", "4"], {"WORLD_SIZE": "2", "RANK": "0"}, drop=())
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_eight_ranks_bind_their_own_gpu_and_size_memory_per_shard():
+    """8-GPU readiness without the node: under `--gpus 8` every child would bind cuda:LOCAL_RANK, the
+    strong split gives each 5 of the 40 samples, and the big per-layer arrays (G, messages) are sized for the SHARD - 1/8 of the
+    40-sample job's 5 GB - far inside one GPU's 288 GB; the weak run (40 samples per rank) needs the single-GPU job's memory."""
+    r = _run(["--gpus", "8"])
+    assert r.returncode == 0, r.stderr
+    ranks = _lines(r.stdout)
+    assert [d["device"] for d in ranks] == [f"cuda:{i}" for i in range(8)]
+    one = _lines(_run(["--gpus", "1"]).stdout)[0]["hbm_plan"]
+    for d in ranks:
+        p = d["hbm_plan"]
+        assert p["samples"] == 5 and p["g_and_messages_bytes_largest_layer"] * 8 == one["g_and_messages_bytes_largest_layer"]
+        assert p["g_and_messages_bytes_largest_layer"] < 0.01 * p["hbm_bytes_per_gpu"]
+    assert 4e9 < one["g_and_messages_bytes_largest_layer"] < 8e9
+    weak = _lines(_run(["--gpus", "8", "--scaling", "weak"]).stdout)
+    assert all(d["hbm_plan"] == one for d in weak) and [d["slice"] for d in weak] == [[40 * i, 40 * i + 40] for i in range(8)]

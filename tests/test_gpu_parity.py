@@ -250,6 +250,37 @@ def test_graph_replay_equals_launch_by_launch(flex):
         assert torch.equal(l0, l1) and torch.equal(a0, a1)
 
 
+@pytest.mark.parametrize("flex", [False, True])
+def test_pipelined_layer_order_is_bitwise_the_serial_one(flex):
+    """Round 4: at 40 samples the direct conv of layer l (receptor<-atom) runs on a side stream beside stage A of layer l + 1
+    (engine._layers, "pipelined"; it reads a snapshot of x_atom(l) while the atom mean updates x_atom in place).  Same kernels,
+    same arguments: the scores of forwards at two schedule positions, launch by launch and through a replayed hipGraph, must be
+    bit for bit those of the serial order (model.overlap_direct_conv = False)."""
+    import bench
+    from diffdock_pocket_amd.diffusion import get_t_schedule
+    from diffdock_pocket_amd.sampler import Sampler, SamplerConfig
+    from diffdock_pocket_amd.synthetic import make_3dpf_complex
+    dev = _dev()
+    sched = get_t_schedule(20)
+    g = make_3dpf_complex(seed=0, flexible_sidechains=flex)
+    out = {}
+    for overlap in (False, True):
+        model, kw = bench.build_model("cfg2", flex, dev)
+        model.overlap_direct_conv = overlap
+        smp = Sampler(model, g, 40, dev, SamplerConfig(inference_steps=20, flexible_sidechains=flex), seed=0)
+        smp.randomize()
+        res = [[t.clone() for t in smp.scores(float(sched[0]))]]
+        for i in range(4):       # two ordinary steps, the capture, one replay
+            smp.step(i, sched)
+        assert bool(smp._graph)
+        res.append([t.clone() for t in smp.scores(float(sched[4]))])
+        res.append([smp.lig_pos.clone(), smp.atom_pos.clone()])
+        out[overlap] = res
+    for a, b in zip(out[False], out[True]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
 def test_a_truncated_ligand_atom_edge_list_is_reported():
     """The ligand<-atom edge list has a capacity per ligand atom (model.la_capacity_per_atom) instead of its worst case.  A
     search that finds more pairs drops them AND raises a flag in pinned host memory: the next forward refuses to go on."""
@@ -1055,6 +1086,40 @@ def test_three_step_trajectory_matches_the_cpu_oracle_trajectory():
         da = float((s_gpu.atom_pos.cpu() - s_cpu.atom_pos).abs().max())
         assert dl < 2e-3 and da < 2e-3, (i, dl, da)       # angstrom; the ligand has moved by several angstrom by then
     assert float((s_cpu.lig_pos - g["ligand"].pos).abs().max()) > 1.0
+
+
+@pytest.mark.parametrize("seed", [9, 3])
+def test_cfg1_job_end_to_end_against_the_cpu_sampler(seed):
+    """BASELINE configs[0] END TO END: 3dpf, 4 samples x ALL 20 denoising steps, the cfg1 score model with flexible side chains and
+    the UNSCALED synthetic weights.  HIP sampler (device-resident step, captured hipGraph from the third step on) against the CPU
+    sampler driven by the oracle (whose loop tests/test_sampler_cpu.py pins to the reference's own utils/sampling.py), same seeded
+    start and noise stream.  The ligands travel 23 - 25 A; measured divergence of the final poses (tools/traj_divergence.py, one
+    MI355X): <= 1.8e-4 A on ligand atoms, <= 1.7e-5 A on pocket atoms.  Bounds: 2e-3 A / 2e-4 A at every step."""
+    from diffdock_pocket_amd.diffusion import get_t_schedule
+    from diffdock_pocket_amd.sampler import Sampler, SamplerConfig
+    from diffdock_pocket_amd.synthetic import make_3dpf_complex
+    dev = _dev()
+    case = CASES["cfg1_full"]
+    _, _, _, sd = case_inputs(case.name)
+    model = _model_for(case, sd)
+    oracle = OracleScoreModel(case.oracle_config(), sd)
+    g = make_3dpf_complex(seed=0, flexible_sidechains=True)
+    sched = get_t_schedule(20)
+    cfg = SamplerConfig(inference_steps=20, flexible_sidechains=True)
+    s_gpu = Sampler(model, g, 4, dev, cfg, seed=seed)
+    s_cpu = Sampler(lambda b: oracle(b), g, 4, torch.device("cpu"), cfg, seed=seed)
+    s_gpu.randomize()
+    s_cpu.randomize()
+    start = s_cpu.lig_pos.clone()
+    for i in range(20):
+        s_gpu.step(i, sched)
+        s_cpu.step(i, sched)
+        dl = float((s_gpu.lig_pos.cpu() - s_cpu.lig_pos).abs().max())
+        da = float((s_gpu.atom_pos.cpu() - s_cpu.atom_pos).abs().max())
+        assert dl < 2e-3 and da < 2e-4, (seed, i, dl, da)
+    assert bool(s_gpu._graph)                                               # steps 3.. were graph replays
+    assert float((s_cpu.lig_pos - start).abs().max()) > 10.0               # the poses did travel
+    s_gpu.check_overflow()
 
 
 def test_csv_driver_on_device(tmp_path):
