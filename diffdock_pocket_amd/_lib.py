@@ -52,7 +52,7 @@ class ConvTask(C.Structure):
                 ("seg_idx", C.c_void_p * DDP_MAX_SEGS), ("seg_ld", C.c_int32 * DDP_MAX_SEGS),
                 ("seg_n", C.c_int32 * DDP_MAX_SEGS), ("w1p", C.c_void_p), ("b1p", C.c_void_p), ("w2p", C.c_void_p),
                 ("b2p", C.c_void_p), ("msg", C.c_void_p), ("g", C.c_void_p * 2),
-                ("pos", C.c_void_p), ("n_edges_dev", C.c_void_p)]
+                ("pos", C.c_void_p), ("n_edges_dev", C.c_void_p), ("w1h", C.c_void_p), ("w2h", C.c_void_p)]
 
 
 class ReduceSrc(C.Structure):
@@ -230,7 +230,7 @@ def load():
         getattr(lib, name).restype = C.c_int
     lib.ddp_node_linear.argtypes = [C.POINTER(NodeJob), C.c_int, C.c_void_p]
     lib.ddp_node_linear.restype = C.c_int
-    if lib.ddp_abi_version() != 11:
+    if lib.ddp_abi_version() != 12:
         raise DdpError("libddp_hip.so ABI version mismatch")
     lib.ddp_source_hash.restype = C.c_char_p
     if "DDP_HIP_LIB" not in os.environ:   # (diagnostic builds loaded through DDP_HIP_LIB carry extra -D flags, same sources)

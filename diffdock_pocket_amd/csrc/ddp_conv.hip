@@ -64,8 +64,36 @@ template <> struct SizeClass<32> { static constexpr int NM = 12; static constexp
 template <> struct SizeClass<24> { static constexpr int NM = 9; static constexpr bool TAIL = false; };   // confidence model
 template <> struct SizeClass<16> { static constexpr int NM = 6; static constexpr bool TAIL = false; };   // BASELINE configs[0]
 
+// ---- fp16 hi/lo split ("h2") forms of the dense fc products.  Both operands of h @ W are split into two
+// halves, v = hi + lo / 2048 (hi = fp16(v), lo = fp16((v - hi) * 2048): 22 significant bits, the low part scaled back into fp16's
+// normal range), and three products per 16 k run on v_mfma_f32_32x32x16_f16 with fp32 accumulation:
+//     h w  ~  hh wh + (hh wl + hl wh) / 2048                   dropped: hl wl / 2^22
+// Measured against fp64 (tools/micro/f16x2_mfma.hip): |err| <= 0.85e-7 sum|h w| - below the exact fp32 MFMA chain's 1.8e-7 (the
+// f16 instruction sums its 16 products before rounding) - at 3.75 x the fp32 MFMA rate (580 against 155 TFLOP/s sustained).
+// The operands keep their byte counts: a weight fragment of 16 k is two 16-byte loads (hi, lo) like two fp32 k-groups.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#define DDP_H2_SCALE 2048.f
+#define DDP_H2_INV (1.f / 2048.f)
+// k16 steps of f_in = hid = 3 SZ (0: no h2 form for this class); LDS row stride of an operand plane = 16 NS + 8 halves
+// (16-byte aligned rows whose 16-lane ds_read_b128 groups fall on distinct banks for NS = 12, 6, 5, 3)
+template <int SZ> struct H2Class { static constexpr int NS = 0; };
+template <> struct H2Class<60> { static constexpr int NS = 12; };
+template <> struct H2Class<32> { static constexpr int NS = 6; };
+template <> struct H2Class<24> { static constexpr int NS = 5; };
+template <> struct H2Class<16> { static constexpr int NS = 3; };
+
+__device__ __forceinline__ void split_h2(const f32x4 v, h4& hi, h4& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hi[i] = (_Float16)v[i];
+    lo[i] = (_Float16)((v[i] - (float)hi[i]) * DDP_H2_SCALE);
+  }
+}
+
 struct ConvLaunch {
   ddp_conv_shape_t shape;
+  int r1_floats;   // h2 kernels: floats of the first LDS region (operand planes of h; 32-edge kernel: later h in fp32)
   int tv_off;   // 32-edge kernels: row stride (floats) of the LDS message tile; unused by the 64-edge kernel
   int ntasks;
   int dev_counts;   // some task carries n_edges_dev: tile table rebuilt on the device (conv_tile)
@@ -776,7 +804,172 @@ __device__ __forceinline__ void seg_tiles_any(const ddp_conv_shape_t& S, const d
   seg_tiles<C, SizeClass<SZ>::NM, FS, SizeClass<SZ>::TAIL>(S, B, T, hbuf, fblk, R, lane, rt, out);
 }
 
-template <int SZ, int ET, int C>
+// The tile loop of seg_tiles on the fp16 matrix cores (h2 form).  hpl: plane 0 (hi) of h, rows of HS2 = 16 NS + 8 halves, plane 1
+// (lo) `pstride` halves behind it; the packed weights T.w2h hold per tile 2 NS fragments of 1 KiB, fragment q = 2 ks + plane:
+// lane (r, hh) reads the 8 halves k = 16 ks + 8 hh .. + 7 of column r (packing.pack_tiles_h2).  RT row tiles of 32 edges share
+// every weight fragment (RT = 2: the 64-edge kernel's scalar blocks).  Same static ring / unconditional loads as seg_tiles.
+template <int C, int NS, int FS, int RT>
+__device__ __forceinline__ void seg_tiles_h2(const ddp_block_t& B, const ddp_conv_task_t& T, const _Float16* hpl, int pstride,
+                                             const float* fblk, const ddp_role_seg_t& R, int lane, int rt0, f32x16* out) {
+  constexpr int NF = 2 * NS;
+#ifndef DDP_H2_RING
+#define DDP_H2_RING 6
+#endif
+  constexpr int RING = (NF % DDP_H2_RING == 0) ? DDP_H2_RING : (NF % 6 == 0) ? 6 : (NF % 5 == 0) ? 5 : NF;
+  constexpr int HS2 = 16 * NS + 8;
+  static_assert(NF % RING == 0 && NF >= RING, "fragment q of every tile lives in ring slot q % RING");
+  const int r = lane & 31, hh = lane >> 5;
+  const int t0 = R.tile0, ts = R.tstride, count = R.count;
+#pragma unroll
+  for (int i = 0; i < RT * C; ++i) out[i] = splat16(0.f);
+  if (count <= 0) return;
+  const f32x4* __restrict__ wt = reinterpret_cast<const f32x4*>(T.w2h) + ((size_t)(B.tile0 + t0) * NF * 2 + hh) * 32 + r;
+  const size_t tstep = (size_t)ts * NF * 64;
+  const _Float16* arow[RT];
+#pragma unroll
+  for (int x = 0; x < RT; ++x) arow[x] = hpl + (size_t)((rt0 + x) * 32 + r) * HS2 + 8 * hh;
+  // tile -> feature of this lane, incrementally (see seg_tiles)
+  const bool lm_inc = (B.nsub == 1) || (ts % B.nsub == 0);
+  int lm_u0 = 0, lm_du = 0;
+  bool lm_ok = false;
+  if (lm_inc) {
+    if (B.nsub > 1) {
+      lm_u0 = t0 / B.nsub;
+      lm_du = ts / B.nsub;
+      lm_ok = (t0 % B.nsub) * 32 + r < B.n;
+    } else {
+      const int us = r / B.n;
+      lm_u0 = t0 * B.ups + us;
+      lm_du = ts * B.ups;
+      lm_ok = us < B.ups;
+    }
+  }
+  float bias = T.b2p[(B.tile0 + t0) * 32 + r];     // (requested before the ring and pinned there: see seg_tiles)
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 ring[RING];
+#pragma unroll
+  for (int k = 0; k < RING; ++k) ring[k] = DDP_ABL_B(wt[k * 64]);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int j = 0; j < count; ++j) {
+    const f32x4* __restrict__ wnx = wt + ((j + 1 < count) ? tstep : 0);   // next tile (the last one re-requests itself: unused)
+    f32x16 acc_m[RT], acc_c[RT];
+#pragma unroll
+    for (int x = 0; x < RT; ++x) {
+      acc_m[x] = splat16(bias);
+      acc_c[x] = splat16(0.f);
+    }
+    bias = T.b2p[(B.tile0 + t0 + min(j + 1, count - 1) * ts) * 32 + r];   // next tile's bias, a whole tile ahead
+    // h does not depend on the tile: left alone, hipcc hoists the 2 NS operand reads out of the tile loop (8 NS registers, spills).
+    // An opaque zero offset per tile keeps them where they are
+    int aoff = 0;
+    asm volatile("" : "+v"(aoff));
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+      const h8 bh = __builtin_bit_cast(h8, ring[(2 * ks) % RING]), bl = __builtin_bit_cast(h8, ring[(2 * ks + 1) % RING]);
+      {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int q0 = 2 * ks + RING, q1 = q0 + 1;   // the fragments that take the two slots this step frees
+        ring[(2 * ks) % RING] = DDP_ABL_B((q0 < NF) ? wt[q0 * 64] : wnx[(q0 - NF) * 64]);
+        ring[(2 * ks + 1) % RING] = DDP_ABL_B((q1 < NF) ? wt[q1 * 64] : wnx[(q1 - NF) * 64]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // (A operands are read right before their MFMAs, single buffered: the co-resident waves of the SIMD cover the LDS round trip,
+      // and the 16 registers of a second buffer are what keeps three workgroups per CU)
+      h8 ah[RT], al[RT];
+#pragma unroll
+      for (int x = 0; x < RT; ++x) {
+        ah[x] = *reinterpret_cast<const h8*>(arow[x] + aoff + 16 * ks);
+        al[x] = *reinterpret_cast<const h8*>(arow[x] + aoff + pstride + 16 * ks);
+      }
+#pragma unroll
+      for (int x = 0; x < RT; ++x) {
+        acc_m[x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[x], bh, acc_m[x], 0, 0, 0);
+        acc_c[x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[x], bl, acc_c[x], 0, 0, 0);
+        acc_c[x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[x], bh, acc_c[x], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // (keeps the next steps' LDS reads and loads behind this step's MFMAs: register pressure)
+    }
+    wt = wnx;
+    // contraction with the basis features, in the MFMA C/D layout: reg i <-> edge row (i&3) + 8*(i>>2) + 4*hh
+    int u;
+    if (lm_inc) {
+      u = lm_u0 + j * lm_du;
+      if (!(lm_ok && u < B.U)) u = 0;
+    } else {
+      int ncol, us;
+      bool valid;
+      tile_lane_map(B, t0 + j * ts, r, u, ncol, us, valid);
+    }
+#pragma unroll
+    for (int x = 0; x < RT; ++x) {
+      const float* frow = &fblk[u * C * FS + (rt0 + x) * 32 + 4 * hh];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        float tq[4];     // the tile's fc2 value of four edge rows: main sum + scaled-back correction sum
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tq[q] = acc_m[x][4 * q4 + q] + acc_c[x][4 * q4 + q] * DDP_H2_INV;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const f32x4 f = *reinterpret_cast<const f32x4*>(frow + c * FS + 8 * q4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) out[x * C + c][4 * q4 + q] += f[q] * tq[q];
+        }
+      }
+    }
+  }
+}
+
+// phase 1 in the h2 form: h = relu(edge_attr_ @ W1 + b1) from the staged operand planes of edge_attr_ (xp: plane 0, plane 1
+// `xstride` halves behind; rows of 16 NS1 + 8 halves), written as the operand planes of h (hp0 / + hstride; rows of 16 NS + 8)
+template <int ET, int NW, int NS1, int NS>
+__device__ __forceinline__ void fc1_tiles_h2(const ddp_conv_shape_t& S, const ddp_conv_task_t& T, const _Float16* xp, int xstride,
+                                             _Float16* hp0, int hstride, int tid) {
+  constexpr int RT = ET / 32, NF = 2 * NS1;
+  constexpr int RING = (NF % 8 == 0) ? 8 : (NF % 6 == 0) ? 6 : (NF % 5 == 0) ? 5 : NF;
+  constexpr int XS2 = 16 * NS1 + 8, HS2 = 16 * NS + 8;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const f32x4* __restrict__ w1h = reinterpret_cast<const f32x4*>(T.w1h);
+  for (int t1 = wave; t1 < RT * S.nct1; t1 += NW) {
+    const int rt = t1 % RT, ct = t1 / RT;
+    f32x16 acc_m = splat16(T.b1p[ct * 32 + r]), acc_c = splat16(0.f);
+    const f32x4* __restrict__ wp = w1h + ((size_t)ct * NF * 2 + hh) * 32 + r;
+    const _Float16* arow = xp + (size_t)(rt * 32 + r) * XS2 + 8 * hh;
+    f32x4 ring[RING];
+#pragma unroll
+    for (int k = 0; k < RING; ++k) ring[k] = wp[64 * k];
+    h8 an_h = *reinterpret_cast<const h8*>(arow), an_l = *reinterpret_cast<const h8*>(arow + xstride);
+#pragma unroll
+    for (int ks = 0; ks < NS1; ++ks) {
+      const h8 bh = __builtin_bit_cast(h8, ring[(2 * ks) % RING]), bl = __builtin_bit_cast(h8, ring[(2 * ks + 1) % RING]);
+      if (2 * ks + RING < NF) ring[(2 * ks) % RING] = wp[64 * (2 * ks + RING)];
+      if (2 * ks + 1 + RING < NF) ring[(2 * ks + 1) % RING] = wp[64 * (2 * ks + 1 + RING)];
+      __builtin_amdgcn_sched_barrier(0);
+      const h8 ah = an_h, al = an_l;
+      if (ks + 1 < NS1) {
+        an_h = *reinterpret_cast<const h8*>(arow + 16 * (ks + 1));
+        an_l = *reinterpret_cast<const h8*>(arow + xstride + 16 * (ks + 1));
+      }
+      acc_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc_m, 0, 0, 0);
+      acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc_c, 0, 0, 0);
+      acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc_c, 0, 0, 0);
+    }
+    const int col = ct * 32 + r;
+    if (col < 16 * NS) {   // (columns [hid, 16 NS) come out as relu(0 + 0) = 0: the K padding of the tile loops' A operand)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        const float v = fmaxf(acc_m[i] + acc_c[i] * DDP_H2_INV, 0.f);
+        const _Float16 hi = (_Float16)v;
+        hp0[row * HS2 + col] = hi;
+        hp0[hstride + row * HS2 + col] = (_Float16)((v - (float)hi) * DDP_H2_SCALE);
+      }
+    }
+  }
+}
+
+template <int SZ, int ET, int C, bool H2 = false>
 __device__ __forceinline__ void run_block_rows(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
                                           const float* hbuf, float* fbuf, int tid,
                                           const TileAux<ET>& aux, int nvalid, int sbase) {
@@ -794,7 +987,12 @@ __device__ __forceinline__ void run_block_rows(const ddp_conv_shape_t& S, const 
     seg.tstride = 4;
     seg.count = (ngroups > wq) ? (ngroups - wq + 3) >> 2 : 0;
     seg.round = 0;
-    seg_tiles_any<SZ, C, FS>(S, B, T, hbuf, fbuf, seg, lane, out, rt);
+    if constexpr (H2) {   // hbuf = the fp16 operand planes of h (plane 1 ET rows behind plane 0)
+      constexpr int NS = H2Class<SZ>::NS;
+      seg_tiles_h2<C, NS, FS, 1>(B, T, reinterpret_cast<const _Float16*>(hbuf), ET * (16 * NS + 8), fbuf, seg, lane, rt, out);
+    } else {
+      seg_tiles_any<SZ, C, FS>(S, B, T, hbuf, fbuf, seg, lane, out, rt);
+    }
   }
 
   // ---- phase 4: deterministic cross-wave / cross-lane reduction.  Every wave parks a 32-row partial tile in its own
@@ -849,6 +1047,67 @@ __device__ __forceinline__ void run_block_rows(const ddp_conv_shape_t& S, const 
     }
   } else {
     static_assert(ET == 64, "run_block_rows is the 64-edge form; 32-edge workgroups run ddp_conv32_kernel");
+  }
+  __syncthreads();  // fbuf is rewritten by the next block's features
+  STAMP(sbase + 2);
+}
+
+// run_block_full in the h2 form (64-edge kernel, scalar blocks with many tiles): wave w owns the tiles w, w + 8, .. of the block
+// for BOTH 32-edge row tiles, so every packed weight tile leaves L2 once per workgroup (seg_tiles_h2 with RT = 2: six MFMAs per
+// pair of 16-byte weight fragments).  The stride 8 is even, so with nsub = 2 a wave only ever holds sub-block w & 1 of the n
+// columns; its 64 x 32 partial tile is parked in LDS and the waves' partials are summed in a FIXED order (waves 0-3, then 4-7).
+template <int SZ>
+__device__ __forceinline__ void run_block_full_h2(const ddp_conv_shape_t& S, const ddp_block_t& B, const ddp_conv_task_t& T,
+                                                  const float* hbuf, float* fbuf, int tid, const TileAux<64>& aux, int nvalid, int sbase) {
+  constexpr int NS = H2Class<SZ>::NS, FS = FS64, NW = DDP_CONV_THREADS / 64;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  f32x16 out[2];
+  {
+    ddp_role_seg_t seg;
+    seg.block = 0;
+    seg.tile0 = wave;
+    seg.tstride = NW;
+    seg.count = (B.ntiles > wave) ? (B.ntiles - wave + NW - 1) / NW : 0;
+    seg.round = 0;
+    seg_tiles_h2<1, NS, FS, 2>(B, T, reinterpret_cast<const _Float16*>(hbuf), 64 * (16 * NS + 8), fbuf, seg, lane, 0, out);
+  }
+  STAMP(sbase);
+  STAMP_SYNC();
+  STAMP(sbase + 1);
+  constexpr int RW = 32;                          // floats per edge row in a wave region
+  constexpr int REGION = 64 * RW;                 // 2048 floats per wave
+  const int nc = B.n;
+  float* part = fbuf;
+  float* carry = fbuf + 4 * REGION;
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();  // F (or the previous pass's partials) no longer needed
+    if ((wave >> 2) == half) {
+      float* mine = part + (wave & 3) * REGION;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mine[(rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh) * RW + r] = out[rt][i];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * nc; idx += DDP_CONV_THREADS) {
+      const int e = idx / nc, ncol = idx - e * nc;
+      float sum = (half == 0) ? 0.f : carry[idx];
+      for (int w = 0; w < 4; ++w) {
+        const float* reg = part + w * REGION + e * RW;
+        if (B.nsub > 1) {
+          if ((w & 1) == (ncol >> 5)) sum += reg[ncol & 31];     // waves 4 half + w hold sub-block w & 1
+        } else {
+          for (int q = 0; q < B.ups; ++q) sum += reg[q * B.n + ncol];
+        }
+      }
+      if (half == 0) {
+        carry[idx] = sum;
+      } else if (e < nvalid) {
+        T.msg[(size_t)aux.pos[e] * S.d_out + B.out_off + ncol] = sum;
+      }
+    }
   }
   __syncthreads();  // fbuf is rewritten by the next block's features
   STAMP(sbase + 2);
@@ -911,9 +1170,16 @@ __device__ __forceinline__ bool conv_tile(const ConvLaunch& L, int& t, int& p0, 
 }
 
 // phase 0: per-edge indices, harmonics, the units of the G pass, then the three row gathers of edge_attr_ into xa
-template <int ET, int NT = ET * 8>
+// NS1 > 0 (h2 form): the tile is written as the two fp16 operand planes of edge_attr_ (rows of 16 NS1 + 8 halves, plane 1
+// ET rows behind plane 0, K zero-padded to 16 NS1) instead of fp32 rows of S.hs floats
+template <int ET, int NS1 = 0, int NT = ET * 8>
 __device__ __forceinline__ void stage_edge_attr(const ddp_conv_shape_t& S, const ddp_conv_task_t& T, TileAux<ET>& aux, float* xa,
                                                 int p0, int nvalid, int tid) {
+  constexpr int XS2 = 16 * NS1 + 8;
+  _Float16* xp0 = reinterpret_cast<_Float16*>(xa);
+  _Float16* xp1 = xp0 + ET * XS2;
+  (void)xp0;
+  (void)xp1;
   if (tid < 64) {   // wave 0, lane = edge
     const bool valid = tid < nvalid;
     const int p = p0 + min(tid, nvalid - 1);
@@ -963,18 +1229,39 @@ __device__ __forceinline__ void stage_edge_attr(const ddp_conv_shape_t& S, const
         for (int i = tid; i < ET * n4; i += NT) {
           const int e = i / n4, c4 = i - e * n4;
           const f32x4 v = reinterpret_cast<const f32x4*>(ptr + (size_t)aux.segi[sg][e] * ld)[c4];
-          *reinterpret_cast<f32x4*>(&xa[e * S.hs + col0 + 4 * c4]) = v;
+          if constexpr (NS1 > 0) {
+            h4 hi, lo;
+            split_h2(v, hi, lo);
+            *reinterpret_cast<h4*>(&xp0[e * XS2 + col0 + 4 * c4]) = hi;
+            *reinterpret_cast<h4*>(&xp1[e * XS2 + col0 + 4 * c4]) = lo;
+          } else {
+            *reinterpret_cast<f32x4*>(&xa[e * S.hs + col0 + 4 * c4]) = v;
+          }
         }
       } else {
         for (int i = tid; i < ET * n; i += NT) {
           const int e = i / n, c = i - e * n;
-          xa[e * S.hs + col0 + c] = ptr[(size_t)aux.segi[sg][e] * ld + c];
+          const float v = ptr[(size_t)aux.segi[sg][e] * ld + c];
+          if constexpr (NS1 > 0) {
+            const _Float16 hi = (_Float16)v;
+            xp0[e * XS2 + col0 + c] = hi;
+            xp1[e * XS2 + col0 + c] = (_Float16)((v - (float)hi) * DDP_H2_SCALE);
+          } else {
+            xa[e * S.hs + col0 + c] = v;
+          }
         }
       }
       col0 += n;
     }
   }
-  {
+  if constexpr (NS1 > 0) {
+    const int npad = 16 * NS1 - S.f_in;
+    for (int i = tid; i < ET * npad; i += NT) {
+      const int e = i / npad, c = i - e * npad;
+      xp0[e * XS2 + S.f_in + c] = (_Float16)0.f;
+      xp1[e * XS2 + S.f_in + c] = (_Float16)0.f;
+    }
+  } else {
     const int npad = S.kp1 - S.f_in;
     for (int i = tid; i < ET * npad; i += NT) {
       const int e = i / npad, c = i - e * npad;
@@ -1061,7 +1348,7 @@ __device__ __forceinline__ void fc1_to_lds(const ddp_conv_shape_t& S, const ddp_
 
 // ------------------------------------------------------------------------------------------------ kernel, 64-edge form
 // (direct shapes: every block's features on the per-edge MFMA path)
-template <int SZ>
+template <int SZ, bool H2 = false>
 __global__ __launch_bounds__(512, 2) void ddp_conv_messages_kernel(const ConvLaunch L) {
   constexpr int ET = 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1071,15 +1358,24 @@ __global__ __launch_bounds__(512, 2) void ddp_conv_messages_kernel(const ConvLau
   int t, p0, nvalid;
   if (!conv_tile<ET>(L, t, p0, nvalid)) return;
   const ddp_conv_task_t& T = L.task[t];
-  float* hbuf = lds;
-  float* fbuf = lds + ET * S.hs;
+  float* hbuf = lds;     // h2: the two fp16 operand planes of h (L.r1_floats floats)
+  float* fbuf = lds + (H2 ? L.r1_floats : ET * S.hs);
   float* xa = fbuf;  // edge_attr_ staging aliases the feature buffer
 
   STAMP(0);
   STAMP(22);  // s_memrealtime (100 MHz) at entry
-  stage_edge_attr<ET>(S, T, aux, xa, p0, nvalid, tid);
-  STAMP(1);
-  fc1_to_lds<SZ, ET>(S, T, xa, hbuf, tid);
+  if constexpr (H2) {
+    constexpr int NS = H2Class<SZ>::NS;
+    stage_edge_attr<ET, NS>(S, T, aux, xa, p0, nvalid, tid);
+    STAMP(1);
+    fc1_tiles_h2<ET, ET / 8, NS, NS>(S, T, reinterpret_cast<const _Float16*>(xa), ET * (16 * NS + 8), reinterpret_cast<_Float16*>(hbuf),
+                                     ET * (16 * NS + 8), tid);
+    __syncthreads();
+  } else {
+    stage_edge_attr<ET>(S, T, aux, xa, p0, nvalid, tid);
+    STAMP(1);
+    fc1_to_lds<SZ, ET>(S, T, xa, hbuf, tid);
+  }
   STAMP(2);
 
   // ---- per weight block
@@ -1090,12 +1386,21 @@ __global__ __launch_bounds__(512, 2) void ddp_conv_messages_kernel(const ConvLau
     STAMP(3 + 4 * bi);
     // scalar blocks with many tiles (140 at ns = 60): 2x2 full-row blocking, 8-way tile split; otherwise single tiles over
     // (4 column groups x 2 row tiles)
-    if (B.C == 1 && B.ntiles >= 64)
-      run_block_full<1>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
-    else if (B.C == 1)
-      run_block_rows<SZ, ET, 1>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
-    else
-      run_block_rows<SZ, ET, 3>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
+    if constexpr (H2) {
+      if (B.C == 1 && B.ntiles >= 64)
+        run_block_full_h2<SZ>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
+      else if (B.C == 1)
+        run_block_rows<SZ, ET, 1, true>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
+      else
+        run_block_rows<SZ, ET, 3, true>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
+    } else {
+      if (B.C == 1 && B.ntiles >= 64)
+        run_block_full<1>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
+      else if (B.C == 1)
+        run_block_rows<SZ, ET, 1>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
+      else
+        run_block_rows<SZ, ET, 3>(S, B, T, hbuf, fbuf, tid, aux, nvalid, 4 + 4 * bi);
+    }
   }
   STAMP(23);  // s_memrealtime at exit
 #ifdef DDP_STAMPS
@@ -1166,7 +1471,7 @@ __device__ __forceinline__ void seg_park(const ddp_block_t& B, const ddp_role_se
 #ifndef DDP_C32_WPE
 #define DDP_C32_WPE 3   // workgroups per CU the register budget of the 32-edge kernel is set for
 #endif
-template <int SZ>
+template <int SZ, bool H2 = false>
 __global__ __launch_bounds__(256, DDP_C32_WPE) void ddp_conv32_kernel(const ConvLaunch L) {
   constexpr int ET = 32, NT = 256, FS = 36;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1178,8 +1483,10 @@ __global__ __launch_bounds__(256, DDP_C32_WPE) void ddp_conv32_kernel(const Conv
   if (!conv_tile<ET>(L, t, p0, nvalid)) return;
   const ddp_conv_task_t& T = L.task[t];
   const int os = L.tv_off;       // row stride of the message tile
+  // h2: region A holds the fp16 operand planes of h during the tile loops and is converted IN PLACE to the fp32 rows of h the G
+  // pass reads (phase 3b); region B starts behind the larger of the two (L.r1_floats)
   float* hbuf = lds;
-  float* rb = lds + ET * S.hs;   // region B: staging tile -> features -> message tile
+  float* rb = lds + (H2 ? L.r1_floats : ET * S.hs);   // region B: staging tile -> features -> message tile
 
   STAMP(0);
   STAMP(22);  // s_memrealtime (100 MHz) at entry
@@ -1193,9 +1500,18 @@ __global__ __launch_bounds__(256, DDP_C32_WPE) void ddp_conv32_kernel(const Conv
       }
     gmap[slot][c] = gm;
   }
-  stage_edge_attr<ET>(S, T, aux, rb, p0, nvalid, tid);
-  STAMP(1);
-  fc1_to_lds<SZ, ET>(S, T, rb, hbuf, tid);
+  if constexpr (H2) {
+    constexpr int NS = H2Class<SZ>::NS;
+    stage_edge_attr<ET, NS>(S, T, aux, rb, p0, nvalid, tid);
+    STAMP(1);
+    fc1_tiles_h2<ET, ET / 8, NS, NS>(S, T, reinterpret_cast<const _Float16*>(rb), ET * (16 * NS + 8), reinterpret_cast<_Float16*>(hbuf),
+                                     ET * (16 * NS + 8), tid);
+    __syncthreads();
+  } else {
+    stage_edge_attr<ET>(S, T, aux, rb, p0, nvalid, tid);
+    STAMP(1);
+    fc1_to_lds<SZ, ET>(S, T, rb, hbuf, tid);
+  }
   STAMP(2);
 
   // ---- phase 2: basis features of every block
@@ -1217,24 +1533,35 @@ __global__ __launch_bounds__(256, DDP_C32_WPE) void ddp_conv32_kernel(const Conv
   const int nseg = S.nrole[wave];
   f32x16 res[4];
   int c0 = 0, c1 = 0, f0 = 0, f1 = 0;   // components and first feature row of the wave's segments
+  [[maybe_unused]] const _Float16* hpl = reinterpret_cast<const _Float16*>(hbuf);
+  [[maybe_unused]] constexpr int PST = ET * (16 * H2Class<SZ>::NS + 8);
   if (nseg > 0) {
     const ddp_role_seg_t& R0 = S.role[wave][0];
     c0 = S.blk[R0.block].C;
     for (int bi = 0; bi < R0.block; ++bi) f0 += S.blk[bi].U * S.blk[bi].C;
-    if (c0 == 1) seg_tiles_any<SZ, 1>(S, S.blk[R0.block], T, hbuf, rb + f0 * FS, R0, lane, res);
-    else seg_tiles_any<SZ, 3>(S, S.blk[R0.block], T, hbuf, rb + f0 * FS, R0, lane, res + 1);
+    if constexpr (H2) {
+      if (c0 == 1) seg_tiles_h2<1, H2Class<SZ>::NS, FS, 1>(S.blk[R0.block], T, hpl, PST, rb + f0 * FS, R0, lane, 0, res);
+      else seg_tiles_h2<3, H2Class<SZ>::NS, FS, 1>(S.blk[R0.block], T, hpl, PST, rb + f0 * FS, R0, lane, 0, res + 1);
+    } else {
+      if (c0 == 1) seg_tiles_any<SZ, 1>(S, S.blk[R0.block], T, hbuf, rb + f0 * FS, R0, lane, res);
+      else seg_tiles_any<SZ, 3>(S, S.blk[R0.block], T, hbuf, rb + f0 * FS, R0, lane, res + 1);
+    }
   }
   if (nseg > 1) {
     const ddp_role_seg_t& R1 = S.role[wave][1];
     c1 = S.blk[R1.block].C;
     for (int bi = 0; bi < R1.block; ++bi) f1 += S.blk[bi].U * S.blk[bi].C;
-    if (c1 == 1) seg_tiles_any<SZ, 1>(S, S.blk[R1.block], T, hbuf, rb + f1 * FS, R1, lane, res + 1);
-    else seg_tiles_any<SZ, 3>(S, S.blk[R1.block], T, hbuf, rb + f1 * FS, R1, lane, res + 1);
+    if constexpr (H2) {
+      if (c1 == 1) seg_tiles_h2<1, H2Class<SZ>::NS, FS, 1>(S.blk[R1.block], T, hpl, PST, rb + f1 * FS, R1, lane, 0, res + 1);
+      else seg_tiles_h2<3, H2Class<SZ>::NS, FS, 1>(S.blk[R1.block], T, hpl, PST, rb + f1 * FS, R1, lane, 0, res + 1);
+    } else {
+      if (c1 == 1) seg_tiles_any<SZ, 1>(S, S.blk[R1.block], T, hbuf, rb + f1 * FS, R1, lane, res + 1);
+      else seg_tiles_any<SZ, 3>(S, S.blk[R1.block], T, hbuf, rb + f1 * FS, R1, lane, res + 1);
+    }
   }
   STAMP(4);
   __syncthreads();   // every wave is done with F: region B becomes the message tile
   STAMP(5);
-
   // ---- phase 4: the segments round by round.  Round 0 stores (every column of a block with tiles has a round-0 writer:
   // the parts of an item cover the same columns); the columns of blocks WITHOUT tiles (all their features factorised) only
   // receive the G pass and are zeroed here, in the same round (disjoint columns)
@@ -1259,6 +1586,28 @@ __global__ __launch_bounds__(256, DDP_C32_WPE) void ddp_conv32_kernel(const Conv
     }
     __syncthreads();
   }
+  if constexpr (H2) {
+    // ---- phase 4b (after the role segments' registers are parked): the operand planes of h -> fp32 rows
+    // h[e][k] = hi + lo / 2048 (exact: 22 significant bits), in place.
+    // Every thread reads its elements, one barrier, then writes them (the fp32 rows overlay both planes)
+    constexpr int NS = H2Class<SZ>::NS, HS2 = 16 * NS + 8;
+    constexpr int NE = (ET * 16 * NS + NT - 1) / NT;
+    float v[NE];
+    const _Float16* p0h = reinterpret_cast<const _Float16*>(hbuf);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int idx = tid + i * NT, e = min(idx / (16 * NS), ET - 1), k = idx % (16 * NS);
+      v[i] = (float)p0h[e * HS2 + k] + (float)p0h[ET * HS2 + e * HS2 + k] * DDP_H2_INV;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int idx = tid + i * NT, e = idx / (16 * NS), k = idx % (16 * NS);
+      if (e < ET && k < S.hp) hbuf[e * S.hs + k] = v[i];
+    }
+    __syncthreads();
+  }
+
   STAMP(6);
 
   // ---- phase 5: factorised features (one pass per G slot)
@@ -1308,6 +1657,9 @@ static int size_class(const ddp_conv_shape_t* S) {
     default: return 0;
   }
 }
+
+// k16 steps of the h2 form of a size class (0: none)
+static int h2_steps(int sc) { return sc == 60 ? 12 : sc == 32 ? 6 : sc == 24 ? 5 : sc == 16 ? 3 : 0; }
 
 template <int ET, typename K>
 static int launch_conv(K kernel, ConvLaunch& L, const ddp_conv_task_t* tasks, int ntasks, size_t lds_bytes, void* stream) {
@@ -1370,6 +1722,12 @@ extern "C" int ddp_conv_messages(const ddp_conv_shape_t* shape, const ddp_conv_t
   }
   ConvLaunch L;
   L.shape = *shape;
+  L.r1_floats = 0;
+  // the h2 form (fp16 hi/lo split of both operands of the fc products) runs when EVERY task of the launch carries the split
+  // weights (w1h, w2h: packing.pack_tiles_h2) and the shape belongs to a size class with unrolled k16 loops
+  bool h2 = ntasks > 0;
+  for (int i = 0; i < ntasks; ++i)
+    if (tasks[i].n_edges > 0 && (!tasks[i].w1h || !tasks[i].w2h || ((reinterpret_cast<size_t>(tasks[i].w1h) | reinterpret_cast<size_t>(tasks[i].w2h)) & 15))) h2 = false;
   if (fact) {
     // 32-edge workgroups.  The role table must cover every tile of every block exactly once, at most two segments and four
     // result components per wave, a vector segment never before a scalar one (register slots of phase 3).
@@ -1399,11 +1757,26 @@ extern "C" int ddp_conv_messages(const ddp_conv_shape_t* shape, const ddp_conv_t
     if (rbf < frows * (ET + 4)) rbf = frows * (ET + 4);   // features of all blocks
     if (rbf < ET * os) rbf = ET * os;               // message tile
     L.tv_off = os;
+    const int sc = size_class(shape);
+    if (h2 && h2_steps(sc) > 0) {
+      // h2 form: region A = the two operand planes of h (ET x HS2 halves each = ET * HS2 floats), later h in fp32; the staging
+      // tile of region B = the two operand planes of edge_attr_
+      const int hs2 = 16 * h2_steps(sc) + 8;
+      L.r1_floats = ET * ((shape->hs > hs2) ? shape->hs : hs2);
+      if (rbf < ET * hs2) rbf = ET * hs2;
+      const size_t ldsh = (size_t)(L.r1_floats + rbf) * sizeof(float);
+      switch (sc) {
+        case 60: return launch_conv<32>(ddp_conv32_kernel<60, true>, L, tasks, ntasks, ldsh, stream);
+        case 32: return launch_conv<32>(ddp_conv32_kernel<32, true>, L, tasks, ntasks, ldsh, stream);
+        case 24: return launch_conv<32>(ddp_conv32_kernel<24, true>, L, tasks, ntasks, ldsh, stream);
+        default: return launch_conv<32>(ddp_conv32_kernel<16, true>, L, tasks, ntasks, ldsh, stream);
+      }
+    }
     size_t lds32 = (size_t)(ET * shape->hs + rbf) * sizeof(float);
 #ifdef DDP_C32_LDS_PAD
     lds32 += DDP_C32_LDS_PAD;   // diagnostic builds: unused LDS on top (fewer workgroups per CU)
 #endif
-    switch (size_class(shape)) {
+    switch (sc) {
       case 60: return launch_conv<32>(ddp_conv32_kernel<60>, L, tasks, ntasks, lds32, stream);
       case 32: return launch_conv<32>(ddp_conv32_kernel<32>, L, tasks, ntasks, lds32, stream);
       case 24: return launch_conv<32>(ddp_conv32_kernel<24>, L, tasks, ntasks, lds32, stream);
@@ -1418,8 +1791,21 @@ extern "C" int ddp_conv_messages(const ddp_conv_shape_t* shape, const ddp_conv_t
       return ddp_fail(DDP_EINVAL, "ddp_conv_messages: fbuf_floats too small");
   if (64 * shape->hs > shape->fbuf_floats) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: fbuf_floats < staging tile");
   L.tv_off = 0;
+  const int sc = size_class(shape);
+  if (h2 && h2_steps(sc) > 0) {
+    const int hs2 = 16 * h2_steps(sc) + 8;
+    L.r1_floats = 64 * hs2;                                           // the two operand planes of h
+    if (64 * hs2 > shape->fbuf_floats) return ddp_fail(DDP_EINVAL, "ddp_conv_messages: fbuf_floats < staging planes");
+    const size_t ldsh = (size_t)(L.r1_floats + shape->fbuf_floats) * sizeof(float);
+    switch (sc) {
+      case 60: return launch_conv<64>(ddp_conv_messages_kernel<60, true>, L, tasks, ntasks, ldsh, stream);
+      case 32: return launch_conv<64>(ddp_conv_messages_kernel<32, true>, L, tasks, ntasks, ldsh, stream);
+      case 24: return launch_conv<64>(ddp_conv_messages_kernel<24, true>, L, tasks, ntasks, ldsh, stream);
+      default: return launch_conv<64>(ddp_conv_messages_kernel<16, true>, L, tasks, ntasks, ldsh, stream);
+    }
+  }
   const size_t lds64 = (size_t)(64 * shape->hs + shape->fbuf_floats) * sizeof(float);
-  switch (size_class(shape)) {
+  switch (sc) {
     case 60: return launch_conv<64>(ddp_conv_messages_kernel<60>, L, tasks, ntasks, lds64, stream);
     case 32: return launch_conv<64>(ddp_conv_messages_kernel<32>, L, tasks, ntasks, lds64, stream);
     case 24: return launch_conv<64>(ddp_conv_messages_kernel<24>, L, tasks, ntasks, lds64, stream);

@@ -199,7 +199,11 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, DDP_SA_WPE) void ddp_stage_a_mfma
   __syncthreads();
   int buf = 0;
   for (int row0 = R0; row0 < R1; row0 += 32, buf ^= 1) {
+#if defined(DDP_SA_ABL) && (DDP_SA_ABL == 5 || DDP_SA_ABL == 6)   // timing only: no loads inside the row-tile loop (stores alone on the vmcnt queue)
+    const bool more = false;
+#else
     const bool more = row0 + 32 < R1;
+#endif
     if (more) fetch(row0 + 32);                                 // in flight during this tile's MFMAs
     float a[KH];
     {
@@ -227,6 +231,9 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, DDP_SA_WPE) void ddp_stage_a_mfma
       for (int s2 = 0; s2 < 1; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], wr[t][s2], acc, 0, 0, 0);
 #else
       for (int s2 = 0; s2 < KH; ++s2) {
+#if defined(DDP_SA_ABL) && (DDP_SA_ABL == 4 || DDP_SA_ABL == 6)   // timing only: 1/5 of the matrix work, the store schedule unchanged
+        if (s2 % 5 == 0)
+#endif
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], wr[t][s2], acc, 0, 0, 0);
         if (wide && LAG) {   // quarter p of the pending block: LDS read at MFMA 2 + p*KH/4, store two MFMAs later
           if ((s2 - 2) % (KH / 4) == 0 && (s2 - 2) / (KH / 4) < 4 && s2 >= 2) drain_read((s2 - 2) / (KH / 4));

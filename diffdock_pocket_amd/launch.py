@@ -196,6 +196,11 @@ class SectionTimer:
 
 
 # ------------------------------------------------------------------------------------------------ conv / reduce
+# The fc products of the conv kernels on the fp16 matrix cores with both operands split in two halves (three products per 16 k,
+# fp32 accumulation; csrc/ddp_conv.hip).  False: the exact fp32 MFMA chains of rounds 1 - 3 (A/B runs, the h2-vs-fp32 tests).
+CONV_H2 = True
+
+
 def make_task(pk, x_src, ldx_src, view: EdgeView, sh, segs, msg, g=None) -> L.ConvTask:
     """segs: [(tensor, idx_int32[E], ld, ncols)], concatenated into edge_attr_ in this order."""
     t = L.ConvTask()
@@ -208,6 +213,9 @@ def make_task(pk, x_src, ldx_src, view: EdgeView, sh, segs, msg, g=None) -> L.Co
         else:
             t.seg_ptr[k], t.seg_idx[k], t.seg_ld[k], t.seg_n[k] = 0, 0, 0, 0
     t.w1p, t.b1p, t.w2p, t.b2p = pk.w1p.data_ptr(), pk.b1p.data_ptr(), pk.w2p.data_ptr(), pk.b2p.data_ptr()
+    # fp16 hi/lo operand planes of the same weights (None / CONV_H2 off: the exact fp32 MFMA form)
+    use_h2 = CONV_H2 and getattr(pk, "w1h", None) is not None and getattr(pk, "w2h", None) is not None
+    t.w1h, t.w2h = (pk.w1h.data_ptr(), pk.w2h.data_ptr()) if use_h2 else (0, 0)
     t.msg = msg.data_ptr()
     for k in range(2):
         t.g[k] = g[k].data_ptr() if (g is not None and g[k] is not None) else 0

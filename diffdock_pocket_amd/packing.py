@@ -377,6 +377,55 @@ def _pack_tiles(Wcols: torch.Tensor, kp: int) -> torch.Tensor:
     return W.permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
 
 
+H2_SCALE = 2048.0     # csrc/ddp_conv.hip DDP_H2_SCALE
+
+
+def h2_steps(spec: "ConvSpec") -> int:
+    """k16 steps of the fp16 hi/lo split ("h2") form of a conv's fc products, 0 if the shape has none: f_in = hid = 3 ns with ns
+    one of the released architectures' multiplicities (the size classes of csrc/ddp_conv.hip, H2Class)."""
+    if spec.f_in != spec.hid:
+        return 0
+    return {180: 12, 96: 6, 72: 5, 48: 3}.get(spec.hid, 0)
+
+
+def _pack_tiles_h2(Wcols: torch.Tensor, ns16: int) -> torch.Tensor:
+    """Wcols [ncols (multiple of 32), K] fp32 -> fp16 operand planes of v_mfma_f32_32x32x16_f16's B operand, v = hi + lo / 2048
+    (hi = fp16(v), lo = fp16((v - hi) * 2048)):  [tile][ks][plane][hh][j][8] = plane(W)[tile*32 + j][16 ks + 8 hh + i], K zero-padded
+    to 16 * ns16 (include/ddp_hip.h, ddp_conv_task_t::w1h / w2h)."""
+    ncols, K = Wcols.shape
+    kp = 16 * ns16
+    assert ncols % 32 == 0 and kp >= K
+    W = torch.zeros(ncols, kp, dtype=torch.float32)
+    W[:, :K] = Wcols
+    hi = W.to(torch.float16)
+    lo = ((W - hi.float()) * H2_SCALE).to(torch.float16)
+    if not bool(torch.isfinite(hi).all()):
+        raise NotImplementedError("fc weight outside the fp16 range (|w| > 65504): the fp16 hi/lo form cannot represent it")
+    Pl = torch.stack([hi, lo], 0).reshape(2, ncols // 32, 32, ns16, 2, 8)      # [plane, tile, j, ks, hh, i]
+    return Pl.permute(1, 3, 0, 4, 2, 5).contiguous().reshape(-1)
+
+
+def pack_fc1_h2(spec: ConvSpec, weight: torch.Tensor):
+    """fc.0 weight [hid, f_in] as fp16 hi/lo planes per 32-column tile (bias: pack_fc1's)."""
+    hid, f_in = weight.shape
+    Wc = torch.zeros(spec.nct1 * 32, f_in)
+    Wc[:hid] = weight.detach().float().cpu()
+    return _pack_tiles_h2(Wc, h2_steps(spec))
+
+
+def pack_fc2_h2(spec: ConvSpec, weight: torch.Tensor):
+    """fc.3 weight [weight_numel, hid] as fp16 hi/lo planes per tile, block scale folded in BEFORE the split (bias: pack_fc2's)."""
+    weight = weight.detach().float().cpu()
+    cols = []
+    for b in spec.blocks:
+        rows = b.column_rows()
+        valid = rows >= 0
+        Wc = torch.zeros(rows.numel(), spec.hid)
+        Wc[valid] = weight[rows[valid]] * b.scale
+        cols.append(Wc)
+    return _pack_tiles_h2(torch.cat(cols, 0), h2_steps(spec))
+
+
 def pack_fc1(spec: ConvSpec, weight: torch.Tensor, bias: torch.Tensor):
     """fc.0: weight [hid, f_in] -> packed [nct1 tiles]; bias -> [nct1*32]."""
     hid, f_in = weight.shape

@@ -144,7 +144,7 @@ def _mlp(n_in, n_hidden, n_out, dropout):
 
 
 class _PackedConv:
-    __slots__ = ("w1p", "b1p", "w2p", "b2p", "bn_scale", "bn_shift", "wg", "bg", "g_in_off")
+    __slots__ = ("w1p", "b1p", "w2p", "b2p", "bn_scale", "bn_shift", "wg", "bg", "g_in_off", "w1h", "w2h")
 
 
 class TensorProductConvLayer(nn.Module):
@@ -168,11 +168,15 @@ class TensorProductConvLayer(nn.Module):
         if self._packed_g is None or self._packed_g.w1p.device != device:
             base = self.packed(device)
             pk = _PackedConv()
-            pk.w1p, pk.b1p, pk.bn_scale, pk.bn_shift = base.w1p, base.b1p, base.bn_scale, base.bn_shift
+            pk.w1p, pk.b1p, pk.bn_scale, pk.bn_shift, pk.w1h = base.w1p, base.b1p, base.bn_scale, base.bn_shift, base.w1h
             w2p, b2p = P.pack_fc2(self.spec_g, self.fc[3].weight, self.fc[3].bias)
             if w2p.numel() == 0:
                 w2p, b2p = torch.zeros(64), torch.zeros(32)
             pk.w2p, pk.b2p = w2p.to(device), b2p.to(device)
+            pk.w2h = None
+            if P.h2_steps(self.spec_g) > 0:
+                w2h = P.pack_fc2_h2(self.spec_g, self.fc[3].weight)
+                pk.w2h = (w2h if w2h.numel() else torch.zeros(64, dtype=torch.float16)).to(device)
             wg, bg, offs = P.factor_weights(self.spec_g, self.fc[3].weight, self.fc[3].bias)
             pk.wg = [w.to(device) if w is not None else None for w in wg]
             pk.bg = [b.to(device) if b is not None else None for b in bg]
@@ -207,6 +211,11 @@ class TensorProductConvLayer(nn.Module):
                 sc, sh = torch.ones(self.spec.d_out), torch.zeros(self.spec.d_out)
             pk.w1p, pk.b1p, pk.w2p, pk.b2p = (t.to(device) for t in (w1p, b1p, w2p, b2p))
             pk.bn_scale, pk.bn_shift = sc.to(device), sh.to(device)
+            # the same weights as fp16 hi/lo operand planes: the fc products then run on the fp16 matrix cores (ddp_conv.hip, h2 form)
+            pk.w1h = pk.w2h = None
+            if P.h2_steps(self.spec) > 0:
+                pk.w1h = P.pack_fc1_h2(self.spec, self.fc[0].weight).to(device)
+                pk.w2h = P.pack_fc2_h2(self.spec, self.fc[3].weight).to(device)
             self._packed = pk
         return self._packed
 

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DDP_ABI_VERSION 11
+#define DDP_ABI_VERSION 12
 #define DDP_EINVAL (-1)   /* bad argument (shape not supported, null pointer, ...) */
 #define DDP_ELIMIT (-2)   /* exceeds a compiled-in limit (see DDP_MAX_*) */
 
@@ -121,6 +121,14 @@ typedef struct {
   const int32_t* pos;   /* [E] message row per listed edge; NULL = identity */
   const int32_t* n_edges_dev; /* optional, device memory: the actual edge count (see "Device-side counts"); n_edges is then the
                            capacity of the edge arrays and sizes the grid */
+  /* Optional (ABI 12): fc.0 / fc.3 weights as fp16 hi/lo operand planes (packing.pack_tiles_h2; 16-byte aligned): when EVERY
+   * task of a launch carries both and f_in = hid = 3 ns with ns in {60, 32, 24, 16}, the fc products run on
+   * v_mfma_f32_32x32x16_f16 with both operands split as v = hi + lo / 2048 (three products per 16 k, fp32 accumulation; error
+   * below the exact fp32 MFMA chain's, csrc/ddp_conv.hip).  Layout per 32-column tile: 2 * NS fragments of 1 KiB (NS = k16 steps,
+   * K zero-padded), fragment q = 2 * ks + plane (0 = hi, 1 = lo): [hh = 0..1][column j = 0..31][8 halves k = 16 ks + 8 hh + i].
+   * b1p / b2p stay fp32.  NULL: the exact fp32 MFMA form (w1p / w2p). */
+  const void* w1h;
+  const void* w2h;
 } ddp_conv_task_t;
 
 /* Fused fc -> tensor product -> per-edge message for up to 9 convs that share one shape.

@@ -250,6 +250,37 @@ def test_graph_replay_equals_launch_by_launch(flex):
         assert torch.equal(l0, l1) and torch.equal(a0, a1)
 
 
+@pytest.mark.parametrize("name", ["cfg2_full_noflex", "cfg2_small", "small32_readme", "ns24_l3", "cfg1_full"])
+def test_fp16_split_products_against_the_fp32_mfma_form(name):
+    """Round 4: the fc products of the conv kernels run on the fp16 matrix cores with both operands split in two halves
+    (v = hi + lo / 2048; three v_mfma_f32_32x32x16_f16 per 16 k, fp32 accumulation: csrc/ddp_conv.hip, "h2").  The exact fp32 MFMA
+    form of rounds 1 - 3 stays in the library (launch.CONV_H2 = False).  Both against the fp64 oracle on the same batch: the h2
+    form must be in the fp32 form's error class (the rounding noise of either form is amplified by the random-weight layers alike:
+    within a factor 4 of it or 5e-6 of the largest component - the path's tolerance is 1e-4), and the two forms must agree to 1e-5 -
+    every size class (ns = 60 / 32 / 24 / 16), factorised and direct kernels.  (Product by product the h2 form is the MORE accurate
+    one - 0.85e-7 against 1.8e-7 of sum|a b|, profiles/r04_f16x2_mfma_micro.txt.)"""
+    from diffdock_pocket_amd import launch as K
+    case, gold, batch, sd = case_inputs(name)
+    want = OracleScoreModel(case.oracle_config(), sd, dtype=torch.float64)(case.make_batch())
+    model = _model_for(case, sd)
+    out = {}
+    try:
+        for h2 in (True, False):
+            K.CONV_H2 = h2
+            got = model(case.make_batch().to(_dev()))
+            out[h2] = [t.double().cpu() for t in got]
+    finally:
+        K.CONV_H2 = True
+    assert any(not torch.equal(a, b) for a, b in zip(out[True], out[False]))      # (the switch does switch)
+    for a, b, w, k in zip(out[True], out[False], want, ("tr", "rot", "tor", "sc_tor")):
+        if w.numel() == 0:
+            continue
+        scale = float(w.abs().max())
+        e_h2, e_32 = float((a - w).abs().max()) / scale, float((b - w).abs().max()) / scale
+        assert e_h2 < max(4.0 * e_32, 5e-6), (name, k, e_h2, e_32)
+        assert float((a - b).abs().max()) / scale < 1e-5, (name, k, float((a - b).abs().max()) / scale)
+
+
 @pytest.mark.parametrize("flex", [False, True])
 def test_pipelined_layer_order_is_bitwise_the_serial_one(flex):
     """Round 4: at 40 samples the direct conv of layer l (receptor<-atom) runs on a side stream beside stage A of layer l + 1

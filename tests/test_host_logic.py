@@ -242,7 +242,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.ddp_abi_version.restype = ctypes.c_int
-    assert lib.ddp_abi_version() == L.load().ddp_abi_version() == 11
+    assert lib.ddp_abi_version() == L.load().ddp_abi_version() == 12
     assert ctypes.sizeof(L.ConvShape) == 11 * 4 + 4 * (11 * 4 + 3 * 12) + 4 + 4 * 4 + 4 * 2 * 20
 
 
@@ -418,3 +418,24 @@ def test_set_time_builds_one_tensor_per_distinct_value():
     assert b.complex_t["tr"].shape == (2,) and torch.equal(b.complex_t["tor"], torch.full((2,), 0.25))
     set_time(b, torch.tensor(0.75), 0.5, 0.5, 0.5)          # a tensor-valued time is multiplied through as before
     assert torch.equal(b["atom"].node_t["tr"], torch.full((b["atom"].num_nodes,), 0.75))
+
+
+def test_h2_operand_planes_layout_and_precision():
+    """packing._pack_tiles_h2: fc weights as the fp16 hi/lo operand planes of v_mfma_f32_32x32x16_f16 (include/ddp_hip.h,
+    ddp_conv_task_t::w2h): [tile][ks][plane][hh][column j][8 halves k = 16 ks + 8 hh + i], K zero-padded; hi + lo / 2048 carries
+    22 significant bits of every weight (tiny and large ones alike)."""
+    from diffdock_pocket_amd import packing as P
+    g = torch.Generator().manual_seed(0)
+    W = torch.randn(64, 180, generator=g) * 0.1
+    W[0, :8] = torch.tensor([1e-6, -3e-5, 6e-5, 1.0, -7.3, 100.0, 0.0, 2.0 ** -14])
+    pl = P._pack_tiles_h2(W, 12)
+    assert pl.dtype == torch.float16 and pl.numel() == 2 * 64 * 192
+    pl = pl.reshape(2, 12, 2, 2, 32, 8).float()                       # [tile, ks, plane, hh, j, i]
+    rec = (pl[:, :, 0] + pl[:, :, 1] / 2048.0).permute(0, 3, 1, 2, 4).reshape(64, 192)     # [tile, j, ks, hh, i] -> [col, k]
+    assert float(rec[:, 180:].abs().max()) == 0.0
+    err = (rec[:, :180].double() - W.double()).abs()
+    assert float((err / W.double().abs().clamp(min=2.0 ** -14)).max()) < 2.0 ** -21
+    spec = P.faster_tp_spec(P.irreps_muls(60, 10, 3), P.irreps_muls(60, 10, 4), 180)
+    assert P.h2_steps(spec) == 12 and P.h2_steps(P.faster_tp_spec(P.irreps_muls(60, 10, 6), (0, 2, 2, 0), 120)) == 0
+    w2 = torch.randn(spec.weight_numel, 180, generator=g) * 0.05
+    assert P.pack_fc2_h2(spec, w2).numel() == spec.ntiles * 2 * 12 * 64 * 8
