@@ -47,6 +47,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+F16_MFMA_PEAK_TFLOPS = 2500.0   # same guide: dense fp16 / bf16 MFMA (v_mfma_f32_32x32x16_f16)
+
+
+def mixed_roofline(fc16, other, sec):
+    """Roofline of a conv launch whose fc products (fc16 FLOPs) run as fp16 hi/lo split products - THREE fp16 matrix-core FLOPs per
+    product FLOP - and whose other useful FLOPs (G pass, contraction; fp32-MFMA launches) run in fp32: the time both parts would
+    take at their instruction's dense peak against the measured time.  Returns (achieved TFLOP/s of ISSUED-useful instruction
+    FLOPs, the blended peak of this instruction mix, frac = achieved / peak = t_at_peak / t)."""
+    issued = 3.0 * fc16 + other
+    t_min = 3.0 * fc16 / (F16_MFMA_PEAK_TFLOPS * 1e12) + other / (FP32_MFMA_PEAK_TFLOPS * 1e12)
+    return issued / sec / 1e12, issued / t_min / 1e12, t_min / sec
 HBM_PEAK_GBS = 8000.0           # same guide: HBM3E ~8 TB/s
 PMC_FILE = os.path.join("profiles", "r04_pmc.json")
 
@@ -87,6 +98,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-roofline-pass", action="store_true", help="skip the instrumented steps behind the timed region")
     ap.add_argument("--no-overlap-direct", action="store_true",
                     help="diagnostic: the serial launch order of the conv layers (model.overlap_direct_conv = False) for same-box A/B runs")
+    ap.add_argument("--layer-order", default=None, choices=["chains", "pipeline", "pipeline2"], help="diagnostic: model.layer_order for A/B runs")
     ap.add_argument("--no-flex-sharing", action="store_true",
                     help="diagnostic: flexible side chains without the partial sharing of layers 0 / 1 (model.share_flex_layer0 = False)")
     return ap.parse_args(argv)
@@ -414,6 +426,8 @@ def main(argv=None):
         model.share_flex_layer0 = False
     if args.no_overlap_direct:
         model.overlap_direct_conv = False
+    if args.layer_order:
+        model.layer_order = args.layer_order
     complex_graph = make_3dpf_complex(seed=0, flexible_sidechains=args.flex)
     n_total = args.samples * world if scaling == "weak" else args.samples
     if n_total < world:
@@ -483,8 +497,8 @@ def main(argv=None):
             os.makedirs(os.path.dirname(os.path.abspath(args.launch_log)), exist_ok=True)
             with open(args.launch_log, "w") as f:
                 json.dump({"workload": workload_key, "src_sha16": loaded_hash(), "warmup_steps": args.warmup, "steps": args.steps,
-                           "launches": [{"kernel": k, "edges": e, "useful_flops": u, "algorithmic_flops": a}
-                                        for k, e, u, a in zip(prof.kernel, prof.edges, prof.useful, prof.flops)]}, f)
+                           "launches": [{"kernel": k, "edges": e, "useful_flops": u, "algorithmic_flops": a, "fc16_flops": (f16 if h else 0.0)}
+                                        for k, e, u, a, f16, h in zip(prof.kernel, prof.edges, prof.useful, prof.flops, prof.fc, prof.h2)]}, f)
         # the dominant kernel = the instantiation with the larger share of the timed region
         kinds = sorted({k for k in prof.kernel}, key=lambda k: -prof.summary(k)[2])
         roof = None
@@ -495,22 +509,32 @@ def main(argv=None):
                 useful = prof.useful_flops(kname) / n_
                 issued_model = prof.executed_flops(kname) / n_
                 p = pmc.get(kname, {})
-                e = {"kernel": kname, "bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TFLOPS,
-                     "achieved": useful / sec / 1e12, "frac": useful / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                fc16, oth = prof.split_flops(kname)
+                ach, peak, frac = mixed_roofline(fc16 / n_, oth / n_, sec)
+                e = {"kernel": kname, "bound": "mfma", "unit": "TFLOP/s", "peak": peak, "achieved": ach, "frac": frac,
+                     "mfma_mix": {"fc_products_as_fp16_hi_lo_split_gflop_per_launch": fc16 / n_ / 1e9, "fp32_gflop_per_launch": oth / n_ / 1e9,
+                                  "fp16_mfma_peak": F16_MFMA_PEAK_TFLOPS, "fp32_mfma_peak": FP32_MFMA_PEAK_TFLOPS,
+                                  "instruction_flops_per_split_product_flop": 3},
+                     "fp32_equivalent_tflops": useful / sec / 1e12, "fp32_equivalent_vs_fp32_mfma_peak": useful / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                      "launches": n_, "avg_launch_ms": ms_ / n_, "useful_mfma_gflop_per_launch": useful / 1e9,
                      "tile_padded_mfma_gflop_per_launch": issued_model / 1e9,
                      "algorithmic_gflop_per_launch": fl_ / n_ / 1e9,
                      "algorithmic_vs_fp32_peak": fl_ / n_ / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                      "share_of_wall": ms_ * 1e-3 / elapsed, "ms_per_step": ms_ / args.steps,
                      "by_layer": {str(tag): {"launches": n_t, "avg_launch_ms": ms_t / n_t, "edges_per_launch": ne_t / n_t,
-                                             "achieved": u_t / (ms_t * 1e-3) / 1e12, "frac": u_t / (ms_t * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
-                                  for tag, (n_t, u_t, ms_t, ne_t) in sorted(prof.by_tag(kname).items(), key=lambda kv: str(kv[0]))},
+                                             "fp32_equivalent_tflops": u_t / (ms_t * 1e-3) / 1e12,
+                                             "achieved": mixed_roofline(f16_t, u_t - f16_t, ms_t * 1e-3)[0],
+                                             "frac": mixed_roofline(f16_t, u_t - f16_t, ms_t * 1e-3)[2]}
+                                  for tag, (n_t, u_t, ms_t, ne_t, f16_t) in sorted(prof.by_tag(kname).items(), key=lambda kv: str(kv[0]))},
                      "traffic": p.get("hbm_bytes_per_launch"), "issued_mfma_gflop_per_launch_pmc": p.get("issued_mfma_gflop_per_launch"),
                      "padding_frac_pmc": p.get("padding_frac"), "mfma_busy_pmc": p.get("mfma_busy_frac")}
                 return e
             roof = entry(kinds[0])
-            roof["note"] = ("achieved = useful fp32 MFMA FLOPs of the kernel's own formulation (fc1 + vector-feature fc2 columns + the "
-                            "per-edge G contraction, no padding) / HIP-event launch time; algorithmic_* = the reference formulation "
+            roof["note"] = ("achieved = matrix-core instruction FLOPs of the kernel's own formulation without padding (fc1 + vector-feature fc2 "
+                            "columns as fp16 hi/lo split products = 3 fp16 MFMA FLOPs per product FLOP; the per-edge G contraction and the "
+                            "feature contraction in fp32) / HIP-event launch time; peak = the same FLOPs / the time they take at each "
+                            "instruction's dense peak (2500 fp16, 157.3 fp32 TFLOP/s), so frac = time at peak / measured time; "
+                            "fp32_equivalent_* counts every product FLOP once; algorithmic_* = the reference formulation "
                             "(BASELINE.md section 3: 2FH + 2HW + 2C per edge), 84 % of which the exact source-node factorisation "
                             "removes (DESIGN.md section 4.2), hence algorithmic_vs_fp32_peak > 1")
             roof["conv_share_of_wall"] = sum(prof.summary(k)[2] for k in kinds) * 1e-3 / elapsed
@@ -527,7 +551,8 @@ def main(argv=None):
                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_mb_per_launch": by_ / n_ / 1e6,
                         "ms_per_step": ms_ / 2.0, "measured": "2 extra steps (schedule positions 5, 15) behind the instrumented pass",
                         "traffic": p.get("hbm_bytes_per_launch"), "mfma_busy_pmc": p.get("mfma_busy_frac")}
-            roof["other_kernels"] += [e for e in (hbm_entry("ddp_stage_a_mfma_kernel"), hbm_entry("ddp_segment_reduce_kernel")) if e]
+            roof["other_kernels"] += [e for e in (hbm_entry("ddp_stage_a_h2_kernel"), hbm_entry("ddp_stage_a_mfma_kernel"),
+                                                  hbm_entry("ddp_segment_reduce_kernel")) if e]
             # whole step: HBM bytes the PMC passes saw against the algorithmic boundary bytes of the convs
             alg_step = prof.boundary_bytes() / args.steps
             step = {"algorithmic_boundary_gb": alg_step / 1e9}
@@ -538,7 +563,8 @@ def main(argv=None):
             roof["per_step"] = step
         line = {"metric": "ligand poses/sec (40 samples x 20 steps) on 3dpf", "value": poses / elapsed, "unit": "poses/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+                "dtype": "f32 (fc products: fp16 hi/lo split of both operands on v_mfma_f32_32x32x16_f16, fp32 accumulate)", "data": "synthetic",
                 "config": {"workload": f"3dpf ({sampler.n_l} lig atoms, 139 residues, {sampler.n_a} pocket atoms), "
                                        f"{n_total} samples over {world} GPU(s) ({n_local} on rank 0) x 20-step schedule, score model "
                                        f"{args.cfg} (ns={kw['ns']} nv={kw['nv']} L={kw['num_conv_layers']}), "
@@ -566,7 +592,10 @@ def main(argv=None):
                 for kname in sorted({k for k in pr.kernel}):
                     n_, _, ms_ = pr.summary(kname)
                     tf = pr.useful_flops(kname) / (ms_ * 1e-3) / 1e12
-                    out[kname] = {"launches": n_, "avg_launch_ms": ms_ / n_, "achieved_tflops": tf, "frac": tf / FP32_MFMA_PEAK_TFLOPS}
+                    fc16, oth = pr.split_flops(kname)
+                    ach, peak, frac = mixed_roofline(fc16, oth, ms_ * 1e-3)
+                    out[kname] = {"launches": n_, "avg_launch_ms": ms_ / n_, "fp32_equivalent_tflops": tf, "achieved_tflops": ach,
+                                  "peak_of_the_instruction_mix": peak, "frac": frac}
                 return out
 
             def sub_job(cfg_, flex_, n_):   # a timed job + its instrumented pass

@@ -68,13 +68,20 @@ template <> struct SizeClass<16> { static constexpr int NM = 6; static constexpr
 // halves, v = hi + lo / 2048 (hi = fp16(v), lo = fp16((v - hi) * 2048): 22 significant bits, the low part scaled back into fp16's
 // normal range), and three products per 16 k run on v_mfma_f32_32x32x16_f16 with fp32 accumulation:
 //     h w  ~  hh wh + (hh wl + hl wh) / 2048                   dropped: hl wl / 2^22
-// Measured against fp64 (tools/micro/f16x2_mfma.hip): |err| <= 0.85e-7 sum|h w| - below the exact fp32 MFMA chain's 1.8e-7 (the
-// f16 instruction sums its 16 products before rounding) - at 3.75 x the fp32 MFMA rate (580 against 155 TFLOP/s sustained).
+// Operands of 22 significant bits: a product is off by <= (2^-21 + 2^-22) |h w| in the worst case; measured against fp64 on the fc
+// shapes (tools/micro/f16x2_mfma.hip, K = 192): |err| <= 0.85e-7 sum|h w| where the exact fp32 MFMA chain shows 1.8e-7 (the f16
+// instruction sums its 16 products before it rounds) - at 3.75 x the fp32 MFMA rate (580 against 155 TFLOP/s sustained).
 // The operands keep their byte counts: a weight fragment of 16 k is two 16-byte loads (hi, lo) like two fp32 k-groups.
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define DDP_H2_SCALE 2048.f
 #define DDP_H2_INV (1.f / 2048.f)
+#ifndef DDP_G_UNIT
+#define DDP_G_UNIT 8   // edges per unit of the G pass in the h2 32-edge kernels (8 or 16; measured: 16 = a third fewer passes over the G rows, but 12.95 against 12.45 ms of conv32 per step)
+#endif
+#ifndef DDP_H2_RING64
+#define DDP_H2_RING64 8   // weight fragments in flight per wave in the 64-edge kernel (256 registers per lane there)
+#endif
 // k16 steps of f_in = hid = 3 SZ (0: no h2 form for this class); LDS row stride of an operand plane = 16 NS + 8 halves
 // (16-byte aligned rows whose 16-lane ds_read_b128 groups fall on distinct banks for NS = 12, 6, 5, 3)
 template <int SZ> struct H2Class { static constexpr int NS = 0; };
@@ -89,6 +96,10 @@ __device__ __forceinline__ void split_h2(const f32x4 v, h4& hi, h4& lo) {
     hi[i] = (_Float16)v[i];
     lo[i] = (_Float16)((v[i] - (float)hi[i]) * DDP_H2_SCALE);
   }
+}
+// a value the h2 form cannot split (outside the fp16 range, or NaN) is REPORTED, never silently saturated: ddp_conv_task_t::h2_range_flag
+__device__ __forceinline__ void h2_range_check(float v, int32_t* flag) {
+  if (!(fabsf(v) <= 65504.f) && flag) *flag = 1;
 }
 
 struct ConvLaunch {
@@ -205,10 +216,12 @@ __device__ __forceinline__ void g_add_out(float* outb, int os, const float (*sh)
 // below has uniform branches inside a step - k range, first / last chunk of a unit, tail steps - and at every such join the
 // pass fell back to "all but the last step's loads have landed": vmcnt(5..8) with 25 loads issued, i.e. each step paid a
 // full memory round trip, 2.3 k ticks under load whatever else it did.)
-template <int ET, int KQ, int NM, int RING>
+template <int ET, int KQ, int NM, int RING, int NG = 2>
 __device__ __forceinline__ void g_main_static(const ddp_conv_shape_t& S, const float* __restrict__ Gb, const f32x4* __restrict__ G4,
                                               size_t gstride, int gc, int gm_, bool act0, int c0, int nmine, int my_e0, int my_len,
                                               int my_node, const float* hbuf, float* outb, int os, const TileAux<ET>& aux, int lane) {
+  // NG = 4-edge row groups of a unit (2: units of <= 8 edges, 4: of <= 16 - fewer passes over the G rows of a source node with many
+  // edges in the tile; the 4x4x1 MFMAs of absent rows are wasted matrix-pipe time, which the h2 kernels have to spare)
   static_assert(NM % RING == 0, "fragment f of every unit lives in ring slot f % RING");
   if (nmine <= 0) return;
   f32x4 ring[RING][KQ];
@@ -229,29 +242,32 @@ __device__ __forceinline__ void g_main_static(const ddp_conv_shape_t& S, const f
     const f32x4* __restrict__ gpn = G4 + (size_t)node_n * gstride + c0;
     const float bias_n = Gb[(size_t)node_n * (4 * gstride) + c0];
     const int e0 = __builtin_amdgcn_readlane(my_e0, ui), len = __builtin_amdgcn_readlane(my_len, ui);
-    f32x4 acc0 = {bias, bias, bias, bias}, acc1 = acc0, acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = acc2;
+    f32x4 acce[NG], acco[NG];     // even / odd k partial sums per row group (two independent chains per group)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      acce[g] = f32x4{bias, bias, bias, bias};
+      acco[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const float* hrow0 = &hbuf[(e0 + (lane & 3)) * S.hs];
-    const float* hrow1 = hrow0 + 4 * S.hs;
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
-      f32x4 a0[KQ], a1[KQ];
+      f32x4 a[NG][KQ];
 #pragma unroll
-      for (int q = 0; q < KQ; ++q) {
-        a0[q] = *reinterpret_cast<const f32x4*>(hrow0 + 4 * (m * KQ + q));
-        a1[q] = *reinterpret_cast<const f32x4*>(hrow1 + 4 * (m * KQ + q));
-      }
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) a[g][q] = *reinterpret_cast<const f32x4*>(hrow0 + 4 * g * S.hs + 4 * (m * KQ + q));
       __builtin_amdgcn_sched_barrier(0);   // (without the fences the scheduler sinks each refill load to its use, RING steps later)
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
         const f32x4 b = ring[m % RING][q];
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q][0], b[0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q][0], b[0], acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q][1], b[1], acc2, 0, 0, 0);
-        acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q][1], b[1], acc3, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q][2], b[2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q][2], b[2], acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q][3], b[3], acc2, 0, 0, 0);
-        acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q][3], b[3], acc3, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acce[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[g][q][0], b[0], acce[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acco[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[g][q][1], b[1], acco[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acce[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[g][q][2], b[2], acce[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acco[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[g][q][3], b[3], acco[g], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       const int f = m + RING;   // the fragment that takes this slot: of this unit, or of the next one
@@ -260,19 +276,19 @@ __device__ __forceinline__ void g_main_static(const ddp_conv_shape_t& S, const f
         ring[m % RING][q] = DDP_ABL_G((f < NM) ? gp[(size_t)(f * KQ + q) * gc] : gpn[(size_t)((f - NM) * KQ + q) * gc], q);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (act0 && DDP_ABL_EPI) {   // rows >= len of the two 4-edge groups are never stored
+    if (act0 && DDP_ABL_EPI) {   // rows >= len of the 4-edge groups are never stored
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (i < len) g_add_out(outb, os, aux.sh, e0 + i, gm_, acc0[i] + acc2[i]);
-        if (4 + i < len) g_add_out(outb, os, aux.sh, e0 + 4 + i, gm_, acc1[i] + acc3[i]);
-      }
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (4 * g + i < len) g_add_out(outb, os, aux.sh, e0 + 4 * g + i, gm_, acce[g][i] + acco[g][i]);
     }
     gp = gpn;
     bias = bias_n;
   }
 }
 
-template <int SZ, int ET, int NW = ET / 8, int KC = 16, int RD = 5>
+template <int SZ, int ET, int UNIT = 8, int NW = ET / 8, int KC = 16, int RD = 5>
 __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, const ddp_conv_task_t& T, const float* hbuf,
                                         float* outb, int os, const int* gmap, const TileAux<ET>& aux, int wave, int lane) {
   // One pass per G slot; a wave takes units wave, wave + NW, ...  For a unit (<= 8 edges of one source node)
@@ -328,9 +344,10 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
     if constexpr (SZ != 0) {   // hid = 3 SZ = 180 / 96 / 72 / 48: the steps of a unit unrolled (g_main_static), nq = 3 x NM steps of 3 k-quads
       constexpr int GNM = (3 * SZ / 4) / 3, GRING = (SZ == 60) ? 5 : (SZ == 24) ? 6 : 4;
       const int gmv = gmap[cb + (act0 ? lane : 0)];
-      g_main_static<ET, 3, GNM, GRING>(S, Gb, G4, gstride, gc, gmv, act0, c0, nmine, my_e0, my_len, my_node, hbuf, outb, os, aux, lane);
+      g_main_static<ET, 3, GNM, GRING, UNIT / 4>(S, Gb, G4, gstride, gc, gmv, act0, c0, nmine, my_e0, my_len, my_node, hbuf, outb, os, aux, lane);
       continue;
     }
+    static_assert(SZ != 0 || UNIT == 8, "the runtime-loop G pass handles units of <= 8 edges");
     f32x4 ring[RD][KC / 4];   // (indices are compile-time constants after unrolling: registers)
     float rbias[RD];
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
@@ -437,15 +454,16 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
       DDP_GX_LOAD(ui + 1, gn, bn)
       __builtin_amdgcn_sched_barrier(0);
       const int e0 = __builtin_amdgcn_readlane(my_e0, ui), len = __builtin_amdgcn_readlane(my_len, ui);
+      constexpr int NGX = UNIT / 4;
       const float* hrow0 = &hbuf[(e0 + (lane & 3)) * S.hs + kx0];
-      const float* hrow1 = hrow0 + 4 * S.hs;
-      f32x4 a0[XK / 4], a1[XK / 4];
+      f32x4 ax[NGX][XK / 4];
 #pragma unroll
-      for (int q4 = 0; q4 < XK / 4; ++q4) {
-        a0[q4] = *reinterpret_cast<const f32x4*>(hrow0 + 4 * q4);
-        a1[q4] = *reinterpret_cast<const f32x4*>(hrow1 + 4 * q4);
-      }
-      f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < NGX; ++g)
+#pragma unroll
+        for (int q4 = 0; q4 < XK / 4; ++q4) ax[g][q4] = *reinterpret_cast<const f32x4*>(hrow0 + 4 * g * S.hs + 4 * q4);
+      f32x4 xs[NGX];
+#pragma unroll
+      for (int g = 0; g < NGX; ++g) xs[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q4 = 0; q4 < XK / 4; ++q4) {
         // quads of the slice beyond the row (and idle columns) contribute exactly 0: both operands are zeroed there
@@ -454,24 +472,23 @@ __device__ __forceinline__ void g_stage(const ddp_conv_shape_t& S, int slot, con
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const float bq = (okk && colv) ? gx[q4][kk] : 0.f;
-          x0 = __builtin_amdgcn_mfma_f32_4x4x1f32(okk ? a0[q4][kk] : 0.f, bq, x0, 0, 0, 0);
-          x1 = __builtin_amdgcn_mfma_f32_4x4x1f32(okk ? a1[q4][kk] : 0.f, bq, x1, 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < NGX; ++g) xs[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(okk ? ax[g][q4][kk] : 0.f, bq, xs[g], 0, 0, 0);
         }
       }
       for (int m = 4 * xnb; m < 64; m <<= 1) {   // sum the K-slices (lane stride 4 * xnb), fixed order
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          x0[i] += __shfl_xor(x0[i], m);
-          x1[i] += __shfl_xor(x1[i], m);
-        }
+        for (int g = 0; g < NGX; ++g)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xs[g][i] += __shfl_xor(xs[g][i], m);
       }
       if (lane < nx) {
         const int gm = gmap[64 + lane];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (i < len) g_add_out(outb, os, aux.sh, e0 + i, gm, bx + x0[i]);
-          if (4 + i < len) g_add_out(outb, os, aux.sh, e0 + 4 + i, gm, bx + x1[i]);
-        }
+        for (int g = 0; g < NGX; ++g)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (4 * g + i < len) g_add_out(outb, os, aux.sh, e0 + 4 * g + i, gm, bx + xs[g][i]);
       }
     }
 #undef DDP_GX_LOAD
@@ -808,14 +825,15 @@ __device__ __forceinline__ void seg_tiles_any(const ddp_conv_shape_t& S, const d
 // (lo) `pstride` halves behind it; the packed weights T.w2h hold per tile 2 NS fragments of 1 KiB, fragment q = 2 ks + plane:
 // lane (r, hh) reads the 8 halves k = 16 ks + 8 hh .. + 7 of column r (packing.pack_tiles_h2).  RT row tiles of 32 edges share
 // every weight fragment (RT = 2: the 64-edge kernel's scalar blocks).  Same static ring / unconditional loads as seg_tiles.
-template <int C, int NS, int FS, int RT>
+template <int C, int NS, int FS, int RT, int RING_ = 0>
 __device__ __forceinline__ void seg_tiles_h2(const ddp_block_t& B, const ddp_conv_task_t& T, const _Float16* hpl, int pstride,
                                              const float* fblk, const ddp_role_seg_t& R, int lane, int rt0, f32x16* out) {
   constexpr int NF = 2 * NS;
 #ifndef DDP_H2_RING
-#define DDP_H2_RING 6
+#define DDP_H2_RING 4   // weight fragments in flight per wave (measured: 4: 12.2 ms of conv32 per step, 6: 12.6 (36 spills), 8: 13.6)
 #endif
-  constexpr int RING = (NF % DDP_H2_RING == 0) ? DDP_H2_RING : (NF % 6 == 0) ? 6 : (NF % 5 == 0) ? 5 : NF;
+  constexpr int RW = (RING_ > 0) ? RING_ : DDP_H2_RING;     // wanted ring depth (fragments)
+  constexpr int RING = (NF % RW == 0) ? RW : (NF % 6 == 0) ? 6 : (NF % 5 == 0) ? 5 : NF;
   constexpr int HS2 = 16 * NS + 8;
   static_assert(NF % RING == 0 && NF >= RING, "fragment q of every tile lives in ring slot q % RING");
   const int r = lane & 31, hh = lane >> 5;
@@ -931,7 +949,12 @@ __device__ __forceinline__ void fc1_tiles_h2(const ddp_conv_shape_t& S, const dd
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const f32x4* __restrict__ w1h = reinterpret_cast<const f32x4*>(T.w1h);
-  for (int t1 = wave; t1 < RT * S.nct1; t1 += NW) {
+  // (row tile, column tile) pairs over the waves in boustrophedon order - wave w takes pairs w, 2 NW - 1 - w, 2 NW + w, ... - so
+  // that the extra pairs (6 column tiles over 4 waves) go to the LAST waves, which hold one role tile less in phase 3
+  for (int it = 0;; ++it) {
+    const int t1 = it * NW + ((it & 1) ? NW - 1 - wave : wave);
+    if (it * NW >= RT * S.nct1) break;
+    if (t1 >= RT * S.nct1) continue;
     const int rt = t1 % RT, ct = t1 / RT;
     f32x16 acc_m = splat16(T.b1p[ct * 32 + r]), acc_c = splat16(0.f);
     const f32x4* __restrict__ wp = w1h + ((size_t)ct * NF * 2 + hh) * 32 + r;
@@ -961,6 +984,7 @@ __device__ __forceinline__ void fc1_tiles_h2(const ddp_conv_shape_t& S, const dd
       for (int i = 0; i < 16; ++i) {
         const int row = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
         const float v = fmaxf(acc_m[i] + acc_c[i] * DDP_H2_INV, 0.f);
+        h2_range_check(acc_m[i] + acc_c[i] * DDP_H2_INV, T.h2_range_flag);     // (before the relu: fmaxf drops a NaN)
         const _Float16 hi = (_Float16)v;
         hp0[row * HS2 + col] = hi;
         hp0[hstride + row * HS2 + col] = (_Float16)((v - (float)hi) * DDP_H2_SCALE);
@@ -989,7 +1013,7 @@ __device__ __forceinline__ void run_block_rows(const ddp_conv_shape_t& S, const 
     seg.round = 0;
     if constexpr (H2) {   // hbuf = the fp16 operand planes of h (plane 1 ET rows behind plane 0)
       constexpr int NS = H2Class<SZ>::NS;
-      seg_tiles_h2<C, NS, FS, 1>(B, T, reinterpret_cast<const _Float16*>(hbuf), ET * (16 * NS + 8), fbuf, seg, lane, rt, out);
+      seg_tiles_h2<C, NS, FS, 1, DDP_H2_RING64>(B, T, reinterpret_cast<const _Float16*>(hbuf), ET * (16 * NS + 8), fbuf, seg, lane, rt, out);
     } else {
       seg_tiles_any<SZ, C, FS>(S, B, T, hbuf, fbuf, seg, lane, out, rt);
     }
@@ -1070,7 +1094,7 @@ __device__ __forceinline__ void run_block_full_h2(const ddp_conv_shape_t& S, con
     seg.tstride = NW;
     seg.count = (B.ntiles > wave) ? (B.ntiles - wave + NW - 1) / NW : 0;
     seg.round = 0;
-    seg_tiles_h2<1, NS, FS, 2>(B, T, reinterpret_cast<const _Float16*>(hbuf), 64 * (16 * NS + 8), fbuf, seg, lane, 0, out);
+    seg_tiles_h2<1, NS, FS, 2, DDP_H2_RING64>(B, T, reinterpret_cast<const _Float16*>(hbuf), 64 * (16 * NS + 8), fbuf, seg, lane, 0, out);
   }
   STAMP(sbase);
   STAMP_SYNC();
@@ -1172,7 +1196,7 @@ __device__ __forceinline__ bool conv_tile(const ConvLaunch& L, int& t, int& p0, 
 // phase 0: per-edge indices, harmonics, the units of the G pass, then the three row gathers of edge_attr_ into xa
 // NS1 > 0 (h2 form): the tile is written as the two fp16 operand planes of edge_attr_ (rows of 16 NS1 + 8 halves, plane 1
 // ET rows behind plane 0, K zero-padded to 16 NS1) instead of fp32 rows of S.hs floats
-template <int ET, int NS1 = 0, int NT = ET * 8>
+template <int ET, int NS1 = 0, int UNIT = 8, int NT = ET * 8>
 __device__ __forceinline__ void stage_edge_attr(const ddp_conv_shape_t& S, const ddp_conv_task_t& T, TileAux<ET>& aux, float* xa,
                                                 int p0, int nvalid, int tid) {
   constexpr int XS2 = 16 * NS1 + 8;
@@ -1193,14 +1217,14 @@ __device__ __forceinline__ void stage_edge_attr(const ddp_conv_shape_t& S, const
       aux.sh[tid][0] = shv[0]; aux.sh[tid][1] = shv[1]; aux.sh[tid][2] = shv[2]; aux.sh[tid][3] = shv[3];
     }
     if (S.g_cols[0] | S.g_cols[1]) {
-      // units = runs of <= 8 valid edges with one source node (the edges are source sorted), found with two ballots:
-      // run starts, then every 8th edge of a run
+      // units = runs of <= UNIT valid edges with one source node (the edges are source sorted), found with two ballots:
+      // run starts, then every UNIT-th edge of a run
       const int prev = __shfl_up(src, 1);
       const bool runstart = valid && (tid == 0 || src != prev);
       const unsigned long long rmask = __ballot(runstart);
       const unsigned long long upto = (tid == 63) ? ~0ull : ((2ull << tid) - 1ull);
       const int rs = 63 - __clzll((long long)(rmask & upto));       // lane 0 is always a run start
-      const bool ustart = valid && (((tid - rs) & 7) == 0);
+      const bool ustart = valid && (((tid - rs) & (UNIT - 1)) == 0);
       const unsigned long long umask = __ballot(ustart);
       if (ustart) aux.ustart[__popcll(umask & ((1ull << tid) - 1ull))] = tid;
       if (tid == 0) {
@@ -1232,6 +1256,7 @@ __device__ __forceinline__ void stage_edge_attr(const ddp_conv_shape_t& S, const
           if constexpr (NS1 > 0) {
             h4 hi, lo;
             split_h2(v, hi, lo);
+            for (int i4 = 0; i4 < 4; ++i4) h2_range_check(v[i4], T.h2_range_flag);
             *reinterpret_cast<h4*>(&xp0[e * XS2 + col0 + 4 * c4]) = hi;
             *reinterpret_cast<h4*>(&xp1[e * XS2 + col0 + 4 * c4]) = lo;
           } else {
@@ -1244,6 +1269,7 @@ __device__ __forceinline__ void stage_edge_attr(const ddp_conv_shape_t& S, const
           const float v = ptr[(size_t)aux.segi[sg][e] * ld + c];
           if constexpr (NS1 > 0) {
             const _Float16 hi = (_Float16)v;
+            h2_range_check(v, T.h2_range_flag);
             xp0[e * XS2 + col0 + c] = hi;
             xp1[e * XS2 + col0 + c] = (_Float16)((v - (float)hi) * DDP_H2_SCALE);
           } else {
@@ -1500,9 +1526,11 @@ __global__ __launch_bounds__(256, DDP_C32_WPE) void ddp_conv32_kernel(const Conv
       }
     gmap[slot][c] = gm;
   }
+  // units of the G pass: runs of <= GUNIT edges of one source node (h2 kernels of the unrolled size classes: 16)
+  constexpr int GUNIT = (H2 && SZ != 0) ? DDP_G_UNIT : 8;
   if constexpr (H2) {
     constexpr int NS = H2Class<SZ>::NS;
-    stage_edge_attr<ET, NS>(S, T, aux, rb, p0, nvalid, tid);
+    stage_edge_attr<ET, NS, GUNIT>(S, T, aux, rb, p0, nvalid, tid);
     STAMP(1);
     fc1_tiles_h2<ET, ET / 8, NS, NS>(S, T, reinterpret_cast<const _Float16*>(rb), ET * (16 * NS + 8), reinterpret_cast<_Float16*>(hbuf),
                                      ET * (16 * NS + 8), tid);
@@ -1613,7 +1641,7 @@ __global__ __launch_bounds__(256, DDP_C32_WPE) void ddp_conv32_kernel(const Conv
   // ---- phase 5: factorised features (one pass per G slot)
   __builtin_amdgcn_s_setprio(DDP_GPRIO);
   for (int slot = 0; slot < 2; ++slot)
-    if (S.g_cols[slot] > 0) g_stage<SZ, ET>(S, slot, T, hbuf, rb, os, gmap[slot], aux, wave, lane);
+    if (S.g_cols[slot] > 0) g_stage<SZ, ET, GUNIT>(S, slot, T, hbuf, rb, os, gmap[slot], aux, wave, lane);
   __builtin_amdgcn_s_setprio(0);
   STAMP(7);
   __syncthreads();

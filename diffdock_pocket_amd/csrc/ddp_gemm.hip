@@ -14,6 +14,7 @@
 //    three terms.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include <stdlib.h>
 
 #include "ddp_hip.h"
@@ -445,9 +446,179 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_x3_kernel(con
   }
 }
 
-extern "C" int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows,
-                           const int32_t* offs, int nbatch, const float* w, const void* w_bf16x3, int k, int ncols, float* out, int ldo,
-                           void* stream) {
+// ---- fp16 hi/lo split form ("h2", round 4): the same product on v_mfma_f32_32x32x16_f16 with BOTH operands split into two
+// halves, v = hi + lo / 2048 (hi = fp16(v), lo = fp16((v - hi) * 2048): 22 significant bits), three products per 16 k -
+//   x w ~ xh wh + (xh wl + xl wh) / 2048                      dropped: xl wl / 2^22
+// - accumulated in fp32 in two registers sets (main, correction), exactly as the conv kernels do (csrc/ddp_conv.hip, h2 form:
+// the fp32 chain's error class: <= 2^-20 sum|x w| over the test products, tools/micro/f16x2_mfma.hip).  12 MFMAs of 32 cycles per 32 x 32 block at K = 60
+// instead of 30 of 64: the matrix side shrinks 5 x and the kernel is left with its stores.  Deterministic, row results do not
+// depend on the tile a row sits in.  Weights arrive pre-split from the host (packing.split_h2): [batch][plane][k/16][k/8 % 2][col][8].
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#ifndef DDP_SAH_CT
+#define DDP_SAH_CT 4   // column tiles per wave: 2 planes x 4 k-steps x 4 registers each = 32 weight registers per tile
+#endif
+
+template <int KT>
+__global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(const float* __restrict__ x, int ldx, int nrows,
+                                                                              const int32_t* __restrict__ rows,
+                                                                              const int32_t* __restrict__ nrows_dev, int out_rows,
+                                                                              int mrows, const GemmOffs offs,
+                                                                              const _Float16* __restrict__ wh, int ncols,
+                                                                              float* __restrict__ out, int ldo, int32_t* range_flag) {
+  if (nrows_dev) nrows = min(nrows, *nrows_dev);
+  if ((int)blockIdx.y * mrows >= nrows) return;
+  constexpr int KP = (KT + 15) / 16 * 16, NS = KP / 16, CT = DDP_SAH_CT;
+  constexpr int XS = KP + 8;                                   // halves per LDS row of an x plane (16-byte aligned rows)
+  constexpr int NV = (32 * KT / 4 + DDP_GEMM_THREADS - 1) / DDP_GEMM_THREADS;
+  constexpr int TS = 36;
+  __shared__ __attribute__((aligned(16))) _Float16 xt[2][2][32 * XS];
+  __shared__ __attribute__((aligned(16))) float st[4][2][32 * TS];
+  const int z = (int)blockIdx.z, tid = (int)threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int col0 = ((int)blockIdx.x * 4 + wave) * (32 * CT);
+  h8 wr[CT][2][NS];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) {
+    const int c = min(col0 + 32 * t + r, ncols - 1);
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2)
+        wr[t][p][s2] = *reinterpret_cast<const h8*>(wh + (((((size_t)z * 2 + p) * NS + s2) * 2 + hh) * ncols + c) * 8);
+  }
+  // the k padding [KT, KP) of both x buffers is zero for good
+  if constexpr (KP > KT) {
+    for (int i = tid; i < 2 * 2 * 32 * (KP - KT); i += DDP_GEMM_THREADS) {
+      const int kk = i % (KP - KT), rr = (i / (KP - KT)) % 32, bp = i / ((KP - KT) * 32);
+      xt[bp / 2][bp % 2][rr * XS + KT + kk] = (_Float16)0.f;
+    }
+  }
+  const float* __restrict__ xb = x + offs.off[z];
+  float* __restrict__ ob = out + (size_t)z * out_rows * ldo;   // the batch slice; row indices below are absolute
+  // Column quad of this lane inside a 32-column block, CLAMPED to the block's last valid quad (ncols % 4 == 0): a lane beyond the
+  // array's last column re-stores its neighbour's quad (same address, same data) instead of sitting under a branch.  Blocks that
+  // start beyond ncols are skipped as a whole (wave-uniform).
+  int cq[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) cq[t] = max(0, min(4 * (lane & 7), ncols - 4 - (col0 + 32 * t)));
+  for (int R0 = (int)blockIdx.y * mrows; R0 < nrows; R0 += (int)gridDim.y * mrows) {
+  const int R1 = min(nrows, R0 + mrows);
+  const bool al4 = ((ldx | offs.off[z]) & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0;
+  f32x4 xv[NV];
+  auto fetch = [&](int row0) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int i = tid + v * DDP_GEMM_THREADS;
+      const int rr = min(i / (KT / 4), 31), q = i % (KT / 4);
+      const int ri = min(row0 + rr, nrows - 1);
+      const float* __restrict__ p = xb + (size_t)(rows ? rows[ri] : ri) * ldx + 4 * q;
+      if (al4)
+        xv[v] = *reinterpret_cast<const f32x4*>(p);
+      else
+        xv[v] = f32x4{p[0], p[1], p[2], p[3]};
+    }
+  };
+  auto park = [&](int buf) {   // split into the two fp16 planes on the way into LDS (once per workgroup, not per wave)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int i = tid + v * DDP_GEMM_THREADS;
+      if (i < 32 * (KT / 4)) {
+        const int rr = i / (KT / 4), q = i % (KT / 4);
+        h4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float f = xv[v][e];
+          if (!(fabsf(f) <= 65504.f) && range_flag) *range_flag = 1;     // outside the fp16 range (or NaN): reported, not saturated
+          h[e] = (_Float16)f;
+          l[e] = (_Float16)((f - (float)h[e]) * 2048.f);
+        }
+        *reinterpret_cast<h4*>(&xt[buf][0][rr * XS + 4 * q]) = h;
+        *reinterpret_cast<h4*>(&xt[buf][1][rr * XS + 4 * q]) = l;
+      }
+    }
+  };
+  // The pending block of this wave: parked in LDS, written out quarter by quarter between the MFMAs of the NEXT block, WITHOUT a
+  // condition in the loop - rows and columns beyond the array are clamped onto valid ones (duplicate stores of identical data), and
+  // the wave's very first block, which has no predecessor, is peeled (DRAIN = false).  (Under `if (pending)` / `if (row < rows)`
+  // hipcc's waitcnt insertion drained the store queue at the branch joins.)
+  size_t pend_off[4] = {0, 0, 0, 0};    // element offset of this lane's 16-byte piece of quarter p of the pending block
+  int pend_lds[4] = {0, 0, 0, 0};       // ... and where it sits in the parked tile
+  int pbuf = 0;
+  f32x4 dv = {0.f, 0.f, 0.f, 0.f};
+  auto block = [&](auto drain_tag, int t, const h8 (&a)[2][NS], const int (&blk_ri)[4], int nr) {
+    constexpr bool DRAIN = decltype(drain_tag)::value;
+    f32x16 am, ac;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { am[i] = 0.f; ac[i] = 0.f; }
+    const float* pt = st[wave][pbuf ^ 1];     // the pending block's tile
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+      if constexpr (DRAIN && NS == 4) dv = *reinterpret_cast<const f32x4*>(&pt[pend_lds[s2]]);
+      am = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][s2], wr[t][0][s2], am, 0, 0, 0);
+      ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][s2], wr[t][1][s2], ac, 0, 0, 0);
+      ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][s2], wr[t][0][s2], ac, 0, 0, 0);
+      if constexpr (DRAIN && NS == 4) *reinterpret_cast<f32x4*>(&ob[pend_off[s2]]) = dv;
+    }
+    if constexpr (DRAIN && NS != 4) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(&ob[pend_off[p]]) = *reinterpret_cast<const f32x4*>(&pt[pend_lds[p]]);
+    }
+    float* tl = st[wave][pbuf];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tl[((i & 3) + 8 * (i >> 2) + 4 * hh) * TS + r] = am[i] + ac[i] * (1.f / 2048.f);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int rr = min(8 * p + (lane >> 3), nr - 1);        // clamped row of the tile (blk_ri is clamped the same way)
+      pend_lds[p] = rr * TS + cq[t];
+      pend_off[p] = (size_t)blk_ri[p] * ldo + (col0 + 32 * t + cq[t]);
+    }
+    pbuf ^= 1;
+  };
+  fetch(R0);
+  park(0);
+  __syncthreads();
+  int buf = 0;
+  bool first = true;
+  for (int row0 = R0; row0 < R1; row0 += 32, buf ^= 1) {
+    const bool more = row0 + 32 < R1;
+    if (more) fetch(row0 + 32);
+    h8 a[2][NS];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) a[p][s2] = *reinterpret_cast<const h8*>(&xt[buf][p][r * XS + 16 * s2 + 8 * hh]);
+    int blk_ri[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ri = min(row0 + 8 * p + (lane >> 3), R1 - 1);
+      blk_ri[p] = rows ? rows[ri] : ri;
+    }
+    const int nr = R1 - row0;
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      if (col0 + 32 * t >= ncols) continue;           // (wave-uniform: a column block beyond the array)
+      if (t == 0 && first)
+        block(std::false_type{}, t, a, blk_ri, nr);
+      else
+        block(std::true_type{}, t, a, blk_ri, nr);
+      first = false;
+    }
+    if (more) park(buf ^ 1);
+    __syncthreads();
+  }
+  if (!first) {   // the last block
+    const float* pt = st[wave][pbuf ^ 1];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(&ob[pend_off[p]]) = *reinterpret_cast<const f32x4*>(&pt[pend_lds[p]]);
+  }
+  __syncthreads();
+  }
+}
+
+static int stage_a_impl(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows,
+                        const int32_t* offs, int nbatch, const float* w, const void* w_bf16x3, const void* w_h2, int k, int ncols, float* out,
+                        int ldo, int32_t* range_flag, void* stream) {
   if (!rows) out_rows = nrows;                       // dense: out[b] has one row per x row
   if (out_rows < 1 && nrows > 0) return ddp_fail(DDP_EINVAL, "ddp_stage_a: out_rows");
   if (nbatch < 0 || nbatch > DDP_MAX_GEMM_BATCH) return ddp_fail(DDP_ELIMIT, "ddp_stage_a: nbatch > DDP_MAX_GEMM_BATCH");
@@ -475,6 +646,23 @@ extern "C" int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* ro
   int gy = (nrows + mrows - 1) / mrows;
   if (listed && gy > 96) gy = 96;
   static const bool no_mfma = getenv("DDP_STAGE_A_VALU") != nullptr;   // diagnostic: force the VALU form
+  // h2 form (fp16 hi/lo split of both operands): wide, 16-byte aligned outputs only, K = 60 / 32 / 24 / 16 (KP = 64 / 32 / 32 / 16)
+  if (w_h2 && wide && (k == 60 || k == 32 || k == 24 || k == 16) && !no_mfma && (reinterpret_cast<size_t>(w_h2) & 15) == 0) {
+    const dim3 grid((ncols + 128 * DDP_SAH_CT - 1) / (128 * DDP_SAH_CT), gy, nbatch);
+#define DDP_GEMM_H2(KT)                                                                                          \
+    hipLaunchKernelGGL((ddp_stage_a_h2_kernel<KT>), grid, dim3(DDP_GEMM_THREADS), 0, s, x, ldx, nrows, rows, nrows_dev, out_rows, mrows, O, \
+                       reinterpret_cast<const _Float16*>(w_h2), ncols, out, ldo, range_flag)
+    switch (k) {
+      case 60: DDP_GEMM_H2(60); break;
+      case 32: DDP_GEMM_H2(32); break;
+      case 24: DDP_GEMM_H2(24); break;
+      default: DDP_GEMM_H2(16); break;
+    }
+#undef DDP_GEMM_H2
+    const hipError_t eh = hipGetLastError();
+    if (eh != hipSuccess) return ddp_fail_hip(eh, "ddp_stage_a (h2) launch");
+    return 0;
+  }
   // bf16x3 form: wide, 16-byte aligned outputs only (its blocks always leave through the LDS transpose)
   if (w_bf16x3 && wide && (k == 60 || k == 32) && !no_mfma && (reinterpret_cast<size_t>(w_bf16x3) & 15) == 0) {
     const dim3 grid((ncols + 128 * DDP_SA3_CT - 1) / (128 * DDP_SA3_CT), gy, nbatch);
@@ -509,4 +697,19 @@ extern "C" int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* ro
   const hipError_t err = hipGetLastError();
   if (err != hipSuccess) return ddp_fail_hip(err, "ddp_stage_a launch");
   return 0;
+}
+
+extern "C" int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows,
+                           const int32_t* offs, int nbatch, const float* w, const void* w_bf16x3, int k, int ncols, float* out, int ldo,
+                           void* stream) {
+  return stage_a_impl(x, ldx, nrows, rows, nrows_dev, out_rows, offs, nbatch, w, w_bf16x3, nullptr, k, ncols, out, ldo, nullptr, stream);
+}
+
+// ddp_stage_a with the weights ALSO given as fp16 hi/lo planes (packing.split_h2): the product then runs on the fp16 matrix cores
+// with both operands split (x in the kernel), when the shape allows it (wide 16-byte aligned outputs, K in {60, 32, 24, 16}); other
+// shapes fall back to the exact fp32 forms on `w`.
+extern "C" int ddp_stage_a_h2(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows,
+                              const int32_t* offs, int nbatch, const float* w, const void* w_h2, int k, int ncols, float* out, int ldo,
+                              int32_t* range_flag, void* stream) {
+  return stage_a_impl(x, ldx, nrows, rows, nrows_dev, out_rows, offs, nbatch, w, nullptr, w_h2, k, ncols, out, ldo, range_flag, stream);
 }

@@ -176,6 +176,44 @@ __global__ __launch_bounds__(256) void ddp_knn_kernel(const float* __restrict__ 
   const int none = 0x7fffffff;
   float pd = -1.f;   // previous selection (squared distances are >= 0)
   int pj = -1;
+  // graphs of up to 64 * CAP points (the 1111-atom pocket of 3dpf: 18 per lane): a lane's distances are evaluated ONCE and kept in
+  // registers; the k selection rounds then only compare (same comparisons, same result as the loop below)
+  constexpr int CAP = 24;
+  if (j1 - j0 <= 64 * CAP) {
+    float dl[CAP];
+#pragma unroll
+    for (int c = 0; c < CAP; ++c) {
+      const int j = j0 + lane + 64 * c;
+      float d = __builtin_inff();
+      if (j < j1 && j != q) d = sqdist(yq, x + 3 * (size_t)j);
+      dl[c] = (d < __builtin_inff()) ? d : __builtin_inff();        // NaN or inf: never selected
+    }
+    for (int t = 0; t < k; ++t) {
+      float bd = __builtin_inff();
+      int bj = none;
+#pragma unroll
+      for (int c = 0; c < CAP; ++c) {
+        const int j = j0 + lane + 64 * c;
+        const float d = dl[c];
+        const bool after = (d > pd) || (d == pd && j > pj);
+        if (d < __builtin_inff() && after && (d < bd || (d == bd && j < bj))) { bd = d; bj = j; }
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const float od = __shfl_xor(bd, off);
+        const int oj = __shfl_xor(bj, off);
+        if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
+      }
+      if (bj == none) {                                              // fewer than k candidates: pad the rest
+        for (int u = t + lane; u < k; u += 64) out_nb[(size_t)q * k + u] = -1;
+        return;
+      }
+      if (lane == 0) out_nb[(size_t)q * k + t] = bj;
+      pd = bd;
+      pj = bj;
+    }
+    return;
+  }
   for (int t = 0; t < k; ++t) {
     float bd = __builtin_inff();
     int bj = none;

@@ -3,6 +3,7 @@
 //   ddp_edge_featurize   edge vector -> RBF -> 2-layer MLP, spherical harmonics (lmax = 1)
 //   ddp_torsion_sh       closed-form 1o block of FullTensorProduct(sh, Y2(bond))
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "ddp_hip.h"
@@ -75,6 +76,64 @@ __global__ void ddp_segment_reduce_kernel(float* __restrict__ x, int ldx, int n_
   }
 }
 
+// The same reduction with four channels per thread (16-byte loads and stores): thread -> (node, channel quad), consecutive lanes
+// read consecutive quads of a message row.  Every element sees exactly the operations of the kernel above, in the same order
+// (bitwise the same result); four times the bytes per load instruction in flight.  Needs d_out, ldx multiples of 4 and 16-byte
+// aligned arrays.
+typedef float red4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void ddp_segment_reduce4_kernel(float* __restrict__ x, int ldx, int n_nodes, int d_out, ReduceLaunch L,
+                                                                  int accumulate, int n_rep, int rep_stride) {
+  const int nq = d_out >> 2;
+  const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int node = (int)(item / nq), ch = 4 * (int)(item - (long long)node * nq);
+  if (node >= n_nodes) return;
+  float* dst = x + (size_t)node * ldx + ch;
+  red4 total = (accumulate && n_rep <= 1) ? *reinterpret_cast<const red4*>(dst) : red4{0.f, 0.f, 0.f, 0.f};
+  int p0[3], p1[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const bool on = k < L.nsrc;
+    p0[k] = on ? L.src[k].rowptr[node] : 0;
+    p1[k] = on ? L.src[k].rowptr[node + 1] : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (k < L.nsrc && !(L.src[k].n_edges_dev && *L.src[k].n_edges_dev <= 0)) {
+      const ddp_reduce_src_t& s = L.src[k];
+      const float* __restrict__ m = s.msg + ch;
+      const int32_t* __restrict__ rm = s.rowmap;
+      red4 sum = {0.f, 0.f, 0.f, 0.f};
+      for (int p = p0[k]; p < p1[k]; p += 8) {
+        red4 v[8];
+        int row[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int q = min(p + i, p1[k] - 1);
+          row[i] = rm ? rm[q] : q;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const red4*>(m + (size_t)row[i] * d_out);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (p + i < p1[k]) sum += v[i];
+      }
+      const int cnt = p1[k] - p0[k];
+      const float den = (float)(cnt > 1 ? cnt : 1);
+      const red4 sc = *reinterpret_cast<const red4*>(s.bn_scale + ch), sh = *reinterpret_cast<const red4*>(s.bn_shift + ch);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) total[c] += (sum[c] / den) * sc[c] + sh[c];
+    }
+  }
+  if (n_rep <= 1) {
+    *reinterpret_cast<red4*>(dst) = total;
+  } else {
+    for (int g = 0; g < n_rep; ++g) {
+      red4* d = reinterpret_cast<red4*>(dst + (size_t)g * rep_stride * ldx);
+      *d = *d + total;
+    }
+  }
+}
+
 extern "C" int ddp_segment_reduce(float* x, int ldx, int n_nodes, int d_out, const ddp_reduce_src_t* srcs, int nsrc,
                                   int accumulate, int n_rep, int rep_stride, void* stream) {
   if (!x || (!srcs && nsrc > 0)) return ddp_fail(DDP_EINVAL, "ddp_segment_reduce: null argument");
@@ -87,9 +146,19 @@ extern "C" int ddp_segment_reduce(float* x, int ldx, int n_nodes, int d_out, con
     if (srcs[i].n_edges > 0) L.src[L.nsrc++] = srcs[i];  // an empty conv contributes exactly 0 (score_model.py:109-111)
   if (L.nsrc == 0 && (accumulate || n_rep > 1)) return 0;
   if (n_rep > 1 && rep_stride < n_nodes) return ddp_fail(DDP_EINVAL, "ddp_segment_reduce: rep_stride < n_nodes");
-  const int threads = ((d_out + 63) / 64) * 64;
-  hipLaunchKernelGGL(ddp_segment_reduce_kernel, dim3(n_nodes), dim3(threads), 0, (hipStream_t)stream, x, ldx, n_nodes,
-                     d_out, L, accumulate, n_rep, rep_stride);
+  bool wide = ((d_out | ldx) & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0;
+  for (int i = 0; i < L.nsrc; ++i)
+    wide = wide && ((reinterpret_cast<size_t>(L.src[i].msg) | reinterpret_cast<size_t>(L.src[i].bn_scale) | reinterpret_cast<size_t>(L.src[i].bn_shift)) & 15) == 0;
+  static const bool narrow_only = getenv("DDP_REDUCE_NARROW") != nullptr;   // diagnostic: the one-channel-per-thread form
+  if (wide && !narrow_only) {
+    const long long items = (long long)n_nodes * (d_out >> 2);
+    hipLaunchKernelGGL(ddp_segment_reduce4_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, n_nodes,
+                       d_out, L, accumulate, n_rep, rep_stride);
+  } else {
+    const int threads = ((d_out + 63) / 64) * 64;
+    hipLaunchKernelGGL(ddp_segment_reduce_kernel, dim3(n_nodes), dim3(threads), 0, (hipStream_t)stream, x, ldx, n_nodes,
+                       d_out, L, accumulate, n_rep, rep_stride);
+  }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return ddp_fail_hip(err, "ddp_segment_reduce launch");
   return 0;

@@ -131,6 +131,7 @@ class ForwardEngine:
         dev = lig.pos.device
         m._refresh_weight_caches()
         m.check_overflow()
+        K.set_range_flag(m.overflow_flag(dev)[1:2])     # where this forward's h2 kernels report values outside the fp16 range
         mark = m.section_timer.mark if m.section_timer is not None else (lambda name: None)
         mark("start")
         if m.no_aminoacid_identities:
@@ -712,11 +713,14 @@ class ForwardEngine:
                         meta.append((k, slot, pk.g_in_off[slot]))
             Wst = torch.stack(Ws).contiguous()
             # (the bf16x3 split of the weights - 1.5 x their size and three copy kernels - only when that option is on)
-            ent = (Wst, meta, (C.c_int32 * len(meta))(*[mm[2] for mm in meta]), P.split_bf16x3(Wst) if m.stage_a_bf16x3 else None)
+            ent = (Wst, meta, (C.c_int32 * len(meta))(*[mm[2] for mm in meta]), P.split_bf16x3(Wst) if m.stage_a_bf16x3 else None,
+                   P.split_h2(Wst) if m.stage_a_h2 else None)
             m._stage_a_stacks[key] = ent
         if m.stage_a_bf16x3 and ent[3] is None:
-            ent = m._stage_a_stacks[key] = ent[:3] + (P.split_bf16x3(ent[0]),)
-        Wst, meta, offs, W3 = ent
+            ent = m._stage_a_stacks[key] = ent[:3] + (P.split_bf16x3(ent[0]), ent[4])
+        if m.stage_a_h2 and ent[4] is None:
+            ent = m._stage_a_stacks[key] = ent[:4] + (P.split_h2(ent[0]),)
+        Wst, meta, offs, W3, Wh = ent
         nb = len(meta)
         if nb > L.DDP_MAX_GEMM_BATCH:
             raise L.DdpError("more (conv, slot) pairs per source array than DDP_MAX_GEMM_BATCH")
@@ -726,7 +730,8 @@ class ForwardEngine:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         n_list = n_rows if rows is None else int(rows.shape[0])
-        K.stage_a(x, n_list, offs, nb, Wst, Gall, rows=rows, rows_cnt=rows_cnt, out_rows=n_rows, W3=W3 if m.stage_a_bf16x3 else None)
+        K.stage_a(x, n_list, offs, nb, Wst, Gall, rows=rows, rows_cnt=rows_cnt, out_rows=n_rows, W3=W3 if m.stage_a_bf16x3 else None,
+                  Wh=Wh if (m.stage_a_h2 and K.CONV_H2 and not m.stage_a_bf16x3) else None)
         if prof is not None:
             e1.record()
             # algorithmic bytes: the G rows written once + the scalar columns of x read once per product + the weights
@@ -735,7 +740,8 @@ class ForwardEngine:
             def nbytes(n_list=n_list, rows_cnt=rows_cnt, row_bytes=row_bytes, wn=Wst.numel()):
                 n = n_list if rows_cnt is None else min(n_list, int(rows_cnt.item()))
                 return row_bytes * n + 4.0 * wn
-            prof.hbm.setdefault("ddp_stage_a_mfma_kernel", []).append((e0, e1, nbytes))
+            use_h2 = m.stage_a_h2 and K.CONV_H2 and not m.stage_a_bf16x3
+            prof.hbm.setdefault("ddp_stage_a_h2_kernel" if use_h2 else "ddp_stage_a_mfma_kernel", []).append((e0, e1, nbytes))
         return {(k, slot): Gall[i] for i, (k, slot, _) in enumerate(meta)}
 
     def _layers(self, S, F, dev, mark):
@@ -766,7 +772,9 @@ class ForwardEngine:
         # small batches: independent launches of a layer side by side (see _Fork); decided by the batch's size, not its content
         plain = m.before_layers is not None
         fork = self._fork(dev) if (m.concurrent_small_batches and Na <= m.concurrent_max_atoms and not plain) else None
-        pipelined = (fork is None and m.overlap_direct_conv and not plain and dbg is None and m.section_timer is None and L_ >= 2)
+        # (the pipelined order relies on the direct convs feeding the RECEPTOR mean only: every other conv must be factorised)
+        pipelined = (fork is None and m.overlap_direct_conv and not plain and dbg is None and m.section_timer is None and L_ >= 2
+                     and F.fact == {0, 1, 2, 3, 4, 5, 6, 7})
         side = self._fork(dev) if pipelined else None
 
         def plan(l):
@@ -868,11 +876,13 @@ class ForwardEngine:
         def launch_direct(P):
             K.launch_convs(P.spec, P.tasks, node_bytes=P.nb_d, tag=f"layer{P.l}")
 
-        def launch_factorised(P):
+        def launch_factorised(P, which="lar"):
+            """The 32-edge conv launch of the factorised convs whose SOURCE-node type is in `which` (all of them in one launch by
+            default; the two-chain order launches the atom-source convs and the others separately)."""
             l, spec, c1 = P.l, P.spec, P.c1
             tasks_g, nb_g = [], 0.0
             for k, (csr, so_k, x_src) in P.per.items():
-                if k in P.msgs:
+                if k in P.msgs or SRC_TYPE[k] not in which:
                     continue
                 x_recv, _, ek = arr[k]
                 conv = m.conv_layers[9 * l + k]
@@ -900,7 +910,7 @@ class ForwardEngine:
                     nb_g += node_bytes(l, k)
                 segs = [(e_base, so_k.eid, ns, ns), (x_recv, so_k.recv, ldx, ns), (x_src, so_k.src, ldx, ns)]
                 tasks_g.append(K.make_task(conv.packed_g(dev), x_src, ldx, so_k, sh_k, segs, msg, g=[P.gmap.get((k, s_)) for s_ in (0, 1)]))
-            P.tasks_g = tasks_g
+            P.tasks_g = getattr(P, "tasks_g", []) + tasks_g
             K.launch_convs(P.spec_g, tasks_g, flops_spec=spec, node_bytes=nb_g, tag=f"layer{l}")
 
         def fix_rowmaps(P):
@@ -926,7 +936,37 @@ class ForwardEngine:
                     n0 = shared[[k for k in ORDER[rt] if k in shared][0]][0]
                     K.launch_reduce(x, ldx, n0, spec.d_out, com, accumulate=True, n_rep=B, rep_stride=n0)
 
+        if pipelined and m.layer_order == "chains":
+            # Two chains per layer on forked streams (parallel branches of the captured step):
+            #   A: stage A of the atom-source rows (the big product, bound by the HBM write of G) -> 32-edge convs with atom sources
+            #   B: stage A of the ligand- / receptor-source rows -> 32-edge convs with those sources -> the direct conv
+            # then the segmented means.  The store-bound product of one chain runs beside the latency-bound conv kernel of the other.
+            for l in range(L_):
+                P = plan(l)
+                direct_tasks(P)        # (first: marks the direct convs, launch_factorised skips them)
+                has_direct = bool(P.tasks)
+
+                def chain_a(P=P):
+                    stage_a(P, "a")
+                    launch_factorised(P, "a")
+
+                def chain_b(P=P, has_direct=has_direct):
+                    stage_a(P, "lr")
+                    launch_factorised(P, "lr")
+                    if has_direct:
+                        launch_direct(P)
+
+                side.run(0, chain_b)
+                chain_a()
+                side.join()
+                fix_rowmaps(P)
+                means(P, "lar")
+                F.keep.append((P.keep, P.per, P.msgs, P.tasks, P.tasks_g, P.gmap))
+            mark("reduce")
+            return
+
         if pipelined:
+            late_side = m.layer_order == "pipeline2"
             P = plan(0)
             stage_a(P, "lar")
             for l in range(L_):
@@ -936,7 +976,14 @@ class ForwardEngine:
                 xa_old = torch.empty_like(xa) if (P.active["a"] and 8 in P.per) else None
                 direct_tasks(P, x_atom_src=xa_old)
                 has_direct = bool(P.tasks)
-                launch_factorised(P)
+                if late_side and l > 0:
+                    # "pipeline2": stage A of the receptor-source rows of THIS layer is still running on a side stream (queued
+                    # behind the receptor mean of layer l - 1); the convs with atom / ligand sources go first, beside it
+                    launch_factorised(P, "la")
+                    side.join(only=1)
+                    launch_factorised(P, "r")
+                else:
+                    launch_factorised(P)
                 fix_rowmaps(P)
                 if has_direct and xa_old is not None:
                     xa_old.copy_(xa)
@@ -950,7 +997,10 @@ class ForwardEngine:
                     side.join()
                 means(P, "r")
                 if nxt is not None:
-                    stage_a(nxt, "r")
+                    if late_side:
+                        side.run(1, lambda nxt=nxt: stage_a(nxt, "r"))
+                    else:
+                        stage_a(nxt, "r")
                 F.keep.append((P.keep, P.per, P.msgs, P.tasks, P.tasks_g, P.gmap, getattr(P, "xa_old", None)))
                 P = nxt
             mark("reduce")

@@ -162,7 +162,7 @@ def _run_csv(csv_path, model, device, confidence_model, samples_per_complex, inf
         # Sampling can fail on ONE rank only (each rank holds other poses: a truncated ligand<-atom list - DdpError after the run's
         # final synchronisation -, DDP_ELIMIT, out of memory): like the reference (inference.py:282-287) the complex is then
         # skipped - on EVERY rank, agreed before anyone enters the gathers below
-        lig = conf = None
+        lig = conf = smp = None
         try:
             smp = Sampler(model, g, n, device, cfg, seed=seed + i, sample_slice=sl)
             smp.randomize()
@@ -173,6 +173,11 @@ def _run_csv(csv_path, model, device, confidence_model, samples_per_complex, inf
         except Exception as e:      # noqa: BLE001
             res.skipped = f"{type(e).__name__}: {e}"
             lig = None
+        finally:
+            if smp is not None and hasattr(smp, "close"):
+                if lig is not None:
+                    lig = lig.clone()       # (the poses live in the sampler's buffers)
+                smp.close()                 # the captured step's memory goes back to the shared pool before the next complex
         if split and not _all_ok(dist, lig is not None, device):
             res.skipped = res.skipped or "skipped: sampling failed on another rank"
             continue

@@ -75,17 +75,18 @@ class ConvProfiler:
     that live in device memory are resolved when a summary is asked for (after the timed region)."""
 
     def __init__(self):
-        self.events, self.kernel, self.specs, self.counts, self.node_bytes, self.tags = [], [], [], [], [], []
+        self.events, self.kernel, self.specs, self.counts, self.node_bytes, self.tags, self.h2 = [], [], [], [], [], [], []
         self.hbm = {}   # HBM-bound kernels: name -> [(event0, event1, bytes or callable)]
         self.hbm_on = False   # their ~45 extra event pairs per step cost wall time: bench.py times them in extra steps
         self._resolved = None
 
     # -- recording (called by the launch wrappers) -------------------------------------------------------------
-    def record_conv(self, e0, e1, spec, flops_spec, tasks_counts, node_bytes, tag=None):
+    def record_conv(self, e0, e1, spec, flops_spec, tasks_counts, node_bytes, tag=None, h2=False):
         """tasks_counts: [(capacity, cnt tensor or None)] of the launch's tasks; tag: where in the forward the launch sits
         ("layer3", "head")."""
         self.events.append((e0, e1))
         self.tags.append(tag)
+        self.h2.append(bool(h2))     # the launch ran the fp16 hi/lo split form of the fc products
         self.kernel.append("ddp_conv32_kernel" if spec.factorized else "ddp_conv_messages_kernel")
         self.specs.append((spec, flops_spec or spec))
         self.counts.append(tasks_counts)
@@ -110,6 +111,7 @@ class ConvProfiler:
             self.flops = [fs.flops_per_edge() * n for (s, fs), n in zip(self.specs, ne)]
             self.executed = [(s.mfma_flops_per_edge_executed() + 2 * s.hid * sum(s.g_cols)) * n for (s, fs), n in zip(self.specs, ne)]
             self.useful = [s.useful_flops_per_edge() * n for (s, fs), n in zip(self.specs, ne)]
+            self.fc = [s.fc_flops_per_edge() * n for (s, fs), n in zip(self.specs, ne)]
             self.boundary = [n * (4.0 * fs.f_in + 32.0) + nb for (s, fs), n, nb in zip(self.specs, ne, self.node_bytes)]
             self._resolved = True
 
@@ -128,15 +130,25 @@ class ConvProfiler:
         ms = sum(self.events[i][0].elapsed_time(self.events[i][1]) for i in sel)
         return len(sel), float(sum(self.flops[i] for i in sel)), float(ms)
 
+    def split_flops(self, kernel=None, tag=False):
+        """(fc-product FLOPs of the launches that ran the h2 form, all other useful FLOPs) of one kernel instantiation: the first run
+        on the fp16 matrix cores at three instruction FLOPs per product FLOP, the rest (fp32-MFMA launches, G pass, contraction) in
+        fp32."""
+        self._resolve()
+        fc16 = sum(f for f, k, h in zip(self.fc, self.kernel, self.h2) if h and (kernel is None or k == kernel))
+        useful = sum(u for u, k in zip(self.useful, self.kernel) if kernel is None or k == kernel)
+        return float(fc16), float(useful - fc16)
+
     def by_tag(self, kernel):
-        """{tag: (launches, useful FLOPs, ms, edges)} of one kernel instantiation, e.g. per conv layer."""
+        """{tag: (launches, useful FLOPs, ms, edges, fc FLOPs run in the h2 form)} of one kernel instantiation, e.g. per conv layer."""
         self._resolve()
         out = {}
         for i, k in enumerate(self.kernel):
             if k != kernel:
                 continue
-            n, u, ms, ne = out.get(self.tags[i], (0, 0.0, 0.0, 0))
-            out[self.tags[i]] = (n + 1, u + self.useful[i], ms + self.events[i][0].elapsed_time(self.events[i][1]), ne + self.edges[i])
+            n, u, ms, ne, f16 = out.get(self.tags[i], (0, 0.0, 0.0, 0, 0.0))
+            out[self.tags[i]] = (n + 1, u + self.useful[i], ms + self.events[i][0].elapsed_time(self.events[i][1]), ne + self.edges[i],
+                                 f16 + (self.fc[i] if self.h2[i] else 0.0))
         return out
 
     def executed_flops(self, kernel=None):
@@ -199,6 +211,14 @@ class SectionTimer:
 # The fc products of the conv kernels on the fp16 matrix cores with both operands split in two halves (three products per 16 k,
 # fp32 accumulation; csrc/ddp_conv.hip).  False: the exact fp32 MFMA chains of rounds 1 - 3 (A/B runs, the h2-vs-fp32 tests).
 CONV_H2 = True
+# where the h2 kernels report a value outside the fp16 range: an int32 in pinned host memory (score_model.overflow_flag(dev)[1:2]),
+# set by the forward that is being queued (engine.forward); None: not reported
+_RANGE_FLAG = None
+
+
+def set_range_flag(t):
+    global _RANGE_FLAG
+    _RANGE_FLAG = t
 
 
 def make_task(pk, x_src, ldx_src, view: EdgeView, sh, segs, msg, g=None) -> L.ConvTask:
@@ -216,6 +236,7 @@ def make_task(pk, x_src, ldx_src, view: EdgeView, sh, segs, msg, g=None) -> L.Co
     # fp16 hi/lo operand planes of the same weights (None / CONV_H2 off: the exact fp32 MFMA form)
     use_h2 = CONV_H2 and getattr(pk, "w1h", None) is not None and getattr(pk, "w2h", None) is not None
     t.w1h, t.w2h = (pk.w1h.data_ptr(), pk.w2h.data_ptr()) if use_h2 else (0, 0)
+    t.h2_range_flag = _p(_RANGE_FLAG) if use_h2 else 0
     t.msg = msg.data_ptr()
     for k in range(2):
         t.g[k] = g[k].data_ptr() if (g is not None and g[k] is not None) else 0
@@ -240,7 +261,8 @@ def launch_convs(spec: P.ConvSpec, tasks: List[L.ConvTask], flops_spec: Optional
     L.check(lib.ddp_conv_messages(C.byref(shape), arr, len(tasks), stream()), "ddp_conv_messages")
     if prof is not None:
         e1.record()
-        prof.record_conv(e0, e1, spec, flops_spec, [t._count for t in tasks], node_bytes, tag)
+        h2 = P.h2_steps(spec) > 0 and all(t.w1h and t.w2h for t in tasks)
+        prof.record_conv(e0, e1, spec, flops_spec, [t._count for t in tasks], node_bytes, tag, h2)
 
 
 def launch_reduce(x, ldx, n_nodes, d_out, sources, accumulate=True, n_rep=1, rep_stride=0):
@@ -343,12 +365,17 @@ def edge_featurize_jobs(calls):
     return outs
 
 
-def stage_a(x, n_rows, offs, nb, W, out, rows=None, rows_cnt=None, out_rows=None, W3=None):
+def stage_a(x, n_rows, offs, nb, W, out, rows=None, rows_cnt=None, out_rows=None, W3=None, Wh=None):
     """ddp_stage_a: out[b][row] = x[row, offs[b]:offs[b]+k] @ W[b] for the listed rows (all n_rows rows if rows is None).
-    W3: the weights pre-split for the bf16x3 form (packing.split_bf16x3), None: exact fp32 MFMA."""
+    Wh: the weights pre-split for the fp16 hi/lo form (packing.split_h2; ddp_stage_a_h2), W3: for the bf16x3 form
+    (packing.split_bf16x3); neither: exact fp32 MFMA."""
     lib = L.load()
     n_in, ncols = W.shape[1], W.shape[2]
     if n_rows == 0:
+        return
+    if Wh is not None:
+        L.check(lib.ddp_stage_a_h2(x.data_ptr(), x.stride(0), n_rows, ptr(rows), ptr(rows_cnt), out_rows if out_rows is not None else n_rows,
+                                   offs, nb, W.data_ptr(), ptr(Wh), n_in, ncols, out.data_ptr(), ncols, ptr(_RANGE_FLAG), stream()), "ddp_stage_a_h2")
         return
     L.check(lib.ddp_stage_a(x.data_ptr(), x.stride(0), n_rows, ptr(rows), ptr(rows_cnt), out_rows if out_rows is not None else n_rows,
                             offs, nb, W.data_ptr(), ptr(W3), n_in, ncols, out.data_ptr(), ncols, stream()), "ddp_stage_a")

@@ -10,6 +10,7 @@ models/layers.py:59 (or the e3nn path weight for the torsion heads, SURVEY Appen
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import List, Sequence, Tuple
 
@@ -131,6 +132,11 @@ class ConvSpec:
         """fp32 MFMA FLOPs per edge the tile loops issue (K and columns padded to the 32-column / 8-k tiles)."""
         return 2 * self.kp1 * self.nct1 * 32 + 2 * self.hp * self.ntiles * 32
 
+    def fc_flops_per_edge(self):
+        """The part of useful_flops_per_edge that is the two dense fc products (fc1 + the kept fc2 columns): what runs as fp16 hi/lo
+        split products (three matrix-core FLOPs per product FLOP) in the h2 form of the kernels."""
+        return 2 * self.f_in * self.hid + 2 * self.hid * sum(b.U * b.n for b in self.blocks)
+
     def useful_flops_per_edge(self):
         """USEFUL fp32 FLOPs per edge of the formulation the kernel executes, without any padding: fc1, the fc2 columns of
         the features that stay on the per-edge path (all of them on the direct path, the vector-input ones on the
@@ -157,7 +163,7 @@ def conv32_roles(blocks: Sequence["BlockSpec"]):
     3dpf launches (in-kernel stamps), and with equal tile counts the waves holding the vector blocks finished ~20 % late.
     Returns ([per wave: [(block index, first tile, tile stride, tile count, round)]], number of rounds)."""
     import itertools
-    COST = {1: 10, 3: 13}
+    COST = {1: 10, 3: int(os.environ.get("DDP_ROLE_COST3", "13"))}     # (diagnostic override: the vector tile's relative cost)
     items = []     # (block index, first tile, stride, count, C)
     for bi, b in enumerate(blocks):
         if b.ntiles == 0:
@@ -343,6 +349,20 @@ def split_bf16x3(W: torch.Tensor) -> torch.Tensor:
     lo = (r1 - mid.float()).to(torch.bfloat16)
     planes = torch.stack([hi, mid, lo], dim=1)                                  # [nb, 3, KP, ncols]
     return planes.reshape(nb, 3, KP // 16, 2, 8, ncols).permute(0, 1, 2, 3, 5, 4).contiguous()
+
+
+def split_h2(W: torch.Tensor) -> torch.Tensor:
+    """Stage-A weights [nb, K, ncols] fp32 as two fp16 planes w = hi + lo / 2048 (hi = fp16(w), lo = fp16((w - hi) * 2048)) in the
+    operand order of v_mfma_f32_32x32x16_f16: [nb][plane][k/16][k/8 % 2][ncols][8] (include/ddp_hip.h, ddp_stage_a_h2 `w_h2`), K
+    zero-padded to a multiple of 16."""
+    nb, K, ncols = W.shape
+    KP = (K + 15) // 16 * 16
+    Wf = torch.zeros((nb, KP, ncols), dtype=torch.float32, device=W.device)
+    Wf[:, :K] = W.float()
+    hi = Wf.to(torch.float16)
+    lo = ((Wf - hi.float()) * H2_SCALE).to(torch.float16)
+    planes = torch.stack([hi, lo], dim=1)                                       # [nb, 2, KP, ncols]
+    return planes.reshape(nb, 2, KP // 16, 2, 8, ncols).permute(0, 1, 2, 3, 5, 4).contiguous()
 
 
 def torsion_tp_spec(in_mul: Sequence[int], ns: int, n_edge_features: int) -> ConvSpec:

@@ -424,6 +424,10 @@ class TensorProductScoreModel(nn.Module):
         # Large batches (round 4): the direct conv of layer l (receptor<-atom) on a side stream beside stage A of layer l + 1 for the
         # atom- and ligand-source rows (engine._layers, "pipelined"); same kernels, same arguments, same bits as the serial order
         self.overlap_direct_conv = True
+        # which overlapped order: "pipeline" = direct conv(l) beside stage A(l + 1); "chains" = per layer two forked chains (atom-source
+        # stage A -> its convs | the other stage-A products -> their convs -> direct conv).  Same box, alternating, after the convs moved
+        # to the fp16 matrix cores: serial 20.48 - 20.51, chains 20.28 - 20.39, pipeline 20.22 - 20.25 ms per 40-sample step
+        self.layer_order = "pipeline"
         self.concurrent_heads = True   # the torsion read-outs on forked streams beside the tr / rot read-out (any batch size)
         # Option, OFF: stage A on the bf16 matrix cores with both operands split into three bfloat16 terms (csrc/ddp_gemm.hip,
         # ddp_stage_a_x3_kernel): fp32-class accuracy (error <= 2^-21 sum |x w|, measured against fp64 in
@@ -432,6 +436,9 @@ class TensorProductScoreModel(nn.Module):
         # follows every stage A runs 5 - 6 % slower (3.26 -> 3.45 ms per launch: the chip holds a lower clock after the bf16
         # bursts) and the step gets 1 ms LONGER (32.0 -> 33.0 ms); at 5 samples 5.48 -> 5.44 ms.  False = exact fp32 MFMA.
         self.stage_a_bf16x3 = False
+        # Stage A on the fp16 matrix cores with both operands split in two halves (hi + lo / 2048, three products per 16 k: the conv
+        # kernels' h2 form, csrc/ddp_gemm.hip ddp_stage_a_h2_kernel): 1/5 of the matrix time, 22-bit operands (error <= 2^-20 sum|x w|, the fp32 MFMA chain's class)
+        self.stage_a_h2 = True
         self._overflow_flag = None
         self.exact_sizes = False       # test mode: device-side list sizes are read back and every list is cut to its length
         self.debug_conv_outputs = None  # set to a dict: forward then stores the output [n_out, d_out] of every conv call in it
@@ -581,13 +588,18 @@ class TensorProductScoreModel(nn.Module):
 
     def overflow_flag(self, dev):
         """int32 [1] in pinned host memory (device-writable, host-readable without a synchronisation)."""
-        if self._overflow_flag is None:
-            self._overflow_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+        if self._overflow_flag is None:     # [0]: ligand<-atom list truncated, [1]: a value outside the fp16 range met the h2 kernels
+            self._overflow_flag = torch.zeros(2, dtype=torch.int32).pin_memory()
         return self._overflow_flag
 
     def check_overflow(self):
+        if self._overflow_flag is not None and int(self._overflow_flag[1]) != 0:
+            self._overflow_flag[1] = 0
+            raise L.DdpError("a node feature / edge feature / fc activation outside the fp16 range (|v| > 65504, or NaN) reached the fp16 "
+                             "hi/lo split kernels of an earlier forward: its scores are not to be trusted; run the exact fp32 MFMA form "
+                             "(diffdock_pocket_amd.launch.CONV_H2 = False)")
         if self._overflow_flag is not None and int(self._overflow_flag[0]) != 0:
-            self._overflow_flag.zero_()
+            self._overflow_flag[0] = 0
             raise L.DdpError(f"a ligand atom had more than la_capacity_per_atom = {self.la_capacity_per_atom} pocket atoms within "
                              f"lig_max_radius: the ligand<-atom edge list of an earlier forward was truncated; raise the capacity")
 

@@ -123,12 +123,16 @@ typedef struct {
                            capacity of the edge arrays and sizes the grid */
   /* Optional (ABI 12): fc.0 / fc.3 weights as fp16 hi/lo operand planes (packing.pack_tiles_h2; 16-byte aligned): when EVERY
    * task of a launch carries both and f_in = hid = 3 ns with ns in {60, 32, 24, 16}, the fc products run on
-   * v_mfma_f32_32x32x16_f16 with both operands split as v = hi + lo / 2048 (three products per 16 k, fp32 accumulation; error
-   * below the exact fp32 MFMA chain's, csrc/ddp_conv.hip).  Layout per 32-column tile: 2 * NS fragments of 1 KiB (NS = k16 steps,
+   * v_mfma_f32_32x32x16_f16 with both operands split as v = hi + lo / 2048 (three products per 16 k, fp32 accumulation: 22-bit
+   * operands, the fp32 MFMA chain's error class, csrc/ddp_conv.hip).  Layout per 32-column tile: 2 * NS fragments of 1 KiB (NS = k16 steps,
    * K zero-padded), fragment q = 2 * ks + plane (0 = hi, 1 = lo): [hh = 0..1][column j = 0..31][8 halves k = 16 ks + 8 hh + i].
    * b1p / b2p stay fp32.  NULL: the exact fp32 MFMA form (w1p / w2p). */
   const void* w1h;
   const void* w2h;
+  /* Optional, host-visible (pinned) or device memory: set to 1 by the h2 form when a value it has to split (an edge_attr_ entry, an
+   * h = relu(fc1) value) lies outside the fp16 range (|v| > 65504, or NaN): the result of that launch is then not to be trusted and
+   * the caller should rerun with the fp32 form (w1h = w2h = NULL).  NULL: not reported. */
+  int32_t* h2_range_flag;
 } ddp_conv_task_t;
 
 /* Fused fc -> tensor product -> per-edge message for up to 9 convs that share one shape.
@@ -322,6 +326,14 @@ int ddp_tor_head(const ddp_tor_args_t* args, void* stream);
  * not bitwise the fp32-MFMA form, at 1/2.7 of its matrix time (csrc/ddp_gemm.hip). */
 int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows, const int32_t* offs,
                 int nbatch, const float* w, const void* w_bf16x3, int k, int ncols, float* out, int ldo, void* stream);
+
+/* ddp_stage_a with the weights ALSO given as fp16 hi/lo operand planes, w_h2 = [nbatch][plane 0 = hi, 1 = lo][ceil(k / 16)][2][ncols][8]
+ * halves (packing.split_h2: v = hi + lo / 2048, K zero-padded to a multiple of 16; 16-byte aligned).  For wide products (ncols % 4
+ * == 0, ncols >= 1024, out 16-byte aligned with ldo % 4 == 0) and k in {60, 32, 24, 16} the product runs on v_mfma_f32_32x32x16_f16
+ * with x split the same way in the kernel, three products per 16 k, fp32 accumulation (the conv kernels' h2 form: 22-bit operands,
+ * error <= 2^-20 sum|x w|); other shapes run the exact fp32 forms on `w`.  ABI 12. */
+int ddp_stage_a_h2(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows, const int32_t* offs,
+                   int nbatch, const float* w, const void* w_h2, int k, int ncols, float* out, int ldo, int32_t* range_flag, void* stream);
 
 /* The pose update between two score-model calls, for all samples of a batch in one launch:
  * modify_conformer(pos, tr_update, rot_update, torsion_updates) of utils/diffusion_utils.py:37-60 = rigid move about the

@@ -139,6 +139,7 @@ def test_bench_batch_samples_match_oracle(flex):
                     assert elementwise_excess(a, w, TOL, ATOL_FRAC) <= 1.0, (flex, t_idx, part, k, elementwise_excess(a, w, TOL, ATOL_FRAC))
                 if k in ("tr", "rot"):
                     assert rowwise_excess(a, w, TOL, ATOL_FRAC) <= 1.0, (flex, t_idx, part, k, rowwise_excess(a, w, TOL, ATOL_FRAC))
+    smp.close()     # (the captured 40-sample step holds ~40 GB of device memory)
 
 
 @pytest.mark.parametrize("name", ["cfg2_full_noflex", "cfg2_full_flex", "cfg1_full", "ns24_l3", "hetero_cfg1", "hetero_cfg2", "small32_readme"])
@@ -281,12 +282,45 @@ def test_fp16_split_products_against_the_fp32_mfma_form(name):
         assert float((a - b).abs().max()) / scale < 1e-5, (name, k, float((a - b).abs().max()) / scale)
 
 
+def test_values_outside_the_fp16_range_are_reported_not_saturated():
+    """The h2 kernels split fp32 values into two fp16 halves; a value beyond +-65504 (or a NaN) cannot be split.  It is neither
+    clamped nor silently turned into an infinity: the kernel raises a flag in pinned host memory (ddp_conv_task_t::h2_range_flag,
+    ddp_stage_a_h2's range_flag) and the next forward / Sampler.run's end / check_overflow() raises.  The exact fp32 form
+    (launch.CONV_H2 = False) runs the same model without complaint."""
+    from diffdock_pocket_amd import _lib as L
+    from diffdock_pocket_amd import launch as K
+    case, gold, batch, sd = case_inputs("cfg1_full")
+    sd = dict(sd)
+    sd["conv_layers.0.fc.0.weight"] = sd["conv_layers.0.fc.0.weight"] * 3e5        # h = relu(fc1) of one conv far beyond 65504
+    model = _model_for(case, sd)
+    b = case.make_batch().to(_dev())
+    model(b)
+    torch.cuda.synchronize()
+    with pytest.raises(L.DdpError, match="fp16 range"):
+        model.check_overflow()
+    model.check_overflow()                                                          # (the report cleared the flag)
+    try:
+        K.CONV_H2 = False
+        model._static_cache = {}
+        out = model(b)
+        torch.cuda.synchronize()
+        model.check_overflow()
+        assert all(torch.isfinite(t).all() for t in out)
+    finally:
+        K.CONV_H2 = True
+
+
 @pytest.mark.parametrize("flex", [False, True])
 def test_pipelined_layer_order_is_bitwise_the_serial_one(flex):
-    """Round 4: at 40 samples the direct conv of layer l (receptor<-atom) runs on a side stream beside stage A of layer l + 1
-    (engine._layers, "pipelined"; it reads a snapshot of x_atom(l) while the atom mean updates x_atom in place).  Same kernels,
-    same arguments: the scores of forwards at two schedule positions, launch by launch and through a replayed hipGraph, must be
-    bit for bit those of the serial order (model.overlap_direct_conv = False)."""
+    """Round 4: for large batches the launches of a conv layer run as parallel branches of the captured step (engine._layers):
+    "pipeline" = the direct conv of layer l beside stage A of layer l + 1 (it reads a snapshot of x_atom(l) while the atom mean
+    updates x_atom in place; "pipeline2": the receptor-source stage A beside the first conv launch as well); "chains" = per layer
+    [stage A of the atom-source rows -> the convs with atom sources] beside [the other stage-A products -> their convs -> the direct
+    conv].  Same kernels, same per-edge arithmetic: the scores of forwards at two schedule positions, launch by launch and through a
+    replayed hipGraph, and the poses must be bit for bit those of the serial order (model.overlap_direct_conv = False).  Eight
+    samples with the small-batch fork switched off (concurrent_max_atoms = 0: the large-batch path whatever the batch size) - a
+    captured 40-sample step holds ~40 GB of device memory; the 40-sample batch runs these orders in
+    test_bench_batch_samples_match_oracle and in bench.py."""
     import bench
     from diffdock_pocket_amd.diffusion import get_t_schedule
     from diffdock_pocket_amd.sampler import Sampler, SamplerConfig
@@ -295,10 +329,11 @@ def test_pipelined_layer_order_is_bitwise_the_serial_one(flex):
     sched = get_t_schedule(20)
     g = make_3dpf_complex(seed=0, flexible_sidechains=flex)
     out = {}
-    for overlap in (False, True):
+    for order in ("serial", "pipeline", "pipeline2", "chains"):
         model, kw = bench.build_model("cfg2", flex, dev)
-        model.overlap_direct_conv = overlap
-        smp = Sampler(model, g, 40, dev, SamplerConfig(inference_steps=20, flexible_sidechains=flex), seed=0)
+        model.concurrent_max_atoms = 0
+        model.overlap_direct_conv, model.layer_order = order != "serial", order
+        smp = Sampler(model, g, 8, dev, SamplerConfig(inference_steps=20, flexible_sidechains=flex), seed=0)
         smp.randomize()
         res = [[t.clone() for t in smp.scores(float(sched[0]))]]
         for i in range(4):       # two ordinary steps, the capture, one replay
@@ -306,10 +341,13 @@ def test_pipelined_layer_order_is_bitwise_the_serial_one(flex):
         assert bool(smp._graph)
         res.append([t.clone() for t in smp.scores(float(sched[4]))])
         res.append([smp.lig_pos.clone(), smp.atom_pos.clone()])
-        out[overlap] = res
-    for a, b in zip(out[False], out[True]):
-        for x, y in zip(a, b):
-            assert torch.equal(x, y)
+        out[order] = res
+        smp.close()
+        del smp, model
+    for order in ("pipeline", "pipeline2", "chains"):
+        for a, b in zip(out["serial"], out[order]):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y), order
 
 
 def test_a_truncated_ligand_atom_edge_list_is_reported():
@@ -688,6 +726,52 @@ def test_stage_a_bf16x3_error(k, ncols, nrows, nb):
                             k, ncols, part.data_ptr(), ldo, _stream()), "ddp_stage_a")
     sel = rows[:-1].long()
     assert torch.equal(part[:, sel], out3[:, sel])
+    rest = torch.ones(nrows, dtype=torch.bool, device=dev)
+    rest[sel] = False
+    assert bool((part[:, rest] == -7.0).all())
+
+
+@pytest.mark.parametrize("k,ncols,nrows,nb", [(60, 12672, 1111, 2), (60, 2560, 37, 3), (32, 3104, 500, 2), (24, 1856, 300, 2), (16, 1056, 77, 1),
+                                              (60, 12672, 4500, 1)])
+def test_stage_a_h2_error(k, ncols, nrows, nb):
+    """The fp16 hi/lo split form of stage A (ddp_stage_a_h2: both operands as hi + lo / 2048, three products per 16 k on
+    v_mfma_f32_32x32x16_f16, fp32 accumulation) against an fp64 product.  The operands carry 22 significant bits each, so a single
+    product is off by at most 2^-21 + 2^-22 of |x w| (both roundings + the dropped xl wl); over all elements of these products - rows
+    and columns of very different magnitude, dot products in which one term dominates - the worst element stays below 2^-20 of
+    sum_u |x w| (measured 5.6e-7 where the exact fp32 MFMA chain, asserted beside it at 2^-21, shows 3.9e-7).  Also on a row list
+    with a device-side length (the listed rows only, bitwise the dense launch's rows)."""
+    import ctypes as C
+    from diffdock_pocket_amd import _lib as L
+    from diffdock_pocket_amd.packing import split_h2
+    from diffdock_pocket_amd.score_model import _stream
+    torch.manual_seed(k + nrows)
+    dev = _dev()
+    lib = L.load()
+    ldx, ldo = 184, ncols
+    x = (torch.randn(nrows, ldx) * torch.exp(torch.randn(nrows, 1))).to(dev)       # rows of very different magnitude
+    w = (torch.randn(nb, k, ncols) * 0.1 * torch.exp(2 * torch.randn(nb, 1, ncols))).to(dev)
+    offs = [0, 120, 60][:nb]
+    offs_c = (C.c_int32 * nb)(*offs)
+    wh = split_h2(w)
+    assert wh.dtype == torch.float16 and wh.shape == (nb, 2, (k + 15) // 16, 2, ncols, 8)
+    exact = torch.stack([x[:, o:o + k].double() @ w[b].double() for b, o in enumerate(offs)])
+    scale = torch.stack([x[:, o:o + k].double().abs() @ w[b].double().abs() for b, o in enumerate(offs)])
+    out32, outh = torch.empty(nb, nrows, ldo, device=dev), torch.full((nb, nrows, ldo), float("nan"), device=dev)
+    L.check(lib.ddp_stage_a(x.data_ptr(), ldx, nrows, None, None, nrows, offs_c, nb, w.data_ptr(), None, k, ncols, out32.data_ptr(), ldo,
+                            _stream()), "ddp_stage_a")
+    L.check(lib.ddp_stage_a_h2(x.data_ptr(), ldx, nrows, None, None, nrows, offs_c, nb, w.data_ptr(), wh.data_ptr(), k, ncols, outh.data_ptr(),
+                               ldo, None, _stream()), "ddp_stage_a_h2")
+    assert not torch.equal(out32, outh)                                              # (another kernel did run)
+    e32 = float(((out32.double() - exact).abs() / scale).max())
+    eh = float(((outh.double() - exact).abs() / scale).max())
+    assert e32 < 2.0 ** -21 and eh < 2.0 ** -20, (e32, eh)
+    rows = torch.randperm(nrows, device=dev)[:max(nrows // 3, 1)].int().contiguous()
+    n_dev = torch.tensor([rows.numel() - 1], dtype=torch.int32, device=dev)
+    part = torch.full((nb, nrows, ldo), -7.0, device=dev)
+    L.check(lib.ddp_stage_a_h2(x.data_ptr(), ldx, rows.numel(), rows.data_ptr(), n_dev.data_ptr(), nrows, offs_c, nb, w.data_ptr(), wh.data_ptr(),
+                               k, ncols, part.data_ptr(), ldo, None, _stream()), "ddp_stage_a_h2")
+    sel = rows[:-1].long()
+    assert torch.equal(part[:, sel], outh[:, sel])
     rest = torch.ones(nrows, dtype=torch.bool, device=dev)
     rest[sel] = False
     assert bool((part[:, rest] == -7.0).all())

@@ -236,7 +236,7 @@ def test_c_abi_exports_every_declared_symbol():
     from diffdock_pocket_amd import build
     build.build(verbose=False)
     header = open(os.path.join(ROOT, "include", "ddp_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(ddp_[a-z_]+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(ddp_[a-z0-9_]+)\s*\(", header, flags=re.M))
     assert declared == set(L.EXPORTS)
     lib = ctypes.CDLL(L.LIB_PATH)
     for name in declared:

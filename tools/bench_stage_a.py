@@ -7,7 +7,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from diffdock_pocket_amd import _lib as L  # noqa: E402
-from diffdock_pocket_amd.packing import split_bf16x3  # noqa: E402
+from diffdock_pocket_amd.packing import split_bf16x3, split_h2  # noqa: E402
 
 
 def timeit(fn, n=10):
@@ -37,11 +37,13 @@ def main():
         t_mine = timeit(lambda: L.check(lib.ddp_stage_a(x.data_ptr(), ldx, N, None, None, N, offs, nb, w.data_ptr(), None, k, ncols, out.data_ptr(), ldo, st), "a"))
         w3 = split_bf16x3(w)
         t_x3 = timeit(lambda: L.check(lib.ddp_stage_a(x.data_ptr(), ldx, N, None, None, N, offs, nb, w.data_ptr(), w3.data_ptr(), k, ncols, out.data_ptr(), ldo, st), "a"))
+        wh = split_h2(w)
+        t_h2 = timeit(lambda: L.check(lib.ddp_stage_a_h2(x.data_ptr(), ldx, N, None, None, N, offs, nb, w.data_ptr(), wh.data_ptr(), k, ncols, out.data_ptr(), ldo, None, st), "a"))
         A = torch.stack([x[:, 120 * (i % 2):120 * (i % 2) + k] for i in range(nb)])
         t_bmm = timeit(lambda: torch.bmm(A, w))
         t_mm = timeit(lambda: [torch.mm(A[i], w[i]) for i in range(nb)])
         gb = nb * N * ncols * 4 / 1e9
-        print(f"{name}: N={N} nb={nb}  {gb:.2f} GB out | ddp_stage_a fp32 {t_mine:.3f} ms ({gb / t_mine:.2f} TB/s)  bf16x3 {t_x3:.3f} ms ({gb / t_x3:.2f})  bmm {t_bmm:.3f} ms ({gb / t_bmm:.2f})  "
+        print(f"{name}: N={N} nb={nb}  {gb:.2f} GB out | ddp_stage_a fp32 {t_mine:.3f} ms ({gb / t_mine:.2f} TB/s)  bf16x3 {t_x3:.3f} ms ({gb / t_x3:.2f})  fp16 hi/lo {t_h2:.3f} ms ({gb / t_h2:.2f})  bmm {t_bmm:.3f} ms ({gb / t_bmm:.2f})  "
               f"mm x{nb} {t_mm:.3f} ms ({gb / t_mm:.2f})")
 
 

@@ -35,6 +35,8 @@ def run_job(cfg, flex, n, device, sampler_kwargs=None):
         torch.cuda.synchronize()
         out[t_idx] = {"scores": scores, "lig_pos": smp.lig_pos.cpu().clone(), "atom_pos": smp.atom_pos.cpu().clone(),
                       "stats": {k: int(v) for k, v in model.last_stats.items() if k.startswith(("E_", "N_", "B"))}}
+    if hasattr(smp, "close"):
+        smp.close()     # (a captured 40-sample step holds tens of GB of device memory)
     return out
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Consolidate the rocprofv3 PMC passes of one build into profiles/r02_pmc.json (read by bench.py).
+"""Consolidate the rocprofv3 PMC passes of one build into profiles/r04_pmc.json (read by bench.py).
 
 Run on the GPU box, every pass in its own process with --kernel-trace only (gpurun refuses --pmc with other trace domains),
 each on the same deterministic workload:
@@ -7,13 +7,13 @@ each on the same deterministic workload:
   B="python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-hbm-pass --no-other-workloads"
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- $B --launch-log gpurun_out/pmc_fetch/launches.json
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- $B --launch-log gpurun_out/pmc_write/launches.json
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv \\
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv \\
             -d gpurun_out/pmc_mfma -- $B --launch-log gpurun_out/pmc_mfma/launches.json
-  python3 tools/pmc_collect.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma profiles/r02_pmc.json
+  python3 tools/pmc_collect.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma profiles/r04_pmc.json
 
 Corrections (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE are in units of 1024 bytes; on gfx950
 FETCH_SIZE counts a 128-byte request as 64 bytes, so it is doubled; WRITE_SIZE is exact for 16-byte-per-lane streaming stores.
-One MOP of SQ_INSTS_VALU_MFMA_MOPS_F32 = 512 FLOP.  mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x
+One MOP of SQ_INSTS_VALU_MFMA_MOPS_F32 / _F16 = 512 FLOP.  mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x
 1024 SIMDs).
 
 Launch matching: bench.py --launch-log lists the conv launches of the TIMED steps in order (kernel instantiation, edges,
@@ -28,7 +28,7 @@ import sys
 import pandas as pd
 
 CONV = ["ddp_conv32_kernel", "ddp_conv_messages_kernel"]
-OTHER = ["ddp_stage_a_mfma_kernel", "ddp_segment_reduce_kernel", "ddp_edge_featurize", "ddp_radius", "ddp_knn", "ddp_pose_update"]
+OTHER = ["ddp_stage_a_h2_kernel", "ddp_stage_a_mfma_kernel", "ddp_segment_reduce_kernel", "ddp_edge_featurize", "ddp_radius", "ddp_knn", "ddp_pose_update"]
 
 
 def load(d):
@@ -82,14 +82,22 @@ def main():
         fe, _ = counter_sum(cf, "FETCH_SIZE", idf[k])
         wr, _ = counter_sum(cw, "WRITE_SIZE", idw[k])
         mops, _ = counter_sum(cm, "SQ_INSTS_VALU_MFMA_MOPS_F32", idm[k])
+        mops16, _ = counter_sum(cm, "SQ_INSTS_VALU_MFMA_MOPS_F16", idm[k])
         busy, _ = counter_sum(cm, "SQ_VALU_MFMA_BUSY_CYCLES", idm[k])
         gui, _ = counter_sum(cm, "GRBM_GUI_ACTIVE", idm[k])
         useful = sum(l["useful_flops"] for l in lm["launches"] if l["kernel"] == k)
-        issued = mops * 512.0
+        # matrix-core instruction FLOPs of the kernel's formulation without padding: the fc products that ran as fp16 hi/lo split
+        # products count three instruction FLOPs per product FLOP (bench.py --launch-log: fc16_flops), the rest once
+        fc16 = sum(l.get("fc16_flops", 0.0) for l in lm["launches"] if l["kernel"] == k)
+        useful_instr = useful + 2.0 * fc16
+        issued = (mops + mops16) * 512.0
         res["kernels"][k] = {"launches_sampled": n, "hbm_bytes_per_launch": (2.0 * fe + wr) * 1024.0 / n,
                              "fetch_bytes_per_launch": 2.0 * fe * 1024.0 / n, "write_bytes_per_launch": wr * 1024.0 / n,
-                             "issued_mfma_gflop_per_launch": issued / n / 1e9, "useful_gflop_per_launch_same_launches": useful / n / 1e9,
-                             "padding_frac": 1.0 - useful / issued if issued > 0 else None,
+                             "issued_mfma_gflop_per_launch": issued / n / 1e9, "issued_f16_mfma_gflop_per_launch": mops16 * 512.0 / n / 1e9,
+                             "issued_f32_mfma_gflop_per_launch": mops * 512.0 / n / 1e9,
+                             "useful_gflop_per_launch_same_launches": useful / n / 1e9,
+                             "useful_instruction_gflop_per_launch_same_launches": useful_instr / n / 1e9,
+                             "padding_frac": 1.0 - useful_instr / issued if issued > 0 else None,
                              "mfma_busy_frac": busy / (gui / 8.0 * 1024.0) if gui > 0 else None}
     # the other kernels inside the timed window, per launch
     for k in OTHER:

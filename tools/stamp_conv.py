@@ -17,7 +17,7 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 from diffdock_pocket_amd import _lib as L  # noqa: E402
-from diffdock_pocket_amd import score_model as sm  # noqa: E402
+from diffdock_pocket_amd import launch as sm  # noqa: E402  (engine.py launches through this module)
 from diffdock_pocket_amd.diffusion import get_t_schedule  # noqa: E402
 from diffdock_pocket_amd.sampler import Sampler, SamplerConfig  # noqa: E402
 from diffdock_pocket_amd.synthetic import make_3dpf_complex  # noqa: E402
@@ -27,11 +27,11 @@ model, kw = bench.build_model("cfg2", False, dev)
 if "--direct" in sys.argv:
     model.factorize_min_degree = 0
 g = make_3dpf_complex(seed=0, flexible_sidechains=False)
-smp = Sampler(model, g, 40, dev, SamplerConfig(flexible_sidechains=False), seed=0)
+smp = Sampler(model, g, 40, dev, SamplerConfig(flexible_sidechains=False, hip_graph=False), seed=0)
 smp.randomize()
 lib = L.load()
 lib.ddp_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
-orig = sm._launch_convs
+orig = sm.launch_convs
 captured = {}
 
 
@@ -39,6 +39,7 @@ WANT_G = "--direct" not in sys.argv
 
 
 def hooked(spec, tasks, **kw):
+    kw.pop("tag", None)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     orig(spec, tasks, **kw)
@@ -60,7 +61,7 @@ def hooked(spec, tasks, **kw):
         captured["tiles"] = [(t.n_edges + ET - 1) // ET for t in tasks]
 
 
-sm._launch_convs = hooked
+sm.launch_convs = hooked
 smp.step(0, get_t_schedule(20))
 smp.step(1, get_t_schedule(20))
 captured.pop("done", None)
