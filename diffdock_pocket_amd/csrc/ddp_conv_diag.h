@@ -54,6 +54,8 @@ extern "C" int ddp_debug_read_stamps(unsigned long long* host_dst, int n_wgs) {
 #endif
 #if defined(DDP_ABLATE) && (DDP_ABLATE == 3 || DDP_ABLATE == 7)   // G pass without its global loads
 #define DDP_ABL_G(x, q) (f32x4{1e-12f, 2e-12f, 3e-12f, 4e-12f} * (float)((q) + lane))
+#elif defined(DDP_G_NT)   // experiment: the G rows as non-temporal (streaming) loads - they should not push the weights out of L2
+#define DDP_ABL_G(x, q) __builtin_nontemporal_load(&(x))
 #else
 #define DDP_ABL_G(x, q) (x)
 #endif

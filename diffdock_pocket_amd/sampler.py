@@ -409,20 +409,23 @@ class Sampler:
     # device: the next capture reuses the segments of the previous, dead one.  PyTorch's rule for shared pools - replay in capture
     # order, one at a time - holds when at most one captured step is alive; a sampler that captures while another captured sampler
     # of the device is still alive gets a pool of its own.
-    _pools = {}          # device index -> (pool handle, [weak references to the samplers that captured into it])
+    _pools = {}          # device index -> (torch.cuda.MemPool, [weak references to the samplers that captured into it])
 
     def _graph_pool(self):
         import weakref
         idx = torch.device(self.device).index or 0
         ent = Sampler._pools.get(idx)
         if ent is None:
-            ent = Sampler._pools[idx] = (torch.cuda.graph_pool_handle(), [])
+            # (a MemPool OBJECT, kept for the life of the process: while it lives the pool's use count stays above zero, so neither a
+            # dying graph nor the torch.cuda.empty_cache() that torch.cuda.graph runs before every capture hands its segments back)
+            with torch.cuda.device(idx):
+                ent = Sampler._pools[idx] = (torch.cuda.MemPool(), [])
         live = [r for r in ent[1] if r() is not None and r() is not self and r()._graph]
         ent[1][:] = live
         if live:
             return None
         ent[1].append(weakref.ref(self))
-        return ent[0]
+        return ent[0].id
 
     def close(self):
         """Drops the captured step and everything it keeps alive (the graph's private memory pool holds a step's intermediates: ~25 GB

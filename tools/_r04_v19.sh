@@ -1,0 +1,9 @@
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04_v19; mkdir -p $O; cd $R
+B="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-workloads"
+for i in 1 2; do
+for v in base notouch; do
+  L=$R/diffdock_pocket_amd/libddp_hip_$v.so; if [ $v = base ]; then L=$R/diffdock_pocket_amd/libddp_hip.so; fi
+  DDP_HIP_LIB=$L timeout 600 $B > $O/bench_${v}_$i.json 2> $O/bench_$v.err; echo "$v rc=$? $(grep -o '"ms_per_step": [0-9.]*' $O/bench_${v}_$i.json | head -2 | tr '\n' ' ')"
+done; done
+timeout 600 python tools/stamp_conv.py > $O/stamps.txt 2>&1; grep -A14 "HIP-event" $O/stamps.txt | grep -v Warn | head -16
+timeout 900 python -m pytest tests -m gpu -q -x -k "forward_matches or single_conv or capacities" > $O/pytest_sel.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_sel.log

@@ -1,0 +1,6 @@
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04_v21; mkdir -p $O; cd $R
+B="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-workloads"
+for v in base rs6 rs8; do for c in 13 18 24; do
+  L=$R/diffdock_pocket_amd/libddp_hip_$v.so; if [ $v = base ]; then L=$R/diffdock_pocket_amd/libddp_hip.so; fi
+  DDP_ROLE_COST3=$c DDP_HIP_LIB=$L timeout 600 $B > $O/bench_${v}_$c.json 2> $O/bench_$v.err; echo "$v cost3=$c rc=$? $(grep -o '"ms_per_step": [0-9.]*' $O/bench_${v}_$c.json | head -2 | tr '\n' ' ')"
+done; done
