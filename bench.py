@@ -552,7 +552,7 @@ def main(argv=None):
                         "ms_per_step": ms_ / 2.0, "measured": "2 extra steps (schedule positions 5, 15) behind the instrumented pass",
                         "traffic": p.get("hbm_bytes_per_launch"), "mfma_busy_pmc": p.get("mfma_busy_frac")}
             roof["other_kernels"] += [e for e in (hbm_entry("ddp_stage_a_h2_kernel"), hbm_entry("ddp_stage_a_mfma_kernel"),
-                                                  hbm_entry("ddp_segment_reduce_kernel")) if e]
+                                                  hbm_entry("ddp_segment_reduce4_kernel")) if e]
             # whole step: HBM bytes the PMC passes saw against the algorithmic boundary bytes of the convs
             alg_step = prof.boundary_bytes() / args.steps
             step = {"algorithmic_boundary_gb": alg_step / 1e9}

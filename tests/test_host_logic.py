@@ -439,3 +439,23 @@ def test_h2_operand_planes_layout_and_precision():
     assert P.h2_steps(spec) == 12 and P.h2_steps(P.faster_tp_spec(P.irreps_muls(60, 10, 6), (0, 2, 2, 0), 120)) == 0
     w2 = torch.randn(spec.weight_numel, 180, generator=g) * 0.05
     assert P.pack_fc2_h2(spec, w2).numel() == spec.ntiles * 2 * 12 * 64 * 8
+
+
+def test_lazy_stats_fresh_view_rereads_the_count_block():
+    """LazyStats memoises its first read, but the count block of a CAPTURED forward is rewritten by every replay -
+    Sampler installs `stats.fresh()` after each replay; a fresh view reads the block again."""
+    from diffdock_pocket_amd.engine import LazyStats
+
+    class Block:
+        def __init__(self):
+            self.v = {"ll": 5}
+
+        def values(self):
+            return dict(self.v)
+
+    blk = Block()
+    st = LazyStats({"B": 2}, blk, {"E_ll": "ll"})
+    assert dict(st) == {"B": 2, "E_ll": 5}
+    blk.v["ll"] = 9                                  # (a replay rewrote the block)
+    assert st["E_ll"] == 5                           # memoised
+    assert st.fresh()["E_ll"] == 9 and st.fresh()["B"] == 2
