@@ -598,6 +598,9 @@ def main(argv=None):
                                   "peak_of_the_instruction_mix": peak, "frac": frac}
                 return out
 
+            if hasattr(sampler, "close"):
+                sampler.close()     # the main job's captured step goes back to the shared graph memory pool before the sub-records
+
             def sub_job(cfg_, flex_, n_):   # a timed job + its instrumented pass
                 m_, kw_ = build_model(cfg_, flex_, device)
                 g_ = make_3dpf_complex(seed=0, flexible_sidechains=flex_)
@@ -615,6 +618,7 @@ def main(argv=None):
 
                 el_, s_, fp_, _, _, _ = timed_job(m_, g_, n_, slice(0, n_), device, flex_, 20, 3, on_timed=inst, cfg=cfg_)
                 assert torch.isfinite(fp_).all() and torch.isfinite(s_.atom_pos).all()
+                s_.close()
                 return {"value": n_ / el_, "unit": "poses/s", "ms_per_step": el_ / 20 * 1e3, "steps": 20,
                         "edges_last_step": dict(m_.last_stats), "conv_kernels": conv_fracs(pr)}
 
@@ -626,6 +630,7 @@ def main(argv=None):
             el5, s5, fp5, _, _, _ = timed_job(model, complex_graph, 40, slice(0, 5), device, False, 20, 3, cfg=args.cfg)
             others["configs[3] shard: samples [0, 5) of the 40 on one GPU, cfg2"] = {
                 "value": 5.0 / el5, "unit": "poses/s per GPU", "ms_per_step": el5 / 20 * 1e3, "steps": 20}
+            s5.close()
             del s5
             line["other_workloads"] = others
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (the other ranks must not wait for it)
