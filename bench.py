@@ -96,6 +96,8 @@ def parse_args(argv=None):
                     help="threads of the CPU baseline (capped at os.cpu_count(); 0 = all cores - on the GPU boxes' many-core hosts the "
                          "oracle's small ops get SLOWER beyond ~32 threads)")
     ap.add_argument("--no-roofline-pass", action="store_true", help="skip the instrumented steps behind the timed region")
+    ap.add_argument("--no-fork-front", action="store_true",
+                    help="diagnostic: the front's chains and the index lists one after the other (model.fork_front = False) for same-box A/B runs")
     ap.add_argument("--no-overlap-direct", action="store_true",
                     help="diagnostic: the serial launch order of the conv layers (model.overlap_direct_conv = False) for same-box A/B runs")
     ap.add_argument("--layer-order", default=None, choices=["chains", "pipeline", "pipeline2"], help="diagnostic: model.layer_order for A/B runs")
@@ -426,6 +428,8 @@ def main(argv=None):
         model.share_flex_layer0 = False
     if args.no_overlap_direct:
         model.overlap_direct_conv = False
+    if args.no_fork_front:
+        model.fork_front = False
     if args.layer_order:
         model.layer_order = args.layer_order
     complex_graph = make_3dpf_complex(seed=0, flexible_sidechains=args.flex)
@@ -603,6 +607,7 @@ def main(argv=None):
 
             def sub_job(cfg_, flex_, n_):   # a timed job + its instrumented pass
                 m_, kw_ = build_model(cfg_, flex_, device)
+                m_.fork_front = model.fork_front
                 g_ = make_3dpf_complex(seed=0, flexible_sidechains=flex_)
                 pr = sm.ConvProfiler()
 

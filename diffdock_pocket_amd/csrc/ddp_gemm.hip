@@ -642,9 +642,21 @@ static int stage_a_impl(const float* x, int ldx, int nrows, const int32_t* rows,
   // a row list with a device-side length is usually a small part of its capacity: 128-row tiles (as many workgroups as an
   // exactly-sized launch of the actual list would get), a bounded grid, the kernel walks its tiles
   const bool listed = rows && nrows_dev;
-  const int mrows = (nrows >= 8192 && !listed) ? DDP_GEMM_MROWS : 128;
+  // rows per workgroup, measured with the h2 kernel (tools/bench_stage_a_rows.py, us for 128 -> 256 rows per workgroup): 695 x 6
+  // products 56 -> 43, 1480 x 6 112 -> 101, 5560 x 6 408 -> 386, 5555 x 2 149 -> 145, a 12000-row list of 44440 307 -> 294 (a
+  // 2903-row one 73 -> 74); 185 x 6: 23 -> 20 with 64.  A list of a small array is usually short: 128 stays
+  int mrows = listed ? (nrows >= 16384 ? 256 : 128) : (nrows >= 8192 ? DDP_GEMM_MROWS : nrows >= 384 ? 256 : 64);
   int gy = (nrows + mrows - 1) / mrows;
   if (listed && gy > 96) gy = 96;
+#ifdef DDP_SA_TUNE   // diagnostic builds: rows per workgroup of products below 8192 rows / the grid cap of listed products from the environment
+  if (nrows < 8192 || listed) {
+    if (const char* e = getenv("DDP_SA_MROWS")) mrows = atoi(e);
+    gy = (nrows + mrows - 1) / mrows;
+    const char* c = getenv("DDP_SA_GYCAP");
+    const int cap = c ? atoi(c) : 96;
+    if (listed && gy > cap) gy = cap;
+  }
+#endif
   static const bool no_mfma = getenv("DDP_STAGE_A_VALU") != nullptr;   // diagnostic: force the VALU form
   // h2 form (fp16 hi/lo split of both operands): wide, 16-byte aligned outputs only, K = 60 / 32 / 24 / 16 (KP = 64 / 32 / 32 / 16)
   if (w_h2 && wide && (k == 60 || k == 32 || k == 24 || k == 16) && !no_mfma && (reinterpret_cast<size_t>(w_h2) & 15) == 0) {

@@ -96,6 +96,12 @@ class _Fork:
         with torch.cuda.stream(st):
             return fn()
 
+    def resync(self, i):
+        """A forked slot additionally waits for what the main stream has queued since the fork."""
+        st = self.side[i % len(self.side)]
+        if st in self.used:
+            st.wait_stream(self.main)
+
     def join(self, only=None):
         """Main waits for the forked streams (`only`: for that slot alone, the others stay forked)."""
         for st in list(self.used):
@@ -113,7 +119,7 @@ class ForwardEngine:
         """Side streams of the current stream for a layer's independent launches."""
         f = self._forks.get(dev)     # (created by the first ordinary step: no stream is created during a capture)
         if f is None:
-            f = self._forks[dev] = _Fork(dev, 4)
+            f = self._forks[dev] = _Fork(dev, 5)     # slots 0 - 2: stage-A groups / front, 3: direct conv, 4: index lists
         f.main = torch.cuda.current_stream(dev)
         return f
 
@@ -137,10 +143,22 @@ class ForwardEngine:
         if m.no_aminoacid_identities:
             rec.x = rec.x * 0
         S = self._static(data, lig, rec, atom, dev)
-        F = self._front(data, S, lig, rec, atom, dev, mark)
-        # (measured without gain, 40 samples 33.0 ms either way and cfg1 x 4 samples 1.6 -> 1.9 ms: the lists on a forked stream
-        # beside layer 0 - they read graph structure only and are first needed by layer 1)
-        self._lists(S, F, dev)
+        # the front's independent chains on forked streams (model.fork_front); not under the section timer / hooks / debug outputs
+        ff = None
+        if (m.fork_front and m.section_timer is None and m.before_layers is None and m.debug_conv_outputs is None
+                and not m.exact_sizes):
+            ff = self._fork(dev)
+        F = self._front(data, S, lig, rec, atom, dev, mark, ff)
+        # The index lists read graph structure only.  Rigid receptor: layer 1 is their first reader, so they run on a stream of
+        # their own beside stage A and the 32-edge conv launch of layer 0 (_layers joins them); with flexible side chains layer 0
+        # reads them (F.flex0).  (Launch by launch in round 3 this was measured without gain - 33.0 ms either way, cfg1 x 4
+        # samples 1.6 -> 1.9 ms of host time; as a branch of the captured step it is free.)
+        F.lists_fork = None
+        if ff is not None and S.num_flex == 0:
+            ff.run(4, lambda: self._lists(S, F, dev))
+            F.lists_fork = ff
+        else:
+            self._lists(S, F, dev)
         mark("lists")
         if m.exact_sizes:
             self._exact(F)
@@ -286,7 +304,7 @@ class ForwardEngine:
         F.keep_pro = (keep, a)
 
     # ================================================================================================ front
-    def _front(self, data, S, lig, rec, atom, dev, mark):
+    def _front(self, data, S, lig, rec, atom, dev, mark, ff=None):
         m = self.m
         ns, B = m.ns, S.B
         F = SimpleNamespace()
@@ -301,7 +319,9 @@ class ForwardEngine:
         self._prologue(data, S, F, lig, dev, ll0, ll1)
 
         # node encoders, sigma embeddings and the per-node part of the edge-embedding MLPs' first Linear: one HIP launch
-        F.xl, F.xr, F.xa, pre = m._node_tables(lig, rec, atom, dev)
+        # (ff: on a forked stream beside the neighbour searches; the edge embeddings below follow on that stream)
+        nt = (lambda: m._node_tables(lig, rec, atom, dev))
+        F.xl, F.xr, F.xa, pre = ff.run(0, nt) if ff is not None else nt()
         F.pre = pre
         mark("node_embed")
         sd_, dd, cd, nf = m.sigma_embed_dim, m.distance_embed_dim, m.cross_distance_embed_dim, m.in_lig_edge_features
@@ -386,7 +406,10 @@ class ForwardEngine:
             "lr": ((epk["lr"], m.cross_distance_expansion, lpos, lr0, rpos, lr1, pre["lr"], lr0), dict(n_edges=S.cap_lr, cnt=cnt["lr"])),
             "la": ((epk["la"], m.cross_distance_expansion, lpos, la0, apos, la1, pre["la"], la0), dict(n_edges=S.cap_la, cnt=cnt["la"])),
             "ar": ((epk["ar"], m.rec_distance_expansion, apos, ar32[0], rpos, ar32[1], pre["ar"], ar32[0]), {})}
-        for key, (o_, s_) in zip(calls, K.edge_featurize_jobs(list(calls.values()))):
+        feat = (lambda: K.edge_featurize_jobs(list(calls.values())))
+        if ff is not None:
+            ff.resync(0)      # the node tables' stream also waits for the searches; the views below are built beside it
+        for key, (o_, s_) in zip(calls, ff.run(0, feat) if ff is not None else feat()):
             F.e[key], F.sh[key] = o_, s_
         mark("edge_featurize")
 
@@ -463,6 +486,8 @@ class ForwardEngine:
             K.group_jobs(g2)
             F.keep.append(g2)
         F.so = so
+        if ff is not None:
+            ff.join(only=0)
         mark("views")
         return F
 
@@ -776,6 +801,15 @@ class ForwardEngine:
         pipelined = (fork is None and m.overlap_direct_conv and not plain and dbg is None and m.section_timer is None and L_ >= 2
                      and F.fact == {0, 1, 2, 3, 4, 5, 6, 7})
         side = self._fork(dev) if pipelined else None
+        lists_fork = getattr(F, "lists_fork", None)     # the index lists still running on a stream of their own (_forward)
+
+        def join_lists():
+            nonlocal lists_fork
+            if lists_fork is not None:
+                lists_fork.join(only=4)
+                lists_fork = None
+        if not (pipelined and m.layer_order != "chains") and fork is None:
+            join_lists()      # (the serial and the two-chain orders: before anything else)
 
         def plan(l):
             """Host side of layer l: per conv its CSR view (mean / direct conv), its source-ordered view and the rows stage A has
@@ -984,6 +1018,7 @@ class ForwardEngine:
                     launch_factorised(P, "r")
                 else:
                     launch_factorised(P)
+                join_lists()      # (layer 0: everything queued so far ran beside the lists; plan(1) and later read them)
                 fix_rowmaps(P)
                 if has_direct and xa_old is not None:
                     xa_old.copy_(xa)
@@ -1019,6 +1054,7 @@ class ForwardEngine:
             stage_a(P, "lar", forked=fork)
             mark("conv_prep")
             launch_factorised(P)
+            join_lists()
             if direct_first:
                 fork.join()
             else:

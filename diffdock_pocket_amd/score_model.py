@@ -428,6 +428,11 @@ class TensorProductScoreModel(nn.Module):
         # stage A -> its convs | the other stage-A products -> their convs -> direct conv).  Same box, alternating, after the convs moved
         # to the fp16 matrix cores: serial 20.48 - 20.51, chains 20.28 - 20.39, pipeline 20.22 - 20.25 ms per 40-sample step
         self.layer_order = "pipeline"
+        # The front's independent chains side by side (parallel branches of the captured step; same kernels, same arguments, same bits):
+        # [node encoders -> edge embeddings] beside [neighbour searches -> CSR / source-ordered views], and - rigid receptor - the index
+        # lists of the work eliminations (first read by layer 1) beside stage A + the 32-edge conv launch of layer 0 (engine._front,
+        # engine._forward)
+        self.fork_front = True
         self.concurrent_heads = True   # the torsion read-outs on forked streams beside the tr / rot read-out (any batch size)
         # Option, OFF: stage A on the bf16 matrix cores with both operands split into three bfloat16 terms (csrc/ddp_gemm.hip,
         # ddp_stage_a_x3_kernel): fp32-class accuracy (error <= 2^-21 sum |x w|, measured against fp64 in

@@ -350,6 +350,42 @@ def test_pipelined_layer_order_is_bitwise_the_serial_one(flex):
                 assert torch.equal(x, y), order
 
 
+@pytest.mark.parametrize("flex,large", [(False, True), (False, False), (True, True)])
+def test_forked_front_is_bitwise_the_serial_one(flex, large):
+    """Round 4: the front's independent chains run as parallel branches of the captured step (model.fork_front): [node encoders ->
+    edge embeddings] beside [neighbour searches -> views], and with a rigid receptor the index lists of the work eliminations beside
+    stage A + the conv launch of layer 0 (engine._forward / _front / _layers).  Same kernels, same arguments: scores at two schedule
+    positions (launch by launch, and after a capture + replay) and the poses are bit for bit those of fork_front = False, on the
+    large-batch launch order (concurrent_max_atoms = 0) and on the small-batch one."""
+    import bench
+    from diffdock_pocket_amd.diffusion import get_t_schedule
+    from diffdock_pocket_amd.sampler import Sampler, SamplerConfig
+    from diffdock_pocket_amd.synthetic import make_3dpf_complex
+    dev = _dev()
+    sched = get_t_schedule(20)
+    g = make_3dpf_complex(seed=0, flexible_sidechains=flex)
+    out = {}
+    for ff in (False, True):
+        model, kw = bench.build_model("cfg2", flex, dev)
+        if large:
+            model.concurrent_max_atoms = 0
+        model.fork_front = ff
+        smp = Sampler(model, g, 6, dev, SamplerConfig(inference_steps=20, flexible_sidechains=flex), seed=0)
+        smp.randomize()
+        res = [[t.clone() for t in smp.scores(float(sched[0]))]]
+        for i in range(5):       # two ordinary steps, the capture, two replays
+            smp.step(i, sched)
+        assert bool(smp._graph)
+        res.append([t.clone() for t in smp.scores(float(sched[5]))])
+        res.append([smp.lig_pos.clone(), smp.atom_pos.clone()])
+        out[ff] = res
+        smp.close()
+        del smp, model
+    for a, b in zip(out[False], out[True]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
 def test_captured_steps_share_one_memory_pool():
     """A captured step keeps its intermediates in the graph's memory pool; on this ROCm stack capture-time memory that PyTorch hands
     back to the driver does not come back (a pool per graph lost 35 - 45 GB per captured 40-sample sampler).  The captured steps of a
