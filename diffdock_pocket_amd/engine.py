@@ -22,6 +22,8 @@ from collections.abc import Mapping
 from types import SimpleNamespace
 from typing import Dict, List, Optional
 
+import math
+
 import torch
 
 from . import _lib as L
@@ -248,6 +250,16 @@ class ForwardEngine:
         t_nodes = torch.cat([t.reshape(-1) for t in ts])
         return bool((t_nodes == t_nodes[0]).all().item()) if t_nodes.numel() else True
 
+    @staticmethod
+    def _smooth_weight(pos_a, idx_a, pos_b, idx_b, max_norm):
+        """get_edge_weight of the reference (all_atom_score_model.py:438-442, smooth_edges) for the edges (idx_a, idx_b);
+        max_norm: a number or one value per edge.  Entries behind a list's device-side count hold no indices: clamped (their
+        rows are never read)."""
+        ia = idx_a.long().clamp(0, pos_a.shape[0] - 1)
+        ib = idx_b.long().clamp(0, pos_b.shape[0] - 1)
+        d = (pos_b[ib] - pos_a[ia]).norm(dim=-1)
+        return 0.5 * (torch.cos(torch.clip(d * math.pi / max_norm, max=math.pi)) + 1.0)
+
     # ================================================================================================ prologue
     def _prologue(self, data, S, F, lig, dev, ll0, ll1):
         """Everything that depends on the times and the poses only, in ONE launch (ddp_step_prologue): t -> sigma (:244-245),
@@ -406,7 +418,19 @@ class ForwardEngine:
             "lr": ((epk["lr"], m.cross_distance_expansion, lpos, lr0, rpos, lr1, pre["lr"], lr0), dict(n_edges=S.cap_lr, cnt=cnt["lr"])),
             "la": ((epk["la"], m.cross_distance_expansion, lpos, la0, apos, la1, pre["la"], la0), dict(n_edges=S.cap_la, cnt=cnt["la"])),
             "ar": ((epk["ar"], m.rec_distance_expansion, apos, ar32[0], rpos, ar32[1], pre["ar"], ar32[0]), {})}
-        feat = (lambda: K.edge_featurize_jobs(list(calls.values())))
+        def feat():
+            res = K.edge_featurize_jobs(list(calls.values()))
+            if m.smooth_edges:
+                # get_edge_weight (:438-442): the fc output of an edge times 0.5 (cos(min(d pi / max_norm, pi)) + 1).  A message is
+                # linear in the fc output and in the edge's harmonics alike: the weight goes into the harmonics (plain PyTorch
+                # launches - a rarely used option).  atom-receptor edges: weight 1 (:580)
+                cut_e = (lambda: F.cut[b32_l.long()[lr0.long().clamp(0, Nl - 1)]]) if m.dynamic_max_cross else (lambda: m.cross_max_distance)
+                for key, mx in (("ll", m.lig_max_radius), ("rr", m.rec_max_radius), ("aa", m.lig_max_radius), ("lr", None), ("la", m.lig_max_radius)):
+                    (_, _, pa, ia, pb, ib, _, _), _ = calls[key]
+                    sh_k = res[list(calls).index(key)][1]
+                    if sh_k.shape[0] > 0:
+                        sh_k.mul_(self._smooth_weight(pa, ia[:sh_k.shape[0]], pb, ib[:sh_k.shape[0]], cut_e() if mx is None else mx).unsqueeze(1))
+            return res
         if ff is not None:
             ff.resync(0)      # the node tables' stream also waits for the searches; the views below are built beside it
         for key, (o_, s_) in zip(calls, ff.run(0, feat) if ff is not None else feat()):
@@ -1173,6 +1197,8 @@ class ForwardEngine:
         bond_attr = torch.empty((T, ns), device=dev)      # (:399,423) x[b0, :ns] + x[b1, :ns]
         L.check(lib.ddp_torsion_sh(K._p(sh_e), K._p(h.bond_vec), K._p(csr.recv), E, K._p(csr.cnt), K._p(tor_sh), K._p(x), ldx, ns,
                                    K._p(st.flat32[:T]), K._p(st.flat32[T:]), T, K._p(bond_attr), K.stream()), "ddp_torsion_sh")
+        if m.smooth_edges and E > 0:      # (:614,634 -> :401,426) the bond-centre graphs' edges are weighted too
+            tor_sh.mul_(self._smooth_weight(h.bond_pos, csr.recv, pos, csr.src, m.lig_max_radius).unsqueeze(1))
         spec, pkc = conv.spec, conv.packed(dev)
         msg = torch.empty((E, spec.d_out), device=dev)
         segs = [(e_t, csr.eid, ns, ns), (x, csr.src, ldx, ns), (bond_attr, csr.recv, ns, ns)]

@@ -14,8 +14,9 @@ reference checkpoints load with `load_state_dict`.  What runs where:
       torsion-head harmonics                                          ddp_torsion_sh
 
 There is no eager/CPU fallback: `forward` raises if the inputs are not on a HIP device or the library is missing.
-Configurations outside the README models (sh_lmax != 1, second-order irreps, smooth_edges, odd_parity, separate or
-asynchronous noise schedules, affinity prediction, parallel > 1) raise NotImplementedError instead of silently differing.
+Configurations outside the README models (sh_lmax != 1, second-order irreps, odd_parity, separate or asynchronous noise
+schedules, affinity prediction, parallel > 1) raise NotImplementedError instead of silently differing; smooth_edges is supported
+(cosine edge weights folded into the edge harmonics, engine._front).
 `confidence_mode=True` builds the confidence model (same convs, scalar-mean + MLP head).
 """
 from __future__ import annotations
@@ -338,7 +339,7 @@ class TensorProductScoreModel(nn.Module):
                  use_old_atom_encoder=False):
         super().__init__()
         unsupported = {"sh_lmax != 1": sh_lmax != 1, "use_second_order_repr": use_second_order_repr,
-                       "smooth_edges": smooth_edges, "odd_parity": odd_parity,
+                       "odd_parity": odd_parity,
                        "separate_noise_schedule": separate_noise_schedule,
                        "asyncronous_noise_schedule": asyncronous_noise_schedule,
                        "affinity_prediction": affinity_prediction, "parallel > 1": parallel != 1,
@@ -367,6 +368,7 @@ class TensorProductScoreModel(nn.Module):
         self.no_aminoacid_identities = no_aminoacid_identities
         self.flexible_sidechains = flexible_sidechains
         self.confidence_mode = bool(confidence_mode)
+        self.smooth_edges = bool(smooth_edges)      # cosine edge weights (engine._front / _torsion_head)
 
         enc = OldAtomEncoder if use_old_atom_encoder else AtomEncoder
         sd, dd, cd = sigma_embed_dim, distance_embed_dim, cross_distance_embed_dim

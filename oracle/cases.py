@@ -53,6 +53,7 @@ class Case:
     # graphs of different ligand / pocket sizes and flexible-residue sets, as the reference's validation and confidence-data
     # loaders batch them
     hetero: Optional[List[Dict]] = None
+    smooth_edges: bool = False            # utils/parsing.py:126 (all_atom_score_model.py:438-442)
 
     def model_kwargs(self) -> Dict:
         """kwargs for TensorProductScoreModel (reference ctor signature, README.md:72 settings)."""
@@ -63,7 +64,7 @@ class Case:
                     fixed_center_conv=self.fixed_center_conv, atom_max_neighbors=self.atom_max_neighbors,
                     flexible_sidechains=self.flexible_sidechains, no_torsion=self.no_torsion,
                     use_old_atom_encoder=self.use_old_atom_encoder, confidence_mode=self.confidence_mode,
-                    num_confidence_outputs=self.num_confidence_outputs)
+                    num_confidence_outputs=self.num_confidence_outputs, smooth_edges=self.smooth_edges)
 
     def oracle_config(self) -> OracleConfig:
         return OracleConfig(ns=self.ns, nv=self.nv, num_conv_layers=self.num_conv_layers, sigma_embed_dim=self.embed,
@@ -73,7 +74,8 @@ class Case:
                             dynamic_max_cross=self.dynamic_max_cross, cross_max_distance=self.cross_max_distance,
                             scale_by_sigma=self.scale_by_sigma, batch_norm=self.batch_norm,
                             atom_max_neighbors=self.atom_max_neighbors,
-                            confidence_mode=self.confidence_mode, embedding_scale=1000.0, tr_sigma_max=self.tr_sigma_max)
+                            confidence_mode=self.confidence_mode, embedding_scale=1000.0, tr_sigma_max=self.tr_sigma_max,
+                            smooth_edges=self.smooth_edges)
 
     def ctor_extras(self):
         sig = SigmaRanges(tr_sigma_max=self.tr_sigma_max)
@@ -157,6 +159,13 @@ CASES: Dict[str, Case] = {c.name: c for c in [
     # 3 * sigma_tr + 20 <= 65 A cross cutoff
     Case("small32_readme", ns=32, nv=6, num_conv_layers=5, embed=32, n_graphs=2, n_rec=40, t=[0.9, 0.3], atom_max_neighbors=12,
          tr_sigma_max=15.0, weight_seed=16, data_seed=10),
+    # smooth_edges (utils/parsing.py:126, all_atom_score_model.py:438-442): every conv's fc output times the cosine weight of its
+    # edge - per-graph dynamic cross cutoff + flexible side chains (both torsion heads' bond graphs are weighted too), and the
+    # fixed cutoff on a rigid receptor
+    Case("smooth_dyn", ns=16, nv=4, num_conv_layers=3, embed=32, n_graphs=2, n_rec=30, t=[0.75, 0.2], smooth_edges=True,
+         weight_seed=17, data_seed=11),
+    Case("smooth_fixed", ns=24, nv=6, num_conv_layers=4, embed=32, flexible_sidechains=False, n_graphs=2, n_rec=24, t=[0.6, 0.35],
+         dynamic_max_cross=False, cross_max_distance=14.0, smooth_edges=True, weight_seed=18, data_seed=12),
 ]}
 
 

@@ -71,6 +71,7 @@ class OracleConfig:
     tor_sigma_max: float = 3.14
     sidechain_tor_sigma_min: float = 0.03
     sidechain_tor_sigma_max: float = 3.14
+    smooth_edges: bool = False      # (all_atom_score_model.py:438-442) cosine edge weights on the fc outputs
 
     def irreps(self, i):
         ns, nv = self.ns, self.nv
@@ -170,6 +171,7 @@ class OracleScoreModel:
         self.sh_irreps = "1x0e+1x1o"
         self.tor_sh_irreps = "1x1o+1x2e+1x2o+1x3o"
         self.record: Dict[str, torch.Tensor] = {}
+        self._w: Dict[str, object] = {}
 
     # ---- small layers
     def _lin(self, prefix, x):
@@ -198,13 +200,22 @@ class OracleScoreModel:
     def _sh(self, vec):
         return tp.spherical_harmonics(self.sh_irreps, vec, normalize=True, normalization="component")
 
+    def _edge_weight(self, vec, max_norm):
+        """get_edge_weight (all_atom_score_model.py:438-442): 1, or with smooth_edges 0.5 (cos(min(|v| pi / max_norm, pi)) + 1)
+        per edge; max_norm a number or one value per edge (the dynamic cross cutoff of the edge's graph, :558-560)."""
+        if not self.cfg.smooth_edges:
+            return 1.0
+        nn_ = torch.clip(vec.norm(dim=-1) * math.pi / max_norm, max=math.pi)
+        return 0.5 * (torch.cos(nn_) + 1.0).unsqueeze(-1)
+
     def _conv(self, prefix, in_irreps, out_irreps, node_attr, edge_index, edge_attr, edge_sh, out_nodes=None,
-              faster=True, sh_irreps=None):
-        """TensorProductConvLayer.forward (models/score_model.py:108-125), residual=False, reduce='mean'."""
+              faster=True, sh_irreps=None, edge_weight=1.0):
+        """TensorProductConvLayer.forward (models/score_model.py:108-125), residual=False, reduce='mean'; edge_weight scales
+        the fc output of an edge (:114)."""
         if edge_index.numel() == 0:
             return torch.tensor(0, dtype=node_attr.dtype)
         recv, src = edge_index[0], edge_index[1]
-        w = self._mlp(prefix + ".fc", edge_attr)
+        w = self._mlp(prefix + ".fc", edge_attr) * edge_weight
         if faster:
             msg = faster_tensor_product(in_irreps, out_irreps, node_attr[src], edge_sh, w)
         else:
@@ -232,6 +243,7 @@ class OracleScoreModel:
         node_attr = torch.cat([lig.x.to(self.dtype), lig.node_sigma_emb], 1)
         vec = pos[ei[1]] - pos[ei[0]]
         ea = torch.cat([ea, gaussian_smearing(vec.norm(dim=-1), self.sd["lig_distance_expansion.offset"])], 1)
+        self._w["ll"] = self._edge_weight(vec, c.lig_max_radius)      # (:482)
         return node_attr, ei, ea, self._sh(vec)
 
     def _rec_graph(self, data):
@@ -243,6 +255,7 @@ class OracleScoreModel:
         vec = pos[ei[1]] - pos[ei[0]]
         ea = torch.cat([rec.node_sigma_emb[ei[0]],
                         gaussian_smearing(vec.norm(dim=-1), self.sd["rec_distance_expansion.offset"])], 1)
+        self._w["rr"] = self._edge_weight(vec, self.cfg.rec_max_radius)   # (:509)
         return node_attr, ei, ea, self._sh(vec)
 
     def _atom_graph(self, data):
@@ -255,6 +268,7 @@ class OracleScoreModel:
         vec = pos[ei[1]] - pos[ei[0]]
         ea = torch.cat([atom.node_sigma_emb[ei[0]],
                         gaussian_smearing(vec.norm(dim=-1), self.sd["lig_distance_expansion.offset"])], 1)
+        self._w["aa"] = self._edge_weight(vec, c.lig_max_radius)      # (:535)
         return node_attr, ei, ea, self._sh(vec)
 
     def _cross_graphs(self, data, cutoff):
@@ -270,10 +284,13 @@ class OracleScoreModel:
         v = rp[lr[1]] - lp[lr[0]]
         lr_attr = torch.cat([lig.node_sigma_emb[lr[0]], gaussian_smearing(v.norm(dim=-1), off_x)], 1)
         lr_sh = self._sh(v)
+        # (:558-560) the cutoff of the ligand atom's graph, or the fixed one
+        self._w["lr"] = self._edge_weight(v, cutoff[lig.batch[lr[0]]].squeeze().to(self.dtype) if torch.is_tensor(cutoff) else cutoff)
         la = tp.radius(atom.pos, lig.pos, c.lig_max_radius, atom.batch, lig.batch, max_num_neighbors=10000)
         v = ap[la[1]] - lp[la[0]]
         la_attr = torch.cat([lig.node_sigma_emb[la[0]], gaussian_smearing(v.norm(dim=-1), off_x)], 1)
         la_sh = self._sh(v)
+        self._w["la"] = self._edge_weight(v, c.lig_max_radius)        # (:571); atom-receptor edges: weight 1 (:580)
         ar = data["atom", "receptor"].edge_index.long()
         v = rp[ar[1]] - ap[ar[0]]
         ar_attr = torch.cat([atom.node_sigma_emb[ar[0]],
@@ -300,6 +317,7 @@ class OracleScoreModel:
         ei = tp.radius(pos32, bond_pos32, self.cfg.lig_max_radius, batch_x=batch, batch_y=bond_batch)
         vec = pos[ei[1]] - bond_pos[ei[0]]
         ea = self._mlp(edge_mlp, gaussian_smearing(vec.norm(dim=-1), self.sd["lig_distance_expansion.offset"]))
+        self._w["bond"] = self._edge_weight(vec, self.cfg.lig_max_radius)   # (:614,634)
         return ei, ea, self._sh(vec)
 
     @staticmethod
@@ -320,7 +338,7 @@ class OracleScoreModel:
         tor_sh = ftp(esh, bonds_sh[ei[0]])
         ea = torch.cat([ea, node_attr[ei[1], :ns], bond_attr[ei[0], :ns]], -1)
         h = self._conv(conv_prefix, in_irreps, f"{ns}x0o+{ns}x0e", node_attr, ei, ea, tor_sh,
-                       out_nodes=bonds.shape[1], faster=False, sh_irreps=self.tor_sh_irreps)
+                       out_nodes=bonds.shape[1], faster=False, sh_irreps=self.tor_sh_irreps, edge_weight=self._w["bond"])
         if h.dim() == 0:  # no edge at all: the reference would crash in tor_final_layer; keep the literal behaviour
             raise RuntimeError("torsion head has no edges")
         h = torch.tanh(h @ self.sd[final_prefix + ".0.weight"].T) @ self.sd[final_prefix + ".3.weight"].T
@@ -334,6 +352,7 @@ class OracleScoreModel:
         c, ns = self.cfg, self.cfg.ns
         conf = _conf
         rec = self.record = {}
+        self._w = {}      # edge weights of the edge sets built below (1.0 without smooth_edges)
         sig = {k: data.complex_t[k].to(self.dtype) for k in ("tr", "rot", "tor", "sc_tor")}
         if c.confidence_mode and not conf:   # (:245) sigmas = times; only the cross cutoff uses them
             return self._forward_confidence(data, sig)
@@ -369,23 +388,24 @@ class OracleScoreModel:
         L = c.num_conv_layers
         for l in range(L):
             ii, oi = c.irreps(l), c.irreps(l + 1)
+            W = self._w
             cv = lambda k, *a, **kw: self._conv(f"conv_layers.{9 * l + k}", ii, oi, *a, **kw)
             s = lambda x: x[:, :ns]
             nl, na_, nr = lig_x.shape[0], atom_x.shape[0], rec_x.shape[0]
-            u0 = cv(0, lig_x, ll, torch.cat([ll_attr, s(lig_x)[ll[0]], s(lig_x)[ll[1]]], -1), ll_sh)
-            u1 = cv(1, rec_x, lr, torch.cat([lr_attr, s(lig_x)[lr[0]], s(rec_x)[lr[1]]], -1), lr_sh, out_nodes=nl)
-            u2 = cv(2, atom_x, la, torch.cat([la_attr, s(lig_x)[la[0]], s(atom_x)[la[1]]], -1), la_sh, out_nodes=nl)
+            u0 = cv(0, lig_x, ll, torch.cat([ll_attr, s(lig_x)[ll[0]], s(lig_x)[ll[1]]], -1), ll_sh, edge_weight=W["ll"])
+            u1 = cv(1, rec_x, lr, torch.cat([lr_attr, s(lig_x)[lr[0]], s(rec_x)[lr[1]]], -1), lr_sh, out_nodes=nl, edge_weight=W["lr"])
+            u2 = cv(2, atom_x, la, torch.cat([la_attr, s(lig_x)[la[0]], s(atom_x)[la[1]]], -1), la_sh, out_nodes=nl, edge_weight=W["la"])
             do_atom = c.flexible_sidechains or l != L - 1
             do_rec = do_atom and l != L - 1
             if do_atom:
-                u3 = cv(3, atom_x, aa, torch.cat([aa_attr, s(atom_x)[aa[0]], s(atom_x)[aa[1]]], -1), aa_sh)
+                u3 = cv(3, atom_x, aa, torch.cat([aa_attr, s(atom_x)[aa[0]], s(atom_x)[aa[1]]], -1), aa_sh, edge_weight=W["aa"])
                 u4 = cv(4, lig_x, torch.flip(la, dims=[0]),
-                        torch.cat([la_attr, s(atom_x)[la[1]], s(lig_x)[la[0]]], -1), la_sh, out_nodes=na_)
+                        torch.cat([la_attr, s(atom_x)[la[1]], s(lig_x)[la[0]]], -1), la_sh, out_nodes=na_, edge_weight=W["la"])
                 u5 = cv(5, rec_x, ar, torch.cat([ar_attr, s(atom_x)[ar[0]], s(rec_x)[ar[1]]], -1), ar_sh, out_nodes=na_)
             if do_rec:
-                u6 = cv(6, rec_x, rr, torch.cat([rr_attr, s(rec_x)[rr[0]], s(rec_x)[rr[1]]], -1), rr_sh)
+                u6 = cv(6, rec_x, rr, torch.cat([rr_attr, s(rec_x)[rr[0]], s(rec_x)[rr[1]]], -1), rr_sh, edge_weight=W["rr"])
                 u7 = cv(7, lig_x, torch.flip(lr, dims=[0]),
-                        torch.cat([lr_attr, s(rec_x)[lr[1]], s(lig_x)[lr[0]]], -1), lr_sh, out_nodes=nr)
+                        torch.cat([lr_attr, s(rec_x)[lr[1]], s(lig_x)[lr[0]]], -1), lr_sh, out_nodes=nr, edge_weight=W["lr"])
                 u8 = cv(8, atom_x, torch.flip(ar, dims=[0]),
                         torch.cat([ar_attr, s(rec_x)[ar[1]], s(atom_x)[ar[0]]], -1), ar_sh, out_nodes=nr)
             d_out = tp.Irreps(oi).dim

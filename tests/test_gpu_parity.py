@@ -251,6 +251,38 @@ def test_graph_replay_equals_launch_by_launch(flex):
         assert torch.equal(l0, l1) and torch.equal(a0, a1)
 
 
+def test_smooth_edges_in_the_sampler_and_under_replay():
+    """smooth_edges (all_atom_score_model.py:438-442; parity: the goldens smooth_dyn / smooth_fixed in
+    test_forward_matches_oracle_and_golden): the edge weights are PyTorch launches on the harmonics behind ddp_edge_featurize.  In a
+    sampling batch (receptor-side sharing, forked front, captured step) the replayed steps must be bit for bit the launch-by-launch
+    ones - and the option must change the scores."""
+    import bench
+    from diffdock_pocket_amd.diffusion import get_t_schedule
+    from diffdock_pocket_amd.sampler import Sampler, SamplerConfig
+    from diffdock_pocket_amd.synthetic import make_3dpf_complex
+    dev = _dev()
+    sched = get_t_schedule(20)
+    g = make_3dpf_complex(seed=0, flexible_sidechains=True)
+    out = {}
+    for smooth, graph in ((True, False), (True, True), (False, True)):
+        model, kw = bench.build_model("cfg1", True, dev)
+        model.smooth_edges = smooth
+        smp = Sampler(model, g, 6, dev, SamplerConfig(inference_steps=20, flexible_sidechains=True, hip_graph=graph), seed=0)
+        smp.randomize()
+        first = [t.clone() for t in smp.scores(float(sched[0]))]
+        for i in range(5):
+            smp.step(i, sched)
+        assert bool(smp._graph) == graph
+        out[smooth, graph] = (first, smp.lig_pos.clone(), smp.atom_pos.clone(), [t.clone() for t in smp.scores(float(sched[5]))])
+        smp.close()
+        del smp, model
+    a, b = out[True, False], out[True, True]
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for x, y in zip(a[0] + a[3], b[0] + b[3]):
+        assert torch.equal(x, y)
+    assert not torch.equal(out[True, True][0][0], out[False, True][0][0])
+
+
 @pytest.mark.parametrize("name", ["cfg2_full_noflex", "cfg2_small", "small32_readme", "ns24_l3", "cfg1_full"])
 def test_fp16_split_products_against_the_fp32_mfma_form(name):
     """Round 4: the fc products of the conv kernels run on the fp16 matrix cores with both operands split in two halves

@@ -208,7 +208,7 @@ def test_state_dict_layout_matches_reference(name):
 
 def test_unsupported_configs_raise():
     case = CASES["cfg1_full"]
-    for bad in ({"sh_lmax": 2}, {"use_second_order_repr": True}, {"smooth_edges": True}, {"affinity_prediction": True, "confidence_mode": True}):
+    for bad in ({"sh_lmax": 2}, {"use_second_order_repr": True}, {"odd_parity": True}, {"affinity_prediction": True, "confidence_mode": True}):
         kw = dict(case.model_kwargs())
         kw.update(case.ctor_extras())
         kw.update(bad)
