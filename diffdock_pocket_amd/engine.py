@@ -139,6 +139,8 @@ class ForwardEngine:
         dev = lig.pos.device
         m._refresh_weight_caches()
         m.check_overflow()
+        if dev in self._forks:      # (a forward that raised may have left streams marked as forked: the next fork waits for main again)
+            self._forks[dev].used.clear()
         K.set_range_flag(m.overflow_flag(dev)[1:2])     # where this forward's h2 kernels report values outside the fp16 range
         mark = m.section_timer.mark if m.section_timer is not None else (lambda name: None)
         mark("start")
