@@ -100,7 +100,7 @@ def parse_args(argv=None):
                     help="diagnostic: the front's chains and the index lists one after the other (model.fork_front = False) for same-box A/B runs")
     ap.add_argument("--no-overlap-direct", action="store_true",
                     help="diagnostic: the serial launch order of the conv layers (model.overlap_direct_conv = False) for same-box A/B runs")
-    ap.add_argument("--layer-order", default=None, choices=["chains", "pipeline", "pipeline2"], help="diagnostic: model.layer_order for A/B runs")
+    ap.add_argument("--layer-order", default=None, choices=["chains", "pipeline", "pipeline2", "pipeline3", "pipeline4"], help="diagnostic: model.layer_order for A/B runs")
     ap.add_argument("--no-flex-sharing", action="store_true",
                     help="diagnostic: flexible side chains without the partial sharing of layers 0 / 1 (model.share_flex_layer0 = False)")
     return ap.parse_args(argv)

@@ -806,7 +806,10 @@ class ForwardEngine:
                      bound - runs on a side stream BESIDE stage A of layer l + 1 for the atom- and ligand-source rows (bound by
                      the HBM write of G): conv32(l) -> means{lig, atom}(l) -> [direct(l) | stage A(l+1){atom, lig sources}] ->
                      mean{rec}(l) -> stage A(l+1){rec sources} -> conv32(l+1).  The direct conv reads x_atom(l) as its source
-                     while the atom mean of layer l updates x_atom in place: it is given a snapshot (one 32-MB copy per layer)."""
+                     while the atom mean of layer l updates x_atom in place: it is given a snapshot (one 32-MB copy per layer).
+                     "pipeline3" / "pipeline4" (default) put whole chains on side streams: [direct(l) -> mean{rec}(l) -> stage
+                     A(l+1){rec sources}] and [mean{lig}(l) -> stage A(l+1){lig sources}] beside [mean{atom}(l) -> stage A(l+1){atom
+                     sources}]."""
         m = self.m
         ns, L_, B, ldx = m.ns, m.num_conv_layers, S.B, m._ldx
         Nl, Nr, Na = S.Nl, S.Nr, S.Na
@@ -1049,6 +1052,39 @@ class ForwardEngine:
                 if has_direct and xa_old is not None:
                     xa_old.copy_(xa)
                 P.xa_old = xa_old
+                if m.layer_order in ("pipeline3", "pipeline4"):
+                    # "pipeline3": the whole receptor chain on a side stream - direct conv(l) -> mean{rec}(l) -> stage A(l + 1) of the
+                    # receptor-source rows - beside stage A(l + 1) of the atom- and ligand-source rows (nothing on main reads or writes
+                    # x_rec meanwhile).  "pipeline4": the ligand chain - mean{lig}(l) -> stage A(l + 1) of the ligand-source rows - on a
+                    # side stream of its own as well, beside mean{atom}(l) -> stage A(l + 1) of the atom-source rows
+                    def rec_chain(P=P, nxt=nxt, has_direct=has_direct):
+                        if has_direct:
+                            launch_direct(P)
+                        means(P, "r")
+                        if nxt is not None:
+                            stage_a(nxt, "r")
+
+                    def lig_chain(P=P, nxt=nxt):
+                        means(P, "l")
+                        if nxt is not None:
+                            stage_a(nxt, "l")
+                    if m.layer_order == "pipeline4":
+                        if has_direct:      # (the direct conv reads the snapshot of x_atom: it need not wait for the means either)
+                            side.run(3, rec_chain)
+                        side.run(2, lig_chain)
+                        means(P, "a")
+                    else:
+                        means(P, "la")
+                        if has_direct:
+                            side.run(3, rec_chain)
+                    if nxt is not None:
+                        stage_a(nxt, "a" if m.layer_order == "pipeline4" else "la")
+                    if not has_direct:
+                        rec_chain()
+                    side.join()
+                    F.keep.append((P.keep, P.per, P.msgs, P.tasks, P.tasks_g, P.gmap, getattr(P, "xa_old", None)))
+                    P = nxt
+                    continue
                 means(P, "la")
                 if has_direct:
                     side.run(3, lambda: launch_direct(P))

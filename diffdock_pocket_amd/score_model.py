@@ -428,8 +428,11 @@ class TensorProductScoreModel(nn.Module):
         self.overlap_direct_conv = True
         # which overlapped order: "pipeline" = direct conv(l) beside stage A(l + 1); "chains" = per layer two forked chains (atom-source
         # stage A -> its convs | the other stage-A products -> their convs -> direct conv).  Same box, alternating, after the convs moved
-        # to the fp16 matrix cores: serial 20.48 - 20.51, chains 20.28 - 20.39, pipeline 20.22 - 20.25 ms per 40-sample step
-        self.layer_order = "pipeline"
+        # to the fp16 matrix cores: serial 20.48 - 20.51, chains 20.28 - 20.39, pipeline 20.22 - 20.25 ms per 40-sample step.
+        # "pipeline3": the receptor chain - direct conv(l) -> mean{rec}(l) -> stage A(l + 1) of the receptor-source rows - on the side
+        # stream (pipeline 20.07 -> 19.91 ms, flexible 24.47 -> 24.15); "pipeline4" (default): the ligand chain - mean{lig}(l) -> stage
+        # A(l + 1) of the ligand-source rows - on a side stream of its own too, the direct conv forked before the means (19.60 -> 19.51)
+        self.layer_order = "pipeline4"
         # The front's independent chains side by side (parallel branches of the captured step; same kernels, same arguments, same bits):
         # [node encoders -> edge embeddings] beside [neighbour searches -> CSR / source-ordered views], and - rigid receptor - the index
         # lists of the work eliminations (first read by layer 1) beside stage A + the 32-edge conv launch of layer 0 (engine._front,

@@ -361,7 +361,7 @@ def test_pipelined_layer_order_is_bitwise_the_serial_one(flex):
     sched = get_t_schedule(20)
     g = make_3dpf_complex(seed=0, flexible_sidechains=flex)
     out = {}
-    for order in ("serial", "pipeline", "pipeline2", "chains"):
+    for order in ("serial", "pipeline", "pipeline2", "pipeline3", "pipeline4", "chains"):
         model, kw = bench.build_model("cfg2", flex, dev)
         model.concurrent_max_atoms = 0
         model.overlap_direct_conv, model.layer_order = order != "serial", order
@@ -376,7 +376,7 @@ def test_pipelined_layer_order_is_bitwise_the_serial_one(flex):
         out[order] = res
         smp.close()
         del smp, model
-    for order in ("pipeline", "pipeline2", "chains"):
+    for order in ("pipeline", "pipeline2", "pipeline3", "pipeline4", "chains"):
         for a, b in zip(out["serial"], out[order]):
             for x, y in zip(a, b):
                 assert torch.equal(x, y), order
