@@ -98,6 +98,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-roofline-pass", action="store_true", help="skip the instrumented steps behind the timed region")
     ap.add_argument("--no-fork-front", action="store_true",
                     help="diagnostic: the front's chains and the index lists one after the other (model.fork_front = False) for same-box A/B runs")
+    ap.add_argument("--concurrent-max-atoms", type=int, default=None,
+                    help="diagnostic: model.concurrent_max_atoms (batches with more pocket atoms take the large-batch launch order) for A/B runs")
     ap.add_argument("--no-overlap-direct", action="store_true",
                     help="diagnostic: the serial launch order of the conv layers (model.overlap_direct_conv = False) for same-box A/B runs")
     ap.add_argument("--layer-order", default=None, choices=["chains", "pipeline", "pipeline2", "pipeline3", "pipeline4"], help="diagnostic: model.layer_order for A/B runs")
@@ -430,6 +432,8 @@ def main(argv=None):
         model.overlap_direct_conv = False
     if args.no_fork_front:
         model.fork_front = False
+    if args.concurrent_max_atoms is not None:
+        model.concurrent_max_atoms = args.concurrent_max_atoms
     if args.layer_order:
         model.layer_order = args.layer_order
     complex_graph = make_3dpf_complex(seed=0, flexible_sidechains=args.flex)
