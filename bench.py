@@ -557,7 +557,9 @@ def main(argv=None):
                 p = pmc.get(kname, {})
                 return {"kernel": kname, "bound": "hbm", "launches": n_, "avg_launch_ms": ms_ / n_, "achieved": gbs, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_mb_per_launch": by_ / n_ / 1e6,
-                        "ms_per_step": ms_ / 2.0, "measured": "2 extra steps (schedule positions 5, 15) behind the instrumented pass",
+                        "ms_per_step": ms_ / 2.0, "measured": "2 extra steps (schedule positions 5, 15) behind the instrumented pass; launches of "
+                        "the layer order's parallel chains overlap: a launch's time includes the share of the chip it left to the others "
+                        "(standalone rates: tools/bench_stage_a.py, DESIGN.md section 4.8), and ms_per_step sums overlapping launches",
                         "traffic": p.get("hbm_bytes_per_launch"), "mfma_busy_pmc": p.get("mfma_busy_frac")}
             roof["other_kernels"] += [e for e in (hbm_entry("ddp_stage_a_h2_kernel"), hbm_entry("ddp_stage_a_mfma_kernel"),
                                                   hbm_entry("ddp_segment_reduce4_kernel")) if e]

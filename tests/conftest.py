@@ -16,6 +16,15 @@ def pytest_configure(config):
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _cpu_threads():
+    """The CPU oracle's many small ops get SLOWER beyond ~32 threads on the GPU boxes' many-core hosts (bench.py's cpu_baseline uses
+    32: 2.4 s per full-size cfg2 graph against 5.5 s with every core): the parity tests' oracle forwards run on at most 32."""
+    import torch
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN_DIR
