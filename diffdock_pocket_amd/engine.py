@@ -1129,7 +1129,14 @@ class ForwardEngine:
                     o_k = torch.zeros((n_k, P.spec.d_out), device=dev)
                     K.launch_reduce(o_k, P.spec.d_out, n_k, P.spec.d_out, [ent], accumulate=False)
                     dbg[f"conv_layers.{9 * l + k}"] = o_k
-            means(P, "lar")
+            if fork is not None and m.fork_small_means:
+                # small batches: the three node types' segmented means are ~20-us launches on disjoint arrays: side by side
+                fork.run(0, lambda: means(P, "l"))
+                fork.run(1, lambda: means(P, "r"))
+                means(P, "a")
+                fork.join()
+            else:
+                means(P, "lar")
             mark("reduce")
             F.keep.append((P.keep, P.per, P.msgs, P.tasks, P.tasks_g, P.gmap))
 

@@ -423,6 +423,7 @@ class TensorProductScoreModel(nn.Module):
         # forked streams (engine._Fork); above this many pocket atoms in the batch every kernel fills the chip on its own
         self.concurrent_small_batches = True
         self.concurrent_max_atoms = 16000
+        self.fork_small_means = True     # ... and a layer's three segmented means (ligand / atom / receptor rows) side by side
         # Large batches (round 4): the direct conv of layer l (receptor<-atom) on a side stream beside stage A of layer l + 1 for the
         # atom- and ligand-source rows (engine._layers, "pipelined"); same kernels, same arguments, same bits as the serial order
         self.overlap_direct_conv = True

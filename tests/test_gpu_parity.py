@@ -405,6 +405,7 @@ def test_forked_front_is_bitwise_the_serial_one(flex, large):
         if large:
             model.concurrent_max_atoms = 0
         model.fork_front = ff
+        model.fork_small_means = ff      # (small batches: the three segmented means of a layer side by side)
         smp = Sampler(model, g, 6, dev, SamplerConfig(inference_steps=20, flexible_sidechains=flex), seed=0)
         smp.randomize()
         res = [[t.clone() for t in smp.scores(float(sched[0]))]]
