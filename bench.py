@@ -100,6 +100,7 @@ def parse_args(argv=None):
                     help="diagnostic: the front's chains and the index lists one after the other (model.fork_front = False) for same-box A/B runs")
     ap.add_argument("--concurrent-max-atoms", type=int, default=None,
                     help="diagnostic: model.concurrent_max_atoms (batches with more pocket atoms take the large-batch launch order) for A/B runs")
+    ap.add_argument("--no-fork-lists-flex", action="store_true", help="diagnostic: model.fork_lists_flex = False (A/B runs)")
     ap.add_argument("--no-fork-means", action="store_true", help="diagnostic: model.fork_small_means = False (A/B runs)")
     ap.add_argument("--no-overlap-direct", action="store_true",
                     help="diagnostic: the serial launch order of the conv layers (model.overlap_direct_conv = False) for same-box A/B runs")
@@ -433,6 +434,8 @@ def main(argv=None):
         model.overlap_direct_conv = False
     if args.no_fork_front:
         model.fork_front = False
+    if args.no_fork_lists_flex:
+        model.fork_lists_flex = False
     if args.no_fork_means:
         model.fork_small_means = False
     if args.concurrent_max_atoms is not None:

@@ -155,14 +155,11 @@ class ForwardEngine:
         F = self._front(data, S, lig, rec, atom, dev, mark, ff)
         # The index lists read graph structure only.  Rigid receptor: layer 1 is their first reader, so they run on a stream of
         # their own beside stage A and the 32-edge conv launch of layer 0 (_layers joins them); with flexible side chains layer 0
-        # reads them (F.flex0).  (Launch by launch in round 3 this was measured without gain - 33.0 ms either way, cfg1 x 4
+        # reads the flex0 lists, which stay on the main stream with the layer-1 lists that build on them - the pruned lists of the
+        # last layers still go to the side stream (_lists).  (Launch by launch in round 3 this was measured without gain - 33.0 ms either way, cfg1 x 4
         # samples 1.6 -> 1.9 ms of host time; as a branch of the captured step it is free.)
-        F.lists_fork = None
-        if ff is not None and S.num_flex == 0:
-            ff.run(4, lambda: self._lists(S, F, dev))
-            F.lists_fork = ff
-        else:
-            self._lists(S, F, dev)
+        F.lists_fork = ff
+        self._lists(S, F, dev, side=(lambda fn: ff.run(4, fn)) if ff is not None else None)
         mark("lists")
         if m.exact_sizes:
             self._exact(F)
@@ -518,7 +515,7 @@ class ForwardEngine:
         return F
 
     # ================================================================================================ index lists
-    def _lists(self, S, F, dev):
+    def _lists(self, S, F, dev, side=None):
         """Index lists of the exact work eliminations, built on the device from graph STRUCTURE only (no features)."""
         m = self.m
         L_, B = m.num_conv_layers, S.B
@@ -527,6 +524,7 @@ class ForwardEngine:
         i32e = lambda n: torch.empty(n, dtype=torch.int32, device=dev)      # noqa: E731
         # (every zero-initialised mask of this function is a slice of ONE zero-filled block: one launch)
         zpool = [torch.zeros(6 * (Na + Nr) + Na + 64, dtype=torch.int32, device=dev), 0]
+        F.keep.append(zpool)      # (allocated on this stream, read and written by the forked part: alive until the forward has joined it)
 
         def i32z(n):
             if zpool[1] + n > zpool[0].numel():
@@ -540,187 +538,204 @@ class ForwardEngine:
         dbg = m.debug_conv_outputs is not None
         E_aa = c[3].n_edges
 
-        # ---- Dead-output elimination over the last layers.  What is read after the last layer: all ligand features (heads),
-        # with flexible side chains the atom features around the flexible bonds (side-chain torsion head), nothing of the
-        # receptor.  Walking backwards, a layer's receptor-side convs only have to produce the rows that are still read
-        # (by the residual of a needed node or as source / receiver of a kept edge of the next layer), so their edge lists
-        # are restricted to the edges that END in a needed node - exact, the other rows of x are simply left stale.
-        # Without flexible side chains this prunes layer L-2 (its atom outputs feed only the final ligand<-atom conv), with
-        # them layers L-1 and L-2; earlier layers feed (almost) everything and run in full.  Layer 0 is never touched.
-        prune_on = (m.prune_last_receptor_layer and L_ >= 2 and not m.confidence_mode and not dbg and E_aa >= m.plan_min_edges
-                    and not (m.flexible_sidechains and F.sc is None))
-        if prune_on:
-            layers = [l for l in (L_ - 1, L_ - 2) if l >= 1 and (l != L_ - 1 or m.flexible_sidechains)]
-            need = {"a": i32z(Na), "r": i32z(Nr)}
-            if F.sc is not None:    # the side-chain head reads the atoms of the flexible bonds and the atoms around them
-                K.mark_jobs([K.mark_job(need["a"], F.sc.st.flat32, 2 * F.sc.st.T),
-                             K.mark_job(need["a"], F.sc.csr.src, F.sc.csr.n_edges, cnt["sc"])])
-            else:                   # layer L-1 (ligand-receiving convs only): sources of ligand<-atom / ligand<-receptor
-                K.mark_jobs([K.mark_job(need["a"], c[2].src, c[2].n_edges, cnt["la"]),
-                             K.mark_job(need["r"], c[1].src, c[1].n_edges, cnt["lr"])])
-            for l in layers:
-                act = {"a": m.flexible_sidechains or l != L_ - 1}
-                act["r"] = act["a"] and l != L_ - 1
-                scans, copies, pl = [], [], {}
-                for rt in ("a", "r"):
-                    if not act[rt]:
-                        continue
-                    for k in RECV_OF[rt]:
-                        full = c[k]
-                        if full.n_edges == 0:
+        def prune():
+            # ---- Dead-output elimination over the last layers.  What is read after the last layer: all ligand features (heads),
+            # with flexible side chains the atom features around the flexible bonds (side-chain torsion head), nothing of the
+            # receptor.  Walking backwards, a layer's receptor-side convs only have to produce the rows that are still read
+            # (by the residual of a needed node or as source / receiver of a kept edge of the next layer), so their edge lists
+            # are restricted to the edges that END in a needed node - exact, the other rows of x are simply left stale.
+            # Without flexible side chains this prunes layer L-2 (its atom outputs feed only the final ligand<-atom conv), with
+            # them layers L-1 and L-2; earlier layers feed (almost) everything and run in full.  Layer 0 is never touched.
+            prune_on = (m.prune_last_receptor_layer and L_ >= 2 and not m.confidence_mode and not dbg and E_aa >= m.plan_min_edges
+                        and not (m.flexible_sidechains and F.sc is None))
+            if prune_on:
+                layers = [l for l in (L_ - 1, L_ - 2) if l >= 1 and (l != L_ - 1 or m.flexible_sidechains)]
+                need = {"a": i32z(Na), "r": i32z(Nr)}
+                if F.sc is not None:    # the side-chain head reads the atoms of the flexible bonds and the atoms around them
+                    K.mark_jobs([K.mark_job(need["a"], F.sc.st.flat32, 2 * F.sc.st.T),
+                                 K.mark_job(need["a"], F.sc.csr.src, F.sc.csr.n_edges, cnt["sc"])])
+                else:                   # layer L-1 (ligand-receiving convs only): sources of ligand<-atom / ligand<-receptor
+                    K.mark_jobs([K.mark_job(need["a"], c[2].src, c[2].n_edges, cnt["la"]),
+                                 K.mark_job(need["r"], c[1].src, c[1].n_edges, cnt["lr"])])
+                for l in layers:
+                    act = {"a": m.flexible_sidechains or l != L_ - 1}
+                    act["r"] = act["a"] and l != L_ - 1
+                    scans, copies, pl = [], [], {}
+                    for rt in ("a", "r"):
+                        if not act[rt]:
                             continue
-                        name = f"p{l}_{k}"
-                        n = n_of[rt]
-                        v = EdgeView(full.n_edges, i32e(full.n_edges), i32e(full.n_edges), i32e(full.n_edges), rowptr=i32e(n + 1), cnt=cnt[name])
-                        scans.append(K.scan_job(n, flag=need[rt], rowptr=full.rowptr, excl=v.rowptr, total=cnt[name]))
-                        copies.append(K.rowcopy_job(n, need[rt], full.rowptr, v.rowptr, [full.recv, full.src, full.eid], [v.recv, v.src, v.eid]))
-                        pl[k] = v
-                K.scan_jobs(scans)
-                K.rowcopy_jobs(copies)
-                F.pruned[l] = pl
-                # source rows of this layer's factorised convs per source-node array (stage A runs on them only) ...
-                rows_mask = {"a": i32z(Na), "r": i32z(Nr)}
-                marks = []
-                for k in range(9):
-                    rt, st_ = RECV_TYPE[k], SRC_TYPE[k]
-                    if st_ == "l" or k == 2 or k not in F.fact or (rt != "l" and not act[rt]):
-                        continue
-                    vw = pl.get(k, c[k])
-                    if vw.n_edges > 0:
-                        marks.append(K.mark_job(rows_mask[st_], vw.src, vw.n_edges, vw.cnt))
-                # ... and the rows the NEXT (earlier) pruned layer has to produce: the needed rows themselves (residual) and the
-                # sources of every kept edge of this layer
-                nxt = None
-                if l != layers[-1]:
-                    nxt = {"a": need["a"].clone(), "r": need["r"].clone()}
+                        for k in RECV_OF[rt]:
+                            full = c[k]
+                            if full.n_edges == 0:
+                                continue
+                            name = f"p{l}_{k}"
+                            n = n_of[rt]
+                            v = EdgeView(full.n_edges, i32e(full.n_edges), i32e(full.n_edges), i32e(full.n_edges), rowptr=i32e(n + 1), cnt=cnt[name])
+                            scans.append(K.scan_job(n, flag=need[rt], rowptr=full.rowptr, excl=v.rowptr, total=cnt[name]))
+                            copies.append(K.rowcopy_job(n, need[rt], full.rowptr, v.rowptr, [full.recv, full.src, full.eid], [v.recv, v.src, v.eid]))
+                            pl[k] = v
+                    K.scan_jobs(scans)
+                    K.rowcopy_jobs(copies)
+                    F.pruned[l] = pl
+                    # source rows of this layer's factorised convs per source-node array (stage A runs on them only) ...
+                    rows_mask = {"a": i32z(Na), "r": i32z(Nr)}
+                    marks = []
                     for k in range(9):
                         rt, st_ = RECV_TYPE[k], SRC_TYPE[k]
-                        if st_ == "l" or (rt != "l" and not act[rt]):
+                        if st_ == "l" or k == 2 or k not in F.fact or (rt != "l" and not act[rt]):
                             continue
                         vw = pl.get(k, c[k])
                         if vw.n_edges > 0:
-                            marks.append(K.mark_job(nxt[st_], vw.src, vw.n_edges, vw.cnt))
+                            marks.append(K.mark_job(rows_mask[st_], vw.src, vw.n_edges, vw.cnt))
+                    # ... and the rows the NEXT (earlier) pruned layer has to produce: the needed rows themselves (residual) and the
+                    # sources of every kept edge of this layer
+                    nxt = None
+                    if l != layers[-1]:
+                        nxt = {"a": need["a"].clone(), "r": need["r"].clone()}
+                        for k in range(9):
+                            rt, st_ = RECV_TYPE[k], SRC_TYPE[k]
+                            if st_ == "l" or (rt != "l" and not act[rt]):
+                                continue
+                            vw = pl.get(k, c[k])
+                            if vw.n_edges > 0:
+                                marks.append(K.mark_job(nxt[st_], vw.src, vw.n_edges, vw.cnt))
+                    K.mark_jobs(marks)
+                    lists = {}
+                    scans = []
+                    for t in ("a", "r"):
+                        rows = i32e(n_of[t])
+                        scans.append(K.scan_job(n_of[t], flag=rows_mask[t], lst=rows, total=cnt[f"rows{l}_{t}"]))
+                        lists[t] = (rows, cnt[f"rows{l}_{t}"])
+                    K.scan_jobs(scans)
+                    F.rows_a[l] = lists
+                    if nxt is not None:
+                        need = nxt
+                # source-ordered views of the pruned factorised convs: one batched grouping call
+                gj = []
+                for l, pl in F.pruned.items():
+                    for k, v in pl.items():
+                        if k in F.fact:
+                            n_keys = n_of[SRC_TYPE[k]]
+                            w = SimpleNamespace(rp=i32e(n_keys + 1), perm=i32e(v.n_edges), key=i32e(v.n_edges), o0=i32e(v.n_edges), o1=i32e(v.n_edges))
+                            gj.append(K.group_job(v.src, v.n_edges, n_keys, [v.recv, v.eid], w.rp, w.perm, w.key, [w.o0, w.o1],
+                                                  i32e(n_keys + v.n_edges), n_dev=v.cnt))
+                            F.pruned_so.setdefault(l, {})[k] = EdgeView(v.n_edges, w.o0, w.key, w.o1, pos=w.perm, cnt=v.cnt)
+                K.group_jobs(gj)
+                F.keep.append(gj)
+
+        def flex0():
+            # ---- Layer 0 with flexible side chains (N poses of one complex, only the flexible residues' side chains differ between
+            # the samples).  The node features entering layer 0 are the same in every sample (one diffusion time), so the message
+            # of an edge is the same wherever its two ends sit where they sit in sample 0.  The atom graph is a kNN graph: the edge
+            # r <- q exists because r is one of the k nearest atoms of the QUERY q (reference :524; receivers have no fixed degree).
+            # "Moved" = position differs from sample 0's.  (1) If q and every member of q's list in sample s AND in sample 0 is
+            # unmoved in s, both lists are the k nearest unmoved atoms around q at identical distances: equal, entry by entry.
+            # (2) A receiver r none of whose incoming edges - in sample s or in sample 0 - leaves a query failing (1) therefore has
+            # the same incoming edges, in the same order (edges are listed by query), with the same geometry as its copy in sample 0
+            # (a moved r fails: every query that found it fails (1)).  Such receivers read sample 0's messages through a row map;
+            # sample 0 and the marked receivers of the other samples are computed (pruned-list machinery: stage A runs on the kept
+            # edges' source rows only).  atom<-receptor (one edge per atom) uses the same receiver marks (a superset of the moved
+            # atoms); receptor<-atom: a residue needs its own messages if one of its atoms moved.
+            # Bitwise the general path (tests/test_gpu_parity.py::test_flexible_layer0_sharing_is_exact).
+            F.flex0 = None
+            fx = getattr(F, "flex_static", None)
+            kk = m.atom_max_neighbors if m.atom_max_neighbors else 32
+            if (fx is not None and m.share_flex_layer0 and S.num_flex > 0 and not dbg and 0 not in F.pruned and L_ >= 2
+                    and 3 in F.fact and 5 in F.fact and E_aa == Na * kk and E_aa % B == 0 and E_aa >= m.plan_min_edges
+                    and E_aa * m.ns >= m.flex_share_min_work):
+                na, e_ar, nr = fx
+                e0 = E_aa // B
+                qdirty, dirty, need_r = i32z(Na), i32z(Na), i32z(Nr)
+                # pass 1, per QUERY atom q (the source end: edge r <- q exists because r is one of q's k nearest): q's list may differ
+                # from sample 0's, or carries other geometry, if q or a member of its list - here or in sample 0 - moved
+                K.flex_mark(c[3].src, c[3].recv, E_aa, e0, na, na, qdirty, pos=F.apos, a_too=True, ref_list=True)
+                # pass 2, per RECEIVER r: its incoming edges are those of its copy in sample 0 unless one of them - here or there -
+                # leaves such a query (r moved itself: then every query that found it is marked, and r with them)
+                K.flex_mark(c[3].recv, c[3].src, E_aa, e0, na, na, dirty, flag=qdirty, a_too=True, ref_list=True)
+                K.flex_mark(c[8].recv, c[8].src, c[8].n_edges, e_ar, nr, na, need_r, pos=F.apos)
+                scans, copies, pl, rowmaps = [], [], {}, {}
+                for k, need, n in ((3, dirty, Na), (5, dirty, Na), (8, need_r, Nr)):
+                    full = c[k]
+                    v = EdgeView(full.n_edges, i32e(full.n_edges), i32e(full.n_edges), i32e(full.n_edges), rowptr=i32e(n + 1), cnt=cnt[f"fx_{k}"])
+                    scans.append(K.scan_job(n, flag=need, rowptr=full.rowptr, excl=v.rowptr, total=cnt[f"fx_{k}"]))
+                    copies.append(K.rowcopy_job(n, need, full.rowptr, v.rowptr, [full.recv, full.src, full.eid], [v.recv, v.src, v.eid]))
+                    pl[k] = v
+                K.scan_jobs(scans)
+                K.rowcopy_jobs(copies)
+                for k, need, n_per in ((3, dirty, na), (5, dirty, na), (8, need_r, nr)):
+                    rowmaps[k] = i32e(c[k].n_edges)
+                    K.fallback_rowmap(need, c[k].recv, c[k].rowptr, pl[k].rowptr, c[k].n_edges, n_per, rowmaps[k])
+                # source rows stage A has to produce: atoms for atom<-atom, residues for atom<-receptor and ligand<-receptor
+                rows_mask = {"a": i32z(Na), "r": i32z(Nr)}
+                marks = [K.mark_job(rows_mask["a"], pl[3].src, pl[3].n_edges, pl[3].cnt),
+                         K.mark_job(rows_mask["r"], pl[5].src, pl[5].n_edges, pl[5].cnt)]
+                if 1 in F.fact and c[1].n_edges > 0:
+                    marks.append(K.mark_job(rows_mask["r"], c[1].src, c[1].n_edges, c[1].cnt))
                 K.mark_jobs(marks)
-                lists = {}
-                scans = []
+                lists, scans = {}, []
                 for t in ("a", "r"):
                     rows = i32e(n_of[t])
-                    scans.append(K.scan_job(n_of[t], flag=rows_mask[t], lst=rows, total=cnt[f"rows{l}_{t}"]))
-                    lists[t] = (rows, cnt[f"rows{l}_{t}"])
+                    scans.append(K.scan_job(n_of[t], flag=rows_mask[t], lst=rows, total=cnt[f"rows0_{t}"]))
+                    lists[t] = (rows, cnt[f"rows0_{t}"])
                 K.scan_jobs(scans)
-                F.rows_a[l] = lists
-                if nxt is not None:
-                    need = nxt
-            # source-ordered views of the pruned factorised convs: one batched grouping call
-            gj = []
-            for l, pl in F.pruned.items():
-                for k, v in pl.items():
-                    if k in F.fact:
-                        n_keys = n_of[SRC_TYPE[k]]
-                        w = SimpleNamespace(rp=i32e(n_keys + 1), perm=i32e(v.n_edges), key=i32e(v.n_edges), o0=i32e(v.n_edges), o1=i32e(v.n_edges))
-                        gj.append(K.group_job(v.src, v.n_edges, n_keys, [v.recv, v.eid], w.rp, w.perm, w.key, [w.o0, w.o1],
-                                              i32e(n_keys + v.n_edges), n_dev=v.cnt))
-                        F.pruned_so.setdefault(l, {})[k] = EdgeView(v.n_edges, w.o0, w.key, w.o1, pos=w.perm, cnt=v.cnt)
-            K.group_jobs(gj)
-            F.keep.append(gj)
+                gj, pso = [], {}
+                for k in (3, 5):
+                    v = pl[k]
+                    n_keys = n_of[SRC_TYPE[k]]
+                    w = SimpleNamespace(rp=i32e(n_keys + 1), perm=i32e(v.n_edges), key=i32e(v.n_edges), o0=i32e(v.n_edges), o1=i32e(v.n_edges))
+                    gj.append(K.group_job(v.src, v.n_edges, n_keys, [v.recv, v.eid], w.rp, w.perm, w.key, [w.o0, w.o1],
+                                          i32e(n_keys + v.n_edges), n_dev=v.cnt))
+                    pso[k] = EdgeView(v.n_edges, w.o0, w.key, w.o1, pos=w.perm, cnt=v.cnt)
+                K.group_jobs(gj)
+                F.keep.append(gj)
+                F.pruned[0], F.pruned_so[0], F.rows_a[0] = pl, pso, lists
+                F.flex0 = SimpleNamespace(dirty=dirty, need_r=need_r, rowmaps=rowmaps, na=na, e0=e0)
 
-        # ---- Layer 0 with flexible side chains (N poses of one complex, only the flexible residues' side chains differ between
-        # the samples).  The node features entering layer 0 are the same in every sample (one diffusion time), so the message
-        # of an edge is the same wherever its two ends sit where they sit in sample 0.  The atom graph is a kNN graph: the edge
-        # r <- q exists because r is one of the k nearest atoms of the QUERY q (reference :524; receivers have no fixed degree).
-        # "Moved" = position differs from sample 0's.  (1) If q and every member of q's list in sample s AND in sample 0 is
-        # unmoved in s, both lists are the k nearest unmoved atoms around q at identical distances: equal, entry by entry.
-        # (2) A receiver r none of whose incoming edges - in sample s or in sample 0 - leaves a query failing (1) therefore has
-        # the same incoming edges, in the same order (edges are listed by query), with the same geometry as its copy in sample 0
-        # (a moved r fails: every query that found it fails (1)).  Such receivers read sample 0's messages through a row map;
-        # sample 0 and the marked receivers of the other samples are computed (pruned-list machinery: stage A runs on the kept
-        # edges' source rows only).  atom<-receptor (one edge per atom) uses the same receiver marks (a superset of the moved
-        # atoms); receptor<-atom: a residue needs its own messages if one of its atoms moved.
-        # Bitwise the general path (tests/test_gpu_parity.py::test_flexible_layer0_sharing_is_exact).
-        F.flex0 = None
-        fx = getattr(F, "flex_static", None)
-        kk = m.atom_max_neighbors if m.atom_max_neighbors else 32
-        if (fx is not None and m.share_flex_layer0 and S.num_flex > 0 and not dbg and 0 not in F.pruned and L_ >= 2
-                and 3 in F.fact and 5 in F.fact and E_aa == Na * kk and E_aa % B == 0 and E_aa >= m.plan_min_edges
-                and E_aa * m.ns >= m.flex_share_min_work):
-            na, e_ar, nr = fx
-            e0 = E_aa // B
-            qdirty, dirty, need_r = i32z(Na), i32z(Na), i32z(Nr)
-            # pass 1, per QUERY atom q (the source end: edge r <- q exists because r is one of q's k nearest): q's list may differ
-            # from sample 0's, or carries other geometry, if q or a member of its list - here or in sample 0 - moved
-            K.flex_mark(c[3].src, c[3].recv, E_aa, e0, na, na, qdirty, pos=F.apos, a_too=True, ref_list=True)
-            # pass 2, per RECEIVER r: its incoming edges are those of its copy in sample 0 unless one of them - here or there -
-            # leaves such a query (r moved itself: then every query that found it is marked, and r with them)
-            K.flex_mark(c[3].recv, c[3].src, E_aa, e0, na, na, dirty, flag=qdirty, a_too=True, ref_list=True)
-            K.flex_mark(c[8].recv, c[8].src, c[8].n_edges, e_ar, nr, na, need_r, pos=F.apos)
-            scans, copies, pl, rowmaps = [], [], {}, {}
-            for k, need, n in ((3, dirty, Na), (5, dirty, Na), (8, need_r, Nr)):
-                full = c[k]
-                v = EdgeView(full.n_edges, i32e(full.n_edges), i32e(full.n_edges), i32e(full.n_edges), rowptr=i32e(n + 1), cnt=cnt[f"fx_{k}"])
-                scans.append(K.scan_job(n, flag=need, rowptr=full.rowptr, excl=v.rowptr, total=cnt[f"fx_{k}"]))
-                copies.append(K.rowcopy_job(n, need, full.rowptr, v.rowptr, [full.recv, full.src, full.eid], [v.recv, v.src, v.eid]))
-                pl[k] = v
-            K.scan_jobs(scans)
-            K.rowcopy_jobs(copies)
-            for k, need, n_per in ((3, dirty, na), (5, dirty, na), (8, need_r, nr)):
-                rowmaps[k] = i32e(c[k].n_edges)
-                K.fallback_rowmap(need, c[k].recv, c[k].rowptr, pl[k].rowptr, c[k].n_edges, n_per, rowmaps[k])
-            # source rows stage A has to produce: atoms for atom<-atom, residues for atom<-receptor and ligand<-receptor
-            rows_mask = {"a": i32z(Na), "r": i32z(Nr)}
-            marks = [K.mark_job(rows_mask["a"], pl[3].src, pl[3].n_edges, pl[3].cnt),
-                     K.mark_job(rows_mask["r"], pl[5].src, pl[5].n_edges, pl[5].cnt)]
-            if 1 in F.fact and c[1].n_edges > 0:
-                marks.append(K.mark_job(rows_mask["r"], c[1].src, c[1].n_edges, c[1].cnt))
-            K.mark_jobs(marks)
-            lists, scans = {}, []
-            for t in ("a", "r"):
-                rows = i32e(n_of[t])
-                scans.append(K.scan_job(n_of[t], flag=rows_mask[t], lst=rows, total=cnt[f"rows0_{t}"]))
-                lists[t] = (rows, cnt[f"rows0_{t}"])
-            K.scan_jobs(scans)
-            gj, pso = [], {}
-            for k in (3, 5):
-                v = pl[k]
-                n_keys = n_of[SRC_TYPE[k]]
-                w = SimpleNamespace(rp=i32e(n_keys + 1), perm=i32e(v.n_edges), key=i32e(v.n_edges), o0=i32e(v.n_edges), o1=i32e(v.n_edges))
-                gj.append(K.group_job(v.src, v.n_edges, n_keys, [v.recv, v.eid], w.rp, w.perm, w.key, [w.o0, w.o1],
-                                      i32e(n_keys + v.n_edges), n_dev=v.cnt))
-                pso[k] = EdgeView(v.n_edges, w.o0, w.key, w.o1, pos=w.perm, cnt=v.cnt)
-            K.group_jobs(gj)
-            F.keep.append(gj)
-            F.pruned[0], F.pruned_so[0], F.rows_a[0] = pl, pso, lists
-            F.flex0 = SimpleNamespace(dirty=dirty, need_r=need_r, rowmaps=rowmaps, na=na, e0=e0)
+        def clean1():
+            # ---- Layer 1, atom<-atom, sampling batches of one rigid complex (shared0 has conv 3): after the shared layer 0 an
+            # atom's features differ between the samples only if an atom<-ligand message reached it ("touched", the atoms within
+            # 5 A of that sample's ligand, ~15 %).  A layer-1 atom<-atom message between two untouched atoms is therefore the same
+            # in every sample: those messages are computed ONCE on the complex's own edge list (e0 edges, rows [E, E + e0) of
+            # the message array) and the segmented mean reads them through a row map; only the edges with a touched end are
+            # computed per sample (source-ordered sub-list, stage A on their source rows only).  Messages of a clean pair are
+            # bitwise those the general path computes (same inputs, per-edge arithmetic), the mean sums the same values in the
+            # same order: the result is bitwise the general path's (GPU test).  Layer 1 must not be one of the pruned layers.
+            # With flexible side chains (F.flex0): the same, with "touched" widened by the receivers layer 0 computed per sample.
+            if (m.share_clean_layer1 and (3 in F.shared0 or F.flex0 is not None) and 3 in so and L_ >= 4 and E_aa > 0
+                    and E_aa >= m.plan_min_edges and not dbg and 1 not in F.pruned):
+                if F.flex0 is not None:
+                    n0, e0 = F.flex0.na, F.flex0.e0
+                    F.touched_l1 = F.touched + F.flex0.dirty
+                else:
+                    n0, e0, _ = F.shared0[3]
+                    F.touched_l1 = F.touched
+                so3 = so[3]
+                d = SimpleNamespace(recv=i32e(E_aa), src=i32e(E_aa), eid=i32e(E_aa), pos=i32e(E_aa))
+                K.select_jobs([K.select_job(E_aa, F.touched_l1, so3.recv, F.touched_l1, so3.src, [so3.recv, so3.src, so3.eid, so3.pos],
+                                            [d.recv, d.src, d.eid, d.pos], cnt["dirty"], i32e(2 * ((E_aa + 2047) // 2048) + 1))])
+                so_d = EdgeView(E_aa, d.recv, d.src, d.eid, pos=d.pos, cnt=cnt["dirty"])
+                mask, rows_d = i32z(Na), i32e(Na)
+                K.mark_jobs([K.mark_job(mask, d.src, E_aa, cnt["dirty"])])
+                K.scan_jobs([K.scan_job(Na, flag=mask, lst=rows_d, total=cnt["rows_dirty"])])
+                rowmap, rows_v = i32e(E_aa), i32e(n0)
+                K.clean_pair_maps(F.touched_l1, c[3].recv, c[3].src, E_aa, e0, B, n0, rowmap, rows_v, rowptr=c[3].rowptr if F.flex0 is not None else None)
+                so_v = m._cached(f"so_v{e0}", (so3.pos,), lambda: G.SourceOrder(e0, so3.recv[:e0], so3.src[:e0], so3.eid[:e0], (so3.pos[:e0] + E_aa).contiguous()))
+                F.clean1 = SimpleNamespace(so_d=so_d, rows_d=rows_d, rows_d_cnt=cnt["rows_dirty"], rowmap=rowmap, so_v=so_v, rows_v=rows_v,
+                                           E=E_aa, e0=e0, n0=n0)
 
-        # ---- Layer 1, atom<-atom, sampling batches of one rigid complex (shared0 has conv 3): after the shared layer 0 an
-        # atom's features differ between the samples only if an atom<-ligand message reached it ("touched", the atoms within
-        # 5 A of that sample's ligand, ~15 %).  A layer-1 atom<-atom message between two untouched atoms is therefore the same
-        # in every sample: those messages are computed ONCE on the complex's own edge list (e0 edges, rows [E, E + e0) of
-        # the message array) and the segmented mean reads them through a row map; only the edges with a touched end are
-        # computed per sample (source-ordered sub-list, stage A on their source rows only).  Messages of a clean pair are
-        # bitwise those the general path computes (same inputs, per-edge arithmetic), the mean sums the same values in the
-        # same order: the result is bitwise the general path's (GPU test).  Layer 1 must not be one of the pruned layers.
-        # With flexible side chains (F.flex0): the same, with "touched" widened by the receivers layer 0 computed per sample.
-        if (m.share_clean_layer1 and (3 in F.shared0 or F.flex0 is not None) and 3 in so and L_ >= 4 and E_aa > 0
-                and E_aa >= m.plan_min_edges and not dbg and 1 not in F.pruned):
-            if F.flex0 is not None:
-                n0, e0 = F.flex0.na, F.flex0.e0
-                F.touched_l1 = F.touched + F.flex0.dirty
-            else:
-                n0, e0, _ = F.shared0[3]
-                F.touched_l1 = F.touched
-            so3 = so[3]
-            d = SimpleNamespace(recv=i32e(E_aa), src=i32e(E_aa), eid=i32e(E_aa), pos=i32e(E_aa))
-            K.select_jobs([K.select_job(E_aa, F.touched_l1, so3.recv, F.touched_l1, so3.src, [so3.recv, so3.src, so3.eid, so3.pos],
-                                        [d.recv, d.src, d.eid, d.pos], cnt["dirty"], i32e(2 * ((E_aa + 2047) // 2048) + 1))])
-            so_d = EdgeView(E_aa, d.recv, d.src, d.eid, pos=d.pos, cnt=cnt["dirty"])
-            mask, rows_d = i32z(Na), i32e(Na)
-            K.mark_jobs([K.mark_job(mask, d.src, E_aa, cnt["dirty"])])
-            K.scan_jobs([K.scan_job(Na, flag=mask, lst=rows_d, total=cnt["rows_dirty"])])
-            rowmap, rows_v = i32e(E_aa), i32e(n0)
-            K.clean_pair_maps(F.touched_l1, c[3].recv, c[3].src, E_aa, e0, B, n0, rowmap, rows_v, rowptr=c[3].rowptr if F.flex0 is not None else None)
-            so_v = m._cached(f"so_v{e0}", (so3.pos,), lambda: G.SourceOrder(e0, so3.recv[:e0], so3.src[:e0], so3.eid[:e0], (so3.pos[:e0] + E_aa).contiguous()))
-            F.clean1 = SimpleNamespace(so_d=so_d, rows_d=rows_d, rows_d_cnt=cnt["rows_dirty"], rowmap=rowmap, so_v=so_v, rows_v=rows_v,
-                                       E=E_aa, e0=e0, n0=n0)
+        # The three parts read graph structure only.  Rigid receptor: all of them on the forked stream (`side`, _forward); with
+        # flexible side chains layer 0 reads the flex0 lists: those and the layer-1 lists (which build on them) stay on the
+        # current stream, the pruned lists of the last layers - independent of both - go to the forked one
+        if side is not None and S.num_flex > 0 and m.fork_lists_flex:
+            side(prune)
+            flex0()
+            clean1()
+        elif side is not None and S.num_flex == 0:
+            side(lambda: (prune(), flex0(), clean1()))
+        else:
+            prune()
+            flex0()
+            clean1()
 
     def _exact(self, F):
         """Test mode (`model.exact_sizes`): every device-side count is read back and every list cut to its actual length, so

@@ -439,6 +439,7 @@ class TensorProductScoreModel(nn.Module):
         # lists of the work eliminations (first read by layer 1) beside stage A + the 32-edge conv launch of layer 0 (engine._front,
         # engine._forward)
         self.fork_front = True
+        self.fork_lists_flex = True     # flexible side chains: the pruned lists of the last layers beside the layer-0 / layer-1 lists
         self.concurrent_heads = True   # the torsion read-outs on forked streams beside the tr / rot read-out (any batch size)
         # Option, OFF: stage A on the bf16 matrix cores with both operands split into three bfloat16 terms (csrc/ddp_gemm.hip,
         # ddp_stage_a_x3_kernel): fp32-class accuracy (error <= 2^-21 sum |x w|, measured against fp64 in
