@@ -216,6 +216,7 @@ class Sampler:
         self.upd = {"tr": torch.zeros(n, 3, device=dev), "rot": torch.zeros(n, 3, device=dev),
                     "tor": torch.zeros(n, T, device=dev) if T > 0 else None, "sc": torch.zeros(n, S_, device=dev) if S_ > 0 else None}
         self._views = {}
+        self._pin = None
         self._bind_batch()
 
     def _bind_batch(self):
@@ -283,13 +284,12 @@ class Sampler:
         return t, coef, noise_off
 
     def _upload_step(self, t_idx, schedule):
-        """Time, coefficients and noise of the step -> the device buffer: one asynchronous copy from a fresh pinned block (the
-        pinned allocator does not hand the block out again before the copy has run; a copy from pageable memory would make the
-        host wait for the stream to drain).  Noise is drawn for ALL samples of the job from the seeded generator - in the
+        """Time, coefficients and noise of the step -> the device buffer: one asynchronous copy from a pinned row (_pinned_row; a
+        copy from pageable memory would make the host wait for the stream to drain).  Noise is drawn for ALL samples of the job from the seeded generator - in the
         reference loop's order tr, rot, tor, side chains - and sliced to this shard."""
         cfg, N, sl, n = self.cfg, self.n_total, self.slice, self.n
         t, coef, noise_off = self._step_coefficients(t_idx, schedule)
-        host = torch.empty(self._n_par, pin_memory=True)
+        host = self._pinned_row()
         host[0] = t
         host[1:8] = 0.0
         host[8:16] = torch.tensor(coef, dtype=torch.float64).float()
@@ -306,6 +306,25 @@ class Sampler:
         if self.z_sc is not None:
             z((N, self.S), "z_sc", self.S)
         self.params.copy_(host, non_blocking=True)
+        self._pin_ev[self._pin_k].record()
+
+    def _pinned_row(self):
+        """The pinned block the step's parameters travel from: a ring of rows allocated ONCE (a fresh `torch.empty(pin_memory=True)`
+        per step finds every earlier block still in flight while the host runs ahead of the device, so steps kept paying a
+        hipHostMalloc - usually ~30 us, but single calls of 1 and of 84 ms were measured inside 20-step jobs, the latter +4.2 ms per
+        step of a cfg1 job: section 8 of DESIGN.md).  A row is reused once
+        the copy issued from it has run (its event; never waited for in practice: 64 steps of run-ahead)."""
+        if self._pin is None:
+            rows = 64
+            self._pin = torch.empty((rows, self._n_par), pin_memory=True)
+            self._pin_ev = [torch.cuda.Event() for _ in range(rows)]
+            self._pin_used = [False] * rows
+            self._pin_k = -1
+        k = self._pin_k = (self._pin_k + 1) % len(self._pin_ev)
+        if self._pin_used[k]:
+            self._pin_ev[k].synchronize()
+        self._pin_used[k] = True
+        return self._pin[k]
 
     def _step_body(self):
         """Everything of a step that runs on the device: score model, SDE step, side-chain and ligand pose update (in place)."""
