@@ -459,3 +459,29 @@ def test_lazy_stats_fresh_view_rereads_the_count_block():
     blk.v["ll"] = 9                                  # (a replay rewrote the block)
     assert st["E_ll"] == 5                           # memoised
     assert st.fresh()["E_ll"] == 9 and st.fresh()["B"] == 2
+
+
+def test_smooth_edge_weight_matches_the_oracle_and_tolerates_unfilled_list_entries():
+    """engine.ForwardEngine._smooth_weight = get_edge_weight of the reference (all_atom_score_model.py:438-442, smooth_edges) as the
+    oracle restates it (pinned by the reference-generated goldens smooth_dyn / smooth_fixed), for a fixed and a per-edge max_norm;
+    entries behind a list's device-side count hold arbitrary indices and must neither fault nor change the valid rows."""
+    from diffdock_pocket_amd.engine import ForwardEngine
+    from oracle.ref_model import OracleScoreModel
+    g = torch.Generator().manual_seed(3)
+    pa, pb = torch.randn(40, 3, generator=g) * 4, torch.randn(25, 3, generator=g) * 4
+    ia = torch.randint(0, 40, (200,), generator=g).to(torch.int32)
+    ib = torch.randint(0, 25, (200,), generator=g).to(torch.int32)
+    orc = OracleScoreModel.__new__(OracleScoreModel)
+    orc.cfg = OracleConfig(smooth_edges=True)
+    vec = pb[ib.long()] - pa[ia.long()]
+    for mx in (5.0, torch.rand(200, generator=g) * 8 + 2):
+        want = orc._edge_weight(vec, mx).squeeze(-1)
+        got = ForwardEngine._smooth_weight(pa, ia, pb, ib, mx)
+        assert torch.equal(got, want)
+        assert float(got.min()) >= 0.0 and float(got.max()) <= 1.0
+    ia2, ib2 = ia.clone(), ib.clone()
+    ia2[150:], ib2[150:] = 10 ** 6, -7          # "unfilled" capacity entries
+    got = ForwardEngine._smooth_weight(pa, ia2, pb, ib2, 5.0)
+    assert torch.equal(got[:150], ForwardEngine._smooth_weight(pa, ia, pb, ib, 5.0)[:150]) and torch.isfinite(got).all()
+    orc.cfg = OracleConfig(smooth_edges=False)
+    assert orc._edge_weight(vec, 5.0) == 1.0
