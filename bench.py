@@ -104,7 +104,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-fork-means", action="store_true", help="diagnostic: model.fork_small_means = False (A/B runs)")
     ap.add_argument("--no-overlap-direct", action="store_true",
                     help="diagnostic: the serial launch order of the conv layers (model.overlap_direct_conv = False) for same-box A/B runs")
-    ap.add_argument("--layer-order", default=None, choices=["chains", "pipeline", "pipeline2", "pipeline3", "pipeline4"], help="diagnostic: model.layer_order for A/B runs")
+    ap.add_argument("--layer-order", default=None, choices=["chains", "pipeline", "pipeline2", "pipeline3", "pipeline4", "pipeline5"], help="diagnostic: model.layer_order for A/B runs")
     ap.add_argument("--no-flex-sharing", action="store_true",
                     help="diagnostic: flexible side chains without the partial sharing of layers 0 / 1 (model.share_flex_layer0 = False)")
     return ap.parse_args(argv)

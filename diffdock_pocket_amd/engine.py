@@ -822,9 +822,10 @@ class ForwardEngine:
                      the HBM write of G): conv32(l) -> means{lig, atom}(l) -> [direct(l) | stage A(l+1){atom, lig sources}] ->
                      mean{rec}(l) -> stage A(l+1){rec sources} -> conv32(l+1).  The direct conv reads x_atom(l) as its source
                      while the atom mean of layer l updates x_atom in place: it is given a snapshot (one 32-MB copy per layer).
-                     "pipeline3" / "pipeline4" (default) put whole chains on side streams: [direct(l) -> mean{rec}(l) -> stage
+                     "pipeline3" / "pipeline4" put whole chains on side streams: [direct(l) -> mean{rec}(l) -> stage
                      A(l+1){rec sources}] and [mean{lig}(l) -> stage A(l+1){lig sources}] beside [mean{atom}(l) -> stage A(l+1){atom
-                     sources}]."""
+                     sources}]; "pipeline5" (default) also starts the direct conv a layer early: direct(l+1) as soon as mean{atom}(l)
+                     and mean{rec}(l) are queued, joined before the means of layer l+1 (no snapshot)."""
         m = self.m
         ns, L_, B, ldx = m.ns, m.num_conv_layers, S.B, m._ldx
         Nl, Nr, Na = S.Nl, S.Nr, S.Na
@@ -1040,6 +1041,53 @@ class ForwardEngine:
                 fix_rowmaps(P)
                 means(P, "lar")
                 F.keep.append((P.keep, P.per, P.msgs, P.tasks, P.tasks_g, P.gmap))
+            mark("reduce")
+            return
+
+        if pipelined and m.layer_order == "pipeline5":
+            # The direct conv of layer l needs x(l) only - not stage A, not the 32-edge launch: it is started as soon as the means of
+            # layer l - 1 are queued, on a stream of its own, and has stage A(l) AND the 32-edge launch of layer l to finish beside
+            # (joined before the means of layer l touch x: no snapshot of x_atom).  The window between two 32-edge launches is then
+            # [mean{rec} -> stage A{rec rows}] | [mean{lig} -> stage A{lig rows}] | [mean{atom} -> stage A{atom rows}].
+            P = plan(0)
+            direct_tasks(P)
+            if P.tasks:
+                side.run(1, lambda P=P: launch_direct(P))
+            stage_a(P, "lar")
+            for l in range(L_):
+                nxt = plan(l + 1) if l + 1 < L_ else None
+                launch_factorised(P)
+                join_lists()
+                fix_rowmaps(P)
+                side.join(only=1)           # direct conv(l) is done: the means below update x in place
+                ev_r = torch.cuda.Event()
+
+                def rec_chain(P=P, nxt=nxt, ev_r=ev_r):
+                    means(P, "r")
+                    ev_r.record()
+                    if nxt is not None:
+                        stage_a(nxt, "r")
+
+                def lig_chain(P=P, nxt=nxt):
+                    means(P, "l")
+                    if nxt is not None:
+                        stage_a(nxt, "l")
+                side.run(3, rec_chain)
+                side.run(2, lig_chain)
+                means(P, "a")
+                if nxt is not None:
+                    direct_tasks(nxt)
+                    if nxt.tasks:     # after mean{atom} (forked from main here) and mean{rec} (the event)
+                        def direct_next(nxt=nxt, ev_r=ev_r):
+                            torch.cuda.current_stream(dev).wait_event(ev_r)
+                            launch_direct(nxt)
+                        side.run(1, direct_next)
+                    stage_a(nxt, "a")
+                side.join(only=2)
+                side.join(only=3)
+                F.keep.append((P.keep, P.per, P.msgs, P.tasks, P.tasks_g, P.gmap, ev_r))
+                P = nxt
+            side.join()
             mark("reduce")
             return
 

@@ -432,8 +432,11 @@ class TensorProductScoreModel(nn.Module):
         # to the fp16 matrix cores: serial 20.48 - 20.51, chains 20.28 - 20.39, pipeline 20.22 - 20.25 ms per 40-sample step.
         # "pipeline3": the receptor chain - direct conv(l) -> mean{rec}(l) -> stage A(l + 1) of the receptor-source rows - on the side
         # stream (pipeline 20.07 -> 19.91 ms, flexible 24.47 -> 24.15); "pipeline4" (default): the ligand chain - mean{lig}(l) -> stage
-        # A(l + 1) of the ligand-source rows - on a side stream of its own too, the direct conv forked before the means (19.60 -> 19.51)
-        self.layer_order = "pipeline4"
+        # A(l + 1) of the ligand-source rows - on a side stream of its own too, the direct conv forked before the means (19.60 -> 19.51);
+        # "pipeline5" (default): the direct conv of layer l + 1 is started as soon as the atom and receptor means of layer l are queued
+        # and has stage A(l + 1) and the whole 32-edge launch of layer l + 1 to finish beside - off the critical path, no snapshot of
+        # x_atom (19.53 -> 19.38 ms; flexible 23.50 either way)
+        self.layer_order = "pipeline5"
         # The front's independent chains side by side (parallel branches of the captured step; same kernels, same arguments, same bits):
         # [node encoders -> edge embeddings] beside [neighbour searches -> CSR / source-ordered views], and - rigid receptor - the index
         # lists of the work eliminations (first read by layer 1) beside stage A + the 32-edge conv launch of layer 0 (engine._front,

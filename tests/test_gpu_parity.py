@@ -363,7 +363,7 @@ def test_pipelined_layer_order_is_bitwise_the_serial_one(flex):
     sched = get_t_schedule(20)
     g = make_3dpf_complex(seed=0, flexible_sidechains=flex)
     out = {}
-    orders = ("serial", "pipeline", "pipeline4") if flex else ("serial", "pipeline", "pipeline2", "pipeline3", "pipeline4", "chains")
+    orders = ("serial", "pipeline", "pipeline4", "pipeline5") if flex else ("serial", "pipeline", "pipeline2", "pipeline3", "pipeline4", "pipeline5", "chains")
     for order in orders:
         model, kw = bench.build_model("cfg2", flex, dev)
         model.concurrent_max_atoms = 0
