@@ -405,6 +405,10 @@ def main(argv=None):
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU product path)")
+    # host-side set-up (weight packing of the models this run builds) on at most 32 threads per rank: PyTorch's small CPU ops get
+    # several times slower with every core of the GPU boxes' many-core hosts (the GPU tests: 1018 -> 327 s with the same cap);
+    # nothing inside a timed region runs on these threads, and cpu_baseline sets its own count (--cpu-threads)
+    torch.set_num_threads(max(1, min(32, (os.cpu_count() or 1) // max(1, world))))
     test_backend = os.environ.get("DDP_BENCH_BACKEND")   # "gloo": several ranks on ONE device (1-GPU box); never a real run
     ndev = torch.cuda.device_count()
     if local_rank >= ndev:
