@@ -104,7 +104,6 @@ def parse_args(argv=None):
     ap.add_argument("--no-fork-means", action="store_true", help="diagnostic: model.fork_small_means = False (A/B runs)")
     ap.add_argument("--no-overlap-direct", action="store_true",
                     help="diagnostic: the serial launch order of the conv layers (model.overlap_direct_conv = False) for same-box A/B runs")
-    ap.add_argument("--layer-order", default=None, choices=["chains", "pipeline", "pipeline2", "pipeline3", "pipeline4", "pipeline5"], help="diagnostic: model.layer_order for A/B runs")
     ap.add_argument("--no-flex-sharing", action="store_true",
                     help="diagnostic: flexible side chains without the partial sharing of layers 0 / 1 (model.share_flex_layer0 = False)")
     return ap.parse_args(argv)
@@ -444,8 +443,6 @@ def main(argv=None):
         model.fork_small_means = False
     if args.concurrent_max_atoms is not None:
         model.concurrent_max_atoms = args.concurrent_max_atoms
-    if args.layer_order:
-        model.layer_order = args.layer_order
     complex_graph = make_3dpf_complex(seed=0, flexible_sidechains=args.flex)
     n_total = args.samples * world if scaling == "weak" else args.samples
     if n_total < world:

@@ -14,9 +14,9 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SOURCES = ["ddp_conv.hip", "ddp_misc.hip", "ddp_gemm.hip", "ddp_pose.hip", "ddp_graph.hip", "ddp_views.hip", "ddp_lists.hip", "ddp_node.hip", "ddp_heads.hip",
+SOURCES = ["ddp_conv.hip", "ddp_conv_rows.hip", "ddp_misc.hip", "ddp_gemm.hip", "ddp_pose.hip", "ddp_graph.hip", "ddp_views.hip", "ddp_lists.hip", "ddp_node.hip", "ddp_heads.hip",
            "ddp_capi.hip"]
-HEADERS = [os.path.join(HERE, "csrc", "ddp_internal.h"), os.path.join(HERE, "csrc", "ddp_conv_diag.h"),
+HEADERS = [os.path.join(HERE, "csrc", "ddp_internal.h"), os.path.join(HERE, "csrc", "ddp_conv_diag.h"), os.path.join(HERE, "csrc", "ddp_conv_common.h"),
            os.path.join(ROOT, "include", "ddp_hip.h")]
 OUT = os.path.join(HERE, "libddp_hip.so")
 OBJ_DIR = os.path.join(HERE, "csrc", ".obj")

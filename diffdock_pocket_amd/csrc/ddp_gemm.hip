@@ -459,13 +459,18 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define DDP_SAH_CT 4   // column tiles per wave: 2 planes x 4 k-steps x 4 registers each = 32 weight registers per tile
 #endif
 
-template <int KT>
+// GH (round 5): the leading 8 gh_groups columns of a row leave as fp16 hi/lo operand planes - the layout ddp_conv_rows reads G in
+// (include/ddp_hip.h, ddp_conv_task_t::gh): a lane then drains 8 consecutive columns of a parked row (one 8-k group of one G column)
+// as two 16-byte pieces, hi plane and lo plane, where the fp32 form stores two 16-byte quads - the same bytes, the same number of
+// store instructions.  Columns behind the planes (Gb) stay fp32.  Needs ncols % 32 == 0.
+template <int KT, bool GH = false>
 __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(const float* __restrict__ x, int ldx, int nrows,
                                                                               const int32_t* __restrict__ rows,
                                                                               const int32_t* __restrict__ nrows_dev, int out_rows,
                                                                               int mrows, const GemmOffs offs,
                                                                               const _Float16* __restrict__ wh, int ncols,
-                                                                              float* __restrict__ out, int ldo, int32_t* range_flag) {
+                                                                              float* __restrict__ out, int ldo, int32_t* range_flag,
+                                                                              int gh_cols = 0, int gh_groups = 0) {
   if (nrows_dev) nrows = min(nrows, *nrows_dev);
   if ((int)blockIdx.y * mrows >= nrows) return;
   constexpr int KP = (KT + 15) / 16 * 16, NS = KP / 16, CT = DDP_SAH_CT;
@@ -544,8 +549,28 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
   // hipcc's waitcnt insertion drained the store queue at the branch joins.)
   size_t pend_off[4] = {0, 0, 0, 0};    // element offset of this lane's 16-byte piece of quarter p of the pending block
   int pend_lds[4] = {0, 0, 0, 0};       // ... and where it sits in the parked tile
+  bool pend_split[2] = {false, false};  // GH: pieces 2 q, 2 q + 1 = the two 16-byte stores of the lane's 8-column group q of the block
   int pbuf = 0;
-  f32x4 dv = {0.f, 0.f, 0.f, 0.f};
+  f32x4 dv = {0.f, 0.f, 0.f, 0.f}, dv2 = dv;
+  // GH: the lane's group q of the pending tile -> the two 16-byte pieces that leave (hi / lo plane, or the two fp32 quads)
+  auto gh_read = [&](const float* pt, int q) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(&pt[pend_lds[2 * q]]), b = *reinterpret_cast<const f32x4*>(&pt[pend_lds[2 * q] + 4]);
+    if (pend_split[q]) {
+      h8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = (e < 4) ? a[e & 3] : b[e & 3];
+        if (!(fabsf(f) <= 65504.f) && range_flag) *range_flag = 1;
+        hi[e] = (_Float16)f;
+        lo[e] = (_Float16)((f - (float)hi[e]) * 2048.f);
+      }
+      dv = __builtin_bit_cast(f32x4, hi);
+      dv2 = __builtin_bit_cast(f32x4, lo);
+    } else {
+      dv = a;
+      dv2 = b;
+    }
+  };
   auto block = [&](auto drain_tag, int t, const h8 (&a)[2][NS], const int (&blk_ri)[4], int nr) {
     constexpr bool DRAIN = decltype(drain_tag)::value;
     f32x16 am, ac;
@@ -554,24 +579,60 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
     const float* pt = st[wave][pbuf ^ 1];     // the pending block's tile
 #pragma unroll
     for (int s2 = 0; s2 < NS; ++s2) {
-      if constexpr (DRAIN && NS == 4) dv = *reinterpret_cast<const f32x4*>(&pt[pend_lds[s2]]);
+      if constexpr (DRAIN && NS == 4) {
+        if constexpr (GH) {
+          if ((s2 & 1) == 0) gh_read(pt, s2 >> 1);
+        } else {
+          dv = *reinterpret_cast<const f32x4*>(&pt[pend_lds[s2]]);
+        }
+      }
       am = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][s2], wr[t][0][s2], am, 0, 0, 0);
       ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][s2], wr[t][1][s2], ac, 0, 0, 0);
       ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][s2], wr[t][0][s2], ac, 0, 0, 0);
-      if constexpr (DRAIN && NS == 4) *reinterpret_cast<f32x4*>(&ob[pend_off[s2]]) = dv;
+      if constexpr (DRAIN && NS == 4) *reinterpret_cast<f32x4*>(&ob[pend_off[s2]]) = (GH && (s2 & 1)) ? dv2 : dv;
     }
     if constexpr (DRAIN && NS != 4) {
+      if constexpr (GH) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(&ob[pend_off[p]]) = *reinterpret_cast<const f32x4*>(&pt[pend_lds[p]]);
+        for (int q = 0; q < 2; ++q) {
+          gh_read(pt, q);
+          *reinterpret_cast<f32x4*>(&ob[pend_off[2 * q]]) = dv;
+          *reinterpret_cast<f32x4*>(&ob[pend_off[2 * q + 1]]) = dv2;
+        }
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(&ob[pend_off[p]]) = *reinterpret_cast<const f32x4*>(&pt[pend_lds[p]]);
+      }
     }
     float* tl = st[wave][pbuf];
 #pragma unroll
     for (int i = 0; i < 16; ++i) tl[((i & 3) + 8 * (i >> 2) + 4 * hh) * TS + r] = am[i] + ac[i] * (1.f / 2048.f);
+    if constexpr (GH) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int rr = min(8 * p + (lane >> 3), nr - 1);        // clamped row of the tile (blk_ri is clamped the same way)
-      pend_lds[p] = rr * TS + cq[t];
-      pend_off[p] = (size_t)blk_ri[p] * ldo + (col0 + 32 * t + cq[t]);
+      for (int q = 0; q < 2; ++q) {
+        const int rr = min(16 * q + (lane >> 2), nr - 1);        // row of the tile; blk_ri[p] holds rows 8 p + (lane >> 3)
+        const int src_lane = ((lane >> 2) & 7) << 3;                // the lane that holds tile row 8 p + ((lane >> 2) & 7) in blk_ri[p]
+        const int ri0 = __shfl(blk_ri[2 * q], src_lane), ri1 = __shfl(blk_ri[2 * q + 1], src_lane);
+        const int ri = ((lane >> 2) >> 3) ? ri1 : ri0;
+        const int col = col0 + 32 * t + 8 * (lane & 3), g = col >> 3;
+        pend_lds[2 * q] = rr * TS + 8 * (lane & 3);
+        pend_split[q] = g < gh_groups;
+        if (pend_split[q]) {
+          const int k8 = g / gh_cols, c = g - k8 * gh_cols;
+          pend_off[2 * q] = (size_t)ri * ldo + 4 * (2 * k8 * gh_cols + c);
+          pend_off[2 * q + 1] = pend_off[2 * q] + 4 * gh_cols;
+        } else {
+          pend_off[2 * q] = (size_t)ri * ldo + col;
+          pend_off[2 * q + 1] = pend_off[2 * q] + 4;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int rr = min(8 * p + (lane >> 3), nr - 1);        // clamped row of the tile (blk_ri is clamped the same way)
+        pend_lds[p] = rr * TS + cq[t];
+        pend_off[p] = (size_t)blk_ri[p] * ldo + (col0 + 32 * t + cq[t]);
+      }
     }
     pbuf ^= 1;
   };
@@ -609,8 +670,17 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
   }
   if (!first) {   // the last block
     const float* pt = st[wave][pbuf ^ 1];
+    if constexpr (GH) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(&ob[pend_off[p]]) = *reinterpret_cast<const f32x4*>(&pt[pend_lds[p]]);
+      for (int q = 0; q < 2; ++q) {
+        gh_read(pt, q);
+        *reinterpret_cast<f32x4*>(&ob[pend_off[2 * q]]) = dv;
+        *reinterpret_cast<f32x4*>(&ob[pend_off[2 * q + 1]]) = dv2;
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(&ob[pend_off[p]]) = *reinterpret_cast<const f32x4*>(&pt[pend_lds[p]]);
+    }
   }
   __syncthreads();
   }
@@ -618,7 +688,7 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
 
 static int stage_a_impl(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows,
                         const int32_t* offs, int nbatch, const float* w, const void* w_bf16x3, const void* w_h2, int k, int ncols, float* out,
-                        int ldo, int32_t* range_flag, void* stream) {
+                        int ldo, int32_t* range_flag, void* stream, int gh_cols = 0, int gh_groups = 0) {
   if (!rows) out_rows = nrows;                       // dense: out[b] has one row per x row
   if (out_rows < 1 && nrows > 0) return ddp_fail(DDP_EINVAL, "ddp_stage_a: out_rows");
   if (nbatch < 0 || nbatch > DDP_MAX_GEMM_BATCH) return ddp_fail(DDP_ELIMIT, "ddp_stage_a: nbatch > DDP_MAX_GEMM_BATCH");
@@ -659,6 +729,25 @@ static int stage_a_impl(const float* x, int ldx, int nrows, const int32_t* rows,
 #endif
   static const bool no_mfma = getenv("DDP_STAGE_A_VALU") != nullptr;   // diagnostic: force the VALU form
   // h2 form (fp16 hi/lo split of both operands): wide, 16-byte aligned outputs only, K = 60 / 32 / 24 / 16 (KP = 64 / 32 / 32 / 16)
+  if (gh_groups > 0 && !(w_h2 && wide && (k == 60 || k == 32 || k == 24 || k == 16) && (reinterpret_cast<size_t>(w_h2) & 15) == 0 && (ncols & 31) == 0 &&
+                         gh_cols > 0 && 8 * gh_groups <= ncols))
+    return ddp_fail(DDP_EINVAL, "ddp_stage_a_gh: plane output needs the h2 path (w_h2, k in {60, 32, 24, 16}), ncols % 32 == 0 and 8 gh_groups <= ncols");
+  if (gh_groups > 0) {
+    const dim3 grid((ncols + 128 * DDP_SAH_CT - 1) / (128 * DDP_SAH_CT), gy, nbatch);
+#define DDP_GEMM_GH(KT)                                                                                          \
+    hipLaunchKernelGGL((ddp_stage_a_h2_kernel<KT, true>), grid, dim3(DDP_GEMM_THREADS), 0, s, x, ldx, nrows, rows, nrows_dev, out_rows, mrows, O, \
+                       reinterpret_cast<const _Float16*>(w_h2), ncols, out, ldo, range_flag, gh_cols, gh_groups)
+    switch (k) {
+      case 60: DDP_GEMM_GH(60); break;
+      case 32: DDP_GEMM_GH(32); break;
+      case 24: DDP_GEMM_GH(24); break;
+      default: DDP_GEMM_GH(16); break;
+    }
+#undef DDP_GEMM_GH
+    const hipError_t eg = hipGetLastError();
+    if (eg != hipSuccess) return ddp_fail_hip(eg, "ddp_stage_a_gh launch");
+    return 0;
+  }
   if (w_h2 && wide && (k == 60 || k == 32 || k == 24 || k == 16) && !no_mfma && (reinterpret_cast<size_t>(w_h2) & 15) == 0) {
     const dim3 grid((ncols + 128 * DDP_SAH_CT - 1) / (128 * DDP_SAH_CT), gy, nbatch);
 #define DDP_GEMM_H2(KT)                                                                                          \
@@ -724,4 +813,10 @@ extern "C" int ddp_stage_a_h2(const float* x, int ldx, int nrows, const int32_t*
                               const int32_t* offs, int nbatch, const float* w, const void* w_h2, int k, int ncols, float* out, int ldo,
                               int32_t* range_flag, void* stream) {
   return stage_a_impl(x, ldx, nrows, rows, nrows_dev, out_rows, offs, nbatch, w, nullptr, w_h2, k, ncols, out, ldo, range_flag, stream);
+}
+
+extern "C" int ddp_stage_a_gh(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows,
+                              const int32_t* offs, int nbatch, const float* w, const void* w_h2, int k, int ncols, float* out, int ldo,
+                              int32_t* range_flag, int gh_cols, int gh_groups, void* stream) {
+  return stage_a_impl(x, ldx, nrows, rows, nrows_dev, out_rows, offs, nbatch, w, nullptr, w_h2, k, ncols, out, ldo, range_flag, stream, gh_cols, gh_groups);
 }

@@ -767,25 +767,33 @@ class ForwardEngine:
         fp32-MFMA kernel, csrc/ddp_gemm.hip; bound by the HBM write of G).  convs: [(k, TensorProductConvLayer)].  With a row
         list only the listed rows of the [n_rows]-row G arrays are computed.  Returns {(k, slot): G rows}."""
         m = self.m
-        key = (l, tuple(k for k, _ in convs))
+        # (G leaves stage A in the layout the conv kernel of this layer reads: plane form for ddp_conv_rows, launch.rows_mode)
+        rows_k = all(K.rows_mode(conv.packed_g(x.device)) for _, conv in convs)
+        key = (l, tuple(k for k, _ in convs), rows_k)
         ent = m._stage_a_stacks.get(key)
         if ent is None or ent[0].device != x.device:
-            Ws, meta = [], []
+            Ws, meta, ghs = [], [], set()
             for k, conv in convs:
                 pk = conv.packed_g(x.device)
                 for slot in (0, 1):
                     if pk.wg[slot] is not None:
-                        Ws.append(pk.wg[slot])
+                        Ws.append(pk.wgh[slot] if rows_k else pk.wg[slot])
                         meta.append((k, slot, pk.g_in_off[slot]))
+                        if rows_k:
+                            ghs.add((conv.spec_g.g_cols[slot], pk.gh_groups[slot]))
             Wst = torch.stack(Ws).contiguous()
+            if len(ghs) > 1:
+                raise L.DdpError("G arrays of one stage-A product with different column counts")
             # (the bf16x3 split of the weights - 1.5 x their size and three copy kernels - only when that option is on)
-            ent = (Wst, meta, (C.c_int32 * len(meta))(*[mm[2] for mm in meta]), P.split_bf16x3(Wst) if m.stage_a_bf16x3 else None,
-                   P.split_h2(Wst) if m.stage_a_h2 else None)
+            ent = (Wst, meta, (C.c_int32 * len(meta))(*[mm[2] for mm in meta]), P.split_bf16x3(Wst) if (m.stage_a_bf16x3 and not rows_k) else None,
+                   P.split_h2(Wst) if (m.stage_a_h2 or rows_k) else None, ghs.pop() if rows_k else None)
             m._stage_a_stacks[key] = ent
-        if m.stage_a_bf16x3 and ent[3] is None:
-            ent = m._stage_a_stacks[key] = ent[:3] + (P.split_bf16x3(ent[0]), ent[4])
+        if m.stage_a_bf16x3 and ent[3] is None and not rows_k:
+            ent = m._stage_a_stacks[key] = ent[:3] + (P.split_bf16x3(ent[0]),) + ent[4:]
         if m.stage_a_h2 and ent[4] is None:
-            ent = m._stage_a_stacks[key] = ent[:4] + (P.split_h2(ent[0]),)
+            ent = m._stage_a_stacks[key] = ent[:4] + (P.split_h2(ent[0]),) + ent[5:]
+        gh = ent[5]
+        ent = ent[:5]
         Wst, meta, offs, W3, Wh = ent
         nb = len(meta)
         if nb > L.DDP_MAX_GEMM_BATCH:
@@ -796,8 +804,11 @@ class ForwardEngine:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         n_list = n_rows if rows is None else int(rows.shape[0])
-        K.stage_a(x, n_list, offs, nb, Wst, Gall, rows=rows, rows_cnt=rows_cnt, out_rows=n_rows, W3=W3 if m.stage_a_bf16x3 else None,
-                  Wh=Wh if (m.stage_a_h2 and K.CONV_H2 and not m.stage_a_bf16x3) else None)
+        if gh is not None:
+            K.stage_a(x, n_list, offs, nb, Wst, Gall, rows=rows, rows_cnt=rows_cnt, out_rows=n_rows, Wh=Wh, gh=gh)
+        else:
+            K.stage_a(x, n_list, offs, nb, Wst, Gall, rows=rows, rows_cnt=rows_cnt, out_rows=n_rows, W3=W3 if m.stage_a_bf16x3 else None,
+                      Wh=Wh if (m.stage_a_h2 and K.CONV_H2 and not m.stage_a_bf16x3) else None)
         if prof is not None:
             e1.record()
             # algorithmic bytes: the G rows written once + the scalar columns of x read once per product + the weights
@@ -806,7 +817,7 @@ class ForwardEngine:
             def nbytes(n_list=n_list, rows_cnt=rows_cnt, row_bytes=row_bytes, wn=Wst.numel()):
                 n = n_list if rows_cnt is None else min(n_list, int(rows_cnt.item()))
                 return row_bytes * n + 4.0 * wn
-            use_h2 = m.stage_a_h2 and K.CONV_H2 and not m.stage_a_bf16x3
+            use_h2 = gh is not None or (m.stage_a_h2 and K.CONV_H2 and not m.stage_a_bf16x3)
             prof.hbm.setdefault("ddp_stage_a_h2_kernel" if use_h2 else "ddp_stage_a_mfma_kernel", []).append((e0, e1, nbytes))
         return {(k, slot): Gall[i] for i, (k, slot, _) in enumerate(meta)}
 
@@ -817,15 +828,12 @@ class ForwardEngine:
         Three launch orders over the same kernels with the same arguments (same bits):
           serial     stage A(l) -> conv32(l) -> direct(l) -> means(l)                      (debug hooks, section timer, resident groups)
           forked     small batches: direct(l) | stage-A groups side by side, then conv32(l) (see _Fork)
-          pipelined  large batches (round 4): the direct conv of layer l - receptor<-atom, one 130-KB workgroup per CU, matrix-pipe
-                     bound - runs on a side stream BESIDE stage A of layer l + 1 for the atom- and ligand-source rows (bound by
-                     the HBM write of G): conv32(l) -> means{lig, atom}(l) -> [direct(l) | stage A(l+1){atom, lig sources}] ->
-                     mean{rec}(l) -> stage A(l+1){rec sources} -> conv32(l+1).  The direct conv reads x_atom(l) as its source
-                     while the atom mean of layer l updates x_atom in place: it is given a snapshot (one 32-MB copy per layer).
-                     "pipeline3" / "pipeline4" put whole chains on side streams: [direct(l) -> mean{rec}(l) -> stage
-                     A(l+1){rec sources}] and [mean{lig}(l) -> stage A(l+1){lig sources}] beside [mean{atom}(l) -> stage A(l+1){atom
-                     sources}]; "pipeline5" (default) also starts the direct conv a layer early: direct(l+1) as soon as mean{atom}(l)
-                     and mean{rec}(l) are queued, joined before the means of layer l+1 (no snapshot)."""
+          pipelined  large batches: the direct conv of layer l + 1 (receptor<-atom, one 130-KB workgroup per CU) needs x(l + 1) only -
+                     neither stage A nor the 32-edge launch - so it starts on a stream of its own as soon as mean{atom}(l) and
+                     mean{rec}(l) are queued and is joined before the means of layer l + 1 update x in place; the window between two
+                     32-edge launches is [mean{rec} -> stage A{rec rows}] | [mean{lig} -> stage A{lig rows}] | [mean{atom} -> stage
+                     A{atom rows}] as parallel branches of the captured step.  (Round 4 measured five other overlapped orders
+                     against this one - DESIGN.md section 4.8 keeps the numbers; their code is gone.)"""
         m = self.m
         ns, L_, B, ldx = m.ns, m.num_conv_layers, S.B, m._ldx
         Nl, Nr, Na = S.Nl, S.Nr, S.Na
@@ -853,8 +861,8 @@ class ForwardEngine:
             if lists_fork is not None:
                 lists_fork.join(only=4)
                 lists_fork = None
-        if not (pipelined and m.layer_order != "chains") and fork is None:
-            join_lists()      # (the serial and the two-chain orders: before anything else)
+        if not pipelined and fork is None:
+            join_lists()      # (the serial order: before anything else)
 
         def plan(l):
             """Host side of layer l: per conv its CSR view (mean / direct conv), its source-ordered view and the rows stage A has
@@ -929,9 +937,8 @@ class ForwardEngine:
                 P.g_v = self._stage_a(l, [(3, conv3)], P.x_clean, c1.n0)
                 P.keep += [P.g_d, P.g_v, P.x_clean]
 
-        def direct_tasks(P, x_atom_src=None):
-            """The direct convs (receptor<-atom: one edge per atom, nothing to factorise): no stage A.  x_atom_src: the array the
-            atom-source rows are read from instead of x_atom (the pipelined order's snapshot)."""
+        def direct_tasks(P):
+            """The direct convs (receptor<-atom: one edge per atom, nothing to factorise): no stage A."""
             l, spec = P.l, P.spec
             tasks, nb_d = [], 0.0
             for k, (csr, so_k, x_src) in P.per.items():
@@ -945,8 +952,6 @@ class ForwardEngine:
                     continue
                 if prof_on:
                     nb_d += node_bytes(l, k)
-                if x_atom_src is not None and SRC_TYPE[k] == "a":
-                    x_src = x_atom_src[:x_src.shape[0]]
                 segs = [(e[ek], csr.eid, ns, ns), (x_recv, csr.recv, ldx, ns), (x_src, csr.src, ldx, ns)]
                 tasks.append(K.make_task(pkc, x_src, ldx, csr, sh[ek], segs, msg))
             P.tasks, P.nb_d = tasks, nb_d
@@ -955,13 +960,12 @@ class ForwardEngine:
         def launch_direct(P):
             K.launch_convs(P.spec, P.tasks, node_bytes=P.nb_d, tag=f"layer{P.l}")
 
-        def launch_factorised(P, which="lar"):
-            """The 32-edge conv launch of the factorised convs whose SOURCE-node type is in `which` (all of them in one launch by
-            default; the two-chain order launches the atom-source convs and the others separately)."""
+        def launch_factorised(P):
+            """The conv launch of all factorised convs of the layer."""
             l, spec, c1 = P.l, P.spec, P.c1
             tasks_g, nb_g = [], 0.0
             for k, (csr, so_k, x_src) in P.per.items():
-                if k in P.msgs or SRC_TYPE[k] not in which:
+                if k in P.msgs:
                     continue
                 x_recv, _, ek = arr[k]
                 conv = m.conv_layers[9 * l + k]
@@ -973,13 +977,14 @@ class ForwardEngine:
                     msg = torch.empty((c1.E + c1.e0, spec.d_out), device=dev)
                     P.msgs[k] = (msg, csr, pkc, c1.rowmap)
                     pkg = conv.packed_g(dev)
+                    rk = K.rows_mode(pkg)
                     sd_ = c1.so_d
                     if sd_.n_edges > 0:
                         segs = [(e_base, sd_.eid, ns, ns), (x_recv, sd_.recv, ldx, ns), (xa, sd_.src, ldx, ns)]
-                        tasks_g.append(K.make_task(pkg, xa, ldx, sd_, sh_k, segs, msg, g=[P.g_d.get((3, s_)) for s_ in (0, 1)]))
+                        tasks_g.append(K.make_task(pkg, xa, ldx, sd_, sh_k, segs, msg, g=[P.g_d.get((3, s_)) for s_ in (0, 1)], rows=rk))
                     sv = c1.so_v
                     segs = [(e_base, sv.eid, ns, ns), (P.x_clean, sv.recv, ldx, ns), (P.x_clean, sv.src, ldx, ns)]
-                    tasks_g.append(K.make_task(pkg, P.x_clean, ldx, sv, sh_k, segs, msg, g=[P.g_v.get((3, s_)) for s_ in (0, 1)]))
+                    tasks_g.append(K.make_task(pkg, P.x_clean, ldx, sv, sh_k, segs, msg, g=[P.g_v.get((3, s_)) for s_ in (0, 1)], rows=rk))
                     continue
                 msg = torch.empty((csr.n_edges, spec.d_out), device=dev)
                 P.msgs[k] = (msg, csr, pkc)
@@ -988,7 +993,8 @@ class ForwardEngine:
                 if prof_on:
                     nb_g += node_bytes(l, k)
                 segs = [(e_base, so_k.eid, ns, ns), (x_recv, so_k.recv, ldx, ns), (x_src, so_k.src, ldx, ns)]
-                tasks_g.append(K.make_task(conv.packed_g(dev), x_src, ldx, so_k, sh_k, segs, msg, g=[P.gmap.get((k, s_)) for s_ in (0, 1)]))
+                pkg = conv.packed_g(dev)
+                tasks_g.append(K.make_task(pkg, x_src, ldx, so_k, sh_k, segs, msg, g=[P.gmap.get((k, s_)) for s_ in (0, 1)], rows=K.rows_mode(pkg)))
             P.tasks_g = getattr(P, "tasks_g", []) + tasks_g
             K.launch_convs(P.spec_g, tasks_g, flops_spec=spec, node_bytes=nb_g, tag=f"layer{l}")
 
@@ -1015,36 +1021,7 @@ class ForwardEngine:
                     n0 = shared[[k for k in ORDER[rt] if k in shared][0]][0]
                     K.launch_reduce(x, ldx, n0, spec.d_out, com, accumulate=True, n_rep=B, rep_stride=n0)
 
-        if pipelined and m.layer_order == "chains":
-            # Two chains per layer on forked streams (parallel branches of the captured step):
-            #   A: stage A of the atom-source rows (the big product, bound by the HBM write of G) -> 32-edge convs with atom sources
-            #   B: stage A of the ligand- / receptor-source rows -> 32-edge convs with those sources -> the direct conv
-            # then the segmented means.  The store-bound product of one chain runs beside the latency-bound conv kernel of the other.
-            for l in range(L_):
-                P = plan(l)
-                direct_tasks(P)        # (first: marks the direct convs, launch_factorised skips them)
-                has_direct = bool(P.tasks)
-
-                def chain_a(P=P):
-                    stage_a(P, "a")
-                    launch_factorised(P, "a")
-
-                def chain_b(P=P, has_direct=has_direct):
-                    stage_a(P, "lr")
-                    launch_factorised(P, "lr")
-                    if has_direct:
-                        launch_direct(P)
-
-                side.run(0, chain_b)
-                chain_a()
-                side.join()
-                fix_rowmaps(P)
-                means(P, "lar")
-                F.keep.append((P.keep, P.per, P.msgs, P.tasks, P.tasks_g, P.gmap))
-            mark("reduce")
-            return
-
-        if pipelined and m.layer_order == "pipeline5":
+        if pipelined:
             # The direct conv of layer l needs x(l) only - not stage A, not the 32-edge launch: it is started as soon as the means of
             # layer l - 1 are queued, on a stream of its own, and has stage A(l) AND the 32-edge launch of layer l to finish beside
             # (joined before the means of layer l touch x: no snapshot of x_atom).  The window between two 32-edge launches is then
@@ -1088,81 +1065,6 @@ class ForwardEngine:
                 F.keep.append((P.keep, P.per, P.msgs, P.tasks, P.tasks_g, P.gmap, ev_r))
                 P = nxt
             side.join()
-            mark("reduce")
-            return
-
-        if pipelined:
-            late_side = m.layer_order == "pipeline2"
-            P = plan(0)
-            stage_a(P, "lar")
-            for l in range(L_):
-                nxt = plan(l + 1) if l + 1 < L_ else None
-                # the direct conv's messages only enter the receptor mean: everything else of the layer goes first.  The atom mean
-                # below updates x_atom in place while the direct conv still reads x_atom(l) as its source: it gets a snapshot
-                xa_old = torch.empty_like(xa) if (P.active["a"] and 8 in P.per) else None
-                direct_tasks(P, x_atom_src=xa_old)
-                has_direct = bool(P.tasks)
-                if late_side and l > 0:
-                    # "pipeline2": stage A of the receptor-source rows of THIS layer is still running on a side stream (queued
-                    # behind the receptor mean of layer l - 1); the convs with atom / ligand sources go first, beside it
-                    launch_factorised(P, "la")
-                    side.join(only=1)
-                    launch_factorised(P, "r")
-                else:
-                    launch_factorised(P)
-                join_lists()      # (layer 0: everything queued so far ran beside the lists; plan(1) and later read them)
-                fix_rowmaps(P)
-                if has_direct and xa_old is not None:
-                    xa_old.copy_(xa)
-                P.xa_old = xa_old
-                if m.layer_order in ("pipeline3", "pipeline4"):
-                    # "pipeline3": the whole receptor chain on a side stream - direct conv(l) -> mean{rec}(l) -> stage A(l + 1) of the
-                    # receptor-source rows - beside stage A(l + 1) of the atom- and ligand-source rows (nothing on main reads or writes
-                    # x_rec meanwhile).  "pipeline4": the ligand chain - mean{lig}(l) -> stage A(l + 1) of the ligand-source rows - on a
-                    # side stream of its own as well, beside mean{atom}(l) -> stage A(l + 1) of the atom-source rows
-                    def rec_chain(P=P, nxt=nxt, has_direct=has_direct):
-                        if has_direct:
-                            launch_direct(P)
-                        means(P, "r")
-                        if nxt is not None:
-                            stage_a(nxt, "r")
-
-                    def lig_chain(P=P, nxt=nxt):
-                        means(P, "l")
-                        if nxt is not None:
-                            stage_a(nxt, "l")
-                    if m.layer_order == "pipeline4":
-                        if has_direct:      # (the direct conv reads the snapshot of x_atom: it need not wait for the means either)
-                            side.run(3, rec_chain)
-                        side.run(2, lig_chain)
-                        means(P, "a")
-                    else:
-                        means(P, "la")
-                        if has_direct:
-                            side.run(3, rec_chain)
-                    if nxt is not None:
-                        stage_a(nxt, "a" if m.layer_order == "pipeline4" else "la")
-                    if not has_direct:
-                        rec_chain()
-                    side.join()
-                    F.keep.append((P.keep, P.per, P.msgs, P.tasks, P.tasks_g, P.gmap, getattr(P, "xa_old", None)))
-                    P = nxt
-                    continue
-                means(P, "la")
-                if has_direct:
-                    side.run(3, lambda: launch_direct(P))
-                if nxt is not None:
-                    stage_a(nxt, "la")
-                if has_direct:
-                    side.join()
-                means(P, "r")
-                if nxt is not None:
-                    if late_side:
-                        side.run(1, lambda nxt=nxt: stage_a(nxt, "r"))
-                    else:
-                        stage_a(nxt, "r")
-                F.keep.append((P.keep, P.per, P.msgs, P.tasks, P.tasks_g, P.gmap, getattr(P, "xa_old", None)))
-                P = nxt
             mark("reduce")
             return
 

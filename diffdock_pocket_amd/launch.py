@@ -81,13 +81,13 @@ class ConvProfiler:
         self._resolved = None
 
     # -- recording (called by the launch wrappers) -------------------------------------------------------------
-    def record_conv(self, e0, e1, spec, flops_spec, tasks_counts, node_bytes, tag=None, h2=False):
+    def record_conv(self, e0, e1, spec, flops_spec, tasks_counts, node_bytes, tag=None, h2=False, rows=False):
         """tasks_counts: [(capacity, cnt tensor or None)] of the launch's tasks; tag: where in the forward the launch sits
         ("layer3", "head")."""
         self.events.append((e0, e1))
         self.tags.append(tag)
         self.h2.append(bool(h2))     # the launch ran the fp16 hi/lo split form of the fc products
-        self.kernel.append("ddp_conv32_kernel" if spec.factorized else "ddp_conv_messages_kernel")
+        self.kernel.append("ddp_conv_rows_kernel" if rows else "ddp_conv32_kernel" if spec.factorized else "ddp_conv_messages_kernel")
         self.specs.append((spec, flops_spec or spec))
         self.counts.append(tasks_counts)
         self.node_bytes.append(node_bytes)
@@ -221,8 +221,20 @@ def set_range_flag(t):
     _RANGE_FLAG = t
 
 
-def make_task(pk, x_src, ldx_src, view: EdgeView, sh, segs, msg, g=None) -> L.ConvTask:
-    """segs: [(tensor, idx_int32[E], ld, ncols)], concatenated into edge_attr_ in this order."""
+# Factorised convs of the size class ns = 60 through the 256-edge row-stationary kernel (ddp_conv_rows, csrc/ddp_conv_rows.hip; needs
+# CONV_H2).  False: the 32-edge kernel of rounds 2 - 4 (A/B runs).  The two read G in different layouts: a task carries one of them.
+CONV_ROWS = True
+
+
+def rows_mode(pk) -> bool:
+    """Does a factorised conv with these packed weights run through ddp_conv_rows?  (Decided where stage A is planned: it writes G in
+    the layout the conv kernel of the same layer reads.)"""
+    return bool(CONV_H2 and CONV_ROWS and getattr(pk, "wsh", None) is not None)
+
+
+def make_task(pk, x_src, ldx_src, view: EdgeView, sh, segs, msg, g=None, rows=False) -> L.ConvTask:
+    """segs: [(tensor, idx_int32[E], ld, ncols)], concatenated into edge_attr_ in this order.  rows: a task of ddp_conv_rows - `g` then
+    holds the G arrays in plane form (ddp_stage_a_gh)."""
     t = L.ConvTask()
     t.x_src, t.ldx_src, t.n_edges = x_src.data_ptr(), ldx_src, view.n_edges
     t.src, t.eid, t.sh = view.src.data_ptr(), view.eid.data_ptr(), sh.data_ptr()
@@ -238,8 +250,11 @@ def make_task(pk, x_src, ldx_src, view: EdgeView, sh, segs, msg, g=None) -> L.Co
     t.w1h, t.w2h = (pk.w1h.data_ptr(), pk.w2h.data_ptr()) if use_h2 else (0, 0)
     t.h2_range_flag = _p(_RANGE_FLAG) if use_h2 else 0
     t.msg = msg.data_ptr()
+    t.wsh, t.bsp = (pk.wsh.data_ptr(), pk.bsp.data_ptr()) if rows else (0, 0)
     for k in range(2):
-        t.g[k] = g[k].data_ptr() if (g is not None and g[k] is not None) else 0
+        gk = g[k].data_ptr() if (g is not None and g[k] is not None) else 0
+        t.g[k], t.gh[k] = (0, gk) if rows else (gk, 0)
+    t._rows = bool(rows)
     t.pos = _p(view.pos)
     t.n_edges_dev = _p(view.cnt)
     t._count = (view.n_edges, view.cnt)      # (python-side only: for the profiler)
@@ -258,11 +273,15 @@ def launch_convs(spec: P.ConvSpec, tasks: List[L.ConvTask], flops_spec: Optional
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    L.check(lib.ddp_conv_messages(C.byref(shape), arr, len(tasks), stream()), "ddp_conv_messages")
+    rows = all(getattr(t, "_rows", False) for t in tasks)
+    if rows:
+        L.check(lib.ddp_conv_rows(C.byref(shape), arr, len(tasks), stream()), "ddp_conv_rows")
+    else:
+        L.check(lib.ddp_conv_messages(C.byref(shape), arr, len(tasks), stream()), "ddp_conv_messages")
     if prof is not None:
         e1.record()
         h2 = P.h2_steps(spec) > 0 and all(t.w1h and t.w2h for t in tasks)
-        prof.record_conv(e0, e1, spec, flops_spec, [t._count for t in tasks], node_bytes, tag, h2)
+        prof.record_conv(e0, e1, spec, flops_spec, [t._count for t in tasks], node_bytes, tag, h2, rows=rows)
 
 
 def launch_reduce(x, ldx, n_nodes, d_out, sources, accumulate=True, n_rep=1, rep_stride=0):
@@ -365,13 +384,19 @@ def edge_featurize_jobs(calls):
     return outs
 
 
-def stage_a(x, n_rows, offs, nb, W, out, rows=None, rows_cnt=None, out_rows=None, W3=None, Wh=None):
+def stage_a(x, n_rows, offs, nb, W, out, rows=None, rows_cnt=None, out_rows=None, W3=None, Wh=None, gh=None):
     """ddp_stage_a: out[b][row] = x[row, offs[b]:offs[b]+k] @ W[b] for the listed rows (all n_rows rows if rows is None).
     Wh: the weights pre-split for the fp16 hi/lo form (packing.split_h2; ddp_stage_a_h2), W3: for the bf16x3 form
-    (packing.split_bf16x3); neither: exact fp32 MFMA."""
+    (packing.split_bf16x3); neither: exact fp32 MFMA.  gh = (G columns, 8-column groups that leave as fp16 hi/lo planes): the
+    layout ddp_conv_rows reads (ddp_stage_a_gh; needs Wh)."""
     lib = L.load()
     n_in, ncols = W.shape[1], W.shape[2]
     if n_rows == 0:
+        return
+    if gh is not None:
+        L.check(lib.ddp_stage_a_gh(x.data_ptr(), x.stride(0), n_rows, ptr(rows), ptr(rows_cnt), out_rows if out_rows is not None else n_rows,
+                                   offs, nb, W.data_ptr(), ptr(Wh), n_in, ncols, out.data_ptr(), ncols, ptr(_RANGE_FLAG), gh[0], gh[1], stream()),
+                "ddp_stage_a_gh")
         return
     if Wh is not None:
         L.check(lib.ddp_stage_a_h2(x.data_ptr(), x.stride(0), n_rows, ptr(rows), ptr(rows_cnt), out_rows if out_rows is not None else n_rows,

@@ -361,6 +361,8 @@ def split_h2(W: torch.Tensor) -> torch.Tensor:
     Wf[:, :K] = W.float()
     hi = Wf.to(torch.float16)
     lo = ((Wf - hi.float()) * H2_SCALE).to(torch.float16)
+    if not bool(torch.isfinite(hi).all()):
+        raise NotImplementedError("stage-A weight outside the fp16 range (|w| > 65504): the fp16 hi/lo form cannot represent it")
     planes = torch.stack([hi, lo], dim=1)                                       # [nb, 2, KP, ncols]
     return planes.reshape(nb, 2, KP // 16, 2, 8, ncols).permute(0, 1, 2, 3, 5, 4).contiguous()
 
@@ -493,3 +495,118 @@ def bn_affine(out_mul_blocks: Sequence[Tuple[int, int, bool]], running_mean, run
         shifts.append(sh.repeat_interleave(dim))
         iw += mul
     return torch.cat(scales).float(), torch.cat(shifts).float()
+
+# ------------------------------------------------------------------------------------------------ row-stationary kernel (ddp_conv_rows)
+def rows_supported(spec: "ConvSpec") -> bool:
+    """Shapes ddp_conv_rows runs: factorised convs of the size class ns = 60 (f_in = hid = 180: the released cfg2 architecture) whose
+    per-wave feature rows fit the kernel's LDS plan."""
+    if not spec.factorized or h2_steps(spec) != 12:
+        return False
+    frows = max([b.U * b.C for b in spec.blocks if b.U > 0] + [0])
+    priv = max((frows * 36 * 4 + 127) // 128 * 128 + 1408, 12 * 1024)
+    return 2 * 24 * 1024 + 8 * ((priv + 127) // 128 * 128) <= 160 * 1024 - 1024
+
+
+def rows_kperm(ns16: int) -> torch.Tensor:
+    """LongTensor [16 ns16]: slot (ks, hh, i) of an A / B operand fragment of ddp_conv_rows -> the h column (k index of fc.3 / G) it holds,
+    DDP_ROWS_KPERM of include/ddp_hip.h.  The kernel computes h = relu(fc1) as the TRANSPOSED product (A = fc.0 tile, B = edge_attr_),
+    whose 32 x 32 accumulator tile ct leaves lane (edge r, hh) with the h columns 32 ct + (j & 3) + 8 (j >> 2) + 4 hh, j < 16, of its own
+    edge: registers j = 0..7 are the fragment ks = 2 ct, j = 8..15 the fragment ks = 2 ct + 1 - no transpose through LDS."""
+    ks = torch.arange(ns16).reshape(-1, 1, 1)
+    hh = torch.arange(2).reshape(1, -1, 1)
+    i = torch.arange(8).reshape(1, 1, -1)
+    j = 8 * (ks % 2) + i
+    return (32 * (ks // 2) + (j % 4) + 8 * (j // 4) + 4 * hh).reshape(-1)
+
+
+def rows_segments(spec: "ConvSpec"):
+    """The output-column segments ddp_conv_rows walks, in order: (block index, 32-column part, [packed tile index of the part's stream
+    tiles in feature order]).  A block with n > 32 has ceil(n / 32) parts (tiles u * nsub + part), one part otherwise; blocks whose
+    features are all factorised have parts without stream tiles."""
+    segs = []
+    for bi, b in enumerate(spec.blocks):
+        nparts = (b.n + 31) // 32
+        for part in range(nparts):
+            if b.U == 0:
+                tiles = []
+            elif b.nsub > 1:
+                tiles = [b.tile0 + u * b.nsub + part for u in range(b.U)]
+            else:
+                tiles = [b.tile0 + t for t in range((b.U + b.ups - 1) // b.ups)]
+            segs.append((bi, part, tiles))
+    return segs
+
+
+def rows_stream(spec: "ConvSpec", w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor):
+    """(wsh, bsp) of ddp_conv_task_t for ddp_conv_rows: fc.0's nct1 column tiles (natural k order: their K is edge_attr_), then the fc.3
+    tiles of `spec` (block scale folded in) segment by segment with the k index permuted by rows_kperm; fp16 hi/lo planes per tile as
+    in _pack_tiles_h2, the bias words fp32 [tiles, 32]."""
+    ns16 = h2_steps(spec)
+    assert ns16 > 0
+    hid, f_in = w1.shape
+    W1c = torch.zeros(spec.nct1 * 32, f_in)
+    W1c[:hid] = w1.detach().float().cpu()
+    b1c = torch.zeros(spec.nct1 * 32)
+    b1c[:hid] = b1.detach().float().cpu()
+    t1 = _pack_tiles_h2(W1c, ns16).reshape(spec.nct1, -1)
+    w2 = w2.detach().float().cpu()
+    b2 = b2.detach().float().cpu()
+    cols, bcols = [], []
+    for b in spec.blocks:
+        rows = b.column_rows()
+        valid = rows >= 0
+        Wc = torch.zeros(rows.numel(), spec.hid)
+        Wc[valid] = w2[rows[valid]] * b.scale
+        bc = torch.zeros(rows.numel())
+        bc[valid] = b2[rows[valid]] * b.scale
+        cols.append(Wc)
+        bcols.append(bc)
+    order = [t for _, _, tiles in rows_segments(spec) for t in tiles]
+    if order:
+        Wall = torch.cat(cols, 0)                                   # [ntiles * 32, hid]
+        Wp = torch.zeros(Wall.shape[0], 16 * ns16)
+        Wp[:, :spec.hid] = Wall
+        Wp = Wp[:, rows_kperm(ns16)]                                # fragment slot -> permuted k
+        t2 = _pack_tiles_h2(Wp, ns16).reshape(Wall.shape[0] // 32, -1)[order]
+        bs2 = torch.cat(bcols, 0).reshape(-1, 32)[order]
+        return torch.cat([t1, t2], 0).reshape(-1).contiguous(), torch.cat([b1c.reshape(-1, 32), bs2], 0).contiguous()
+    return t1.reshape(-1).contiguous(), b1c.reshape(-1, 32).contiguous()
+
+
+def gh_ld(hid: int, gcols: int) -> int:
+    """DDP_GH_LD: floats per node of a G array in plane form."""
+    return (((hid + 7) // 8 * 8 + 1) * gcols + 31) // 32 * 32
+
+
+def factor_weights_gh(spec: "ConvSpec", weight: torch.Tensor, bias: torch.Tensor):
+    """factor_weights for ddp_conv_rows: the right-hand sides whose product columns are ordered [k8 group][G column c][8 k's of the group]
+    (the k's of group g = 2 ks + hh are rows_kperm's slots (ks, hh, 0..7); h columns >= hid are zero rows), then the Gb columns, then
+    zero padding to DDP_GH_LD.  ddp_stage_a_gh writes the first n8 * g_cols groups of a row as fp16 hi/lo planes
+    [k8][plane][c][8] (ddp_conv_task_t::gh).  Returns ([Wg0, Wg1], [in_off0, in_off1], [groups0, groups1])."""
+    ns16 = h2_steps(spec)
+    assert ns16 > 0
+    weight = weight.detach().float().cpu()
+    bias = bias.detach().float().cpu()
+    n8 = (spec.hid + 7) // 8
+    kp = rows_kperm(ns16)[:8 * n8]
+    Wg, offs, groups = [None, None], [0, 0], [0, 0]
+    for slot in (0, 1):
+        blks = [b for b in spec.blocks if b.g_slot == slot]
+        if not blks:
+            continue
+        gc = spec.g_cols[slot]
+        n_in = blks[0].g_count
+        assert all(b.g_count == n_in and b.g_in_off == blks[0].g_in_off for b in blks)
+        W = torch.zeros(n_in, 16 * ns16, gc)
+        Bm = torch.zeros(n_in, gc)
+        for b in blks:
+            rows = b.w_off + (b.g_u0 + torch.arange(n_in)).reshape(-1, 1) * b.n + torch.arange(b.n).reshape(1, -1)
+            W[:, :spec.hid, b.g_col0:b.g_col0 + b.n] = (weight[rows] * b.scale).permute(0, 2, 1)     # [u, n, hid] -> [u, hid, n]
+            Bm[:, b.g_col0:b.g_col0 + b.n] = bias[rows] * b.scale
+        Wq = W[:, kp].reshape(n_in, n8, 8, gc).permute(0, 1, 3, 2)                                    # [u, k8, c, 8]
+        ld = gh_ld(spec.hid, gc)
+        Wfull = torch.zeros(n_in, ld)
+        Wfull[:, :8 * n8 * gc] = Wq.reshape(n_in, -1)
+        Wfull[:, 8 * n8 * gc:8 * n8 * gc + gc] = Bm
+        Wg[slot], offs[slot], groups[slot] = Wfull.contiguous(), blks[0].g_in_off, n8 * gc
+    return Wg, offs, groups

@@ -145,7 +145,8 @@ def _mlp(n_in, n_hidden, n_out, dropout):
 
 
 class _PackedConv:
-    __slots__ = ("w1p", "b1p", "w2p", "b2p", "bn_scale", "bn_shift", "wg", "bg", "g_in_off", "w1h", "w2h")
+    __slots__ = ("w1p", "b1p", "w2p", "b2p", "bn_scale", "bn_shift", "wg", "bg", "g_in_off", "w1h", "w2h",
+                 "wsh", "bsp", "wgh", "gh_groups")     # (the last four: ddp_conv_rows' weight stream and stage-A right-hand sides)
 
 
 class TensorProductConvLayer(nn.Module):
@@ -182,14 +183,36 @@ class TensorProductConvLayer(nn.Module):
             pk.wg = [w.to(device) if w is not None else None for w in wg]
             pk.bg = [b.to(device) if b is not None else None for b in bg]
             pk.g_in_off = offs
+            # the 256-edge row-stationary kernel (ddp_conv_rows; size class ns = 60): the fc.0 / fc.3 tiles as one stream in the
+            # kernel's k order, and stage-A right-hand sides whose product ddp_stage_a_gh writes as fp16 hi/lo planes
+            pk.wsh = pk.bsp = pk.wgh = pk.gh_groups = None
+            if P.rows_supported(self.spec_g):
+                wsh, bsp = P.rows_stream(self.spec_g, self.fc[0].weight, self.fc[0].bias, self.fc[3].weight, self.fc[3].bias)
+                pk.wsh, pk.bsp = wsh.to(device), bsp.to(device)
+                wgh, _, groups = P.factor_weights_gh(self.spec_g, self.fc[3].weight, self.fc[3].bias)
+                pk.wgh = [w.to(device) if w is not None else None for w in wgh]
+                pk.gh_groups = groups
             self._packed_g = pk
         return self._packed_g
 
-    def node_tensors(self, pk: _PackedConv, x_src: torch.Tensor):
-        """Stage A of the factorised conv: per-source-node rows [G | Gb | pad] = x_scalar @ Wg (ddp_stage_a)."""
+    def node_tensors(self, pk: _PackedConv, x_src: torch.Tensor, rows: bool = False):
+        """Stage A of the factorised conv: per-source-node rows [G | Gb | pad] = x_scalar @ Wg (ddp_stage_a); rows: in the plane
+        form ddp_conv_rows reads (ddp_stage_a_gh)."""
         lib = L.load()
         g = [None, None]
         N = x_src.shape[0]
+        if rows:
+            for slot in (0, 1):
+                if pk.wgh[slot] is None:
+                    continue
+                w = pk.wgh[slot]
+                wh = P.split_h2(w.unsqueeze(0))
+                g[slot] = torch.empty((N, w.shape[1]), device=x_src.device, dtype=torch.float32)
+                offs = (C.c_int32 * 1)(pk.g_in_off[slot])
+                L.check(lib.ddp_stage_a_gh(x_src.data_ptr(), x_src.shape[1], N, None, None, N, offs, 1, w.data_ptr(), wh.data_ptr(), w.shape[0],
+                                           w.shape[1], g[slot].data_ptr(), w.shape[1], None, self.spec_g.g_cols[slot], pk.gh_groups[slot],
+                                           _stream()), "ddp_stage_a_gh")
+            return g
         for slot in (0, 1):
             if pk.wg[slot] is None:
                 continue
@@ -241,8 +264,14 @@ class TensorProductConvLayer(nn.Module):
                 raise NotImplementedError("this conv has no factorised variant")
             pk = self.packed_g(dev)
             so = G.source_order(csr, x.shape[0])
-            g = self.node_tensors(pk, x)
-            task = _make_task(pk, x, x.shape[1], so, sh, [(ea, so.eid, ea.shape[1], ea.shape[1])], msg, g=g)
+            rows = K.rows_mode(pk) and ea.shape[1] % 12 == 0
+            g = self.node_tensors(pk, x, rows=rows)
+            if rows:     # (ddp_conv_rows gathers edge_attr_ as three segments of ns columns: here three column ranges of one array)
+                w3 = ea.shape[1] // 3
+                segs = [(ea[:, i * w3:], so.eid, ea.shape[1], w3) for i in range(3)]
+            else:
+                segs = [(ea, so.eid, ea.shape[1], ea.shape[1])]
+            task = _make_task(pk, x, x.shape[1], so, sh, segs, msg, g=g, rows=rows)
             _launch_convs(self.spec_g, [task], flops_spec=self.spec)
         else:
             task = _make_task(self.packed(dev), x, x.shape[1], csr, sh, [(ea, csr.eid, ea.shape[1], ea.shape[1])], msg)
@@ -424,19 +453,10 @@ class TensorProductScoreModel(nn.Module):
         self.concurrent_small_batches = True
         self.concurrent_max_atoms = 16000
         self.fork_small_means = True     # ... and a layer's three segmented means (ligand / atom / receptor rows) side by side
-        # Large batches (round 4): the direct conv of layer l (receptor<-atom) on a side stream beside stage A of layer l + 1 for the
-        # atom- and ligand-source rows (engine._layers, "pipelined"); same kernels, same arguments, same bits as the serial order
+        # Large batches: the layer's chains as parallel branches of the captured step (engine._layers, "pipelined": the direct conv of
+        # layer l + 1 starts as soon as the atom and receptor means of layer l are queued; receptor / ligand / atom chains
+        # [mean -> stage A] side by side); same kernels, same arguments, same bits as the serial order (False)
         self.overlap_direct_conv = True
-        # which overlapped order: "pipeline" = direct conv(l) beside stage A(l + 1); "chains" = per layer two forked chains (atom-source
-        # stage A -> its convs | the other stage-A products -> their convs -> direct conv).  Same box, alternating, after the convs moved
-        # to the fp16 matrix cores: serial 20.48 - 20.51, chains 20.28 - 20.39, pipeline 20.22 - 20.25 ms per 40-sample step.
-        # "pipeline3": the receptor chain - direct conv(l) -> mean{rec}(l) -> stage A(l + 1) of the receptor-source rows - on the side
-        # stream (pipeline 20.07 -> 19.91 ms, flexible 24.47 -> 24.15); "pipeline4" (default): the ligand chain - mean{lig}(l) -> stage
-        # A(l + 1) of the ligand-source rows - on a side stream of its own too, the direct conv forked before the means (19.60 -> 19.51);
-        # "pipeline5" (default): the direct conv of layer l + 1 is started as soon as the atom and receptor means of layer l are queued
-        # and has stage A(l + 1) and the whole 32-edge launch of layer l + 1 to finish beside - off the critical path, no snapshot of
-        # x_atom (19.53 -> 19.38 ms; flexible 23.50 either way)
-        self.layer_order = "pipeline5"
         # The front's independent chains side by side (parallel branches of the captured step; same kernels, same arguments, same bits):
         # [node encoders -> edge embeddings] beside [neighbour searches -> CSR / source-ordered views], and - rigid receptor - the index
         # lists of the work eliminations (first read by layer 1) beside stage A + the 32-edge conv launch of layer 0 (engine._front,

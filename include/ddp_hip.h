@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DDP_ABI_VERSION 12
+#define DDP_ABI_VERSION 13
 #define DDP_EINVAL (-1)   /* bad argument (shape not supported, null pointer, ...) */
 #define DDP_ELIMIT (-2)   /* exceeds a compiled-in limit (see DDP_MAX_*) */
 
@@ -133,7 +133,24 @@ typedef struct {
    * h = relu(fc1) value) lies outside the fp16 range (|v| > 65504, or NaN): the result of that launch is then not to be trusted and
    * the caller should rerun with the fp32 form (w1h = w2h = NULL).  NULL: not reported. */
   int32_t* h2_range_flag;
+  /* Optional (ABI 13), for ddp_conv_rows (256-edge, row-stationary workgroups; csrc/ddp_conv_rows.hip):
+   *  wsh   the SAME fc.0 / fc.3 weights as w1h / w2h, as ONE stream of 32-column tiles in the order the kernel walks them: the nct1
+   *        tiles of fc.0, then for every block and every 32-column part of its n output columns the part's tiles in feature order
+   *        (packing.rows_stream).  Tile layout as w1h / w2h (2 NS fragments of 1 KiB), but the K index of the fc.3 tiles is
+   *        PERMUTED (DDP_ROWS_KPERM below): the kernel computes h = relu(fc1) as the transposed product, whose accumulator
+   *        registers then ARE the A-operand fragments of the fc.3 products in that k order (no transpose through LDS).
+   *  bsp   the tiles' bias words, fp32 [stream tiles][32]
+   *  gh    G[s] of a factorised conv as fp16 hi/lo operand planes (v = hi + lo / 2048), per source node DDP_GH_LD(hid, g_cols[s])
+   *        floats: [k8 < ceil(hid/8)][plane][c < g_cols[s]][8 halves]  (k8 group g holds the permuted k's DDP_ROWS_KPERM(g >> 1, g & 1, i),
+   *        i < 8), then Gb[c] as fp32, then padding to 128 bytes; written by ddp_stage_a_h2 with its `gh_cols` argument.
+   * NULL: the task can only run through ddp_conv_messages. */
+  const void* wsh;
+  const float* bsp;
+  const void* gh[2];
 } ddp_conv_task_t;
+/* k index held by element i of the 8-k group (ks, hh) of an h / fc.3 / G operand fragment in ddp_conv_rows */
+#define DDP_ROWS_KPERM(ks, hh, i) (32 * ((ks) >> 1) + ((8 * ((ks) & 1) + (i)) & 3) + 8 * ((8 * ((ks) & 1) + (i)) >> 2) + 4 * (hh))
+#define DDP_GH_LD(hid, gcols) ((((((hid) + 7) / 8) * 8 + 1) * (gcols) + 31) / 32 * 32)   /* floats per node of a G array in plane form */
 
 /* Fused fc -> tensor product -> per-edge message for up to 9 convs that share one shape.
  * All tasks of one call share `shape` (factorised and plain convs therefore go in separate calls).
@@ -141,6 +158,16 @@ typedef struct {
  * (models/score_model.py:108-114) + FasterTensorProduct.forward (models/layers.py:34-85) + the edge_attr_
  * concatenations (models/all_atom_score_model.py:273-312).  The [E, weight_numel] tensor never exists. */
 int ddp_conv_messages(const ddp_conv_shape_t* shape, const ddp_conv_task_t* tasks, int ntasks, void* stream);
+
+/* The same contract as ddp_conv_messages for FACTORISED shapes of the size classes with an h2 form (f_in = hid = 3 ns), through
+ * 256-edge workgroups (8 waves, one workgroup per CU): every wave keeps h of ITS 32 edges as A-operand fragments in registers, the
+ * weight tiles (task.wsh) are staged ONCE per workgroup through an LDS ring and read from there by all eight waves, the factorised
+ * features are G tiles (task.gh: one pass of the same tile product per run of edges with one source node), and a wave accumulates
+ * all contributions to its output columns in registers and stores message rows directly: the fc.3 weights leave L2 once per 256
+ * edges instead of once per 32 (the 32-edge kernel was bound by that traffic: 15 TB/s of L2 -> CU reads, L2 90 % busy).
+ * Every task needs wsh, bsp and - for shapes with g_cols != 0 - gh.  Results: within fp32 rounding of ddp_conv_messages (another
+ * summation order), deterministic. */
+int ddp_conv_rows(const ddp_conv_shape_t* shape, const ddp_conv_task_t* tasks, int ntasks, void* stream);
 
 /* Segmented mean over CSR rows + e3nn BatchNorm (eval) + residual accumulate:
  *   x[n, :d_out] (+)= sum_k ( mean_{p in rowptr_k[n]..rowptr_k[n+1]} msg_k[p, :] * bn_scale_k + bn_shift_k )
@@ -334,6 +361,14 @@ int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* rows, const i
  * error <= 2^-20 sum|x w|); other shapes run the exact fp32 forms on `w`.  ABI 12. */
 int ddp_stage_a_h2(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows, const int32_t* offs,
                    int nbatch, const float* w, const void* w_h2, int k, int ncols, float* out, int ldo, int32_t* range_flag, void* stream);
+/* ... with the leading gh_groups * 8 columns of every output row written as fp16 hi/lo operand planes (ddp_conv_task_t::gh): the
+ * product's columns [8 g, 8 g + 8), g = k8 * gh_cols + c, are the 8 k's of group k8 for G column c; their values v = hi + lo / 2048
+ * go to halves [8 ((2 k8) gh_cols + c), + 8) (hi) and [8 ((2 k8 + 1) gh_cols + c), + 8) (lo) of the row - the same bytes as the fp32
+ * form, as two 16-byte pieces.  Columns >= 8 gh_groups (the Gb part) stay fp32 at their own offsets.  Only on the h2 path (w_h2
+ * given, wide product); gh_groups = 0: ddp_stage_a_h2.  ABI 13. */
+int ddp_stage_a_gh(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows, const int32_t* offs,
+                   int nbatch, const float* w, const void* w_h2, int k, int ncols, float* out, int ldo, int32_t* range_flag,
+                   int gh_cols, int gh_groups, void* stream);
 
 /* The pose update between two score-model calls, for all samples of a batch in one launch:
  * modify_conformer(pos, tr_update, rot_update, torsion_updates) of utils/diffusion_utils.py:37-60 = rigid move about the
