@@ -198,7 +198,7 @@ def load():
     lib.ddp_stage_a.restype = C.c_int
     lib.ddp_stage_a_h2.argtypes = lib.ddp_stage_a.argtypes[:-1] + [C.c_void_p, C.c_void_p]
     lib.ddp_stage_a_h2.restype = C.c_int
-    lib.ddp_stage_a_gh.argtypes = lib.ddp_stage_a_h2.argtypes[:-1] + [C.c_int, C.c_int, C.c_void_p]
+    lib.ddp_stage_a_gh.argtypes = lib.ddp_stage_a_h2.argtypes[:-1] + [C.c_void_p, C.c_void_p]
     lib.ddp_stage_a_gh.restype = C.c_int
     lib.ddp_pose_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]

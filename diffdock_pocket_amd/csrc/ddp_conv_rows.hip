@@ -8,12 +8,14 @@
 // through every 32-edge workgroup: 278 M L2 requests of 128 B per 2.3-ms launch = 15.3 TB/s of L2 -> CU traffic, L2 busy 90 %
 // (profiles/r05_pmc_conv32_h2_l1_l2.json) against the 16.8 - 18.8 TB/s the chip delivers from its XCD L2s - the matrix pipe sat at
 // 31 %.  Here the weights leave L2 once per 256 edges:
-//   workgroup = 8 waves (two per SIMD, 256 registers each), ONE per CU, 256 consecutive (source-ordered) edges of one conv;
+//   workgroup = 4 waves (one per SIMD, 256 registers each), TWO per CU, 128 consecutive (source-ordered) edges of one conv: the two
+//     co-resident workgroups are independent, so one's memory-bound G runs overlap the other's matrix-bound stream tiles (one
+//     8-wave workgroup per CU ran every phase in lock-step behind its barriers: 480 k ticks per 256 edges, G runs 45 % of them);
 //   wave w owns the 32 edges [32 w, 32 w + 32) for the whole kernel and keeps h = relu(fc1) of them as the A-operand fragments
 //     of v_mfma_f32_32x32x16_f16 in REGISTERS (fp16 hi/lo planes: 8 NS registers);
 //   the weight tiles (task.wsh: the fc.0 tiles, then the fc.3 tiles segment by segment) are staged once per workgroup through a
-//     two-slot LDS ring - every wave loads 1/8 of the next tile, one barrier per tile - and all eight waves read their B operands
-//     from LDS (conflict-free lane-linear 16-byte reads);
+//     three-slot LDS ring of THIRD tiles (8 KiB each) by LDS-DMA - every wave moves 1/4 of the piece after next, one barrier per piece -
+//     and all four waves read their B operands from LDS (conflict-free lane-linear 16-byte reads);
 //   h comes from the TRANSPOSED fc1 product (A = fc.0 tile, B = edge_attr_ fragments gathered straight from the three row
 //     segments): the accumulator of column tile ct leaves lane (edge, hh) with 16 h values of its own edge, which ARE the k-groups
 //     (2 ct, hh) and (2 ct + 1, hh) of the next products in the permuted k order DDP_ROWS_KPERM (the host packs fc.3 and G in it);
@@ -33,17 +35,46 @@
 #undef DDP_STAMPS   // (the in-kernel stamps of tools/stamp_conv.py belong to ddp_conv.hip)
 #include "ddp_conv_common.h"
 
-#define ROWS_NW 8
-#define ROWS_NT 512
-#define ROWS_ET 256
+#define ROWS_NW 4
+#define ROWS_NT 256
+#define ROWS_ET 128
 #define ROWS_FS 36     // floats per feature row F[u * C + c][edge]
-#ifndef DDP_ROWS_GRING
-#define DDP_ROWS_GRING 4
+#ifndef DDP_ROWS_GRING1
+#define DDP_ROWS_GRING1 8
+#endif
+#ifndef DDP_ROWS_GRING3
+#define DDP_ROWS_GRING3 4
+#endif
+
+// Diagnostic build only (-DDDP_ROWS_STAMPS, tools/stamp_rows.py): lane 0 of every wave records s_memtime at the phase boundaries
+#ifdef DDP_ROWS_STAMPS
+#define RS_SLOTS 32
+#define RS_WGS 16384
+__device__ unsigned long long ddp_rows_stamp_buf[(size_t)RS_WGS * ROWS_NW * RS_SLOTS];
+#define RSTAMP(k)                                                                                          \
+  do {                                                                                                     \
+    unsigned long long t_;                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    if (lane == 0 && blockIdx.x < RS_WGS) ddp_rows_stamp_buf[((size_t)blockIdx.x * ROWS_NW + wave) * RS_SLOTS + (k)] = t_; \
+  } while (0)
+#define RSTAMP_VAL(k, v)                                                                                   \
+  do {                                                                                                     \
+    if (lane == 0 && blockIdx.x < RS_WGS) ddp_rows_stamp_buf[((size_t)blockIdx.x * ROWS_NW + wave) * RS_SLOTS + (k)] = (unsigned long long)(v); \
+  } while (0)
+extern "C" int ddp_debug_read_rows_stamps(unsigned long long* host_dst, int n_wgs) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(ddp_rows_stamp_buf), sizeof(unsigned long long) * RS_SLOTS * ROWS_NW * (size_t)n_wgs);
+}
+#else
+#define RSTAMP(k) do {} while (0)
+#define RSTAMP_VAL(k, v) do {} while (0)
 #endif
 
 struct RowsLaunch {
   ConvLaunch L;
   int nts;         // stream tiles per conv (fc.0 tiles + fc.3 tiles of all segments)
+  int bias_bytes;  // LDS bytes of the bias table behind the ring
   int priv_bytes;  // LDS bytes of a wave's private area
   int aux_off;     // byte offset of the per-edge tables inside it
 };
@@ -92,45 +123,98 @@ __device__ __forceinline__ void rows_epilogue_run(const f32x16& am, const f32x16
   }
 }
 
-// One stream step: tile t is complete in slot t & 1 and nobody reads tile t - 1 any more (barrier); the staged registers (tile
-// t + 1, requested a tile ago) go to the other slot, tile t + 2 is requested.
-template <int NF>
-__device__ __forceinline__ void rows_stream_step(f32x4* ring, const f32x4* __restrict__ wsh, int t, int nts, int wave, int lane, f32x4 (&st)[(NF + ROWS_NW - 1) / ROWS_NW]) {
-  constexpr int FPW = (NF + ROWS_NW - 1) / ROWS_NW, TILE_Q = NF * 64;
+// The weight stream: a tile travels as ROWS_NP pieces of NS / ROWS_NP k-steps (8 KiB at NS = 12), piece p of every tile through slot p of
+// a three-slot LDS ring.  One stream step j = ROWS_NP t + p: every wave's part of piece j has landed (the wave waits for its own LDS-DMA
+// copies of piece j - those of piece j + 1 stay in flight - then the barrier), nobody reads piece j - 1 any more, so piece j + 2 is
+// requested into its slot (global_load_lds_dwordx4: no staging registers; every wave moves 2 NS / (ROWS_NP ROWS_NW) fragments of 1 KiB,
+// lane-linear in LDS).  A copy has two piece products to land (one was not enough: ~1 k ticks of every 3.4 k-tick tile waited for it).
+#define ROWS_NP 3
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+template <int NS>
+__device__ __forceinline__ void rows_request_piece(f32x4* ring, const f32x4* __restrict__ wsh, int jn, int npieces, int slot, int wave, int lane) {
+  constexpr int FPP = 2 * NS / ROWS_NP, FPW = FPP / ROWS_NW, PIECE_Q = FPP * 64;
+  static_assert(NS % ROWS_NP == 0 && FPP % ROWS_NW == 0, "every wave moves the same number of fragments per piece");
+  f32x4* nslot = ring + slot * PIECE_Q;
+  const f32x4* __restrict__ wn = wsh + (size_t)min(jn, npieces - 1) * PIECE_Q;
+#pragma unroll
+  for (int f = 0; f < FPW; ++f)
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(wn + (wave + ROWS_NW * f) * 64 + lane), (lds_ptr_t)(nslot + (wave + ROWS_NW * f) * 64), 16, 0, 0);
+}
+template <int NS, int P>
+__device__ __forceinline__ void rows_stream_step(f32x4* ring, const f32x4* __restrict__ wsh, int t, int nts, int wave, int lane) {
+  constexpr int FPW = 2 * NS / ROWS_NP / ROWS_NW;
+  // (hipcc does NOT wait for an LDS-DMA in front of a barrier: without this a wave can pass while its part of the piece is in flight.
+  // vmcnt counts in order: "at most FPW outstanding" = everything older than the copies of piece j + 1 has landed)
+  static_assert(FPW == 2, "the literal below");
+  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   __syncthreads();
-  f32x4* nslot = ring + ((t + 1) & 1) * TILE_Q;
-#pragma unroll
-  for (int f = 0; f < FPW; ++f)
-    if (wave + ROWS_NW * f < NF) nslot[(wave + ROWS_NW * f) * 64 + lane] = st[f];
-  const f32x4* __restrict__ wn = wsh + (size_t)min(t + 2, nts - 1) * TILE_Q;
-#pragma unroll
-  for (int f = 0; f < FPW; ++f)
-    if (wave + ROWS_NW * f < NF) st[f] = wn[(wave + ROWS_NW * f) * 64 + lane];
+  rows_request_piece<NS>(ring, wsh, ROWS_NP * t + P + 2, ROWS_NP * nts, (P + 2) % ROWS_NP, wave, lane);
 }
 
-// acc += A(regs) x B(tile in LDS): 3 split products per 16 k, B fragments read one k-step ahead
-template <int NS>
-__device__ __forceinline__ void rows_tile_lds(const f32x4* slot, const h8 (&ah)[NS], const h8 (&al)[NS], int lane, f32x16& am, f32x16& ac) {
+// acc += A(regs, k-steps KS0 ..) x B(piece in LDS): 3 split products per 16 k, B fragments read one k-step ahead
+template <int NS, int KS0>
+__device__ __forceinline__ void rows_piece_lds(const f32x4* slot, const h8 (&ah)[NS], const h8 (&al)[NS], int lane, f32x16& am, f32x16& ac) {
+  constexpr int NK = NS / ROWS_NP;
   f32x4 b0 = slot[lane], b1 = slot[64 + lane];
 #pragma unroll
-  for (int ks = 0; ks < NS; ++ks) {
+  for (int k = 0; k < NK; ++k) {
     const h8 bh = __builtin_bit_cast(h8, b0), bl = __builtin_bit_cast(h8, b1);
-    if (ks + 1 < NS) {
-      b0 = slot[(2 * ks + 2) * 64 + lane];
-      b1 = slot[(2 * ks + 3) * 64 + lane];
+    if (k + 1 < NK) {
+      b0 = slot[(2 * k + 2) * 64 + lane];
+      b1 = slot[(2 * k + 3) * 64 + lane];
     }
-    am = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh, am, 0, 0, 0);
-    ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl, ac, 0, 0, 0);
-    ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh, ac, 0, 0, 0);
+    am = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS0 + k], bh, am, 0, 0, 0);
+    ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS0 + k], bl, ac, 0, 0, 0);
+    ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[KS0 + k], bh, ac, 0, 0, 0);
   }
+}
+
+// Where the G tile of segment (block bi, part) sits inside a node's row of task.gh[slot]: byte offset of the tile, padded width, padded
+// columns of the slot and in front of the part (include/ddp_hip.h, ddp_conv_task_t::gh).  Returns false if the block has no G part.
+__device__ __forceinline__ bool rows_gpart(const ddp_conv_shape_t& S, int bi, int part, int& wp, int& cumw, int& gcp) {
+  const ddp_block_t& B = S.blk[bi];
+  wp = cumw = gcp = 0;
+  if (B.g_slot < 0) return false;
+  for (int bj = 0; bj < S.nblocks; ++bj) {
+    const ddp_block_t& Bj = S.blk[bj];
+    if (Bj.g_slot != B.g_slot) continue;
+    for (int pj = 0; pj < ((Bj.n + 31) >> 5); ++pj) {
+      const int wj = (min(32, Bj.n - 32 * pj) + 3) & ~3;
+      if (bj < bi || (bj == bi && pj < part)) cumw += wj;
+      if (bj == bi && pj == part) wp = wj;
+      gcp += wj;
+    }
+  }
+  return true;
+}
+
+// G tiles come from HBM (first touch: ~3.5 k ticks per round trip under this kernel's load, two round trips per tile with the register
+// ring) - so a wave TOUCHES the tile of its next run (one dword per 128-byte line: three loads) while it works on the current one: the
+// lines are in L2 when the ring asks for them.  The touched words are kept until the end of the current tile and never used.
+struct RowsTouch {
+  float v[3];
+};
+__device__ __forceinline__ RowsTouch rows_touch_tile(const char* __restrict__ tile, int tile_bytes, int lane) {
+  RowsTouch t;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) t.v[i] = *reinterpret_cast<const float*>(tile + min((i * 64 + lane) * 128, tile_bytes - 4));
+  return t;
+}
+__device__ __forceinline__ void rows_touch_done(const RowsTouch& t) {
+  asm volatile("" ::"v"(t.v[0]), "v"(t.v[1]), "v"(t.v[2]));
 }
 
 // One segment = the 32-column part `part` of block B: G runs, stream tiles, store.  Returns the stream position behind it.
 template <int NS, int C>
-__device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_block_t& B, int part, const ddp_conv_task_t& T, const h8 (&ah)[NS],
-                                            const h8 (&al)[NS], f32x4* ring, f32x4 (&st)[(2 * NS + ROWS_NW - 1) / ROWS_NW], int t, const float* F,
-                                            const RowsAux* aux, unsigned rmask, int src_reg, int nvw, int wave, int lane) {
-  constexpr int NF = 2 * NS, TILE_Q = NF * 64, GR = DDP_ROWS_GRING;
+__device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_block_t& B, int bi, int part, const ddp_conv_task_t& T, const h8 (&ah)[NS],
+                                            const h8 (&al)[NS], f32x4* ring, const float* lbias, int t, const float* F,
+                                            const RowsAux* aux, unsigned rmask, int src_reg, int nvw, int wave, int lane, int sgi,
+                                            const char* __restrict__ next_g, size_t next_ld, int next_bytes) {
+  // G fragments in flight per wave: a G tile comes from HBM (first touch; ~1 us per round trip under load) and a fragment is one 32-cycle
+  // MFMA triple per row tile - the ring is what the registers allow (scalar segments hold 16 result registers, vector segments 48)
+  constexpr int NF = 2 * NS, GR = (C == 1) ? DDP_ROWS_GRING1 : DDP_ROWS_GRING3;
+  (void)sgi;
   static_assert(NF % GR == 0, "fragment f of every G tile lives in ring slot f % GR");
   const ddp_conv_shape_t& S = RL.L.shape;
   const int r = lane & 31, hh = lane >> 5;
@@ -153,26 +237,39 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
 
   // ---- factorised features: one tile product per run of edges with one source node, B = the node's G tile (plane form)
   if (B.g_slot >= 0 && rmask != 0u) {
-    const int gc = S.g_cols[B.g_slot];
+    // G of a source node and slot (task.gh): the column parts of the slot's blocks one after the other, each a CONTIGUOUS tile
+    // [k8][plane][wp columns][8 halves] (wp = the part's width rounded up to 4), then Gb per padded column - a run reads one tile as one
+    // linear stream (stage A writes it in 64-byte pieces that never straddle a 128-byte line)
     const int n8 = (S.hid + 7) >> 3;
     const int nmine = min(32, B.n - 32 * part);                                   // G columns of this part
-    const int gcol = B.g_col0 + 32 * part + ((r < nmine) ? r : 0);
-    const size_t gld = (size_t)DDP_GH_LD(S.hid, gc) / 4;                          // node stride in 16-byte units
-    const f32x4* __restrict__ G4 = reinterpret_cast<const f32x4*>(T.gh[B.g_slot]);
-    const float* __restrict__ Gb = reinterpret_cast<const float*>(T.gh[B.g_slot]) + 8 * (size_t)n8 * gc;   // Gb[c] behind the planes
-    // fragment q = 2 ks + plane of lane (r, hh): 16-byte unit ((2 k8 + plane) gc + gcol), k8 = min(2 ks + hh, n8 - 1)
-    const int o_main = 2 * hh * gc + gcol;                                         // + (4 ks + plane) gc
+    int wp, cumw, gcp;
+    rows_gpart(S, bi, part, wp, cumw, gcp);
+    const int cl = (r < nmine) ? r : 0;
+    const size_t gldb = (size_t)DDP_GH_LD(S.hid, gcp) * 4;                         // node stride in bytes
+    const char* __restrict__ Gc = reinterpret_cast<const char*>(T.gh[B.g_slot]) + (size_t)(2 * n8 * cumw) * 16;
+    // fragment q = 2 ks + plane of lane (r, hh): 16-byte unit (2 k8 + plane) wp + column, k8 = min(2 ks + hh, n8 - 1).  Addressed as
+    // (wave-uniform node base + uniform fragment offset) + a 32-bit per-lane offset: the loads take their base from SGPRs - per-fragment
+    // 64-bit lane addresses cost ~40 registers here
+    const int gc = wp;
+    const unsigned lo_main = (unsigned)(2 * hh * gc + cl) * 16u;                   // + (4 ks + plane) wp * 16
     const int k8l = min(2 * (NS - 1) + hh, n8 - 1);
-    const int o_last = 2 * k8l * gc + gcol;                                        // + plane gc
+    const unsigned lo_last = (unsigned)(2 * k8l * gc + cl) * 16u;                  // + plane wp * 16
+    const unsigned lo_bias = (unsigned)(8 * n8 * gcp + cumw + cl) * 4u - (unsigned)(2 * n8 * cumw) * 16u;   // Gb[c] behind the slot's tiles
     unsigned m = rmask;
     int a0 = __builtin_ctz(m);
-    int node = __builtin_amdgcn_readlane(src_reg, a0);
-    const f32x4* __restrict__ gp = G4 + (size_t)node * gld;
-    float bias = Gb[(size_t)node * (4 * gld) + gcol];
+#ifdef DDP_ROWS_ABL_G0   // timing-only ablation: every run reads node 0's G (L2 hits): is the G phase bound by where G comes from?
+#define ROWS_NODE(a) 0
+#else
+#define ROWS_NODE(a) __builtin_amdgcn_readlane(src_reg, (a))
+#endif
+    const char* __restrict__ gp = Gc + (size_t)ROWS_NODE(a0) * gldb;
+#define ROWS_GFRAG(base, kq, plane) \
+    (*reinterpret_cast<const f32x4*>((base) + (((kq) == NS - 1) ? (size_t)((plane) * gc) * 16 : (size_t)((4 * (kq) + (plane)) * gc) * 16) + (((kq) == NS - 1) ? lo_last : lo_main)))
+    float bias = *reinterpret_cast<const float*>(gp + lo_bias);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 gr[GR];
 #pragma unroll
-    for (int k = 0; k < GR; ++k) gr[k] = gp[((k >> 1) == NS - 1 ? o_last : o_main + 4 * (k >> 1) * gc) + (k & 1) * gc];
+    for (int k = 0; k < GR; ++k) gr[k] = ROWS_GFRAG(gp, k >> 1, k & 1);
     __builtin_amdgcn_sched_barrier(0);
     int run = 0;
     const float* shrow = &aux->shT[(C == 1) ? 0 : 1][4 * hh];
@@ -180,20 +277,26 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
     while (m != 0u) {
       m &= m - 1u;
       const int an = (m != 0u) ? __builtin_ctz(m) : a0;
-      const int node_n = __builtin_amdgcn_readlane(src_reg, an);
-      const f32x4* __restrict__ gpn = G4 + (size_t)node_n * gld;
-      const float bias_n = Gb[(size_t)node_n * (4 * gld) + gcol];
+      const char* __restrict__ gpn = Gc + (size_t)ROWS_NODE(an) * gldb;
+      const float bias_n = *reinterpret_cast<const float*>(gpn + lo_bias);
+      // the tile after this one: of the next run, or - behind the last run - of the first run of the next segment with a G part
+#ifdef DDP_ROWS_TOUCH   // measured (round 5): G phases 174 k -> 288 k ticks per workgroup - the touches sit in the same in-order queue as the ring
+      const RowsTouch tch = (m != 0u) ? rows_touch_tile(gpn, 2 * n8 * wp * 16, lane)
+                                      : rows_touch_tile(next_g ? next_g + (size_t)__builtin_amdgcn_readlane(src_reg, __builtin_ctz(rmask)) * next_ld : gp,
+                                                        next_g ? next_bytes : 2 * n8 * wp * 16, lane);
+#endif
       f32x16 am = splat16(bias), ac = splat16(0.f);
 #pragma unroll
       for (int ks = 0; ks < NS; ++ks) {
         const h8 bh = __builtin_bit_cast(h8, gr[(2 * ks) % GR]), bl = __builtin_bit_cast(h8, gr[(2 * ks + 1) % GR]);
         {
+          constexpr int dummy = 0;
+          (void)dummy;
           const int q0 = 2 * ks + GR;                      // the pair of fragments that takes the two slots this step frees
           const int kq = (q0 < NF) ? (q0 >> 1) : ((q0 - NF) >> 1);
-          const f32x4* __restrict__ src4 = (q0 < NF) ? gp : gpn;
-          const int o = (kq == NS - 1) ? o_last : o_main + 4 * kq * gc;
-          gr[(2 * ks) % GR] = src4[o];
-          gr[(2 * ks + 1) % GR] = src4[o + gc];
+          const char* __restrict__ srcb = (q0 < NF) ? gp : gpn;
+          gr[(2 * ks) % GR] = ROWS_GFRAG(srcb, kq, 0);
+          gr[(2 * ks + 1) % GR] = ROWS_GFRAG(srcb, kq, 1);
         }
         __builtin_amdgcn_sched_barrier(0);
         am = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh, am, 0, 0, 0);
@@ -204,28 +307,38 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
       // (lanes behind the part's last G column hold a clamped column's product: they add nothing - with several features per tile
       // their registers are summed into the first lane group at the end)
       rows_epilogue_run<C>(am, ac, shrow, ridrow, (r < nmine) ? run : -2, res);
+#ifdef DDP_ROWS_TOUCH
+      rows_touch_done(tch);
+#endif
       gp = gpn;
       bias = bias_n;
       a0 = an;
       ++run;
     }
+#undef ROWS_GFRAG
   }
 
+  RSTAMP(5 + 3 * sgi);
   // ---- the segment's stream tiles (vector-input features)
   const int cnt = (B.ntiles == 0 || B.U == 0) ? 0 : (B.nsub > 1 ? B.U : (B.U + B.ups - 1) / B.ups);
   if (cnt > 0) {
-    float bias = T.bsp[(size_t)t * 32 + r];
     for (int j = 0; j < cnt; ++j, ++t) {
-      rows_stream_step<NF>(ring, wsh, t, RL.nts, wave, lane, st);
-      f32x16 am = splat16(bias), ac = splat16(0.f);
-      bias = T.bsp[(size_t)min(t + 1, RL.nts - 1) * 32 + r];
-      rows_tile_lds<NS>(ring + (t & 1) * TILE_Q, ah, al, lane, am, ac);
+      constexpr int KPP = NS / ROWS_NP, PIECE_Q = 2 * KPP * 64;
+      f32x16 am, ac = splat16(0.f);
+      rows_stream_step<NS, 0>(ring, wsh, t, RL.nts, wave, lane);
+      am = splat16(lbias[t * 32 + r]);
+      rows_piece_lds<NS, 0>(ring, ah, al, lane, am, ac);                      // (piece p of every tile sits in slot p)
+      rows_stream_step<NS, 1>(ring, wsh, t, RL.nts, wave, lane);
+      rows_piece_lds<NS, KPP>(ring + PIECE_Q, ah, al, lane, am, ac);
+      rows_stream_step<NS, 2>(ring, wsh, t, RL.nts, wave, lane);
+      rows_piece_lds<NS, 2 * KPP>(ring + 2 * PIECE_Q, ah, al, lane, am, ac);
       int u = (B.nsub > 1) ? j : j * B.ups + us;
       if (!(valid && u < B.U)) u = 0;
       rows_epilogue<C>(am, ac, F + (u * C) * ROWS_FS + 4 * hh, ROWS_FS, res);
     }
   }
 
+  RSTAMP(6 + 3 * sgi);
   // ---- several features per tile (n <= 16): the lane groups us = 1, 2, .. are added to group 0 in order
   if (B.nsub == 1 && B.ups > 1 && cnt > 0) {
     for (int s = 1; s < B.ups; ++s) {
@@ -255,14 +368,15 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
         }
     }
   }
+  RSTAMP(7 + 3 * sgi);
   return t;
 }
 
 template <int SZ>
-__global__ __launch_bounds__(ROWS_NT, 1) void ddp_conv_rows_kernel(const RowsLaunch RL) {
-  constexpr int NS = H2Class<SZ>::NS, NF = 2 * NS, TILE_Q = NF * 64, FPW = (NF + ROWS_NW - 1) / ROWS_NW;
+__global__ __launch_bounds__(ROWS_NT, 2) void ddp_conv_rows_kernel(const RowsLaunch RL) {
+  constexpr int NS = H2Class<SZ>::NS, RING_Q = 2 * NS * 64;     // the ring holds one tile's worth of pieces
   constexpr int NCT1 = (3 * SZ + 31) / 32, NQ = SZ / 4;     // fc.0 column tiles; 16-byte quads per edge_attr_ segment (ns floats each)
-  static_assert(NS > 0 && SZ % 4 == 0, "size classes with an h2 form");
+  static_assert(NS > 0 && NS % ROWS_NP == 0 && SZ % 4 == 0, "size classes with an h2 form whose k16 steps split into ROWS_NP pieces");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const ConvLaunch& L = RL.L;
   const ddp_conv_shape_t& S = L.shape;
@@ -272,9 +386,11 @@ __global__ __launch_bounds__(ROWS_NT, 1) void ddp_conv_rows_kernel(const RowsLau
   const ddp_conv_task_t& T = L.task[ti];
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, hh = lane >> 5;
   f32x4* ring = reinterpret_cast<f32x4*>(lds);
-  char* priv = reinterpret_cast<char*>(lds) + 2 * TILE_Q * 16 + (size_t)wave * RL.priv_bytes;
+  float* lbias = lds + RING_Q * 4;                                        // [nts][32] bias words of the stream tiles
+  char* priv = reinterpret_cast<char*>(lds) + RING_Q * 16 + RL.bias_bytes + (size_t)wave * RL.priv_bytes;
   const f32x4* __restrict__ wsh = reinterpret_cast<const f32x4*>(T.wsh);
   const int nvw = max(0, min(32, nvalid - 32 * wave));      // valid edges of this wave
+  RSTAMP(0);
 
   // ---- the wave's edges (rows behind the last valid one repeat it: every load stays in bounds, nothing of theirs is stored)
   const int pr = p0 + min(32 * wave + r, nvalid - 1);
@@ -286,17 +402,11 @@ __global__ __launch_bounds__(ROWS_NT, 1) void ddp_conv_rows_kernel(const RowsLau
   const float* __restrict__ xb2 = T.seg_ptr[2] + (size_t)T.seg_idx[2][pr] * T.seg_ld[2];
 
   // ---- stage tile 0, request tile 1
-  f32x4 st[FPW];
-#pragma unroll
-  for (int f = 0; f < FPW; ++f)
-    if (wave + ROWS_NW * f < NF) st[f] = wsh[(wave + ROWS_NW * f) * 64 + lane];
-#pragma unroll
-  for (int f = 0; f < FPW; ++f)
-    if (wave + ROWS_NW * f < NF) ring[(wave + ROWS_NW * f) * 64 + lane] = st[f];
-#pragma unroll
-  for (int f = 0; f < FPW; ++f)
-    if (wave + ROWS_NW * f < NF) st[f] = wsh[(size_t)min(1, RL.nts - 1) * TILE_Q + (wave + ROWS_NW * f) * 64 + lane];
-
+  // ---- request tile 0; the tiles' bias words: one table in LDS for the whole kernel (no global load inside the tile loops)
+  rows_request_piece<NS>(ring, wsh, 0, ROWS_NP * RL.nts, 0, wave, lane);
+  rows_request_piece<NS>(ring, wsh, 1, ROWS_NP * RL.nts, 1, wave, lane);
+  for (int i = tid; i < RL.nts * 32; i += ROWS_NT) lbias[i] = T.bsp[i];
+  RSTAMP(1);
   // ---- edge_attr_ of the wave's edges as B-operand fragments: lane (edge r, hh) holds k = 16 ks + 8 hh + i.  hi plane in registers,
   // lo plane in the wave's private LDS area (each lane reads back what it wrote)
   h8 xh[NS];
@@ -334,6 +444,7 @@ __global__ __launch_bounds__(ROWS_NT, 1) void ddp_conv_rows_kernel(const RowsLau
     }
   }
 
+  RSTAMP(2);
   // ---- fc1, transposed: D[h column m][edge n] = sum_k W1[k][32 ct + m] x[n][k]; lane (edge r, hh) ends with the h columns
   // 32 ct + (j & 3) + 8 (j >> 2) + 4 hh, j < 16, of its own edge = the k-groups (2 ct, hh) and (2 ct + 1, hh) of DDP_ROWS_KPERM
   h8 ah[NS], al[NS];
@@ -341,30 +452,37 @@ __global__ __launch_bounds__(ROWS_NT, 1) void ddp_conv_rows_kernel(const RowsLau
 #pragma unroll
   for (int ct = 0; ct < NCT1; ++ct, ++t) {
     f32x16 am, ac = splat16(0.f);
-    {
-      const f32x4* __restrict__ bp = reinterpret_cast<const f32x4*>(T.bsp + (size_t)t * 32 + 4 * hh);
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const f32x4 b = bp[2 * q4];
+    for (int pc = 0; pc < ROWS_NP; ++pc) {
+      constexpr int KPP = NS / ROWS_NP, PIECE_Q = 2 * KPP * 64;
+      if (pc == 0) rows_stream_step<NS, 0>(ring, wsh, t, RL.nts, wave, lane);
+      else if (pc == 1) rows_stream_step<NS, 1>(ring, wsh, t, RL.nts, wave, lane);
+      else rows_stream_step<NS, 2>(ring, wsh, t, RL.nts, wave, lane);
+      if (pc == 0) {
+        const f32x4* bp = reinterpret_cast<const f32x4*>(lbias + t * 32 + 4 * hh);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) am[4 * q4 + q] = b[q];
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const f32x4 b = bp[2 * q4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) am[4 * q4 + q] = b[q];
+        }
       }
-    }
-    rows_stream_step<NF>(ring, wsh, t, RL.nts, wave, lane, st);
-    const f32x4* slot = ring + (t & 1) * TILE_Q;
-    f32x4 w0 = slot[lane], w1 = slot[64 + lane];
-    f32x4 xl = xlo[lane];
+      const f32x4* slot = ring + pc * PIECE_Q;
+      f32x4 w0 = slot[lane], w1 = slot[64 + lane];
+      f32x4 xl = xlo[(pc * KPP) * 64 + lane];
 #pragma unroll
-    for (int ks = 0; ks < NS; ++ks) {
-      const h8 wh = __builtin_bit_cast(h8, w0), wl = __builtin_bit_cast(h8, w1), xlk = __builtin_bit_cast(h8, xl);
-      if (ks + 1 < NS) {
-        w0 = slot[(2 * ks + 2) * 64 + lane];
-        w1 = slot[(2 * ks + 3) * 64 + lane];
-        xl = xlo[(ks + 1) * 64 + lane];
+      for (int k = 0; k < KPP; ++k) {
+        const int ks = pc * KPP + k;
+        const h8 wh = __builtin_bit_cast(h8, w0), wl = __builtin_bit_cast(h8, w1), xlk = __builtin_bit_cast(h8, xl);
+        if (k + 1 < KPP) {
+          w0 = slot[(2 * k + 2) * 64 + lane];
+          w1 = slot[(2 * k + 3) * 64 + lane];
+          xl = xlo[(ks + 1) * 64 + lane];
+        }
+        am = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[ks], am, 0, 0, 0);
+        ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xlk, ac, 0, 0, 0);
+        ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[ks], ac, 0, 0, 0);
       }
-      am = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[ks], am, 0, 0, 0);
-      ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xlk, ac, 0, 0, 0);
-      ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[ks], ac, 0, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -382,6 +500,7 @@ __global__ __launch_bounds__(ROWS_NT, 1) void ddp_conv_rows_kernel(const RowsLau
     }
   }
 
+  RSTAMP(3);
   // ---- per-edge tables of the wave (the private area is free: the lo plane of edge_attr_ is dead)
   float* F = reinterpret_cast<float*>(priv);
   RowsAux* aux = reinterpret_cast<RowsAux*>(priv + RL.aux_off);
@@ -401,16 +520,39 @@ __global__ __launch_bounds__(ROWS_NT, 1) void ddp_conv_rows_kernel(const RowsLau
     }
   }
 
+  RSTAMP(4);
+  RSTAMP_VAL(30, __popc(rmask));
+  RSTAMP_VAL(31, p0 / ROWS_ET);
   // ---- the segments: blocks in order, the 32-column parts of a block in order
+  int sgi = 0;
   for (int bi = 0; bi < S.nblocks; ++bi) {
     const ddp_block_t& B = S.blk[bi];
     if (B.ntiles > 0 && B.U > 0) build_features<32, 2>(B, T, aux->src, aux->sh, F, lane);
     const int nparts = (B.n + 31) >> 5;
-    for (int part = 0; part < nparts; ++part) {
+    for (int part = 0; part < nparts; ++part, ++sgi) {
+      // the next segment with a G part (its first run's tile is touched behind this segment's last run)
+      const char* next_g = nullptr;
+      size_t next_ld = 0;
+      int next_bytes = 0;
+      {
+        int nb = bi, np = part + 1;
+        for (int guard = 0; guard < 2 * DDP_MAX_BLOCKS && nb < S.nblocks; ++guard) {
+          if (np >= ((S.blk[nb].n + 31) >> 5)) { ++nb; np = 0; continue; }
+          int wp, cumw, gcp;
+          if (rows_gpart(S, nb, np, wp, cumw, gcp)) {
+            const int n8 = (S.hid + 7) >> 3;
+            next_g = reinterpret_cast<const char*>(T.gh[S.blk[nb].g_slot]) + (size_t)(2 * n8 * cumw) * 16;
+            next_ld = (size_t)DDP_GH_LD(S.hid, gcp) * 4;
+            next_bytes = 2 * n8 * wp * 16;
+            break;
+          }
+          ++np;
+        }
+      }
       if (B.C == 1)
-        t = rows_segment<NS, 1>(RL, B, part, T, ah, al, ring, st, t, F, aux, rmask, src, nvw, wave, lane);
+        t = rows_segment<NS, 1>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane, sgi, next_g, next_ld, next_bytes);
       else
-        t = rows_segment<NS, 3>(RL, B, part, T, ah, al, ring, st, t, F, aux, rmask, src, nvw, wave, lane);
+        t = rows_segment<NS, 3>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane, sgi, next_g, next_ld, next_bytes);
     }
   }
 }
@@ -476,8 +618,9 @@ extern "C" int ddp_conv_rows(const ddp_conv_shape_t* shape, const ddp_conv_task_
   if (priv < NS * 1024) priv = NS * 1024;          // the lo plane of edge_attr_ during fc1
   priv = (priv + 127) / 128 * 128;
   RL.priv_bytes = priv;
-  const size_t lds_bytes = (size_t)2 * (2 * NS * 1024) + (size_t)ROWS_NW * priv;
-  if (lds_bytes > 160 * 1024 - 1024) return ddp_fail(DDP_ELIMIT, "ddp_conv_rows: LDS budget exceeded (too many vector features per block)");
+  RL.bias_bytes = (nts * 128 + 127) / 128 * 128;
+  const size_t lds_bytes = (size_t)2 * (NS * 1024) + RL.bias_bytes + (size_t)ROWS_NW * priv;
+  if (2 * lds_bytes > 160 * 1024) return ddp_fail(DDP_ELIMIT, "ddp_conv_rows: LDS budget of two workgroups per CU exceeded (too many vector features per block)");
   static int lds_have = 0;
   hipError_t err = ddp_need_lds(reinterpret_cast<const void*>(ddp_conv_rows_kernel<60>), (int)lds_bytes, &lds_have);
   if (err != hipSuccess) return ddp_fail_hip(err, "hipFuncSetAttribute(conv rows)");

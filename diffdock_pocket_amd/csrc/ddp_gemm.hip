@@ -455,14 +455,19 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_x3_kernel(con
 // depend on the tile a row sits in.  Weights arrive pre-split from the host (packing.split_h2): [batch][plane][k/16][k/8 % 2][col][8].
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#ifndef DDP_SAH_CT_GH
+#define DDP_SAH_CT_GH 3
+#endif
 #ifndef DDP_SAH_CT
 #define DDP_SAH_CT 4   // column tiles per wave: 2 planes x 4 k-steps x 4 registers each = 32 weight registers per tile
 #endif
 
-// GH (round 5): the leading 8 gh_groups columns of a row leave as fp16 hi/lo operand planes - the layout ddp_conv_rows reads G in
+// GH (round 5): the G part of a row leaves as fp16 hi/lo operand planes - the layout ddp_conv_rows reads G in
 // (include/ddp_hip.h, ddp_conv_task_t::gh): a lane then drains 8 consecutive columns of a parked row (one 8-k group of one G column)
 // as two 16-byte pieces, hi plane and lo plane, where the fp32 form stores two 16-byte quads - the same bytes, the same number of
-// store instructions.  Columns behind the planes (Gb) stay fp32.  Needs ncols % 32 == 0.
+// store instructions.  Where the two pieces of every 8-column group go is a table (gh_dest[batch][ncols / 8][2], float offsets inside
+// the row, built by the host from the parts of the G array): the drain has no arithmetic of its own.  Groups whose pieces are 4 floats
+// apart are fp32 columns (Gb, padding) and leave unconverted.  Needs ncols % 32 == 0.
 template <int KT, bool GH = false>
 __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(const float* __restrict__ x, int ldx, int nrows,
                                                                               const int32_t* __restrict__ rows,
@@ -470,10 +475,11 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
                                                                               int mrows, const GemmOffs offs,
                                                                               const _Float16* __restrict__ wh, int ncols,
                                                                               float* __restrict__ out, int ldo, int32_t* range_flag,
-                                                                              int gh_cols = 0, int gh_groups = 0) {
+                                                                              const int32_t* __restrict__ gh_dest = nullptr) {
   if (nrows_dev) nrows = min(nrows, *nrows_dev);
   if ((int)blockIdx.y * mrows >= nrows) return;
-  constexpr int KP = (KT + 15) / 16 * 16, NS = KP / 16, CT = DDP_SAH_CT;
+  // (GH: three column tiles per wave - the plane split of the drain needs the registers of the fourth tile's weights)
+  constexpr int KP = (KT + 15) / 16 * 16, NS = KP / 16, CT = GH ? DDP_SAH_CT_GH : DDP_SAH_CT;
   constexpr int XS = KP + 8;                                   // halves per LDS row of an x plane (16-byte aligned rows)
   constexpr int NV = (32 * KT / 4 + DDP_GEMM_THREADS - 1) / DDP_GEMM_THREADS;
   constexpr int TS = 36;
@@ -507,6 +513,22 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
   int cq[CT];
 #pragma unroll
   for (int t = 0; t < CT; ++t) cq[t] = max(0, min(4 * (lane & 7), ncols - 4 - (col0 + 32 * t)));
+  // GH: float offsets (inside a row) of the two 16-byte pieces of this lane's 8-column group of every column tile
+  int gh_o1[CT], gh_o2[CT];
+  bool gh_sp[CT];
+  float gh_max = 0.f;                   // GH: largest |G value| split (outside the fp16 range: reported through range_flag)
+#pragma unroll
+  for (int t = 0; t < CT; ++t) {
+    gh_o1[t] = gh_o2[t] = 0;
+    gh_sp[t] = false;
+    if constexpr (GH) {
+      const int g = min(col0 + 32 * t + 8 * (lane & 3), ncols - 8) >> 3;
+      const int32_t* __restrict__ d = gh_dest + ((size_t)z * (ncols >> 3) + g) * 2;
+      gh_o1[t] = d[0];
+      gh_o2[t] = d[1];
+      gh_sp[t] = (gh_o2[t] - gh_o1[t]) != 4;
+    }
+  }
   for (int R0 = (int)blockIdx.y * mrows; R0 < nrows; R0 += (int)gridDim.y * mrows) {
   const int R1 = min(nrows, R0 + mrows);
   const bool al4 = ((ldx | offs.off[z]) & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0;
@@ -549,26 +571,25 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
   // hipcc's waitcnt insertion drained the store queue at the branch joins.)
   size_t pend_off[4] = {0, 0, 0, 0};    // element offset of this lane's 16-byte piece of quarter p of the pending block
   int pend_lds[4] = {0, 0, 0, 0};       // ... and where it sits in the parked tile
-  bool pend_split[2] = {false, false};  // GH: pieces 2 q, 2 q + 1 = the two 16-byte stores of the lane's 8-column group q of the block
+  bool pend_sp = false;                 // GH: the pending block's groups are plane groups
   int pbuf = 0;
   f32x4 dv = {0.f, 0.f, 0.f, 0.f}, dv2 = dv;
-  // GH: the lane's group q of the pending tile -> the two 16-byte pieces that leave (hi / lo plane, or the two fp32 quads)
+  // GH: the lane's group q (row 16 q + lane / 4) of the pending tile -> the two 16-byte pieces that leave (hi / lo plane, or the two fp32
+  // quads).  Packed conversions, the range check as one running max, no branch (a NaN needs an inf or a NaN in x, which the x split reports)
   auto gh_read = [&](const float* pt, int q) {
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
     const f32x4 a = *reinterpret_cast<const f32x4*>(&pt[pend_lds[2 * q]]), b = *reinterpret_cast<const f32x4*>(&pt[pend_lds[2 * q] + 4]);
-    if (pend_split[q]) {
-      h8 hi, lo;
+    const f32x8 f = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    const h8 hi = __builtin_convertvector(f, h8);
+    const f32x8 rest = (f - __builtin_convertvector(hi, f32x8)) * 2048.f;
+    const h8 lo = __builtin_convertvector(rest, h8);
+    const float m8 = fmaxf(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))), fmaxf(fmaxf(fabsf(f[4]), fabsf(f[5])), fmaxf(fabsf(f[6]), fabsf(f[7]))));
+    gh_max = fmaxf(gh_max, pend_sp ? m8 : 0.f);
+    const f32x4 vh = __builtin_bit_cast(f32x4, hi), vl = __builtin_bit_cast(f32x4, lo);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float f = (e < 4) ? a[e & 3] : b[e & 3];
-        if (!(fabsf(f) <= 65504.f) && range_flag) *range_flag = 1;
-        hi[e] = (_Float16)f;
-        lo[e] = (_Float16)((f - (float)hi[e]) * 2048.f);
-      }
-      dv = __builtin_bit_cast(f32x4, hi);
-      dv2 = __builtin_bit_cast(f32x4, lo);
-    } else {
-      dv = a;
-      dv2 = b;
+    for (int e = 0; e < 4; ++e) {
+      dv[e] = pend_sp ? vh[e] : a[e];
+      dv2[e] = pend_sp ? vl[e] : b[e];
     }
   };
   auto block = [&](auto drain_tag, int t, const h8 (&a)[2][NS], const int (&blk_ri)[4], int nr) {
@@ -608,23 +629,20 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
 #pragma unroll
     for (int i = 0; i < 16; ++i) tl[((i & 3) + 8 * (i >> 2) + 4 * hh) * TS + r] = am[i] + ac[i] * (1.f / 2048.f);
     if constexpr (GH) {
+#if defined(DDP_GH_ABL) && DDP_GH_ABL == 1     // timing only: the plane destinations without the conversion
+      pend_sp = false;
+#else
+      pend_sp = gh_sp[t];
+#endif
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int rr = min(16 * q + (lane >> 2), nr - 1);        // row of the tile; blk_ri[p] holds rows 8 p + (lane >> 3)
         const int src_lane = ((lane >> 2) & 7) << 3;                // the lane that holds tile row 8 p + ((lane >> 2) & 7) in blk_ri[p]
         const int ri0 = __shfl(blk_ri[2 * q], src_lane), ri1 = __shfl(blk_ri[2 * q + 1], src_lane);
         const int ri = ((lane >> 2) >> 3) ? ri1 : ri0;
-        const int col = col0 + 32 * t + 8 * (lane & 3), g = col >> 3;
         pend_lds[2 * q] = rr * TS + 8 * (lane & 3);
-        pend_split[q] = g < gh_groups;
-        if (pend_split[q]) {
-          const int k8 = g / gh_cols, c = g - k8 * gh_cols;
-          pend_off[2 * q] = (size_t)ri * ldo + 4 * (2 * k8 * gh_cols + c);
-          pend_off[2 * q + 1] = pend_off[2 * q] + 4 * gh_cols;
-        } else {
-          pend_off[2 * q] = (size_t)ri * ldo + col;
-          pend_off[2 * q + 1] = pend_off[2 * q] + 4;
-        }
+        pend_off[2 * q] = (size_t)ri * ldo + gh_o1[t];
+        pend_off[2 * q + 1] = (size_t)ri * ldo + gh_o2[t];
       }
     } else {
 #pragma unroll
@@ -684,11 +702,14 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
   }
   __syncthreads();
   }
+  if constexpr (GH) {
+    if (!(gh_max <= 65504.f) && range_flag) *range_flag = 1;
+  }
 }
 
 static int stage_a_impl(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows,
                         const int32_t* offs, int nbatch, const float* w, const void* w_bf16x3, const void* w_h2, int k, int ncols, float* out,
-                        int ldo, int32_t* range_flag, void* stream, int gh_cols = 0, int gh_groups = 0) {
+                        int ldo, int32_t* range_flag, void* stream, const int32_t* gh_dest = nullptr) {
   if (!rows) out_rows = nrows;                       // dense: out[b] has one row per x row
   if (out_rows < 1 && nrows > 0) return ddp_fail(DDP_EINVAL, "ddp_stage_a: out_rows");
   if (nbatch < 0 || nbatch > DDP_MAX_GEMM_BATCH) return ddp_fail(DDP_ELIMIT, "ddp_stage_a: nbatch > DDP_MAX_GEMM_BATCH");
@@ -729,14 +750,14 @@ static int stage_a_impl(const float* x, int ldx, int nrows, const int32_t* rows,
 #endif
   static const bool no_mfma = getenv("DDP_STAGE_A_VALU") != nullptr;   // diagnostic: force the VALU form
   // h2 form (fp16 hi/lo split of both operands): wide, 16-byte aligned outputs only, K = 60 / 32 / 24 / 16 (KP = 64 / 32 / 32 / 16)
-  if (gh_groups > 0 && !(w_h2 && wide && (k == 60 || k == 32 || k == 24 || k == 16) && (reinterpret_cast<size_t>(w_h2) & 15) == 0 && (ncols & 31) == 0 &&
-                         gh_cols > 0 && 8 * gh_groups <= ncols))
-    return ddp_fail(DDP_EINVAL, "ddp_stage_a_gh: plane output needs the h2 path (w_h2, k in {60, 32, 24, 16}), ncols % 32 == 0 and 8 gh_groups <= ncols");
-  if (gh_groups > 0) {
-    const dim3 grid((ncols + 128 * DDP_SAH_CT - 1) / (128 * DDP_SAH_CT), gy, nbatch);
+  if (gh_dest) {
+    if (!(w_h2 && wide && (k == 60 || k == 32 || k == 24 || k == 16) && (reinterpret_cast<size_t>(w_h2) & 15) == 0 && (ncols & 31) == 0 &&
+          (reinterpret_cast<size_t>(gh_dest) & 7) == 0))
+      return ddp_fail(DDP_EINVAL, "ddp_stage_a_gh: plane output needs the h2 path (w_h2, k in {60, 32, 24, 16}) and ncols % 32 == 0");
+    const dim3 grid((ncols + 128 * DDP_SAH_CT_GH - 1) / (128 * DDP_SAH_CT_GH), gy, nbatch);
 #define DDP_GEMM_GH(KT)                                                                                          \
     hipLaunchKernelGGL((ddp_stage_a_h2_kernel<KT, true>), grid, dim3(DDP_GEMM_THREADS), 0, s, x, ldx, nrows, rows, nrows_dev, out_rows, mrows, O, \
-                       reinterpret_cast<const _Float16*>(w_h2), ncols, out, ldo, range_flag, gh_cols, gh_groups)
+                       reinterpret_cast<const _Float16*>(w_h2), ncols, out, ldo, range_flag, gh_dest)
     switch (k) {
       case 60: DDP_GEMM_GH(60); break;
       case 32: DDP_GEMM_GH(32); break;
@@ -817,6 +838,7 @@ extern "C" int ddp_stage_a_h2(const float* x, int ldx, int nrows, const int32_t*
 
 extern "C" int ddp_stage_a_gh(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows,
                               const int32_t* offs, int nbatch, const float* w, const void* w_h2, int k, int ncols, float* out, int ldo,
-                              int32_t* range_flag, int gh_cols, int gh_groups, void* stream) {
-  return stage_a_impl(x, ldx, nrows, rows, nrows_dev, out_rows, offs, nbatch, w, nullptr, w_h2, k, ncols, out, ldo, range_flag, stream, gh_cols, gh_groups);
+                              int32_t* range_flag, const int32_t* dest, void* stream) {
+  if (!dest) return ddp_fail(DDP_EINVAL, "ddp_stage_a_gh: dest");
+  return stage_a_impl(x, ldx, nrows, rows, nrows_dev, out_rows, offs, nbatch, w, nullptr, w_h2, k, ncols, out, ldo, range_flag, stream, dest);
 }

@@ -772,7 +772,7 @@ class ForwardEngine:
         key = (l, tuple(k for k, _ in convs), rows_k)
         ent = m._stage_a_stacks.get(key)
         if ent is None or ent[0].device != x.device:
-            Ws, meta, ghs = [], [], set()
+            Ws, meta, ghs = [], [], []
             for k, conv in convs:
                 pk = conv.packed_g(x.device)
                 for slot in (0, 1):
@@ -780,13 +780,12 @@ class ForwardEngine:
                         Ws.append(pk.wgh[slot] if rows_k else pk.wg[slot])
                         meta.append((k, slot, pk.g_in_off[slot]))
                         if rows_k:
-                            ghs.add((conv.spec_g.g_cols[slot], pk.gh_groups[slot]))
+                            ghs.append(pk.gh_groups[slot])
             Wst = torch.stack(Ws).contiguous()
-            if len(ghs) > 1:
-                raise L.DdpError("G arrays of one stage-A product with different column counts")
             # (the bf16x3 split of the weights - 1.5 x their size and three copy kernels - only when that option is on)
             ent = (Wst, meta, (C.c_int32 * len(meta))(*[mm[2] for mm in meta]), P.split_bf16x3(Wst) if (m.stage_a_bf16x3 and not rows_k) else None,
-                   P.split_h2(Wst) if (m.stage_a_h2 or rows_k) else None, ghs.pop() if rows_k else None)
+                   P.split_h2(Wst) if (m.stage_a_h2 or rows_k) else None,
+                   torch.stack([P.gh_dest_table(ws, (convs[0][1].spec_g.hid + 7) // 8, Wst.shape[2]) for ws in ghs]).contiguous().to(x.device) if rows_k else None)
             m._stage_a_stacks[key] = ent
         if m.stage_a_bf16x3 and ent[3] is None and not rows_k:
             ent = m._stage_a_stacks[key] = ent[:3] + (P.split_bf16x3(ent[0]),) + ent[4:]

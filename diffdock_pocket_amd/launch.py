@@ -8,6 +8,7 @@ whatever the process-wide current device is.  Nothing here synchronises with the
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -223,7 +224,7 @@ def set_range_flag(t):
 
 # Factorised convs of the size class ns = 60 through the 256-edge row-stationary kernel (ddp_conv_rows, csrc/ddp_conv_rows.hip; needs
 # CONV_H2).  False: the 32-edge kernel of rounds 2 - 4 (A/B runs).  The two read G in different layouts: a task carries one of them.
-CONV_ROWS = True
+CONV_ROWS = os.environ.get("DDP_CONV_ROWS", "1") != "0"     # (environment: same-box A/B runs)
 
 
 def rows_mode(pk) -> bool:
@@ -387,16 +388,16 @@ def edge_featurize_jobs(calls):
 def stage_a(x, n_rows, offs, nb, W, out, rows=None, rows_cnt=None, out_rows=None, W3=None, Wh=None, gh=None):
     """ddp_stage_a: out[b][row] = x[row, offs[b]:offs[b]+k] @ W[b] for the listed rows (all n_rows rows if rows is None).
     Wh: the weights pre-split for the fp16 hi/lo form (packing.split_h2; ddp_stage_a_h2), W3: for the bf16x3 form
-    (packing.split_bf16x3); neither: exact fp32 MFMA.  gh = (G columns, 8-column groups that leave as fp16 hi/lo planes): the
-    layout ddp_conv_rows reads (ddp_stage_a_gh; needs Wh)."""
+    (packing.split_bf16x3); neither: exact fp32 MFMA.  gh = the destination table of the plane form (int32 device tensor
+    [nb, ncols / 8, 2], packing.gh_dest_table): the output leaves in the layout ddp_conv_rows reads (ddp_stage_a_gh; needs Wh)."""
     lib = L.load()
     n_in, ncols = W.shape[1], W.shape[2]
     if n_rows == 0:
         return
     if gh is not None:
         L.check(lib.ddp_stage_a_gh(x.data_ptr(), x.stride(0), n_rows, ptr(rows), ptr(rows_cnt), out_rows if out_rows is not None else n_rows,
-                                   offs, nb, W.data_ptr(), ptr(Wh), n_in, ncols, out.data_ptr(), ncols, ptr(_RANGE_FLAG), gh[0], gh[1], stream()),
-                "ddp_stage_a_gh")
+                                   offs, nb, W.data_ptr(), ptr(Wh), n_in, ncols, out.data_ptr(), ncols, ptr(_RANGE_FLAG), gh.data_ptr(),
+                                   stream()), "ddp_stage_a_gh")
         return
     if Wh is not None:
         L.check(lib.ddp_stage_a_h2(x.data_ptr(), x.stride(0), n_rows, ptr(rows), ptr(rows_cnt), out_rows if out_rows is not None else n_rows,

@@ -504,7 +504,9 @@ def rows_supported(spec: "ConvSpec") -> bool:
         return False
     frows = max([b.U * b.C for b in spec.blocks if b.U > 0] + [0])
     priv = max((frows * 36 * 4 + 127) // 128 * 128 + 1408, 12 * 1024)
-    return 2 * 24 * 1024 + 8 * ((priv + 127) // 128 * 128) <= 160 * 1024 - 1024
+    nts = spec.nct1 + sum(len(t) for _, _, t in rows_segments(spec))
+    # two 4-wave workgroups per CU: ring of two half tiles + bias table + four private areas each
+    return 2 * (2 * 12 * 1024 + (nts * 128 + 127) // 128 * 128 + 4 * ((priv + 127) // 128 * 128)) <= 160 * 1024
 
 
 def rows_kperm(ns16: int) -> torch.Tensor:
@@ -573,23 +575,39 @@ def rows_stream(spec: "ConvSpec", w1: torch.Tensor, b1: torch.Tensor, w2: torch.
     return t1.reshape(-1).contiguous(), b1c.reshape(-1, 32).contiguous()
 
 
-def gh_ld(hid: int, gcols: int) -> int:
-    """DDP_GH_LD: floats per node of a G array in plane form."""
-    return (((hid + 7) // 8 * 8 + 1) * gcols + 31) // 32 * 32
+def gh_parts(spec: "ConvSpec", slot: int):
+    """The column parts of G array `slot` in plane form (ddp_conv_task_t::gh), in layout order: [(block index, part, G column of the
+    part's first column, width, width rounded up to 4, padded columns in front)]."""
+    parts, cum = [], 0
+    for bi, b in enumerate(spec.blocks):
+        if b.g_slot != slot:
+            continue
+        for part in range((b.n + 31) // 32):
+            w = min(32, b.n - 32 * part)
+            wp = (w + 3) // 4 * 4
+            parts.append((bi, part, b.g_col0 + 32 * part, w, wp, cum))
+            cum += wp
+    return parts
+
+
+def gh_ld(hid: int, gcp: int) -> int:
+    """DDP_GH_LD: floats per node of a G array in plane form with gcp padded columns."""
+    return (((hid + 7) // 8 * 8 + 1) * gcp + 31) // 32 * 32
 
 
 def factor_weights_gh(spec: "ConvSpec", weight: torch.Tensor, bias: torch.Tensor):
-    """factor_weights for ddp_conv_rows: the right-hand sides whose product columns are ordered [k8 group][G column c][8 k's of the group]
-    (the k's of group g = 2 ks + hh are rows_kperm's slots (ks, hh, 0..7); h columns >= hid are zero rows), then the Gb columns, then
-    zero padding to DDP_GH_LD.  ddp_stage_a_gh writes the first n8 * g_cols groups of a row as fp16 hi/lo planes
-    [k8][plane][c][8] (ddp_conv_task_t::gh).  Returns ([Wg0, Wg1], [in_off0, in_off1], [groups0, groups1])."""
+    """factor_weights for ddp_conv_rows: right-hand sides whose product columns are ordered [part][k8 group][column c of the part][8 k's
+    of the group] (gh_parts; the k's of group g = 2 ks + hh are rows_kperm's slots (ks, hh, 0..7); h columns >= hid and the padding
+    columns of a part are zero), then Gb per padded column, then zero padding to DDP_GH_LD.  ddp_stage_a_gh writes the groups of a row
+    as fp16 hi/lo planes, every part a contiguous tile [k8][plane][c][8] (ddp_conv_task_t::gh).
+    Returns ([Wg0, Wg1], [in_off0, in_off1], [part widths of slot 0, of slot 1])."""
     ns16 = h2_steps(spec)
     assert ns16 > 0
     weight = weight.detach().float().cpu()
     bias = bias.detach().float().cpu()
     n8 = (spec.hid + 7) // 8
     kp = rows_kperm(ns16)[:8 * n8]
-    Wg, offs, groups = [None, None], [0, 0], [0, 0]
+    Wg, offs, widths = [None, None], [0, 0], [None, None]
     for slot in (0, 1):
         blks = [b for b in spec.blocks if b.g_slot == slot]
         if not blks:
@@ -603,10 +621,38 @@ def factor_weights_gh(spec: "ConvSpec", weight: torch.Tensor, bias: torch.Tensor
             rows = b.w_off + (b.g_u0 + torch.arange(n_in)).reshape(-1, 1) * b.n + torch.arange(b.n).reshape(1, -1)
             W[:, :spec.hid, b.g_col0:b.g_col0 + b.n] = (weight[rows] * b.scale).permute(0, 2, 1)     # [u, n, hid] -> [u, hid, n]
             Bm[:, b.g_col0:b.g_col0 + b.n] = bias[rows] * b.scale
-        Wq = W[:, kp].reshape(n_in, n8, 8, gc).permute(0, 1, 3, 2)                                    # [u, k8, c, 8]
-        ld = gh_ld(spec.hid, gc)
+        parts = gh_parts(spec, slot)
+        gcp = sum(p[4] for p in parts)
+        ld = gh_ld(spec.hid, gcp)
         Wfull = torch.zeros(n_in, ld)
-        Wfull[:, :8 * n8 * gc] = Wq.reshape(n_in, -1)
-        Wfull[:, 8 * n8 * gc:8 * n8 * gc + gc] = Bm
-        Wg[slot], offs[slot], groups[slot] = Wfull.contiguous(), blks[0].g_in_off, n8 * gc
-    return Wg, offs, groups
+        Wk = W[:, kp].reshape(n_in, n8, 8, gc)                                                       # [u, k8, i, column]
+        for _, _, c0, w, wp, cum in parts:
+            tile = torch.zeros(n_in, n8, wp, 8)
+            tile[:, :, :w] = Wk[:, :, :, c0:c0 + w].permute(0, 1, 3, 2)
+            Wfull[:, 8 * n8 * cum:8 * n8 * (cum + wp)] = tile.reshape(n_in, -1)
+            Wfull[:, 8 * n8 * gcp + cum:8 * n8 * gcp + cum + w] = Bm[:, c0:c0 + w]
+        Wg[slot], offs[slot], widths[slot] = Wfull.contiguous(), blks[0].g_in_off, [p[4] for p in parts]
+    return Wg, offs, widths
+
+
+def gh_dest_table(widths: Sequence[int], n8: int, ncols: int) -> torch.Tensor:
+    """int32 [ncols / 8, 2] for ddp_stage_a_gh: float offsets inside a G row of the two 16-byte pieces of every 8-column group of the
+    product factor_weights_gh sets up.  Group g = n8 cum_p + k8 w_p + c of part p (cum_p = the widths in front of it) is the k8 group of
+    column c: hi piece at 16-byte unit 2 n8 cum_p + 2 k8 w_p + c, lo piece w_p units behind.  Groups behind the parts (Gb, padding) are 8
+    fp32 columns at their own place (pieces 4 floats apart)."""
+    ng = ncols // 8
+    tab = torch.empty((ng, 2), dtype=torch.int32)
+    g = torch.arange(ng, dtype=torch.int64)
+    tab[:, 0] = (8 * g).int()
+    tab[:, 1] = (8 * g + 4).int()
+    cum = 0
+    for w in widths:
+        gs = n8 * cum
+        gl = torch.arange(n8 * w, dtype=torch.int64)
+        k8, c = gl // w, gl % w
+        unit = 2 * gs + 2 * k8 * w + c
+        tab[gs:gs + n8 * w, 0] = (4 * unit).int()
+        tab[gs:gs + n8 * w, 1] = (4 * (unit + w)).int()
+        cum += w
+    assert 8 * n8 * cum + cum <= ncols
+    return tab

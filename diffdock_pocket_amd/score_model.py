@@ -189,9 +189,9 @@ class TensorProductConvLayer(nn.Module):
             if P.rows_supported(self.spec_g):
                 wsh, bsp = P.rows_stream(self.spec_g, self.fc[0].weight, self.fc[0].bias, self.fc[3].weight, self.fc[3].bias)
                 pk.wsh, pk.bsp = wsh.to(device), bsp.to(device)
-                wgh, _, groups = P.factor_weights_gh(self.spec_g, self.fc[3].weight, self.fc[3].bias)
+                wgh, _, widths = P.factor_weights_gh(self.spec_g, self.fc[3].weight, self.fc[3].bias)
                 pk.wgh = [w.to(device) if w is not None else None for w in wgh]
-                pk.gh_groups = groups
+                pk.gh_groups = widths          # (per slot: the padded widths of the G array's column parts)
             self._packed_g = pk
         return self._packed_g
 
@@ -209,9 +209,9 @@ class TensorProductConvLayer(nn.Module):
                 wh = P.split_h2(w.unsqueeze(0))
                 g[slot] = torch.empty((N, w.shape[1]), device=x_src.device, dtype=torch.float32)
                 offs = (C.c_int32 * 1)(pk.g_in_off[slot])
+                dest = P.gh_dest_table(pk.gh_groups[slot], (self.spec_g.hid + 7) // 8, w.shape[1]).to(x_src.device)
                 L.check(lib.ddp_stage_a_gh(x_src.data_ptr(), x_src.shape[1], N, None, None, N, offs, 1, w.data_ptr(), wh.data_ptr(), w.shape[0],
-                                           w.shape[1], g[slot].data_ptr(), w.shape[1], None, self.spec_g.g_cols[slot], pk.gh_groups[slot],
-                                           _stream()), "ddp_stage_a_gh")
+                                           w.shape[1], g[slot].data_ptr(), w.shape[1], None, dest.data_ptr(), _stream()), "ddp_stage_a_gh")
             return g
         for slot in (0, 1):
             if pk.wg[slot] is None:

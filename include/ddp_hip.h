@@ -140,18 +140,19 @@ typedef struct {
    *        PERMUTED (DDP_ROWS_KPERM below): the kernel computes h = relu(fc1) as the transposed product, whose accumulator
    *        registers then ARE the A-operand fragments of the fc.3 products in that k order (no transpose through LDS).
    *  bsp   the tiles' bias words, fp32 [stream tiles][32]
-   *  gh    G[s] of a factorised conv as fp16 hi/lo operand planes (v = hi + lo / 2048), per source node DDP_GH_LD(hid, g_cols[s])
-   *        floats: [k8 < ceil(hid/8)][plane][c < g_cols[s]][8 halves]  (k8 group g holds the permuted k's DDP_ROWS_KPERM(g >> 1, g & 1, i),
-   *        i < 8), then Gb[c] as fp32, then padding to 128 bytes; written by ddp_stage_a_h2 with its `gh_cols` argument.
-   * NULL: the task can only run through ddp_conv_messages. */
+   *  gh    G[s] of a factorised conv as fp16 hi/lo operand planes (v = hi + lo / 2048), per source node DDP_GH_LD(hid, gcp) floats: the
+ *        32-column parts of the slot's blocks (in block order, a block's parts in order) one after the other, part p a CONTIGUOUS tile
+ *        [k8 < ceil(hid/8)][plane][c < wp][8 halves] with wp = the part's width rounded up to 4 (k8 group g holds the permuted k's
+ *        DDP_ROWS_KPERM(g >> 1, g & 1, i), i < 8; padding columns are zero), then Gb per padded column as fp32 [gcp = sum of the wp],
+ *        then padding to 128 bytes; written by ddp_stage_a_gh.
+ * NULL: the task can only run through ddp_conv_messages. */
   const void* wsh;
   const float* bsp;
   const void* gh[2];
 } ddp_conv_task_t;
 /* k index held by element i of the 8-k group (ks, hh) of an h / fc.3 / G operand fragment in ddp_conv_rows */
 #define DDP_ROWS_KPERM(ks, hh, i) (32 * ((ks) >> 1) + ((8 * ((ks) & 1) + (i)) & 3) + 8 * ((8 * ((ks) & 1) + (i)) >> 2) + 4 * (hh))
-#define DDP_GH_LD(hid, gcols) ((((((hid) + 7) / 8) * 8 + 1) * (gcols) + 31) / 32 * 32)   /* floats per node of a G array in plane form */
-
+#define DDP_GH_LD(hid, gcp) ((((((hid) + 7) / 8) * 8 + 1) * (gcp) + 31) / 32 * 32)   /* floats per node of a G array in plane form, gcp = padded columns */
 /* Fused fc -> tensor product -> per-edge message for up to 9 convs that share one shape.
  * All tasks of one call share `shape` (factorised and plain convs therefore go in separate calls).
  * Replaces: TensorProductConvLayer.forward up to (not including) the scatter
@@ -361,14 +362,15 @@ int ddp_stage_a(const float* x, int ldx, int nrows, const int32_t* rows, const i
  * error <= 2^-20 sum|x w|); other shapes run the exact fp32 forms on `w`.  ABI 12. */
 int ddp_stage_a_h2(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows, const int32_t* offs,
                    int nbatch, const float* w, const void* w_h2, int k, int ncols, float* out, int ldo, int32_t* range_flag, void* stream);
-/* ... with the leading gh_groups * 8 columns of every output row written as fp16 hi/lo operand planes (ddp_conv_task_t::gh): the
- * product's columns [8 g, 8 g + 8), g = k8 * gh_cols + c, are the 8 k's of group k8 for G column c; their values v = hi + lo / 2048
- * go to halves [8 ((2 k8) gh_cols + c), + 8) (hi) and [8 ((2 k8 + 1) gh_cols + c), + 8) (lo) of the row - the same bytes as the fp32
- * form, as two 16-byte pieces.  Columns >= 8 gh_groups (the Gb part) stay fp32 at their own offsets.  Only on the h2 path (w_h2
- * given, wide product); gh_groups = 0: ddp_stage_a_h2.  ABI 13. */
+/* ... with every output row written in the plane form of ddp_conv_task_t::gh.  The host orders the product's columns [part][k8][c][8]
+ * (packing.factor_weights_gh) and passes, per batch entry and per group of 8 columns, the float offsets inside the row of the group's two
+ * 16-byte pieces: dest[b][g][0..1], device int32 [nbatch][ncols / 8][2].  A group whose offsets are 4 apart is 8 fp32 columns stored
+ * as they are (Gb, padding); any other group holds the 8 k's of one k8 group of one G column: its values v = hi + lo / 2048 leave as 8
+ * fp16 hi words at dest[..][0] and 8 fp16 lo words at dest[..][1] - the same bytes as the fp32 form, the same number of stores.
+ * Only on the h2 path (w_h2 given, k in {60, 32, 24, 16}, ncols % 32 == 0).  ABI 13. */
 int ddp_stage_a_gh(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows, const int32_t* offs,
                    int nbatch, const float* w, const void* w_h2, int k, int ncols, float* out, int ldo, int32_t* range_flag,
-                   int gh_cols, int gh_groups, void* stream);
+                   const int32_t* dest, void* stream);
 
 /* The pose update between two score-model calls, for all samples of a batch in one launch:
  * modify_conformer(pos, tr_update, rot_update, torsion_updates) of utils/diffusion_utils.py:37-60 = rigid move about the

@@ -884,13 +884,19 @@ def test_stage_a_h2_error(k, ncols, nrows, nb):
 def test_forward_with_bf16x3_stage_a_agrees_with_the_exact_form():
     """model.stage_a_bf16x3 (an option, off by default): the same forward with stage A as bf16x3 products - scores within 2e-5
     of the exact-fp32 form's (parity tolerance of the path: 1e-4)."""
+    from diffdock_pocket_amd import launch as K
     case, gold, batch, sd = case_inputs("cfg2_noflex")
     model = _model_for(case, sd)
     b = batch.to(_dev())
     out = {}
-    for flag in (False, True):
-        model.stage_a_bf16x3 = flag
-        out[flag] = [t.clone() for t in model(b)]
+    rows_was = K.CONV_ROWS
+    K.CONV_ROWS = False      # (the option belongs to the 32-edge kernel's fp32 G layout; ddp_conv_rows reads G in plane form from ddp_stage_a_gh)
+    try:
+        for flag in (False, True):
+            model.stage_a_bf16x3 = flag
+            out[flag] = [t.clone() for t in model(b)]
+    finally:
+        K.CONV_ROWS = rows_was
     assert any(not torch.equal(a, c) for a, c in zip(out[False], out[True]))      # (the option did switch kernels)
     for a, c in zip(out[False], out[True]):
         assert elementwise_excess(c, a, 2e-5, 2e-5) <= 1
