@@ -23,13 +23,16 @@ Synthetic data: real 3dpf geometry + random categorical features / ESM block, ra
 checkpoints).  Inputs are resident in HBM before the timed region.
 
 The JSON line also carries
-  roofline      the dominant kernel (ddp_conv32_kernel, fp32-MFMA bound).  `achieved` = USEFUL fp32 MFMA FLOPs the
-                kernel's own formulation needs per launch (no tile padding; packing.ConvSpec.useful_flops_per_edge x the
-                launch's edge count) / mean launch time from HIP events on the launch stream inside the timed region;
-                `frac` = achieved / 157.3 TFLOP/s <= 1.  The reference formulation's FLOPs, most of
-                which the source-node factorisation removes, are reported separately as `algorithmic_vs_fp32_peak`.
-                PMC-derived fields (traffic, issued MFMA FLOPs, padding, pipe-busy) come from profiles/r04_pmc.json (collected on the builder's box, see `pmc_source`) and are
-                dropped when that file was taken from other kernel sources than the ones loaded (source hash).
+  roofline      the dominant kernel (ddp_conv_rows_kernel since round 5; matrix-core bound by its instruction mix).  `achieved` =
+                matrix-core instruction FLOPs of the kernel's own formulation without padding - the two fc products and (rows kernel) the
+                per-edge G contraction as fp16 hi/lo split products = three fp16 MFMA FLOPs per product FLOP, the rest fp32 - / mean
+                launch time from HIP events on the launch stream over the instrumented steps behind the timed region; `peak` = the same
+                FLOPs / the time they take at each instruction's dense peak (2500 fp16, 157.3 fp32 TFLOP/s); `frac` = achieved / peak.
+                `l2` carries the counter-derived L2 -> CU traffic of the kernel against the rate the guide measures for rows shared
+                through the XCD L2s.  The reference formulation's FLOPs, most of which the source-node
+                factorisation removes, are reported separately as `algorithmic_vs_fp32_peak`.  PMC-derived fields come from
+                profiles/r05_pmc.json (collected on the builder's box, see `pmc_source`) and are dropped when that file was taken from
+                other kernel sources than the ones loaded (source hash).
   cpu_baseline  the CPU oracle (reference-equivalent restatement, kind "port") on a bounded sample of the same workload
   other_workloads  BASELINE configs[2] (flexible side chains) and configs[0] (cfg1, 4 samples) measured in the same run.
 """
@@ -59,7 +62,7 @@ def mixed_roofline(fc16, other, sec):
     t_min = 3.0 * fc16 / (F16_MFMA_PEAK_TFLOPS * 1e12) + other / (FP32_MFMA_PEAK_TFLOPS * 1e12)
     return issued / sec / 1e12, issued / t_min / 1e12, t_min / sec
 HBM_PEAK_GBS = 8000.0           # same guide: HBM3E ~8 TB/s
-PMC_FILE = os.path.join("profiles", "r04_pmc.json")
+PMC_FILE = os.path.join("profiles", "r05_pmc.json")
 
 
 def parse_args(argv=None):
@@ -264,19 +267,22 @@ def cpu_baseline(args, model, kw, complex_graph):
         oracle(b)
     steps_t = (1.0, 0.5)[: args.cpu_steps]
     batches = [[] for _ in steps_t]
+    last = None
     for i in range(0, n, bs):
         for si, t in enumerate(steps_t):
+            # one more BATCH while it fits the budget (every step position is timed at least once)
+            if last is not None and all(batches) and (time.perf_counter() - t_begin) + last > budget:
+                break
             t0 = time.perf_counter()
             b = collate(gs[i:i + bs])
             set_time(b, t, t, t, t)
             with torch.no_grad():
                 oracle(b)
-            batches[si].append((len(gs[i:i + bs]), time.perf_counter() - t0))
-        # (every step position has the same number of batches; at least one round is always timed)
-        spent = time.perf_counter() - t_begin
-        per_round = sum(bt[-1][1] for bt in batches)
-        if spent + per_round > budget:
-            break
+            last = time.perf_counter() - t0
+            batches[si].append((len(gs[i:i + bs]), last))
+        else:
+            continue
+        break
     per_graph = [sum(x[1] for x in bt) / sum(x[0] for x in bt) for bt in batches]
     s_per_step = float(np.mean(per_graph)) * n
     n_timed = [sum(x[0] for x in bt) for bt in batches]
@@ -618,9 +624,11 @@ def main(argv=None):
             if hasattr(sampler, "close"):
                 sampler.close()     # the main job's captured step goes back to the shared graph memory pool before the sub-records
 
-            def sub_job(cfg_, flex_, n_):   # a timed job + its instrumented pass
+            def sub_job(cfg_, flex_, n_, conv_h2=True, conv_rows=True):   # a timed job + its instrumented pass
                 m_, kw_ = build_model(cfg_, flex_, device)
                 m_.fork_front = model.fork_front
+                m_.conv_h2 = conv_h2
+                rows_was, sm.CONV_ROWS = sm.CONV_ROWS, (sm.CONV_ROWS and conv_rows)
                 g_ = make_3dpf_complex(seed=0, flexible_sidechains=flex_)
                 pr = sm.ConvProfiler()
 
@@ -637,9 +645,14 @@ def main(argv=None):
                 el_, s_, fp_, _, _, _ = timed_job(m_, g_, n_, slice(0, n_), device, flex_, 20, 3, on_timed=inst, cfg=cfg_)
                 assert torch.isfinite(fp_).all() and torch.isfinite(s_.atom_pos).all()
                 s_.close()
+                sm.CONV_ROWS = rows_was
                 return {"value": n_ / el_, "unit": "poses/s", "ms_per_step": el_ / 20 * 1e3, "steps": 20,
                         "edges_last_step": dict(m_.last_stats), "conv_kernels": conv_fracs(pr)}
 
+            # the headline workload in the exact fp32 MFMA form of every fc product (model.conv_h2 = False: the kernels of rounds 1 - 3), and
+            # in the h2 form through the 32-edge kernel of round 4 (launch.CONV_ROWS = False): driver-timed beside the headline
+            others["configs[1] exact fp32 MFMA form (model.conv_h2 = False), 40 samples, cfg2, rigid"] = sub_job("cfg2", False, 40, conv_h2=False)
+            others["configs[1] fp16 hi/lo form through the 32-edge kernel of round 4 (launch.CONV_ROWS = False)"] = sub_job("cfg2", False, 40, conv_rows=False)
             others["configs[2] 3dpf flexible side chains, 40 samples, cfg2"] = sub_job("cfg2", True, 40)
             others["configs[0] 3dpf 4 samples, cfg1 (ns=16 nv=4 L=2), flexible side chains"] = sub_job("cfg1", True, 4)
             others["README small score model (README.md:82: ns=32 nv=6 L=5, atom_max_neighbors=12, tr_sigma_max=15), 40 samples, rigid receptor"] = \

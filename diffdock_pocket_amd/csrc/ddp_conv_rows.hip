@@ -238,8 +238,8 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
   // ---- factorised features: one tile product per run of edges with one source node, B = the node's G tile (plane form)
   if (B.g_slot >= 0 && rmask != 0u) {
     // G of a source node and slot (task.gh): the column parts of the slot's blocks one after the other, each a CONTIGUOUS tile
-    // [k8][plane][wp columns][8 halves] (wp = the part's width rounded up to 4), then Gb per padded column - a run reads one tile as one
-    // linear stream (stage A writes it in 64-byte pieces that never straddle a 128-byte line)
+    // [k8][wp columns][plane][8 halves] (wp = the part's width rounded up to 4), then Gb per padded column - a run reads one tile as one
+    // linear stream, and stage A fills it in whole 128-byte lines (hi and lo words of four neighbouring columns)
     const int n8 = (S.hid + 7) >> 3;
     const int nmine = min(32, B.n - 32 * part);                                   // G columns of this part
     int wp, cumw, gcp;
@@ -247,13 +247,13 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
     const int cl = (r < nmine) ? r : 0;
     const size_t gldb = (size_t)DDP_GH_LD(S.hid, gcp) * 4;                         // node stride in bytes
     const char* __restrict__ Gc = reinterpret_cast<const char*>(T.gh[B.g_slot]) + (size_t)(2 * n8 * cumw) * 16;
-    // fragment q = 2 ks + plane of lane (r, hh): 16-byte unit (2 k8 + plane) wp + column, k8 = min(2 ks + hh, n8 - 1).  Addressed as
+    // fragment q = 2 ks + plane of lane (r, hh): 16-byte unit 2 (k8 wp + column) + plane, k8 = min(2 ks + hh, n8 - 1).  Addressed as
     // (wave-uniform node base + uniform fragment offset) + a 32-bit per-lane offset: the loads take their base from SGPRs - per-fragment
     // 64-bit lane addresses cost ~40 registers here
     const int gc = wp;
-    const unsigned lo_main = (unsigned)(2 * hh * gc + cl) * 16u;                   // + (4 ks + plane) wp * 16
+    const unsigned lo_main = (unsigned)(2 * hh * gc + 2 * cl) * 16u;               // + (4 ks wp + plane) * 16
     const int k8l = min(2 * (NS - 1) + hh, n8 - 1);
-    const unsigned lo_last = (unsigned)(2 * k8l * gc + cl) * 16u;                  // + plane wp * 16
+    const unsigned lo_last = (unsigned)(2 * k8l * gc + 2 * cl) * 16u;              // + plane * 16
     const unsigned lo_bias = (unsigned)(8 * n8 * gcp + cumw + cl) * 4u - (unsigned)(2 * n8 * cumw) * 16u;   // Gb[c] behind the slot's tiles
     unsigned m = rmask;
     int a0 = __builtin_ctz(m);
@@ -264,7 +264,7 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
 #endif
     const char* __restrict__ gp = Gc + (size_t)ROWS_NODE(a0) * gldb;
 #define ROWS_GFRAG(base, kq, plane) \
-    (*reinterpret_cast<const f32x4*>((base) + (((kq) == NS - 1) ? (size_t)((plane) * gc) * 16 : (size_t)((4 * (kq) + (plane)) * gc) * 16) + (((kq) == NS - 1) ? lo_last : lo_main)))
+    (*reinterpret_cast<const f32x4*>((base) + (((kq) == NS - 1) ? (size_t)(plane) * 16 : (size_t)(4 * (kq) * gc + (plane)) * 16) + (((kq) == NS - 1) ? lo_last : lo_main)))
     float bias = *reinterpret_cast<const float*>(gp + lo_bias);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 gr[GR];

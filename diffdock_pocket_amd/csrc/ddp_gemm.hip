@@ -466,8 +466,8 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 // (include/ddp_hip.h, ddp_conv_task_t::gh): a lane then drains 8 consecutive columns of a parked row (one 8-k group of one G column)
 // as two 16-byte pieces, hi plane and lo plane, where the fp32 form stores two 16-byte quads - the same bytes, the same number of
 // store instructions.  Where the two pieces of every 8-column group go is a table (gh_dest[batch][ncols / 8][2], float offsets inside
-// the row, built by the host from the parts of the G array): the drain has no arithmetic of its own.  Groups whose pieces are 4 floats
-// apart are fp32 columns (Gb, padding) and leave unconverted.  Needs ncols % 32 == 0.
+// the row, built by the host from the parts of the G array; bit 0 of the first = a plane group): the drain has no arithmetic of its
+// own.  The other groups are fp32 columns (Gb, padding) and leave unconverted.  Needs ncols % 32 == 0.
 template <int KT, bool GH = false>
 __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(const float* __restrict__ x, int ldx, int nrows,
                                                                               const int32_t* __restrict__ rows,
@@ -524,9 +524,9 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
     if constexpr (GH) {
       const int g = min(col0 + 32 * t + 8 * (lane & 3), ncols - 8) >> 3;
       const int32_t* __restrict__ d = gh_dest + ((size_t)z * (ncols >> 3) + g) * 2;
-      gh_o1[t] = d[0];
+      gh_o1[t] = d[0] & ~3;
       gh_o2[t] = d[1];
-      gh_sp[t] = (gh_o2[t] - gh_o1[t]) != 4;
+      gh_sp[t] = (d[0] & 1) != 0;
     }
   }
   for (int R0 = (int)blockIdx.y * mrows; R0 < nrows; R0 += (int)gridDim.y * mrows) {

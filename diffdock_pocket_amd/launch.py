@@ -112,7 +112,10 @@ class ConvProfiler:
             self.flops = [fs.flops_per_edge() * n for (s, fs), n in zip(self.specs, ne)]
             self.executed = [(s.mfma_flops_per_edge_executed() + 2 * s.hid * sum(s.g_cols)) * n for (s, fs), n in zip(self.specs, ne)]
             self.useful = [s.useful_flops_per_edge() * n for (s, fs), n in zip(self.specs, ne)]
-            self.fc = [s.fc_flops_per_edge() * n for (s, fs), n in zip(self.specs, ne)]
+            # product FLOPs that run as fp16 hi/lo split products: the two fc products; ddp_conv_rows also runs the per-edge G contraction
+            # (h @ G[src]: 2 hid g_cols per edge) as tile products of the same form
+            self.fc = [(s.fc_flops_per_edge() + (2 * s.hid * sum(s.g_cols) if k == "ddp_conv_rows_kernel" else 0)) * n
+                       for (s, fs), n, k in zip(self.specs, ne, self.kernel)]
             self.boundary = [n * (4.0 * fs.f_in + 32.0) + nb for (s, fs), n, nb in zip(self.specs, ne, self.node_bytes)]
             self._resolved = True
 

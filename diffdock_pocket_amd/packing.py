@@ -637,9 +637,10 @@ def factor_weights_gh(spec: "ConvSpec", weight: torch.Tensor, bias: torch.Tensor
 
 def gh_dest_table(widths: Sequence[int], n8: int, ncols: int) -> torch.Tensor:
     """int32 [ncols / 8, 2] for ddp_stage_a_gh: float offsets inside a G row of the two 16-byte pieces of every 8-column group of the
-    product factor_weights_gh sets up.  Group g = n8 cum_p + k8 w_p + c of part p (cum_p = the widths in front of it) is the k8 group of
-    column c: hi piece at 16-byte unit 2 n8 cum_p + 2 k8 w_p + c, lo piece w_p units behind.  Groups behind the parts (Gb, padding) are 8
-    fp32 columns at their own place (pieces 4 floats apart)."""
+    product factor_weights_gh sets up; bit 0 of entry [g][0] set = a plane group (its values leave as fp16 hi / lo words).  Group
+    g = n8 cum_p + k8 w_p + c of part p (cum_p = the widths in front of it) is the k8 group of column c: its hi piece sits at 16-byte unit
+    2 (n8 cum_p + k8 w_p + c), its lo piece right behind it - so the pieces of four neighbouring columns (one 32-column block of the
+    product) fill one 128-byte line.  Groups behind the parts (Gb, padding) are 8 fp32 columns at their own place."""
     ng = ncols // 8
     tab = torch.empty((ng, 2), dtype=torch.int32)
     g = torch.arange(ng, dtype=torch.int64)
@@ -649,10 +650,9 @@ def gh_dest_table(widths: Sequence[int], n8: int, ncols: int) -> torch.Tensor:
     for w in widths:
         gs = n8 * cum
         gl = torch.arange(n8 * w, dtype=torch.int64)
-        k8, c = gl // w, gl % w
-        unit = 2 * gs + 2 * k8 * w + c
-        tab[gs:gs + n8 * w, 0] = (4 * unit).int()
-        tab[gs:gs + n8 * w, 1] = (4 * (unit + w)).int()
+        unit = 2 * (gs + gl)
+        tab[gs:gs + n8 * w, 0] = (4 * unit + 1).int()
+        tab[gs:gs + n8 * w, 1] = (4 * (unit + 1)).int()
         cum += w
     assert 8 * n8 * cum + cum <= ncols
     return tab

@@ -570,12 +570,24 @@ class Sampler:
         seen = self.__dict__.setdefault("_weights_checked", set())
         if not hasattr(model, "check_weight_values") or id(model) not in seen:
             seen.add(id(model))
-            return model(b)
+            return self._model_call(model, b)
         prev, model.check_weight_values = model.check_weight_values, False
+        try:
+            return self._model_call(model, b)
+        finally:
+            model.check_weight_values = prev
+
+    def _model_call(self, model, b):
+        """model(b) with the per-forward h2 range check (a host synchronisation) switched off: a sampler checks once per run and recovers
+        the whole run (run / confidence)."""
+        prev = getattr(model, "range_check_in_forward", None)
+        if prev is None:
+            return model(b)
+        model.range_check_in_forward = False
         try:
             return model(b)
         finally:
-            model.check_weight_values = prev
+            model.range_check_in_forward = prev
 
     # -- confidence pass + ranking (reference utils/sampling.py:263-283, inference.py:212-219) ------------------------
     def confidence(self, confidence_model):
@@ -593,8 +605,11 @@ class Sampler:
         conf = self._call_model(confidence_model, b)
         if self.on_hip and hasattr(confidence_model, "check_overflow"):
             # a truncated ligand<-atom list is reported for THIS complex, before its scores are ranked (the flag is written by the
-            # search kernel: visible once the forward has run)
+            # search kernel: visible once the forward has run); a value outside the fp16 range reruns the pass in the fp32 form
             torch.cuda.synchronize(self.device)
+            if hasattr(confidence_model, "range_flag_raised") and confidence_model.range_flag_raised():
+                conf = confidence_model.forward_fp32(b)
+                torch.cuda.synchronize(self.device)
             confidence_model.check_overflow()
         key = conf[:, 0] if conf.dim() == 2 else conf
         return conf, torch.argsort(key, descending=True)
@@ -606,8 +621,25 @@ class Sampler:
             # replays never enter the model's Python forward: the value check (param.data.copy_, EMA) is made here, and a change
             # drops the packed weights -> the epoch test in _step_hip recaptures
             self.model._refresh_weight_caches()
+        snap = self.snapshot() if self.on_hip else None
         for i in range(len(schedule)):
             self.step(i, schedule)
+        if self.on_hip and hasattr(self.model, "range_flag_raised"):
+            # The fp16 hi/lo form of the fc products is not total (|v| > 65504 cannot be split); its kernels report such a value through a
+            # flag in pinned host memory.  One check per run: a raised flag puts the job back to its first step (poses, noise stream) and
+            # runs it again in the exact fp32 MFMA form - a new capture, the model's switch restored afterwards.
+            torch.cuda.synchronize(self.device)
+            if self.model.range_flag_raised():
+                self.model.__dict__["h2_recoveries"] = self.model.__dict__.get("h2_recoveries", 0) + 1
+                prev = self.model.conv_h2
+                self.model.conv_h2 = False          # (bumps the packed epoch: the captured step is dropped and recaptured)
+                try:
+                    self.restore(snap)
+                    for i in range(len(schedule)):
+                        self.step(i, schedule)
+                    torch.cuda.synchronize(self.device)
+                finally:
+                    self.model.conv_h2 = prev
         self.check_overflow()
         return self.lig_pos, self.atom_pos
 
@@ -719,8 +751,25 @@ class PipelinedSampler:
 
     def run(self, schedule: Optional[np.ndarray] = None):
         schedule = get_t_schedule(self.parts[0].cfg.inference_steps) if schedule is None else schedule
+        snap = self.snapshot() if self.on_hip else None
         for i in range(len(schedule)):
             self.step(i, schedule)
+        if self.on_hip and hasattr(self.model, "range_flag_raised"):
+            # The fp16 hi/lo form of the fc products is not total (|v| > 65504 cannot be split); its kernels report such a value through a
+            # flag in pinned host memory.  One check per run: a raised flag puts the job back to its first step (poses, noise stream) and
+            # runs it again in the exact fp32 MFMA form - a new capture, the model's switch restored afterwards.
+            torch.cuda.synchronize(self.device)
+            if self.model.range_flag_raised():
+                self.model.__dict__["h2_recoveries"] = self.model.__dict__.get("h2_recoveries", 0) + 1
+                prev = self.model.conv_h2
+                self.model.conv_h2 = False          # (bumps the packed epoch: the captured step is dropped and recaptured)
+                try:
+                    self.restore(snap)
+                    for i in range(len(schedule)):
+                        self.step(i, schedule)
+                    torch.cuda.synchronize(self.device)
+                finally:
+                    self.model.conv_h2 = prev
         self.check_overflow()
         return self.lig_pos, self.atom_pos
 

@@ -443,6 +443,7 @@ class TensorProductScoreModel(nn.Module):
         self._stage_a_stacks = {}      # (layer, conv ids) -> stacked stage-A right-hand sides, see _stage_a()
         self.section_timer = None      # optional SectionTimer (tools/time_sections.py): per-section GPU + host time
         self.check_weight_values = True  # see _refresh_weight_caches
+        self.range_check_in_forward = True   # forward(): read the h2 range flag before returning and recover in fp32 (samplers: per run)
         # Capacity of the ligand<-atom edge list: pocket atoms within lig_max_radius of a ligand atom, per ligand atom (its
         # worst case, every atom of the pocket, is ~80 x what occurs: the grids of every consumer are sized for the capacity).
         # 128 is ~3 x the densest packing of protein heavy atoms inside 5 A; a search that finds more sets a flag in pinned host
@@ -627,16 +628,55 @@ class TensorProductScoreModel(nn.Module):
             self._overflow_flag = torch.zeros(2, dtype=torch.int32).pin_memory()
         return self._overflow_flag
 
-    def check_overflow(self):
-        if self._overflow_flag is not None and int(self._overflow_flag[1]) != 0:
-            self._overflow_flag[1] = 0
-            raise L.DdpError("a node feature / edge feature / fc activation outside the fp16 range (|v| > 65504, or NaN) reached the fp16 "
-                             "hi/lo split kernels of an earlier forward: its scores are not to be trusted; run the exact fp32 MFMA form "
-                             "(diffdock_pocket_amd.launch.CONV_H2 = False)")
-        if self._overflow_flag is not None and int(self._overflow_flag[0]) != 0:
+    def check_overflow(self, range_too=True):
+        """Raises for what the flag block (pinned host memory, written by the kernels) holds from forwards that have run: a truncated
+        ligand<-atom list and / or a value outside the fp16 range in the h2 kernels of a forward whose result was NOT recovered (forwards
+        entered through `forward` and samplers' runs recover by themselves: `_forward_recovering`, `Sampler.run`).  The whole block is
+        cleared first, so a later, healthy forward is not blamed."""
+        if self._overflow_flag is None:
+            return
+        # (range_too = False: the caller - a sampler's step - checks and recovers the range flag itself, once per run: it is left as it is)
+        trunc, rng = int(self._overflow_flag[0]) != 0, range_too and int(self._overflow_flag[1]) != 0
+        if not (trunc or rng):
+            return
+        if range_too:
+            self._overflow_flag.zero_()
+        else:
             self._overflow_flag[0] = 0
-            raise L.DdpError(f"a ligand atom had more than la_capacity_per_atom = {self.la_capacity_per_atom} pocket atoms within "
-                             f"lig_max_radius: the ligand<-atom edge list of an earlier forward was truncated; raise the capacity")
+        msgs = []
+        if rng:
+            msgs.append("a node feature / edge feature / fc activation / G value outside the fp16 range (|v| > 65504, or NaN) reached the fp16 "
+                        "hi/lo split kernels of an earlier forward whose scores were consumed without the range check (a hand-driven "
+                        "Sampler.step sequence without Sampler.check_overflow): they are not to be trusted - model.conv_h2 = False runs the "
+                        "exact fp32 MFMA form")
+        if trunc:
+            msgs.append(f"a ligand atom had more than la_capacity_per_atom = {self.la_capacity_per_atom} pocket atoms within lig_max_radius: "
+                        f"the ligand<-atom edge list of an earlier forward was truncated; raise the capacity")
+        raise L.DdpError("; ".join(msgs))
+
+    def range_flag_raised(self, clear=True):
+        """Did an h2 kernel of a forward that has RUN (the caller synchronised) meet a value it cannot split?"""
+        if self._overflow_flag is None or int(self._overflow_flag[1]) == 0:
+            return False
+        if clear:
+            self._overflow_flag[1] = 0
+        return True
+
+    @property
+    def conv_h2(self):
+        """The fc products (and stage A) as fp16 hi/lo split products on the fp16 matrix cores (22-bit operands, fp32 accumulation;
+        csrc/ddp_conv.hip, ddp_conv_rows.hip); False: the exact fp32 MFMA kernels of rounds 1 - 3.  The split form is not total - a value
+        beyond +-65504 cannot be split - so a forward that meets one is run again in the fp32 form before its result is returned
+        (`forward`, `Sampler.run`); this switch only chooses what is TRIED first.  Changing it drops captured steps (they carry the
+        kernels' form)."""
+        return self.__dict__.get("_conv_h2", True)
+
+    @conv_h2.setter
+    def conv_h2(self, value):
+        value = bool(value)
+        if value != self.conv_h2:
+            self.__dict__["_conv_h2"] = value
+            self.__dict__["_packed_epoch"] = self.__dict__.get("_packed_epoch", 0) + 1
 
     def invalidate_packed(self):
         # (a captured step holds the ADDRESSES of what is dropped here: sampler.Sampler compares this counter before a replay)
@@ -839,4 +879,25 @@ class TensorProductScoreModel(nn.Module):
         if eng is None:
             from .engine import ForwardEngine
             eng = self.__dict__["_engine"] = ForwardEngine(self)
-        return eng.forward(data)
+        out = eng.forward(data)
+        if not (self.conv_h2 and self.range_check_in_forward) or torch.cuda.is_current_stream_capturing():
+            return out
+        # The fp16 hi/lo form is not total: the kernels report a value they cannot split (|v| > 65504) through a flag in pinned host
+        # memory.  The reference's caller synchronises on the next line anyway (utils/sampling.py:122-125), so the flag is read HERE, in
+        # the same call, and a raised one reruns this forward in the exact fp32 MFMA form - the caller never sees the spoiled scores.
+        # (Samplers switch this per-forward check off around their steps and recover a whole run: Sampler.run.)
+        torch.cuda.current_stream(data["ligand"].pos.device).synchronize()
+        if not self.range_flag_raised():
+            return out
+        self.__dict__["h2_recoveries"] = self.__dict__.get("h2_recoveries", 0) + 1
+        return self.forward_fp32(data)
+
+    def forward_fp32(self, data):
+        """This forward with every fc product in the exact fp32 MFMA form (launch.CONV_H2 off for the tasks it builds), whatever conv_h2
+        says; the packed fp32 weights always exist, nothing is invalidated."""
+        prev, prev_chk = self.__dict__.get("_conv_h2", True), self.range_check_in_forward
+        self.__dict__["_conv_h2"], self.range_check_in_forward = False, False
+        try:
+            return self.forward(data)
+        finally:
+            self.__dict__["_conv_h2"], self.range_check_in_forward = prev, prev_chk

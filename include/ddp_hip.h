@@ -142,8 +142,9 @@ typedef struct {
    *  bsp   the tiles' bias words, fp32 [stream tiles][32]
    *  gh    G[s] of a factorised conv as fp16 hi/lo operand planes (v = hi + lo / 2048), per source node DDP_GH_LD(hid, gcp) floats: the
  *        32-column parts of the slot's blocks (in block order, a block's parts in order) one after the other, part p a CONTIGUOUS tile
- *        [k8 < ceil(hid/8)][plane][c < wp][8 halves] with wp = the part's width rounded up to 4 (k8 group g holds the permuted k's
- *        DDP_ROWS_KPERM(g >> 1, g & 1, i), i < 8; padding columns are zero), then Gb per padded column as fp32 [gcp = sum of the wp],
+ *        [k8 < ceil(hid/8)][c < wp][plane][8 halves] with wp = the part's width rounded up to 4 (k8 group g holds the permuted k's
+ *        DDP_ROWS_KPERM(g >> 1, g & 1, i), i < 8; padding columns are zero; hi and lo words of a column side by side, so that stage A
+ *        fills whole 128-byte lines), then Gb per padded column as fp32 [gcp = sum of the wp],
  *        then padding to 128 bytes; written by ddp_stage_a_gh.
  * NULL: the task can only run through ddp_conv_messages. */
   const void* wsh;
@@ -364,9 +365,10 @@ int ddp_stage_a_h2(const float* x, int ldx, int nrows, const int32_t* rows, cons
                    int nbatch, const float* w, const void* w_h2, int k, int ncols, float* out, int ldo, int32_t* range_flag, void* stream);
 /* ... with every output row written in the plane form of ddp_conv_task_t::gh.  The host orders the product's columns [part][k8][c][8]
  * (packing.factor_weights_gh) and passes, per batch entry and per group of 8 columns, the float offsets inside the row of the group's two
- * 16-byte pieces: dest[b][g][0..1], device int32 [nbatch][ncols / 8][2].  A group whose offsets are 4 apart is 8 fp32 columns stored
- * as they are (Gb, padding); any other group holds the 8 k's of one k8 group of one G column: its values v = hi + lo / 2048 leave as 8
- * fp16 hi words at dest[..][0] and 8 fp16 lo words at dest[..][1] - the same bytes as the fp32 form, the same number of stores.
+ * 16-byte pieces: dest[b][g][0..1], device int32 [nbatch][ncols / 8][2]; bit 0 of dest[b][g][0] marks a plane group: the 8 k's of one
+ * k8 group of one G column, whose values v = hi + lo / 2048 leave as 8 fp16 hi words at dest[..][0] & ~3 and 8 fp16 lo words at
+ * dest[..][1] - the same bytes as the fp32 form, the same number of stores.  The other groups are 8 fp32 columns stored as they are (Gb,
+ * padding).
  * Only on the h2 path (w_h2 given, k in {60, 32, 24, 16}, ncols % 32 == 0).  ABI 13. */
 int ddp_stage_a_gh(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows, const int32_t* offs,
                    int nbatch, const float* w, const void* w_h2, int k, int ncols, float* out, int ldo, int32_t* range_flag,
