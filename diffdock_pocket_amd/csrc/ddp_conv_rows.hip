@@ -43,7 +43,7 @@
 #define DDP_ROWS_GRING1 8
 #endif
 #ifndef DDP_ROWS_GRING3
-#define DDP_ROWS_GRING3 4
+#define DDP_ROWS_GRING3 8
 #endif
 
 // Diagnostic build only (-DDDP_ROWS_STAMPS, tools/stamp_rows.py): lane 0 of every wave records s_memtime at the phase boundaries
@@ -104,23 +104,27 @@ __device__ __forceinline__ void rows_epilogue(const f32x16& am, const f32x16& ac
   }
 }
 
-// the same with the rows outside run `run` masked out (G tiles: the B operand was ONE source node's G)
-template <int C>
-__device__ __forceinline__ void rows_epilogue_run(const f32x16& am, const f32x16& ac, const float* frow, const int* rid, int run, f32x16* out) {
+// G tiles: every row of the wave's tile belongs to exactly ONE run, so the runs' tile products are only SELECTED into tg[row] = the
+// product of the row's own run (16 registers whatever C) and multiplied by the harmonics once, behind the last run
+__device__ __forceinline__ void rows_select_run(const f32x16& am, const f32x16& ac, const int* rid, int run, f32x16& tg) {
   typedef int i32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int q4 = 0; q4 < 4; ++q4) {
     const i32x4 id = *reinterpret_cast<const i32x4*>(rid + 8 * q4);
-    float tq[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) tq[q] = (id[q] == run) ? am[4 * q4 + q] + ac[4 * q4 + q] * DDP_H2_INV : 0.f;
+    for (int q = 0; q < 4; ++q) tg[4 * q4 + q] = (id[q] == run) ? am[4 * q4 + q] + ac[4 * q4 + q] * DDP_H2_INV : tg[4 * q4 + q];
+  }
+}
+template <int C>
+__device__ __forceinline__ void rows_apply_harmonics(const f32x16& tg, const float* frow, f32x16* out) {
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4)
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const f32x4 f = *reinterpret_cast<const f32x4*>(frow + c * 32 + 8 * q4);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) out[c][4 * q4 + q] += f[q] * tq[q];
+      for (int q = 0; q < 4; ++q) out[c][4 * q4 + q] = f[q] * tg[4 * q4 + q];
     }
-  }
 }
 
 // The weight stream: a tile travels as ROWS_NP pieces of NS / ROWS_NP k-steps (8 KiB at NS = 12), piece p of every tile through slot p of
@@ -148,7 +152,9 @@ __device__ __forceinline__ void rows_stream_step(f32x4* ring, const f32x4* __res
   // vmcnt counts in order: "at most FPW outstanding" = everything older than the copies of piece j + 1 has landed)
   static_assert(FPW == 2, "the literal below");
   asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#ifndef DDP_ROWS_ABL_NOBAR   // (timing-only ablation: no barrier - what do the four waves wait for each other?)
   __syncthreads();
+#endif
   rows_request_piece<NS>(ring, wsh, ROWS_NP * t + P + 2, ROWS_NP * nts, (P + 2) % ROWS_NP, wave, lane);
 }
 
@@ -167,6 +173,49 @@ __device__ __forceinline__ void rows_piece_lds(const f32x4* slot, const h8 (&ah)
     am = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS0 + k], bh, am, 0, 0, 0);
     ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS0 + k], bl, ac, 0, 0, 0);
     ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[KS0 + k], bh, ac, 0, 0, 0);
+  }
+}
+
+// The basis features of a block's vector-input segments (DOT, VEC_S0, CROSS; build_features of ddp_conv_common.h restated for one wave):
+// ALL loads of a segment first - clamped, unconditional - then the arithmetic.  build_features issues one load per feature inside a
+// runtime loop, and with the stream's LDS-DMA copies in flight hipcc waits vmcnt(0) at every use: ~700 ticks per feature, 6 - 13 k per block.
+template <int MAXI>
+__device__ __forceinline__ void rows_build_features(const ddp_block_t& B, const ddp_conv_task_t& T, const RowsAux* aux, float* F, int lane) {
+  constexpr int FS = ROWS_FS;
+  const int e = lane & 31, half = lane >> 5;
+  const float* __restrict__ xrow = T.x_src + (size_t)aux->src[e] * T.ldx_src;
+  const float s0 = aux->sh[e][0], sx = aux->sh[e][1], sy = aux->sh[e][2], sz = aux->sh[e][3];
+  const float inv_sqrt3 = 0.57735026918962576f, inv_sqrt2 = 0.70710678118654752f;
+  int ubase = 0;
+  for (int si = 0; si < B.nseg; ++si) {
+    const int kind = B.seg[si].kind, off = B.seg[si].in_off, cnt = B.seg[si].count;
+    float ax[MAXI], ay[MAXI], az[MAXI];
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      const int ul = min(half + 2 * i, cnt - 1);
+      ax[i] = xrow[off + 3 * ul];
+      ay[i] = xrow[off + 3 * ul + 1];
+      az[i] = xrow[off + 3 * ul + 2];
+    }
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      const int ul = half + 2 * i;
+      if (ul < cnt) {
+        const int u = ubase + ul;
+        if (kind == DDP_F_DOT) {
+          F[u * FS + e] = (ax[i] * sx + ay[i] * sy + az[i] * sz) * inv_sqrt3;
+        } else if (kind == DDP_F_VEC_S0) {
+          F[(u * 3 + 0) * FS + e] = ax[i] * s0;
+          F[(u * 3 + 1) * FS + e] = ay[i] * s0;
+          F[(u * 3 + 2) * FS + e] = az[i] * s0;
+        } else {  // DDP_F_CROSS: a x s1 / sqrt(2)
+          F[(u * 3 + 0) * FS + e] = (ay[i] * sz - az[i] * sy) * inv_sqrt2;
+          F[(u * 3 + 1) * FS + e] = (az[i] * sx - ax[i] * sz) * inv_sqrt2;
+          F[(u * 3 + 2) * FS + e] = (ax[i] * sy - ay[i] * sx) * inv_sqrt2;
+        }
+      }
+    }
+    ubase += cnt;
   }
 }
 
@@ -214,6 +263,7 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
   // G fragments in flight per wave: a G tile comes from HBM (first touch; ~1 us per round trip under load) and a fragment is one 32-cycle
   // MFMA triple per row tile - the ring is what the registers allow (scalar segments hold 16 result registers, vector segments 48)
   constexpr int NF = 2 * NS, GR = (C == 1) ? DDP_ROWS_GRING1 : DDP_ROWS_GRING3;
+  (void)DDP_ROWS_GRING3;
   (void)sgi;
   static_assert(NF % GR == 0, "fragment f of every G tile lives in ring slot f % GR");
   const ddp_conv_shape_t& S = RL.L.shape;
@@ -272,8 +322,8 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
     for (int k = 0; k < GR; ++k) gr[k] = ROWS_GFRAG(gp, k >> 1, k & 1);
     __builtin_amdgcn_sched_barrier(0);
     int run = 0;
-    const float* shrow = &aux->shT[(C == 1) ? 0 : 1][4 * hh];
     const int* ridrow = &aux->rid[4 * hh];
+    f32x16 tg = splat16(0.f);
     while (m != 0u) {
       m &= m - 1u;
       const int an = (m != 0u) ? __builtin_ctz(m) : a0;
@@ -306,7 +356,7 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
       }
       // (lanes behind the part's last G column hold a clamped column's product: they add nothing - with several features per tile
       // their registers are summed into the first lane group at the end)
-      rows_epilogue_run<C>(am, ac, shrow, ridrow, (r < nmine) ? run : -2, res);
+      rows_select_run(am, ac, ridrow, (r < nmine) ? run : -2, tg);
 #ifdef DDP_ROWS_TOUCH
       rows_touch_done(tch);
 #endif
@@ -316,6 +366,7 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
       ++run;
     }
 #undef ROWS_GFRAG
+    rows_apply_harmonics<C>(tg, &aux->shT[(C == 1) ? 0 : 1][4 * hh], res);
   }
 
   RSTAMP(5 + 3 * sgi);
@@ -334,7 +385,12 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
       rows_piece_lds<NS, 2 * KPP>(ring + 2 * PIECE_Q, ah, al, lane, am, ac);
       int u = (B.nsub > 1) ? j : j * B.ups + us;
       if (!(valid && u < B.U)) u = 0;
+#ifdef DDP_ROWS_ABL_NOEPI   // (timing-only ablation: the tile's feature contraction reduced to one add)
+      res[0] += am + ac;
+      (void)u;
+#else
       rows_epilogue<C>(am, ac, F + (u * C) * ROWS_FS + 4 * hh, ROWS_FS, res);
+#endif
     }
   }
 
@@ -400,6 +456,21 @@ __global__ __launch_bounds__(ROWS_NT, 2) void ddp_conv_rows_kernel(const RowsLau
   const float* __restrict__ xb0 = T.seg_ptr[0] + (size_t)T.seg_idx[0][pr] * T.seg_ld[0];
   const float* __restrict__ xb1 = T.seg_ptr[1] + (size_t)T.seg_idx[1][pr] * T.seg_ld[1];
   const float* __restrict__ xb2 = T.seg_ptr[2] + (size_t)T.seg_idx[2][pr] * T.seg_ld[2];
+  // the source rows' vector irreps (the features of the blocks: first read ~25 k ticks from here) are touched now, one word per
+  // 128-byte line and lane half: they arrive beside the edge_attr_ gather and wait in L2
+  float vtouch[2];
+  {
+    int lo = 1 << 30, hi = 0;
+    for (int bi = 0; bi < S.nblocks; ++bi)
+      if (S.blk[bi].ntiles > 0)
+        for (int si = 0; si < S.blk[bi].nseg; ++si) {
+          lo = min(lo, S.blk[bi].seg[si].in_off);
+          hi = max(hi, S.blk[bi].seg[si].in_off + 3 * S.blk[bi].seg[si].count);
+        }
+    const float* __restrict__ xs = T.x_src + (size_t)src * T.ldx_src;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) vtouch[i] = (hi > lo) ? xs[min(lo + 32 * (2 * i + hh), hi - 1)] : 0.f;
+  }
 
   // ---- stage tile 0, request tile 1
   // ---- request tile 0; the tiles' bias words: one table in LDS for the whole kernel (no global load inside the tile loops)
@@ -445,6 +516,7 @@ __global__ __launch_bounds__(ROWS_NT, 2) void ddp_conv_rows_kernel(const RowsLau
   }
 
   RSTAMP(2);
+  asm volatile("" ::"v"(vtouch[0]), "v"(vtouch[1]));     // (the touched words: never used)
   // ---- fc1, transposed: D[h column m][edge n] = sum_k W1[k][32 ct + m] x[n][k]; lane (edge r, hh) ends with the h columns
   // 32 ct + (j & 3) + 8 (j >> 2) + 4 hh, j < 16, of its own edge = the k-groups (2 ct, hh) and (2 ct + 1, hh) of DDP_ROWS_KPERM
   h8 ah[NS], al[NS];
@@ -527,7 +599,15 @@ __global__ __launch_bounds__(ROWS_NT, 2) void ddp_conv_rows_kernel(const RowsLau
   int sgi = 0;
   for (int bi = 0; bi < S.nblocks; ++bi) {
     const ddp_block_t& B = S.blk[bi];
-    if (B.ntiles > 0 && B.U > 0) build_features<32, 2>(B, T, aux->src, aux->sh, F, lane);
+    if (B.ntiles > 0 && B.U > 0) {
+      bool fast = true;     // (vector-input segments of at most 16 features: the factorised shapes of nv <= 16)
+      for (int si = 0; si < B.nseg; ++si)
+        fast = fast && B.seg[si].count <= 16 && (B.seg[si].kind == DDP_F_DOT || B.seg[si].kind == DDP_F_VEC_S0 || B.seg[si].kind == DDP_F_CROSS);
+      if (fast)
+        rows_build_features<8>(B, T, aux, F, lane);
+      else
+        build_features<32, 2>(B, T, aux->src, aux->sh, F, lane);
+    }
     const int nparts = (B.n + 31) >> 5;
     for (int part = 0; part < nparts; ++part, ++sgi) {
       // the next segment with a G part (its first run's tile is touched behind this segment's last run)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Consolidate the rocprofv3 PMC passes of one build into profiles/r04_pmc.json (read by bench.py).
+"""Consolidate the rocprofv3 PMC passes of one build into profiles/r05_pmc.json (read by bench.py).
 
 Run on the GPU box, every pass in its own process with --kernel-trace only (gpurun refuses --pmc with other trace domains),
 each on the same deterministic workload:
@@ -9,7 +9,7 @@ each on the same deterministic workload:
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- $B --launch-log gpurun_out/pmc_write/launches.json
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv \\
             -d gpurun_out/pmc_mfma -- $B --launch-log gpurun_out/pmc_mfma/launches.json
-  python3 tools/pmc_collect.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma profiles/r04_pmc.json
+  python3 tools/pmc_collect.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma profiles/r05_pmc.json
 
 Corrections (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE are in units of 1024 bytes; on gfx950
 FETCH_SIZE counts a 128-byte request as 64 bytes, so it is doubled; WRITE_SIZE is exact for 16-byte-per-lane streaming stores.
@@ -27,7 +27,7 @@ import sys
 
 import pandas as pd
 
-CONV = ["ddp_conv32_kernel", "ddp_conv_messages_kernel"]
+CONV = ["ddp_conv_rows_kernel", "ddp_conv32_kernel", "ddp_conv_messages_kernel"]
 OTHER = ["ddp_stage_a_h2_kernel", "ddp_stage_a_mfma_kernel", "ddp_segment_reduce4_kernel", "ddp_segment_reduce_kernel", "ddp_edge_featurize", "ddp_radius", "ddp_knn", "ddp_pose_update"]
 
 
