@@ -549,12 +549,24 @@ def main(argv=None):
                                   for tag, (n_t, u_t, ms_t, ne_t, f16_t) in sorted(prof.by_tag(kname).items(), key=lambda kv: str(kv[0]))},
                      "traffic": p.get("hbm_bytes_per_launch"), "issued_mfma_gflop_per_launch_pmc": p.get("issued_mfma_gflop_per_launch"),
                      "padding_frac_pmc": p.get("padding_frac"), "mfma_busy_pmc": p.get("mfma_busy_frac")}
+                l2 = p.get("l2")
+                if l2:   # counter-derived L2 -> CU traffic of the kernel (128-byte requests) against what the chip delivers from its XCD L2s
+                    cyc = l2.get("cycles_per_launch") or 0.0
+                    e["l2"] = {"request_bytes_per_launch": l2.get("l2_request_bytes_per_launch"), "hit_rate": l2.get("l2_hit_rate"),
+                               "busy_frac": l2.get("l2_busy_frac"), "tcp_tcc_read_latency_cycles": l2.get("tcp_tcc_read_latency_cycles"),
+                               "bytes_per_cycle_chip": l2.get("l2_bytes_per_cycle_chip"),
+                               "tb_per_s_at_the_profiled_launch_time": (l2.get("l2_bytes_per_cycle_chip") or 0.0) * 2.1e9 / 1e12 if cyc else None,
+                               "guide_measured_peak_tb_per_s": [16.8, 18.8],
+                               "note": "rocprofv3 --pmc TCC_REQ_sum x 128 B per launch / GRBM_GUI_ACTIVE (per XCD) cycles; the 32-edge kernel of round 4 "
+                                       "read 15.3 TB/s here with the L2 90 % busy (profiles/r05_pmc_conv32_h2_l1_l2.json)"}
                 return e
             roof = entry(kinds[0])
-            roof["note"] = ("achieved = matrix-core instruction FLOPs of the kernel's own formulation without padding (fc1 + vector-feature fc2 "
-                            "columns as fp16 hi/lo split products = 3 fp16 MFMA FLOPs per product FLOP; the per-edge G contraction and the "
-                            "feature contraction in fp32) / HIP-event launch time; peak = the same FLOPs / the time they take at each "
-                            "instruction's dense peak (2500 fp16, 157.3 fp32 TFLOP/s), so frac = time at peak / measured time; "
+            roof["note"] = ("achieved = matrix-core instruction FLOPs of the kernel's own formulation without padding (fc1, the vector-feature fc2 "
+                            "columns and - ddp_conv_rows - the per-edge G contraction as fp16 hi/lo split products = 3 fp16 MFMA FLOPs per "
+                            "product FLOP; the feature contraction in fp32) / HIP-event launch time; peak = the same FLOPs / the time they "
+                            "take at each instruction's dense peak (2500 fp16, 157.3 fp32 TFLOP/s), so frac = time at peak / measured time; "
+                            "ddp_conv_rows runs a whole 32 x 32 tile product per run of edges with one source node, of which only the run's "
+                            "rows are useful (counted) - the issued work is in issued_mfma_gflop_per_launch_pmc; "
                             "fp32_equivalent_* counts every product FLOP once; algorithmic_* = the reference formulation "
                             "(BASELINE.md section 3: 2FH + 2HW + 2C per edge), 84 % of which the exact source-node factorisation "
                             "removes (DESIGN.md section 4.2), hence algorithmic_vs_fp32_peak > 1")
@@ -587,12 +599,13 @@ def main(argv=None):
         line = {"metric": "ligand poses/sec (40 samples x 20 steps) on 3dpf", "value": poses / elapsed, "unit": "poses/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                 "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-                "dtype": "f32 (fc products: fp16 hi/lo split of both operands on v_mfma_f32_32x32x16_f16, fp32 accumulate)", "data": "synthetic",
+                "dtype": "f32 (fc and G products: fp16 hi/lo split of both operands on v_mfma_f32_32x32x16_f16, fp32 accumulate; the exact fp32 MFMA form is timed in other_workloads)", "data": "synthetic",
                 "config": {"workload": f"3dpf ({sampler.n_l} lig atoms, 139 residues, {sampler.n_a} pocket atoms), "
                                        f"{n_total} samples over {world} GPU(s) ({n_local} on rank 0) x 20-step schedule, score model "
                                        f"{args.cfg} (ns={kw['ns']} nv={kw['nv']} L={kw['num_conv_layers']}), "
                                        f"flexible_sidechains={args.flex}", "samples_total": n_total, "samples_rank0": n_local,
-                           "parallelism": f"samples sharded over {world} rank(s), one final all_gather of poses",
+                           "parallelism": f"samples sharded over {world} rank(s), one final all_gather of poses" +
+                                          ("; NO run on more than one GPU exists (no multi-GPU node was available to the builder)" if world == 1 else ""),
                            "ways": args.ways, "ms_per_step_by_rank": rank_ms, "src_sha16": loaded_hash(), "device": str(device),
                            "hbm_plan_rank0": shard_hbm_plan(args.cfg, n_local),
                            "hip_graph_replay": info.get("hip_graph"), "rccl_ranks_seen": ranks_seen, "backend": backend,

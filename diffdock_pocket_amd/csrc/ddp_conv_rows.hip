@@ -150,8 +150,11 @@ __device__ __forceinline__ void rows_stream_step(f32x4* ring, const f32x4* __res
   constexpr int FPW = 2 * NS / ROWS_NP / ROWS_NW;
   // (hipcc does NOT wait for an LDS-DMA in front of a barrier: without this a wave can pass while its part of the piece is in flight.
   // vmcnt counts in order: "at most FPW outstanding" = everything older than the copies of piece j + 1 has landed)
-  static_assert(FPW == 2, "the literal below");
-  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  static_assert(FPW == 2 || FPW == 1, "the literals below");
+  if constexpr (FPW == 2)
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
 #ifndef DDP_ROWS_ABL_NOBAR   // (timing-only ablation: no barrier - what do the four waves wait for each other?)
   __syncthreads();
 #endif
@@ -262,8 +265,8 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
                                             const char* __restrict__ next_g, size_t next_ld, int next_bytes) {
   // G fragments in flight per wave: a G tile comes from HBM (first touch; ~1 us per round trip under load) and a fragment is one 32-cycle
   // MFMA triple per row tile - the ring is what the registers allow (scalar segments hold 16 result registers, vector segments 48)
-  constexpr int NF = 2 * NS, GR = (C == 1) ? DDP_ROWS_GRING1 : DDP_ROWS_GRING3;
-  (void)DDP_ROWS_GRING3;
+  constexpr int NF = 2 * NS, GRW = (C == 1) ? DDP_ROWS_GRING1 : DDP_ROWS_GRING3;
+  constexpr int GR = (NF % GRW == 0) ? GRW : (NF % 6 == 0) ? 6 : (NF % 4 == 0) ? 4 : 2;
   (void)sgi;
   static_assert(NF % GR == 0, "fragment f of every G tile lives in ring slot f % GR");
   const ddp_conv_shape_t& S = RL.L.shape;
@@ -642,7 +645,8 @@ extern "C" int ddp_conv_rows(const ddp_conv_shape_t* shape, const ddp_conv_task_
   if (!shape || !tasks) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: null argument");
   if (ntasks < 0 || ntasks > DDP_MAX_TASKS) return ddp_fail(DDP_ELIMIT, "ddp_conv_rows: ntasks > DDP_MAX_TASKS");
   if (shape->nblocks < 1 || shape->nblocks > DDP_MAX_BLOCKS) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: nblocks");
-  if (shape->f_in != shape->hid || shape->hid != 180) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: shapes of the size class ns = 60 (f_in = hid = 180) only");
+  const int sc = (shape->f_in != shape->hid) ? 0 : (shape->hid == 180) ? 60 : (shape->hid == 96) ? 32 : 0;
+  if (sc == 0) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: shapes of the size classes ns = 60 / 32 (f_in = hid = 180 / 96) only");
   RowsLaunch RL;
   ConvLaunch& L = RL.L;
   L.shape = *shape;
@@ -650,7 +654,7 @@ extern "C" int ddp_conv_rows(const ddp_conv_shape_t* shape, const ddp_conv_task_
   L.tv_off = 0;
   L.ntasks = 0;
   L.dev_counts = 0;
-  const int NS = 12, nct1 = shape->nct1;
+  const int NS = (sc == 60) ? 12 : 6, nct1 = shape->nct1;
   if (nct1 != (shape->hid + 31) / 32) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: nct1");
   int nts = nct1, frows = 0;
   for (int b = 0; b < shape->nblocks; ++b) {
@@ -701,10 +705,17 @@ extern "C" int ddp_conv_rows(const ddp_conv_shape_t* shape, const ddp_conv_task_
   RL.bias_bytes = (nts * 128 + 127) / 128 * 128;
   const size_t lds_bytes = (size_t)2 * (NS * 1024) + RL.bias_bytes + (size_t)ROWS_NW * priv;
   if (2 * lds_bytes > 160 * 1024) return ddp_fail(DDP_ELIMIT, "ddp_conv_rows: LDS budget of two workgroups per CU exceeded (too many vector features per block)");
-  static int lds_have = 0;
-  hipError_t err = ddp_need_lds(reinterpret_cast<const void*>(ddp_conv_rows_kernel<60>), (int)lds_bytes, &lds_have);
-  if (err != hipSuccess) return ddp_fail_hip(err, "hipFuncSetAttribute(conv rows)");
-  hipLaunchKernelGGL(ddp_conv_rows_kernel<60>, dim3(tiles), dim3(ROWS_NT), lds_bytes, (hipStream_t)stream, RL);
+  static int lds_have[2] = {0, 0};
+  hipError_t err;
+  if (sc == 60) {
+    err = ddp_need_lds(reinterpret_cast<const void*>(ddp_conv_rows_kernel<60>), (int)lds_bytes, &lds_have[0]);
+    if (err != hipSuccess) return ddp_fail_hip(err, "hipFuncSetAttribute(conv rows)");
+    hipLaunchKernelGGL(ddp_conv_rows_kernel<60>, dim3(tiles), dim3(ROWS_NT), lds_bytes, (hipStream_t)stream, RL);
+  } else {
+    err = ddp_need_lds(reinterpret_cast<const void*>(ddp_conv_rows_kernel<32>), (int)lds_bytes, &lds_have[1]);
+    if (err != hipSuccess) return ddp_fail_hip(err, "hipFuncSetAttribute(conv rows)");
+    hipLaunchKernelGGL(ddp_conv_rows_kernel<32>, dim3(tiles), dim3(ROWS_NT), lds_bytes, (hipStream_t)stream, RL);
+  }
   err = hipGetLastError();
   if (err != hipSuccess) return ddp_fail_hip(err, "ddp_conv_rows launch");
   return 0;

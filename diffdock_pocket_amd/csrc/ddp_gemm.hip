@@ -513,19 +513,21 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
   int cq[CT];
 #pragma unroll
   for (int t = 0; t < CT; ++t) cq[t] = max(0, min(4 * (lane & 7), ncols - 4 - (col0 + 32 * t)));
-  // GH: float offsets (inside a row) of the two 16-byte pieces of this lane's 8-column group of every column tile
-  int gh_o1[CT], gh_o2[CT];
+  // GH: a store instruction writes 8 rows x 128 bytes like the fp32 form: lane (row 8 p + lane / 8, piece lane & 7) stores the hi
+  // (even piece) or lo (odd piece) words of column group (lane & 7) >> 1 of the block - two lanes convert the same 8 columns and keep one
+  // plane each.  gh_o[t]: float offset (inside a row) of this lane's piece; gh_sp[t]: a plane group (else 8 fp32 columns: the lane
+  // stores their first or second quad)
+  int gh_o[CT];
   bool gh_sp[CT];
   float gh_max = 0.f;                   // GH: largest |G value| split (outside the fp16 range: reported through range_flag)
 #pragma unroll
   for (int t = 0; t < CT; ++t) {
-    gh_o1[t] = gh_o2[t] = 0;
+    gh_o[t] = 0;
     gh_sp[t] = false;
     if constexpr (GH) {
-      const int g = min(col0 + 32 * t + 8 * (lane & 3), ncols - 8) >> 3;
+      const int g = min(col0 + 32 * t + 8 * ((lane & 7) >> 1), ncols - 8) >> 3;
       const int32_t* __restrict__ d = gh_dest + ((size_t)z * (ncols >> 3) + g) * 2;
-      gh_o1[t] = d[0] & ~3;
-      gh_o2[t] = d[1];
+      gh_o[t] = (lane & 1) ? d[1] : (d[0] & ~3);
       gh_sp[t] = (d[0] & 1) != 0;
     }
   }
@@ -573,12 +575,13 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
   int pend_lds[4] = {0, 0, 0, 0};       // ... and where it sits in the parked tile
   bool pend_sp = false;                 // GH: the pending block's groups are plane groups
   int pbuf = 0;
-  f32x4 dv = {0.f, 0.f, 0.f, 0.f}, dv2 = dv;
-  // GH: the lane's group q (row 16 q + lane / 4) of the pending tile -> the two 16-byte pieces that leave (hi / lo plane, or the two fp32
-  // quads).  Packed conversions, the range check as one running max, no branch (a NaN needs an inf or a NaN in x, which the x split reports)
-  auto gh_read = [&](const float* pt, int q) {
+  f32x4 dv = {0.f, 0.f, 0.f, 0.f};
+  // GH: this lane's 16-byte piece of quarter p of the pending tile: the hi or lo words of the 8 columns at pend_lds[p] (or, for fp32
+  // groups, their first or second quad).  Packed conversions, the range check as one running max, no branch (a NaN needs an inf or a NaN
+  // in x, which the x split reports)
+  auto gh_read = [&](const float* pt, int p) {
     typedef float f32x8 __attribute__((ext_vector_type(8)));
-    const f32x4 a = *reinterpret_cast<const f32x4*>(&pt[pend_lds[2 * q]]), b = *reinterpret_cast<const f32x4*>(&pt[pend_lds[2 * q] + 4]);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(&pt[pend_lds[p]]), b = *reinterpret_cast<const f32x4*>(&pt[pend_lds[p] + 4]);
     const f32x8 f = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     const h8 hi = __builtin_convertvector(f, h8);
     const f32x8 rest = (f - __builtin_convertvector(hi, f32x8)) * 2048.f;
@@ -586,11 +589,9 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
     const float m8 = fmaxf(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))), fmaxf(fmaxf(fabsf(f[4]), fabsf(f[5])), fmaxf(fabsf(f[6]), fabsf(f[7]))));
     gh_max = fmaxf(gh_max, pend_sp ? m8 : 0.f);
     const f32x4 vh = __builtin_bit_cast(f32x4, hi), vl = __builtin_bit_cast(f32x4, lo);
+    const bool odd = (lane & 1) != 0;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      dv[e] = pend_sp ? vh[e] : a[e];
-      dv2[e] = pend_sp ? vl[e] : b[e];
-    }
+    for (int e = 0; e < 4; ++e) dv[e] = pend_sp ? (odd ? vl[e] : vh[e]) : (odd ? b[e] : a[e]);
   };
   auto block = [&](auto drain_tag, int t, const h8 (&a)[2][NS], const int (&blk_ri)[4], int nr) {
     constexpr bool DRAIN = decltype(drain_tag)::value;
@@ -601,28 +602,24 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
 #pragma unroll
     for (int s2 = 0; s2 < NS; ++s2) {
       if constexpr (DRAIN && NS == 4) {
-        if constexpr (GH) {
-          if ((s2 & 1) == 0) gh_read(pt, s2 >> 1);
-        } else {
+        if constexpr (GH)
+          gh_read(pt, s2);
+        else
           dv = *reinterpret_cast<const f32x4*>(&pt[pend_lds[s2]]);
-        }
       }
       am = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][s2], wr[t][0][s2], am, 0, 0, 0);
       ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][s2], wr[t][1][s2], ac, 0, 0, 0);
       ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][s2], wr[t][0][s2], ac, 0, 0, 0);
-      if constexpr (DRAIN && NS == 4) *reinterpret_cast<f32x4*>(&ob[pend_off[s2]]) = (GH && (s2 & 1)) ? dv2 : dv;
+      if constexpr (DRAIN && NS == 4) *reinterpret_cast<f32x4*>(&ob[pend_off[s2]]) = dv;
     }
     if constexpr (DRAIN && NS != 4) {
-      if constexpr (GH) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          gh_read(pt, q);
-          *reinterpret_cast<f32x4*>(&ob[pend_off[2 * q]]) = dv;
-          *reinterpret_cast<f32x4*>(&ob[pend_off[2 * q + 1]]) = dv2;
-        }
-      } else {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(&ob[pend_off[p]]) = *reinterpret_cast<const f32x4*>(&pt[pend_lds[p]]);
+      for (int p = 0; p < 4; ++p) {
+        if constexpr (GH)
+          gh_read(pt, p);
+        else
+          dv = *reinterpret_cast<const f32x4*>(&pt[pend_lds[p]]);
+        *reinterpret_cast<f32x4*>(&ob[pend_off[p]]) = dv;
       }
     }
     float* tl = st[wave][pbuf];
@@ -635,14 +632,10 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
       pend_sp = gh_sp[t];
 #endif
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int rr = min(16 * q + (lane >> 2), nr - 1);        // row of the tile; blk_ri[p] holds rows 8 p + (lane >> 3)
-        const int src_lane = ((lane >> 2) & 7) << 3;                // the lane that holds tile row 8 p + ((lane >> 2) & 7) in blk_ri[p]
-        const int ri0 = __shfl(blk_ri[2 * q], src_lane), ri1 = __shfl(blk_ri[2 * q + 1], src_lane);
-        const int ri = ((lane >> 2) >> 3) ? ri1 : ri0;
-        pend_lds[2 * q] = rr * TS + 8 * (lane & 3);
-        pend_off[2 * q] = (size_t)ri * ldo + gh_o1[t];
-        pend_off[2 * q + 1] = (size_t)ri * ldo + gh_o2[t];
+      for (int p = 0; p < 4; ++p) {
+        const int rr = min(8 * p + (lane >> 3), nr - 1);        // clamped row of the tile (blk_ri is clamped the same way)
+        pend_lds[p] = rr * TS + 8 * ((lane & 7) >> 1);
+        pend_off[p] = (size_t)blk_ri[p] * ldo + gh_o[t];
       }
     } else {
 #pragma unroll
@@ -688,16 +681,13 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
   }
   if (!first) {   // the last block
     const float* pt = st[wave][pbuf ^ 1];
-    if constexpr (GH) {
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        gh_read(pt, q);
-        *reinterpret_cast<f32x4*>(&ob[pend_off[2 * q]]) = dv;
-        *reinterpret_cast<f32x4*>(&ob[pend_off[2 * q + 1]]) = dv2;
-      }
-    } else {
-#pragma unroll
-      for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(&ob[pend_off[p]]) = *reinterpret_cast<const f32x4*>(&pt[pend_lds[p]]);
+    for (int p = 0; p < 4; ++p) {
+      if constexpr (GH)
+        gh_read(pt, p);
+      else
+        dv = *reinterpret_cast<const f32x4*>(&pt[pend_lds[p]]);
+      *reinterpret_cast<f32x4*>(&ob[pend_off[p]]) = dv;
     }
   }
   __syncthreads();

@@ -313,7 +313,10 @@ def launch_reduce(x, ldx, n_nodes, d_out, sources, accumulate=True, n_rep=1, rep
         def nbytes(views=views, d_out=d_out, n_nodes=n_nodes, n_rep=n_rep):
             ne = sum(v.n_edges if v.cnt is None else min(v.n_edges, int(v.cnt.item())) for v in views)
             return 4.0 * d_out * (ne + 2 * n_nodes * max(n_rep, 1))
-        prof.hbm.setdefault("ddp_segment_reduce4_kernel", []).append((e0, e1, nbytes))     # (the 16-byte form runs whenever d_out % 4 == 0)
+        # (the same predicate as csrc/ddp_misc.hip: the 16-byte form needs 16-byte aligned arrays and d_out, ldx multiples of 4)
+        wide = (d_out % 4 == 0 and ldx % 4 == 0 and x.data_ptr() % 16 == 0 and not os.environ.get("DDP_REDUCE_NARROW")
+                and all(s_[0].data_ptr() % 16 == 0 and s_[2].bn_scale.data_ptr() % 16 == 0 and s_[2].bn_shift.data_ptr() % 16 == 0 for s_ in sources))
+        prof.hbm.setdefault("ddp_segment_reduce4_kernel" if wide else "ddp_segment_reduce_kernel", []).append((e0, e1, nbytes))
 
 
 class EdgeMLPPack:

@@ -498,15 +498,16 @@ def bn_affine(out_mul_blocks: Sequence[Tuple[int, int, bool]], running_mean, run
 
 # ------------------------------------------------------------------------------------------------ row-stationary kernel (ddp_conv_rows)
 def rows_supported(spec: "ConvSpec") -> bool:
-    """Shapes ddp_conv_rows runs: factorised convs of the size class ns = 60 (f_in = hid = 180: the released cfg2 architecture) whose
-    per-wave feature rows fit the kernel's LDS plan."""
-    if not spec.factorized or h2_steps(spec) != 12:
+    """Shapes ddp_conv_rows runs: factorised convs of the size classes ns = 60 / 32 (f_in = hid = 180 / 96: the README's large and small
+    score models) whose per-wave feature rows fit the kernel's LDS plan."""
+    ns16 = h2_steps(spec)
+    if not spec.factorized or ns16 not in (12, 6):
         return False
     frows = max([b.U * b.C for b in spec.blocks if b.U > 0] + [0])
-    priv = max((frows * 36 * 4 + 127) // 128 * 128 + 1408, 12 * 1024)
+    priv = max((frows * 36 * 4 + 127) // 128 * 128 + 1408, ns16 * 1024)
     nts = spec.nct1 + sum(len(t) for _, _, t in rows_segments(spec))
-    # two 4-wave workgroups per CU: ring of two half tiles + bias table + four private areas each
-    return 2 * (2 * 12 * 1024 + (nts * 128 + 127) // 128 * 128 + 4 * ((priv + 127) // 128 * 128)) <= 160 * 1024
+    # two 4-wave workgroups per CU: ring of one tile's pieces + bias table + four private areas each
+    return 2 * (2 * ns16 * 1024 + (nts * 128 + 127) // 128 * 128 + 4 * ((priv + 127) // 128 * 128)) <= 160 * 1024
 
 
 def rows_kperm(ns16: int) -> torch.Tensor:

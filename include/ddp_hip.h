@@ -124,7 +124,9 @@ typedef struct {
   /* Optional (ABI 12): fc.0 / fc.3 weights as fp16 hi/lo operand planes (packing.pack_tiles_h2; 16-byte aligned): when EVERY
    * task of a launch carries both and f_in = hid = 3 ns with ns in {60, 32, 24, 16}, the fc products run on
    * v_mfma_f32_32x32x16_f16 with both operands split as v = hi + lo / 2048 (three products per 16 k, fp32 accumulation: 22-bit
-   * operands, the fp32 MFMA chain's error class, csrc/ddp_conv.hip).  Layout per 32-column tile: 2 * NS fragments of 1 KiB (NS = k16 steps,
+   * operands, the fp32 MFMA chain's error class, csrc/ddp_conv.hip; the 22 bits hold while both halves are normal fp16 numbers: below
+   * |v| ~ 6.1e-5 the split resolves v to an ABSOLUTE 2^-36, i.e. |err| <= 2^-20 sum|x w| + K 2^-35 max|w| for small x -
+   * tests/test_gpu_parity.py::test_stage_a_h2_error_floor_for_small_operands).  Layout per 32-column tile: 2 * NS fragments of 1 KiB (NS = k16 steps,
    * K zero-padded), fragment q = 2 * ks + plane (0 = hi, 1 = lo): [hh = 0..1][column j = 0..31][8 halves k = 16 ks + 8 hh + i].
    * b1p / b2p stay fp32.  NULL: the exact fp32 MFMA form (w1p / w2p). */
   const void* w1h;

@@ -906,6 +906,38 @@ def test_stage_a_h2_error(k, ncols, nrows, nb):
     assert bool((part[:, rest] == -7.0).all())
 
 
+@pytest.mark.parametrize("mag", [1e-3, 1e-5, 3e-7])
+def test_stage_a_h2_error_floor_for_small_operands(mag):
+    """the split v = hi + lo / 2048 keeps 22 significant bits only while both halves are NORMAL fp16 numbers.  Below
+    |v| ~ 6.1e-5 the hi half is subnormal (spacing 2^-24) and the low half, scaled by 2048, resolves v to 2^-24 / 2048 / 2 = 2^-36: the
+    error of a product then has an ABSOLUTE floor of ~2^-36 |other operand| per term instead of a relative 2^-21.  The bound the kernels
+    document is therefore  |err| <= 2^-20 sum|x w| + K 2^-35 max|w|  (x the small operand): asserted here for x of magnitude 1e-3 ... 3e-7
+    against fp64, next to the fp32 MFMA form - which has no such floor.  (The model's operands - edge embeddings, relu activations, BatchNorm-ed
+    node features - are O(1e-2 ... 10); the parity suites and the fp64 comparison of all size classes run on them.)"""
+    import ctypes as C
+    from diffdock_pocket_amd import _lib as L
+    from diffdock_pocket_amd.packing import split_h2
+    from diffdock_pocket_amd.score_model import _stream
+    torch.manual_seed(3)
+    dev = _dev()
+    lib = L.load()
+    k, ncols, nrows, ldx = 60, 2560, 300, 184
+    x = (torch.randn(nrows, ldx) * mag).to(dev)
+    w = (torch.randn(1, k, ncols) * 0.3).to(dev)
+    offs_c = (C.c_int32 * 1)(0)
+    wh = split_h2(w)
+    exact = x[:, :k].double() @ w[0].double()
+    scale = x[:, :k].double().abs() @ w[0].double().abs()
+    outh = torch.empty(1, nrows, ncols, device=dev)
+    L.check(lib.ddp_stage_a_h2(x.data_ptr(), ldx, nrows, None, None, nrows, offs_c, 1, w.data_ptr(), wh.data_ptr(), k, ncols, outh.data_ptr(),
+                               ncols, None, _stream()), "ddp_stage_a_h2")
+    err = (outh[0].double() - exact).abs()
+    bound = 2.0 ** -20 * scale + k * 2.0 ** -35 * float(w.abs().max())
+    assert bool((err <= bound).all()), (mag, float((err / bound).max()))
+    if mag <= 1e-5:     # (the floor is real: the relative bound alone does not hold down there)
+        assert float((err / scale).max()) > 2.0 ** -20
+
+
 def test_forward_with_bf16x3_stage_a_agrees_with_the_exact_form():
     """model.stage_a_bf16x3 (an option, off by default): the same forward with stage A as bf16x3 products - scores within 2e-5
     of the exact-fp32 form's (parity tolerance of the path: 1e-4)."""

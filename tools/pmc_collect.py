@@ -63,6 +63,39 @@ def counter_sum(c, name, disp_ids=None, lo=None, hi=None, kernel=None):
     return float(s.Counter_Value.sum()), int(s.Dispatch_Id.nunique())
 
 
+def l2_block(l2_dir, lat_dir):
+    """Per-kernel L2 figures from two further passes (TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum ... / TCP_TCC_READ_REQ_LATENCY_sum
+    TCC_BUSY_avr TCC_EA0_RDREQ_sum GRBM_GUI_ACTIVE): requests are 128 bytes; GRBM_GUI_ACTIVE sums the 8 XCDs."""
+    out = {}
+    def per_kernel(d):
+        f = max(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+        c = pd.read_csv(f)
+        res = {}
+        for k in CONV + OTHER:
+            s = c[c.Kernel_Name.str.contains(k, regex=False)]
+            if len(s):
+                n = s.Dispatch_Id.nunique()
+                res[k] = {name: float(g.Counter_Value.sum()) / n for name, g in s.groupby("Counter_Name")}
+                res[k]["launches_sampled"] = int(n)
+        return res
+    a, b = per_kernel(l2_dir), per_kernel(lat_dir)
+    for k in a:
+        r, t = a[k], b.get(k, {})
+        gui = r.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        e = {"launches_sampled": r["launches_sampled"], "l2_requests_per_launch": r.get("TCC_REQ_sum"), "l2_request_bytes_per_launch": 128.0 * r.get("TCC_REQ_sum", 0.0),
+             "l2_hit_rate": r.get("TCC_HIT_sum", 0.0) / max(r.get("TCC_HIT_sum", 0.0) + r.get("TCC_MISS_sum", 0.0), 1.0),
+             "cycles_per_launch": gui, "l2_bytes_per_cycle_chip": 128.0 * r.get("TCC_REQ_sum", 0.0) / gui if gui else None,
+             "ta_busy_frac": r.get("TA_BUSY_avr", 0.0) / gui if gui else None,
+             "tcp_pending_stall_frac": r.get("TCP_PENDING_STALL_CYCLES_sum", 0.0) / (gui * 256.0) if gui else None}
+        if t:
+            gui2 = t.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+            e["l2_busy_frac"] = t.get("TCC_BUSY_avr", 0.0) / gui2 if gui2 else None
+            e["tcp_tcc_read_latency_cycles"] = t.get("TCP_TCC_READ_REQ_LATENCY_sum", 0.0) / max(t.get("TCP_TCC_READ_REQ_sum", 1.0), 1.0)
+            e["hbm_read_bytes_per_launch_ea"] = 128.0 * t.get("TCC_EA0_RDREQ_sum", 0.0)
+        out[k] = e
+    return out
+
+
 def main():
     fetch_dir, write_dir, mfma_dir, out = sys.argv[1:5]
     (cf, lf), (cw, lw), (cm, lm) = load(fetch_dir), load(write_dir), load(mfma_dir)
@@ -125,6 +158,9 @@ def main():
     res["_per_step"] = {"timed_steps": steps, "hbm_bytes_per_step": (2.0 * fe_all + wr_all) * 1024.0 / steps,
                         "fetch_bytes_per_step": 2.0 * fe_all * 1024.0 / steps, "write_bytes_per_step": wr_all * 1024.0 / steps,
                         "window": "all dispatches from the first to the last logged conv launch (the last step's pose update falls outside)"}
+    if len(sys.argv) >= 7:      # optional: the L1 / L2 passes
+        for k, e in l2_block(sys.argv[5], sys.argv[6]).items():
+            res["kernels"].setdefault(k, {})["l2"] = e
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps(res, indent=1))
