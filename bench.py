@@ -641,7 +641,9 @@ def main(argv=None):
                 m_, kw_ = build_model(cfg_, flex_, device)
                 m_.fork_front = model.fork_front
                 m_.conv_h2 = conv_h2
-                rows_was, sm.CONV_ROWS = sm.CONV_ROWS, (sm.CONV_ROWS and conv_rows)
+                from diffdock_pocket_amd import launch as launch_
+                rows_was = launch_.CONV_ROWS
+                launch_.CONV_ROWS = rows_was and conv_rows
                 g_ = make_3dpf_complex(seed=0, flexible_sidechains=flex_)
                 pr = sm.ConvProfiler()
 
@@ -658,7 +660,7 @@ def main(argv=None):
                 el_, s_, fp_, _, _, _ = timed_job(m_, g_, n_, slice(0, n_), device, flex_, 20, 3, on_timed=inst, cfg=cfg_)
                 assert torch.isfinite(fp_).all() and torch.isfinite(s_.atom_pos).all()
                 s_.close()
-                sm.CONV_ROWS = rows_was
+                launch_.CONV_ROWS = rows_was
                 return {"value": n_ / el_, "unit": "poses/s", "ms_per_step": el_ / 20 * 1e3, "steps": 20,
                         "edges_last_step": dict(m_.last_stats), "conv_kernels": conv_fracs(pr)}
 

@@ -241,34 +241,117 @@ __device__ __forceinline__ bool rows_gpart(const ddp_conv_shape_t& S, int bi, in
   return true;
 }
 
-// G tiles come from HBM (first touch: ~3.5 k ticks per round trip under this kernel's load, two round trips per tile with the register
-// ring) - so a wave TOUCHES the tile of its next run (one dword per 128-byte line: three loads) while it works on the current one: the
-// lines are in L2 when the ring asks for them.  The touched words are kept until the end of the current tile and never used.
-struct RowsTouch {
-  float v[3];
+// The G runs of one segment: per run of edges with one source node ONE tile product h[32 x 16 NS] @ G[node][16 NS x 32], B = the node's G
+// tile (plane form, task.gh) straight from memory through a register ring of GR fragments; every row belongs to exactly one run, so the
+// products are SELECTED into tg[row] (rows_select_run).  Returns tg (0 in the lanes behind the tile's last column).
+// G of a source node and slot: the column parts of the slot's blocks one after the other, each a CONTIGUOUS tile [k8][wp columns][plane]
+// [8 halves] (wp = the part's width rounded up to 4), then Gb per padded column - a run reads one tile as one linear stream, and stage A
+// fills it in whole 128-byte lines.  Fragment q = 2 ks + plane of lane (r, hh): 16-byte unit 2 (k8 wp + column) + plane, k8 = min(2 ks +
+// hh, n8 - 1), addressed as (node base + uniform fragment offset) + a 32-bit per-lane offset (per-fragment 64-bit lane addresses cost ~40
+// registers).
+// MERGE (two vector blocks of the same width n <= 16 with one G part each, e.g. 1o and 1e at nv = 10): lanes [0, n) take block A's
+// columns, lanes [n, 2 n) block B's (another G array, the same node): ONE tile product per run for both - in block B's own tiles lane
+// n + j is feature group 1 of output column j, i.e. where its lane-group sum expects that column.
+struct RowsGPart {
+  const char* base;      // the part's tile inside node 0's row of its G array
+  size_t gldb;           // node stride in bytes
+  int wp, nmine, bias_off;   // padded width, columns, byte offset of Gb[column 0] from `base`
 };
-__device__ __forceinline__ RowsTouch rows_touch_tile(const char* __restrict__ tile, int tile_bytes, int lane) {
-  RowsTouch t;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) t.v[i] = *reinterpret_cast<const float*>(tile + min((i * 64 + lane) * 128, tile_bytes - 4));
-  return t;
+__device__ __forceinline__ RowsGPart rows_gpart_of(const ddp_conv_shape_t& S, const ddp_conv_task_t& T, int bi, int part) {
+  RowsGPart P;
+  int wp, cumw, gcp;
+  rows_gpart(S, bi, part, wp, cumw, gcp);
+  const int n8 = (S.hid + 7) >> 3;
+  P.base = reinterpret_cast<const char*>(T.gh[S.blk[bi].g_slot]) + (size_t)(2 * n8 * cumw) * 16;
+  P.gldb = (size_t)DDP_GH_LD(S.hid, gcp) * 4;
+  P.wp = wp;
+  P.nmine = min(32, S.blk[bi].n - 32 * part);
+  P.bias_off = (8 * n8 * gcp + cumw) * 4 - (2 * n8 * cumw) * 16;
+  return P;
 }
-__device__ __forceinline__ void rows_touch_done(const RowsTouch& t) {
-  asm volatile("" ::"v"(t.v[0]), "v"(t.v[1]), "v"(t.v[2]));
+template <int NS, int GR, bool MERGE>
+__device__ __forceinline__ f32x16 rows_g_runs(const ddp_conv_shape_t& S, const RowsGPart& PA, const RowsGPart& PB, const h8 (&ah)[NS], const h8 (&al)[NS],
+                                              const RowsAux* aux, unsigned rmask, int src_reg, int lane) {
+  constexpr int NF = 2 * NS;
+  static_assert(NF % GR == 0, "fragment f of every G tile lives in ring slot f % GR");
+  const int r = lane & 31, hh = lane >> 5;
+  const int n8 = (S.hid + 7) >> 3;
+  const int ncols = MERGE ? PA.nmine + PB.nmine : PA.nmine;
+  const bool inb = MERGE && r >= PA.nmine;                                          // this lane reads block B's array
+  const int cl = (r < ncols) ? (inb ? r - PA.nmine : r) : 0;
+  const int gc = PA.wp;                                                             // (MERGE: the same for both parts)
+  const unsigned lo_main = (unsigned)(2 * hh * gc + 2 * cl) * 16u;                  // + (4 ks wp + plane) * 16
+  const int k8l = min(2 * (NS - 1) + hh, n8 - 1);
+  const unsigned lo_last = (unsigned)(2 * k8l * gc + 2 * cl) * 16u;                 // + plane * 16
+  const unsigned lo_bias = (unsigned)((inb ? PB.bias_off : PA.bias_off) + 4 * cl);
+#ifdef DDP_ROWS_ABL_G0   // timing-only ablation: every run reads node 0's G (L2 hits): is the G phase bound by where G comes from?
+#define ROWS_NODE(a) 0
+#else
+#define ROWS_NODE(a) __builtin_amdgcn_readlane(src_reg, (a))
+#endif
+  // node base of this lane's array: wave-uniform without MERGE (SGPRs), a per-lane select of two uniform bases with it
+#define ROWS_GBASE(a) (inb ? PB.base + (size_t)ROWS_NODE(a) * PB.gldb : PA.base + (size_t)ROWS_NODE(a) * PA.gldb)
+#define ROWS_GFRAG(base, kq, plane) \
+  (*reinterpret_cast<const f32x4*>((base) + (((kq) == NS - 1) ? (size_t)(plane) * 16 : (size_t)(4 * (kq) * gc + (plane)) * 16) + (((kq) == NS - 1) ? lo_last : lo_main)))
+  unsigned m = rmask;
+  int a0 = __builtin_ctz(m);
+  const char* __restrict__ gp = ROWS_GBASE(a0);
+  float bias = *reinterpret_cast<const float*>(gp + lo_bias);
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 gr[GR];
+#pragma unroll
+  for (int k = 0; k < GR; ++k) gr[k] = ROWS_GFRAG(gp, k >> 1, k & 1);
+  __builtin_amdgcn_sched_barrier(0);
+  int run = 0;
+  const int* ridrow = &aux->rid[4 * hh];
+  f32x16 tg = splat16(0.f);
+  while (m != 0u) {
+    m &= m - 1u;
+    const int an = (m != 0u) ? __builtin_ctz(m) : a0;
+    const char* __restrict__ gpn = ROWS_GBASE(an);
+    const float bias_n = *reinterpret_cast<const float*>(gpn + lo_bias);
+    f32x16 am = splat16(bias), ac = splat16(0.f);
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+      const h8 bh = __builtin_bit_cast(h8, gr[(2 * ks) % GR]), bl = __builtin_bit_cast(h8, gr[(2 * ks + 1) % GR]);
+      {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int q0 = 2 * ks + GR;                      // the pair of fragments that takes the two slots this step frees
+        const int kq = (q0 < NF) ? (q0 >> 1) : ((q0 - NF) >> 1);
+        const char* __restrict__ srcb = (q0 < NF) ? gp : gpn;
+        gr[(2 * ks) % GR] = ROWS_GFRAG(srcb, kq, 0);
+        gr[(2 * ks + 1) % GR] = ROWS_GFRAG(srcb, kq, 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      am = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh, am, 0, 0, 0);
+      ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl, ac, 0, 0, 0);
+      ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh, ac, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // (lanes behind the tile's last G column hold a clamped column's product: they select nothing)
+    rows_select_run(am, ac, ridrow, (r < ncols) ? run : -2, tg);
+    gp = gpn;
+    bias = bias_n;
+    a0 = an;
+    ++run;
+  }
+#undef ROWS_GFRAG
+#undef ROWS_GBASE
+#undef ROWS_NODE
+  return tg;
 }
 
-// One segment = the 32-column part `part` of block B: G runs, stream tiles, store.  Returns the stream position behind it.
+// gmode: 0 = the segment runs its own G tiles; 1 = it runs the MERGED tiles of its block and the next one (tg_io <- the products);
+// 2 = its G products were computed by the segment before (tg_io, lanes [n, 2 n))
 template <int NS, int C>
 __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_block_t& B, int bi, int part, const ddp_conv_task_t& T, const h8 (&ah)[NS],
                                             const h8 (&al)[NS], f32x4* ring, const float* lbias, int t, const float* F,
                                             const RowsAux* aux, unsigned rmask, int src_reg, int nvw, int wave, int lane, int sgi,
-                                            const char* __restrict__ next_g, size_t next_ld, int next_bytes) {
-  // G fragments in flight per wave: a G tile comes from HBM (first touch; ~1 us per round trip under load) and a fragment is one 32-cycle
-  // MFMA triple per row tile - the ring is what the registers allow (scalar segments hold 16 result registers, vector segments 48)
+                                            int gmode, f32x16& tg_io) {
   constexpr int NF = 2 * NS, GRW = (C == 1) ? DDP_ROWS_GRING1 : DDP_ROWS_GRING3;
   constexpr int GR = (NF % GRW == 0) ? GRW : (NF % 6 == 0) ? 6 : (NF % 4 == 0) ? 4 : 2;
   (void)sgi;
-  static_assert(NF % GR == 0, "fragment f of every G tile lives in ring slot f % GR");
   const ddp_conv_shape_t& S = RL.L.shape;
   const int r = lane & 31, hh = lane >> 5;
   const f32x4* __restrict__ wsh = reinterpret_cast<const f32x4*>(T.wsh);
@@ -288,88 +371,26 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
 #pragma unroll
   for (int c = 0; c < C; ++c) res[c] = splat16(0.f);
 
-  // ---- factorised features: one tile product per run of edges with one source node, B = the node's G tile (plane form)
+  // ---- factorised features (G runs), multiplied by the harmonics once
   if (B.g_slot >= 0 && rmask != 0u) {
-    // G of a source node and slot (task.gh): the column parts of the slot's blocks one after the other, each a CONTIGUOUS tile
-    // [k8][wp columns][plane][8 halves] (wp = the part's width rounded up to 4), then Gb per padded column - a run reads one tile as one
-    // linear stream, and stage A fills it in whole 128-byte lines (hi and lo words of four neighbouring columns)
-    const int n8 = (S.hid + 7) >> 3;
-    const int nmine = min(32, B.n - 32 * part);                                   // G columns of this part
-    int wp, cumw, gcp;
-    rows_gpart(S, bi, part, wp, cumw, gcp);
-    const int cl = (r < nmine) ? r : 0;
-    const size_t gldb = (size_t)DDP_GH_LD(S.hid, gcp) * 4;                         // node stride in bytes
-    const char* __restrict__ Gc = reinterpret_cast<const char*>(T.gh[B.g_slot]) + (size_t)(2 * n8 * cumw) * 16;
-    // fragment q = 2 ks + plane of lane (r, hh): 16-byte unit 2 (k8 wp + column) + plane, k8 = min(2 ks + hh, n8 - 1).  Addressed as
-    // (wave-uniform node base + uniform fragment offset) + a 32-bit per-lane offset: the loads take their base from SGPRs - per-fragment
-    // 64-bit lane addresses cost ~40 registers here
-    const int gc = wp;
-    const unsigned lo_main = (unsigned)(2 * hh * gc + 2 * cl) * 16u;               // + (4 ks wp + plane) * 16
-    const int k8l = min(2 * (NS - 1) + hh, n8 - 1);
-    const unsigned lo_last = (unsigned)(2 * k8l * gc + 2 * cl) * 16u;              // + plane * 16
-    const unsigned lo_bias = (unsigned)(8 * n8 * gcp + cumw + cl) * 4u - (unsigned)(2 * n8 * cumw) * 16u;   // Gb[c] behind the slot's tiles
-    unsigned m = rmask;
-    int a0 = __builtin_ctz(m);
-#ifdef DDP_ROWS_ABL_G0   // timing-only ablation: every run reads node 0's G (L2 hits): is the G phase bound by where G comes from?
-#define ROWS_NODE(a) 0
-#else
-#define ROWS_NODE(a) __builtin_amdgcn_readlane(src_reg, (a))
-#endif
-    const char* __restrict__ gp = Gc + (size_t)ROWS_NODE(a0) * gldb;
-#define ROWS_GFRAG(base, kq, plane) \
-    (*reinterpret_cast<const f32x4*>((base) + (((kq) == NS - 1) ? (size_t)(plane) * 16 : (size_t)(4 * (kq) * gc + (plane)) * 16) + (((kq) == NS - 1) ? lo_last : lo_main)))
-    float bias = *reinterpret_cast<const float*>(gp + lo_bias);
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 gr[GR];
+    const float* shrow = &aux->shT[(C == 1) ? 0 : 1][4 * hh];
+    if (gmode == 2) {
+      f32x16 tsel;
 #pragma unroll
-    for (int k = 0; k < GR; ++k) gr[k] = ROWS_GFRAG(gp, k >> 1, k & 1);
-    __builtin_amdgcn_sched_barrier(0);
-    int run = 0;
-    const int* ridrow = &aux->rid[4 * hh];
-    f32x16 tg = splat16(0.f);
-    while (m != 0u) {
-      m &= m - 1u;
-      const int an = (m != 0u) ? __builtin_ctz(m) : a0;
-      const char* __restrict__ gpn = Gc + (size_t)ROWS_NODE(an) * gldb;
-      const float bias_n = *reinterpret_cast<const float*>(gpn + lo_bias);
-      // the tile after this one: of the next run, or - behind the last run - of the first run of the next segment with a G part
-#ifdef DDP_ROWS_TOUCH   // measured (round 5): G phases 174 k -> 288 k ticks per workgroup - the touches sit in the same in-order queue as the ring
-      const RowsTouch tch = (m != 0u) ? rows_touch_tile(gpn, 2 * n8 * wp * 16, lane)
-                                      : rows_touch_tile(next_g ? next_g + (size_t)__builtin_amdgcn_readlane(src_reg, __builtin_ctz(rmask)) * next_ld : gp,
-                                                        next_g ? next_bytes : 2 * n8 * wp * 16, lane);
-#endif
-      f32x16 am = splat16(bias), ac = splat16(0.f);
+      for (int i = 0; i < 16; ++i) tsel[i] = (r >= B.n && r < 2 * B.n) ? tg_io[i] : 0.f;
+      rows_apply_harmonics<C>(tsel, shrow, res);
+    } else if (gmode == 1) {
+      const RowsGPart PA = rows_gpart_of(S, T, bi, part), PB = rows_gpart_of(S, T, bi + 1, 0);
+      tg_io = rows_g_runs<NS, GR, true>(S, PA, PB, ah, al, aux, rmask, src_reg, lane);
+      f32x16 tsel;
 #pragma unroll
-      for (int ks = 0; ks < NS; ++ks) {
-        const h8 bh = __builtin_bit_cast(h8, gr[(2 * ks) % GR]), bl = __builtin_bit_cast(h8, gr[(2 * ks + 1) % GR]);
-        {
-          constexpr int dummy = 0;
-          (void)dummy;
-          const int q0 = 2 * ks + GR;                      // the pair of fragments that takes the two slots this step frees
-          const int kq = (q0 < NF) ? (q0 >> 1) : ((q0 - NF) >> 1);
-          const char* __restrict__ srcb = (q0 < NF) ? gp : gpn;
-          gr[(2 * ks) % GR] = ROWS_GFRAG(srcb, kq, 0);
-          gr[(2 * ks + 1) % GR] = ROWS_GFRAG(srcb, kq, 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        am = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh, am, 0, 0, 0);
-        ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl, ac, 0, 0, 0);
-        ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh, ac, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // (lanes behind the part's last G column hold a clamped column's product: they add nothing - with several features per tile
-      // their registers are summed into the first lane group at the end)
-      rows_select_run(am, ac, ridrow, (r < nmine) ? run : -2, tg);
-#ifdef DDP_ROWS_TOUCH
-      rows_touch_done(tch);
-#endif
-      gp = gpn;
-      bias = bias_n;
-      a0 = an;
-      ++run;
+      for (int i = 0; i < 16; ++i) tsel[i] = (r < B.n) ? tg_io[i] : 0.f;
+      rows_apply_harmonics<C>(tsel, shrow, res);
+    } else {
+      const RowsGPart PA = rows_gpart_of(S, T, bi, part);
+      const f32x16 tg = rows_g_runs<NS, GR, false>(S, PA, PA, ah, al, aux, rmask, src_reg, lane);
+      rows_apply_harmonics<C>(tg, shrow, res);
     }
-#undef ROWS_GFRAG
-    rows_apply_harmonics<C>(tg, &aux->shT[(C == 1) ? 0 : 1][4 * hh], res);
   }
 
   RSTAMP(5 + 3 * sgi);
@@ -399,7 +420,7 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
 
   RSTAMP(6 + 3 * sgi);
   // ---- several features per tile (n <= 16): the lane groups us = 1, 2, .. are added to group 0 in order
-  if (B.nsub == 1 && B.ups > 1 && cnt > 0) {
+  if (B.nsub == 1 && B.ups > 1 && (cnt > 0 || gmode == 2)) {     // (gmode 2: the G products sit in lane group 1)
     for (int s = 1; s < B.ups; ++s) {
       const int from = (hh << 5) + min(r + s * B.n, 31);
 #pragma unroll
@@ -600,6 +621,7 @@ __global__ __launch_bounds__(ROWS_NT, 2) void ddp_conv_rows_kernel(const RowsLau
   RSTAMP_VAL(31, p0 / ROWS_ET);
   // ---- the segments: blocks in order, the 32-column parts of a block in order
   int sgi = 0;
+  f32x16 tg_pair = splat16(0.f);     // the G products a merged pair of vector blocks shares
   for (int bi = 0; bi < S.nblocks; ++bi) {
     const ddp_block_t& B = S.blk[bi];
     if (B.ntiles > 0 && B.U > 0) {
@@ -613,29 +635,20 @@ __global__ __launch_bounds__(ROWS_NT, 2) void ddp_conv_rows_kernel(const RowsLau
     }
     const int nparts = (B.n + 31) >> 5;
     for (int part = 0; part < nparts; ++part, ++sgi) {
-      // the next segment with a G part (its first run's tile is touched behind this segment's last run)
-      const char* next_g = nullptr;
-      size_t next_ld = 0;
-      int next_bytes = 0;
-      {
-        int nb = bi, np = part + 1;
-        for (int guard = 0; guard < 2 * DDP_MAX_BLOCKS && nb < S.nblocks; ++guard) {
-          if (np >= ((S.blk[nb].n + 31) >> 5)) { ++nb; np = 0; continue; }
-          int wp, cumw, gcp;
-          if (rows_gpart(S, nb, np, wp, cumw, gcp)) {
-            const int n8 = (S.hid + 7) >> 3;
-            next_g = reinterpret_cast<const char*>(T.gh[S.blk[nb].g_slot]) + (size_t)(2 * n8 * cumw) * 16;
-            next_ld = (size_t)DDP_GH_LD(S.hid, gcp) * 4;
-            next_bytes = 2 * n8 * wp * 16;
-            break;
-          }
-          ++np;
-        }
+      // two neighbouring vector blocks of one width with a single G part each (1o, 1e): one merged G tile product per run (rows_g_runs)
+      int gmode = 0;
+      if (B.C == 3 && B.g_slot >= 0 && nparts == 1 && 2 * B.n <= 32) {
+        const bool with_next = bi + 1 < S.nblocks && S.blk[bi + 1].C == 3 && S.blk[bi + 1].g_slot >= 0 && S.blk[bi + 1].n == B.n;
+        const bool with_prev = bi > 0 && S.blk[bi - 1].C == 3 && S.blk[bi - 1].g_slot >= 0 && S.blk[bi - 1].n == B.n;
+        // (pairs are (1, 2): a block that is the second of a pair is never the first of another)
+        const bool prev_is_second = with_prev && bi > 1 && S.blk[bi - 2].C == 3 && S.blk[bi - 2].g_slot >= 0 && S.blk[bi - 2].n == B.n;
+        if (with_prev && !prev_is_second) gmode = 2;
+        else if (with_next) gmode = 1;
       }
       if (B.C == 1)
-        t = rows_segment<NS, 1>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane, sgi, next_g, next_ld, next_bytes);
+        t = rows_segment<NS, 1>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane, sgi, 0, tg_pair);
       else
-        t = rows_segment<NS, 3>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane, sgi, next_g, next_ld, next_bytes);
+        t = rows_segment<NS, 3>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane, sgi, gmode, tg_pair);
     }
   }
 }
