@@ -342,13 +342,13 @@ __device__ __forceinline__ f32x16 rows_g_runs(const ddp_conv_shape_t& S, const R
   return tg;
 }
 
-// gmode: 0 = the segment runs its own G tiles; 1 = it runs the MERGED tiles of its block and the next one (tg_io <- the products);
-// 2 = its G products were computed by the segment before (tg_io, lanes [n, 2 n))
+// gmode: 0 = the segment runs its own G tiles; 1 = it runs the MERGED tiles of its block and the next one (block B's products are
+// parked behind the wave's per-edge tables); 2 = its G products were computed by the segment before (lanes [n, 2 n))
 template <int NS, int C>
 __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_block_t& B, int bi, int part, const ddp_conv_task_t& T, const h8 (&ah)[NS],
                                             const h8 (&al)[NS], f32x4* ring, const float* lbias, int t, const float* F,
                                             const RowsAux* aux, unsigned rmask, int src_reg, int nvw, int wave, int lane, int sgi,
-                                            int gmode, f32x16& tg_io) {
+                                            int gmode) {
   constexpr int NF = 2 * NS, GRW = (C == 1) ? DDP_ROWS_GRING1 : DDP_ROWS_GRING3;
   constexpr int GR = (NF % GRW == 0) ? GRW : (NF % 6 == 0) ? 6 : (NF % 4 == 0) ? 4 : 2;
   (void)sgi;
@@ -374,17 +374,28 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
   // ---- factorised features (G runs), multiplied by the harmonics once
   if (B.g_slot >= 0 && rmask != 0u) {
     const float* shrow = &aux->shT[(C == 1) ? 0 : 1][4 * hh];
+    // (the pair's products of block B wait in the wave's private LDS area, not in 16 registers across block A's stream tiles)
+    f32x4* pair = reinterpret_cast<f32x4*>(const_cast<RowsAux*>(aux) + 1) + (hh * 16 + min(max(r - B.n, 0), 15)) * 4;
+    const bool in_b = r >= B.n && r < 2 * B.n;
     if (gmode == 2) {
       f32x16 tsel;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) tsel[i] = (r >= B.n && r < 2 * B.n) ? tg_io[i] : 0.f;
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 v = pair[q4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tsel[4 * q4 + q] = in_b ? v[q] : 0.f;
+      }
       rows_apply_harmonics<C>(tsel, shrow, res);
     } else if (gmode == 1) {
       const RowsGPart PA = rows_gpart_of(S, T, bi, part), PB = rows_gpart_of(S, T, bi + 1, 0);
-      tg_io = rows_g_runs<NS, GR, true>(S, PA, PB, ah, al, aux, rmask, src_reg, lane);
+      const f32x16 tg = rows_g_runs<NS, GR, true>(S, PA, PB, ah, al, aux, rmask, src_reg, lane);
+      if (in_b) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) pair[q4] = f32x4{tg[4 * q4], tg[4 * q4 + 1], tg[4 * q4 + 2], tg[4 * q4 + 3]};
+      }
       f32x16 tsel;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) tsel[i] = (r < B.n) ? tg_io[i] : 0.f;
+      for (int i = 0; i < 16; ++i) tsel[i] = (r < B.n) ? tg[i] : 0.f;
       rows_apply_harmonics<C>(tsel, shrow, res);
     } else {
       const RowsGPart PA = rows_gpart_of(S, T, bi, part);
@@ -621,7 +632,6 @@ __global__ __launch_bounds__(ROWS_NT, 2) void ddp_conv_rows_kernel(const RowsLau
   RSTAMP_VAL(31, p0 / ROWS_ET);
   // ---- the segments: blocks in order, the 32-column parts of a block in order
   int sgi = 0;
-  f32x16 tg_pair = splat16(0.f);     // the G products a merged pair of vector blocks shares
   for (int bi = 0; bi < S.nblocks; ++bi) {
     const ddp_block_t& B = S.blk[bi];
     if (B.ntiles > 0 && B.U > 0) {
@@ -646,9 +656,9 @@ __global__ __launch_bounds__(ROWS_NT, 2) void ddp_conv_rows_kernel(const RowsLau
         else if (with_next) gmode = 1;
       }
       if (B.C == 1)
-        t = rows_segment<NS, 1>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane, sgi, 0, tg_pair);
+        t = rows_segment<NS, 1>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane, sgi, 0);
       else
-        t = rows_segment<NS, 3>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane, sgi, gmode, tg_pair);
+        t = rows_segment<NS, 3>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane, sgi, gmode);
     }
   }
 }
@@ -711,7 +721,7 @@ extern "C" int ddp_conv_rows(const ddp_conv_shape_t* shape, const ddp_conv_task_
   int fbytes = frows * ROWS_FS * 4;
   fbytes = (fbytes + 127) / 128 * 128;
   RL.aux_off = fbytes;
-  int priv = fbytes + (int)sizeof(RowsAux);
+  int priv = fbytes + (int)sizeof(RowsAux) + 2048;      // (+ the parked G products of a merged pair of vector blocks)
   if (priv < NS * 1024) priv = NS * 1024;          // the lo plane of edge_attr_ during fc1
   priv = (priv + 127) / 128 * 128;
   RL.priv_bytes = priv;

@@ -504,7 +504,7 @@ def rows_supported(spec: "ConvSpec") -> bool:
     if not spec.factorized or ns16 not in (12, 6):
         return False
     frows = max([b.U * b.C for b in spec.blocks if b.U > 0] + [0])
-    priv = max((frows * 36 * 4 + 127) // 128 * 128 + 1408, ns16 * 1024)
+    priv = max((frows * 36 * 4 + 127) // 128 * 128 + 1408 + 2048, ns16 * 1024)
     nts = spec.nct1 + sum(len(t) for _, _, t in rows_segments(spec))
     # two 4-wave workgroups per CU: ring of one tile's pieces + bias table + four private areas each
     return 2 * (2 * ns16 * 1024 + (nts * 128 + 127) // 128 * 128 + 4 * ((priv + 127) // 128 * 128)) <= 160 * 1024
