@@ -46,6 +46,25 @@
 #define DDP_ROWS_GRING3 8
 #endif
 
+// Operand planes of this kernel ("unified" fp16 hi/lo planes, include/ddp_hip.h DDP_ROWS_S*): V = v * 2^s = hi + lo with hi = fp16(V),
+// lo = fp16(V - hi) at the SAME scale, so that the three split products hh wh + hh wl + hl wh land in ONE accumulator (the common form
+// v = hi + lo / 2048 of ddp_conv_common.h needs two and a multiply-add per element to join them: 32 registers of every tile product
+// here).  22 significant bits while lo is a normal fp16 number (|V| >= 0.125), an absolute 2^-25 / 2^s below; |V| <= 65504 or the
+// range flag is raised.  The accumulators carry 2^(sa + sb); the feature rows / harmonics they are multiplied with carry the inverse.
+#define ROWS_SX ((float)DDP_ROWS_SX)
+#define ROWS_SW ((float)DDP_ROWS_SW)
+#define ROWS_SH ((float)DDP_ROWS_SH)
+#define ROWS_SG ((float)DDP_ROWS_SG)
+__device__ __forceinline__ void rows_split(const f32x4 v, float scale, h4& hi, h4& lo, int32_t* flag) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float V = v[i] * scale;
+    h2_range_check(V, flag);
+    hi[i] = (_Float16)V;
+    lo[i] = (_Float16)(V - (float)hi[i]);
+  }
+}
+
 // Diagnostic build only (-DDDP_ROWS_STAMPS, tools/stamp_rows.py): lane 0 of every wave records s_memtime at the phase boundaries
 #ifdef DDP_ROWS_STAMPS
 #define RS_SLOTS 32
@@ -87,32 +106,30 @@ struct RowsAux {
   int src[32], pos[32], rid[32];
 };
 
-// out[c][i] += F[(u * C + c)][row_i] * (am[i] + ac[i] / 2048), rows in the MFMA C/D layout: reg i <-> row (i & 3) + 8 (i >> 2) + 4 hh
+// out[c][i] += F[(u * C + c)][row_i] * acc[i], rows in the MFMA C/D layout: reg i <-> row (i & 3) + 8 (i >> 2) + 4 hh
+// (acc carries the operands' plane scales; the feature rows carry their inverse)
 template <int C>
-__device__ __forceinline__ void rows_epilogue(const f32x16& am, const f32x16& ac, const float* frow, int cstride, f32x16* out) {
+__device__ __forceinline__ void rows_epilogue(const f32x16& acc, const float* frow, int cstride, f32x16* out) {
 #pragma unroll
   for (int q4 = 0; q4 < 4; ++q4) {
-    float tq[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) tq[q] = am[4 * q4 + q] + ac[4 * q4 + q] * DDP_H2_INV;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const f32x4 f = *reinterpret_cast<const f32x4*>(frow + c * cstride + 8 * q4);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) out[c][4 * q4 + q] += f[q] * tq[q];
+      for (int q = 0; q < 4; ++q) out[c][4 * q4 + q] += f[q] * acc[4 * q4 + q];
     }
   }
 }
 
 // G tiles: every row of the wave's tile belongs to exactly ONE run, so the runs' tile products are only SELECTED into tg[row] = the
 // product of the row's own run (16 registers whatever C) and multiplied by the harmonics once, behind the last run
-__device__ __forceinline__ void rows_select_run(const f32x16& am, const f32x16& ac, const int* rid, int run, f32x16& tg) {
+__device__ __forceinline__ void rows_select_run(const f32x16& acc, const int* rid, int run, f32x16& tg) {
   typedef int i32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int q4 = 0; q4 < 4; ++q4) {
     const i32x4 id = *reinterpret_cast<const i32x4*>(rid + 8 * q4);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) tg[4 * q4 + q] = (id[q] == run) ? am[4 * q4 + q] + ac[4 * q4 + q] * DDP_H2_INV : tg[4 * q4 + q];
+    for (int q = 0; q < 4; ++q) tg[4 * q4 + q] = (id[q] == run) ? acc[4 * q4 + q] : tg[4 * q4 + q];
   }
 }
 template <int C>
@@ -145,16 +162,23 @@ __device__ __forceinline__ void rows_request_piece(f32x4* ring, const f32x4* __r
   for (int f = 0; f < FPW; ++f)
     __builtin_amdgcn_global_load_lds((glb_ptr_t)(wn + (wave + ROWS_NW * f) * 64 + lane), (lds_ptr_t)(nslot + (wave + ROWS_NW * f) * 64), 16, 0, 0);
 }
-template <int NS, int P>
+// GL = vector-memory operations a wave issues BETWEEN two piece requests besides them (the interleaved G steps of rows_segment: 4 fragment
+// loads per stream step); the literal must not exceed the operations younger than piece j's copies on ANY path that reaches the wait:
+// a smaller one only waits longer, a larger one lets the barrier pass with the copy in flight.
+template <int NS, int P, int GL = 0>
 __device__ __forceinline__ void rows_stream_step(f32x4* ring, const f32x4* __restrict__ wsh, int t, int nts, int wave, int lane) {
   constexpr int FPW = 2 * NS / ROWS_NP / ROWS_NW;
   // (hipcc does NOT wait for an LDS-DMA in front of a barrier: without this a wave can pass while its part of the piece is in flight.
   // vmcnt counts in order: "at most FPW outstanding" = everything older than the copies of piece j + 1 has landed)
-  static_assert(FPW == 2 || FPW == 1, "the literals below");
-  if constexpr (FPW == 2)
+  static_assert((FPW == 2 || FPW == 1) && (GL == 0 || GL == 4), "the literals below");
+  if constexpr (FPW + 2 * GL == 2)
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else
+  else if constexpr (FPW + 2 * GL == 1)
     asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (FPW + 2 * GL == 10)
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
 #ifndef DDP_ROWS_ABL_NOBAR   // (timing-only ablation: no barrier - what do the four waves wait for each other?)
   __syncthreads();
 #endif
@@ -163,7 +187,7 @@ __device__ __forceinline__ void rows_stream_step(f32x4* ring, const f32x4* __res
 
 // acc += A(regs, k-steps KS0 ..) x B(piece in LDS): 3 split products per 16 k, B fragments read one k-step ahead
 template <int NS, int KS0>
-__device__ __forceinline__ void rows_piece_lds(const f32x4* slot, const h8 (&ah)[NS], const h8 (&al)[NS], int lane, f32x16& am, f32x16& ac) {
+__device__ __forceinline__ void rows_piece_lds(const f32x4* slot, const h8 (&ah)[NS], const h8 (&al)[NS], int lane, f32x16& acc) {
   constexpr int NK = NS / ROWS_NP;
   f32x4 b0 = slot[lane], b1 = slot[64 + lane];
 #pragma unroll
@@ -173,9 +197,9 @@ __device__ __forceinline__ void rows_piece_lds(const f32x4* slot, const h8 (&ah)
       b0 = slot[(2 * k + 2) * 64 + lane];
       b1 = slot[(2 * k + 3) * 64 + lane];
     }
-    am = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS0 + k], bh, am, 0, 0, 0);
-    ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS0 + k], bl, ac, 0, 0, 0);
-    ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[KS0 + k], bh, ac, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS0 + k], bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS0 + k], bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[KS0 + k], bh, acc, 0, 0, 0);
   }
 }
 
@@ -187,6 +211,7 @@ __device__ __forceinline__ void rows_build_features(const ddp_block_t& B, const 
   constexpr int FS = ROWS_FS;
   const int e = lane & 31, half = lane >> 5;
   const float* __restrict__ xrow = T.x_src + (size_t)aux->src[e] * T.ldx_src;
+  // (aux->sh carries 1 / (DDP_ROWS_SH DDP_ROWS_SW): the stream tiles' accumulators carry the planes' scales)
   const float s0 = aux->sh[e][0], sx = aux->sh[e][1], sy = aux->sh[e][2], sz = aux->sh[e][3];
   const float inv_sqrt3 = 0.57735026918962576f, inv_sqrt2 = 0.70710678118654752f;
   int ubase = 0;
@@ -310,7 +335,7 @@ __device__ __forceinline__ f32x16 rows_g_runs(const ddp_conv_shape_t& S, const R
     const int an = (m != 0u) ? __builtin_ctz(m) : a0;
     const char* __restrict__ gpn = ROWS_GBASE(an);
     const float bias_n = *reinterpret_cast<const float*>(gpn + lo_bias);
-    f32x16 am = splat16(bias), ac = splat16(0.f);
+    f32x16 acc = splat16(bias);
 #pragma unroll
     for (int ks = 0; ks < NS; ++ks) {
       const h8 bh = __builtin_bit_cast(h8, gr[(2 * ks) % GR]), bl = __builtin_bit_cast(h8, gr[(2 * ks + 1) % GR]);
@@ -324,13 +349,13 @@ __device__ __forceinline__ f32x16 rows_g_runs(const ddp_conv_shape_t& S, const R
         gr[(2 * ks + 1) % GR] = ROWS_GFRAG(srcb, kq, 1);
       }
       __builtin_amdgcn_sched_barrier(0);
-      am = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh, am, 0, 0, 0);
-      ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl, ac, 0, 0, 0);
-      ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh, ac, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh, acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     // (lanes behind the tile's last G column hold a clamped column's product: they select nothing)
-    rows_select_run(am, ac, ridrow, (r < ncols) ? run : -2, tg);
+    rows_select_run(acc, ridrow, (r < ncols) ? run : -2, tg);
     gp = gpn;
     bias = bias_n;
     a0 = an;
@@ -340,6 +365,130 @@ __device__ __forceinline__ f32x16 rows_g_runs(const ddp_conv_shape_t& S, const R
 #undef ROWS_GBASE
 #undef ROWS_NODE
   return tg;
+}
+
+// The G runs of a SCALAR segment as a resumable sequence of k-steps (round 5, second half): the runs' tile products are issued BETWEEN
+// the k-steps of the segment's stream tiles (rows_segment), so that the fragment loads of a run - 8 KiB in flight per wave against ~1 us of
+// loaded HBM latency: ~6 k ticks per tile product on their own - travel behind the stream tiles' MFMAs.  Same ring, same fragment order and
+// the same select as rows_g_runs; a run's product is added to the segment's accumulator when its last k-step is done (run by run, between
+// the stream tiles' contributions: the order is fixed by the segment's tile count alone, bitwise reproducible).
+// The interleaved tiles run while a run is left (no branch inside them: a branch around an MFMA chain made hipcc keep two copies of the
+// accumulators - 73 spilled registers); the last run's steps fetch the first run's fragments again instead of a next run's (nothing
+// reads them): every step issues its two loads, which is what rows_stream_step's wait literal counts on.
+struct RowsGSeq {        // (scalars only: the ring and the accumulators are separate locals, so that everything stays in registers)
+  const char* gp;        // node base of the current run's tile (wave-uniform)
+  const char* gpn;       // ... of the next run's
+  const char* gfirst;
+  const char* base;
+  size_t gldb;
+  float bias, bias_n;
+  unsigned m;            // runs not yet started (bit = first row)
+  int run, nruns;
+  unsigned lo_main, lo_last, lo_bias;
+  int gc;
+};
+#define ROWS_GSEQ_FRAG(G, basep, kq, plane) \
+  (*reinterpret_cast<const f32x4*>((basep) + (((kq) == NS - 1) ? (size_t)(plane) * 16 : (size_t)(4 * (kq) * (G).gc + (plane)) * 16) + (((kq) == NS - 1) ? (G).lo_last : (G).lo_main)))
+__device__ __forceinline__ void rows_gseq_next(RowsGSeq& G, int src_reg, f32x16& gacc) {
+  G.m &= G.m - 1u;
+  G.gpn = (G.m != 0u) ? G.base + (size_t)__builtin_amdgcn_readlane(src_reg, __builtin_ctz(G.m)) * G.gldb : G.gfirst;
+  G.bias_n = *reinterpret_cast<const float*>(G.gpn + G.lo_bias);
+  gacc = splat16(G.bias);
+}
+template <int NS, int GR>
+__device__ __forceinline__ void rows_gseq_init(RowsGSeq& G, f32x4 (&gr)[GR], f32x16& gacc, const ddp_conv_shape_t& S, const RowsGPart& PA,
+                                               unsigned rmask, int src_reg, int lane) {
+  const int r = lane & 31, hh = lane >> 5;
+  const int n8 = (S.hid + 7) >> 3;
+  const int cl = (r < PA.nmine) ? r : 0;
+  G.gc = PA.wp;
+  G.lo_main = (unsigned)(2 * hh * G.gc + 2 * cl) * 16u;
+  const int k8l = min(2 * (NS - 1) + hh, n8 - 1);
+  G.lo_last = (unsigned)(2 * k8l * G.gc + 2 * cl) * 16u;
+  G.lo_bias = (unsigned)(PA.bias_off + 4 * cl);
+  G.base = PA.base;
+  G.gldb = PA.gldb;
+  G.m = rmask;
+  G.nruns = __builtin_amdgcn_readfirstlane(__popc(rmask));
+  G.run = 0;
+  G.gp = G.gfirst = PA.base + (size_t)__builtin_amdgcn_readlane(src_reg, __builtin_ctz(rmask)) * PA.gldb;
+  G.bias = *reinterpret_cast<const float*>(G.gp + G.lo_bias);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < GR; ++k) gr[k] = ROWS_GSEQ_FRAG(G, G.gp, k >> 1, k & 1);
+  __builtin_amdgcn_sched_barrier(0);
+  rows_gseq_next(G, src_reg, gacc);
+}
+// k-step KS of the current run: three split products from ring slots (2 KS, 2 KS + 1) % GR, which then take the fragments GR / 2 k-steps on
+template <int NS, int GR, int KS>
+__device__ __forceinline__ void rows_gseq_step(RowsGSeq& G, f32x4 (&gr)[GR], f32x16& gacc, const h8 (&ah)[NS], const h8 (&al)[NS]) {
+  constexpr int NF = 2 * NS, q0 = 2 * KS + GR, kq = (q0 < NF) ? (q0 >> 1) : ((q0 - NF) >> 1);
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    const h8 bh = __builtin_bit_cast(h8, gr[(2 * KS) % GR]), bl = __builtin_bit_cast(h8, gr[(2 * KS + 1) % GR]);
+    gacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS], bh, gacc, 0, 0, 0);
+    gacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS], bl, gacc, 0, 0, 0);
+    gacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[KS], bh, gacc, 0, 0, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const char* __restrict__ srcb = (q0 < NF) ? G.gp : G.gpn;
+  gr[(2 * KS) % GR] = ROWS_GSEQ_FRAG(G, srcb, kq, 0);
+  gr[(2 * KS + 1) % GR] = ROWS_GSEQ_FRAG(G, srcb, kq, 1);
+  __builtin_amdgcn_sched_barrier(0);
+}
+// the run's last k-step is done: res[row] += sh0[row] * product for the rows of THIS run (lanes behind the tile's last column: nothing)
+__device__ __forceinline__ void rows_gseq_finish(RowsGSeq& G, f32x16& gacc, const int* ridrow, const float* shrow, bool mine, int src_reg,
+                                                 f32x16& res) {
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  {
+    const int sel = mine ? G.run : -2;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const i32x4 id = *reinterpret_cast<const i32x4*>(ridrow + 8 * q4);
+      const f32x4 f = *reinterpret_cast<const f32x4*>(shrow + 8 * q4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) res[4 * q4 + q] = (id[q] == sel) ? res[4 * q4 + q] + f[q] * gacc[4 * q4 + q] : res[4 * q4 + q];
+    }
+  }
+  G.gp = G.gpn;
+  G.bias = G.bias_n;
+  ++G.run;
+  rows_gseq_next(G, src_reg, gacc);
+}
+
+// one piece of a stream tile with the G k-steps GK0, GK0 + 1 between its own: the first in front of the piece's first product (its
+// operands are in registers: it runs while the piece's first LDS reads are on their way), the second half-way
+template <int NS, int GR, int KS0, int GK0>
+__device__ __forceinline__ void rows_piece_lds_g(const f32x4* slot, const h8 (&ah)[NS], const h8 (&al)[NS], int lane, f32x16& acc, RowsGSeq& G,
+                                                 f32x4 (&gr)[GR], f32x16& gacc) {
+  constexpr int NK = NS / ROWS_NP;
+  f32x4 b0 = slot[lane], b1 = slot[64 + lane];
+  rows_gseq_step<NS, GR, GK0>(G, gr, gacc, ah, al);
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const h8 bh = __builtin_bit_cast(h8, b0), bl = __builtin_bit_cast(h8, b1);
+    if (k + 1 < NK) {
+      b0 = slot[(2 * k + 2) * 64 + lane];
+      b1 = slot[(2 * k + 3) * 64 + lane];
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS0 + k], bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS0 + k], bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[KS0 + k], bh, acc, 0, 0, 0);
+    if (k == (NK - 1) / 2) rows_gseq_step<NS, GR, GK0 + 1>(G, gr, gacc, ah, al);
+  }
+}
+// TPR stream tiles (tile TT of them) with one G run between their k-steps: 2 G k-steps per piece, NS = 2 ROWS_NP TPR
+template <int NS, int GR, int TT>
+__device__ __forceinline__ void rows_tile_g(f32x4* ring, const f32x4* __restrict__ wsh, const float* lbias, int t, int nts, const h8 (&ah)[NS],
+                                            const h8 (&al)[NS], int wave, int lane, f32x16& acc, RowsGSeq& G, f32x4 (&gr)[GR], f32x16& gacc) {
+  constexpr int KPP = NS / ROWS_NP, PIECE_Q = 2 * KPP * 64, G0 = 2 * ROWS_NP * TT;
+  rows_stream_step<NS, 0, 4>(ring, wsh, t, nts, wave, lane);
+  acc = splat16(lbias[t * 32 + (lane & 31)]);
+  rows_piece_lds_g<NS, GR, 0, G0>(ring, ah, al, lane, acc, G, gr, gacc);
+  rows_stream_step<NS, 1, 4>(ring, wsh, t, nts, wave, lane);
+  rows_piece_lds_g<NS, GR, KPP, G0 + 2>(ring + PIECE_Q, ah, al, lane, acc, G, gr, gacc);
+  rows_stream_step<NS, 2, 4>(ring, wsh, t, nts, wave, lane);
+  rows_piece_lds_g<NS, GR, 2 * KPP, G0 + 4>(ring + 2 * PIECE_Q, ah, al, lane, acc, G, gr, gacc);
 }
 
 // gmode: 0 = the segment runs its own G tiles; 1 = it runs the MERGED tiles of its block and the next one (block B's products are
@@ -371,8 +520,75 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
 #pragma unroll
   for (int c = 0; c < C; ++c) res[c] = splat16(0.f);
 
+  // ---- scalar segment with factorised features: the G runs travel between the k-steps of the stream tiles (RowsGSeq)
+  bool interleaved = false;
+  if constexpr (C == 1) {
+    if (B.g_slot >= 0 && rmask != 0u && B.ntiles > 0 && B.U > 0) {
+      constexpr int TPR = NS / (2 * ROWS_NP);     // stream tiles per G run: 2 G k-steps per piece
+      static_assert(NS == 2 * ROWS_NP * TPR && (TPR == 1 || TPR == 2), "2 G k-steps per piece of the stream");
+      const int cnt1 = B.nsub > 1 ? B.U : (B.U + B.ups - 1) / B.ups;
+      const RowsGPart PA = rows_gpart_of(S, T, bi, part);
+      RowsGSeq G;
+      f32x4 gr[GR];
+      f32x16 gacc;
+      rows_gseq_init<NS, GR>(G, gr, gacc, S, PA, rmask, src_reg, lane);
+      const int* ridrow = &aux->rid[4 * hh];
+      const float* shrow = &aux->shT[0][4 * hh];
+      const bool mine = r < PA.nmine;
+      RSTAMP(5 + 3 * sgi);
+      int j = 0;
+      for (; j + TPR <= cnt1 && G.run < G.nruns; j += TPR) {
+#pragma unroll
+        for (int tt = 0; tt < TPR; ++tt, ++t) {
+          f32x16 acc;
+          if (tt == 0) rows_tile_g<NS, GR, 0>(ring, wsh, lbias, t, RL.nts, ah, al, wave, lane, acc, G, gr, gacc);
+          else rows_tile_g<NS, GR, TPR - 1>(ring, wsh, lbias, t, RL.nts, ah, al, wave, lane, acc, G, gr, gacc);
+          int u = (B.nsub > 1) ? j + tt : (j + tt) * B.ups + us;
+          if (!(valid && u < B.U)) u = 0;
+          rows_epilogue<1>(acc, F + u * ROWS_FS + 4 * hh, ROWS_FS, res);
+        }
+        rows_gseq_finish(G, gacc, ridrow, shrow, mine, src_reg, res[0]);
+      }
+      // the runs the tiles did not cover, on their own (the same steps back to back), then the tiles left over
+      while (G.run < G.nruns) {
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) {
+          // (static k-steps: the switch is resolved at compile time)
+          if (ks == 0) rows_gseq_step<NS, GR, 0>(G, gr, gacc, ah, al);
+          else if (ks == 1) rows_gseq_step<NS, GR, 1 % NS>(G, gr, gacc, ah, al);
+          else if (ks == 2) rows_gseq_step<NS, GR, 2 % NS>(G, gr, gacc, ah, al);
+          else if (ks == 3) rows_gseq_step<NS, GR, 3 % NS>(G, gr, gacc, ah, al);
+          else if (ks == 4) rows_gseq_step<NS, GR, 4 % NS>(G, gr, gacc, ah, al);
+          else if (ks == 5) rows_gseq_step<NS, GR, 5 % NS>(G, gr, gacc, ah, al);
+          else if (ks == 6) rows_gseq_step<NS, GR, 6 % NS>(G, gr, gacc, ah, al);
+          else if (ks == 7) rows_gseq_step<NS, GR, 7 % NS>(G, gr, gacc, ah, al);
+          else if (ks == 8) rows_gseq_step<NS, GR, 8 % NS>(G, gr, gacc, ah, al);
+          else if (ks == 9) rows_gseq_step<NS, GR, 9 % NS>(G, gr, gacc, ah, al);
+          else if (ks == 10) rows_gseq_step<NS, GR, 10 % NS>(G, gr, gacc, ah, al);
+          else rows_gseq_step<NS, GR, 11 % NS>(G, gr, gacc, ah, al);
+        }
+        rows_gseq_finish(G, gacc, ridrow, shrow, mine, src_reg, res[0]);
+      }
+      for (; j < cnt1; ++j, ++t) {
+        constexpr int KPP = NS / ROWS_NP, PIECE_Q = 2 * KPP * 64;
+        f32x16 acc;
+        rows_stream_step<NS, 0>(ring, wsh, t, RL.nts, wave, lane);
+        acc = splat16(lbias[t * 32 + r]);
+        rows_piece_lds<NS, 0>(ring, ah, al, lane, acc);
+        rows_stream_step<NS, 1>(ring, wsh, t, RL.nts, wave, lane);
+        rows_piece_lds<NS, KPP>(ring + PIECE_Q, ah, al, lane, acc);
+        rows_stream_step<NS, 2>(ring, wsh, t, RL.nts, wave, lane);
+        rows_piece_lds<NS, 2 * KPP>(ring + 2 * PIECE_Q, ah, al, lane, acc);
+        int u = (B.nsub > 1) ? j : j * B.ups + us;
+        if (!(valid && u < B.U)) u = 0;
+        rows_epilogue<1>(acc, F + u * ROWS_FS + 4 * hh, ROWS_FS, res);
+      }
+      interleaved = true;
+    }
+  }
+
   // ---- factorised features (G runs), multiplied by the harmonics once
-  if (B.g_slot >= 0 && rmask != 0u) {
+  if (!interleaved && B.g_slot >= 0 && rmask != 0u) {
     const float* shrow = &aux->shT[(C == 1) ? 0 : 1][4 * hh];
     // (the pair's products of block B wait in the wave's private LDS area, not in 16 registers across block A's stream tiles)
     f32x4* pair = reinterpret_cast<f32x4*>(const_cast<RowsAux*>(aux) + 1) + (hh * 16 + min(max(r - B.n, 0), 15)) * 4;
@@ -404,27 +620,27 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
     }
   }
 
-  RSTAMP(5 + 3 * sgi);
+  if (!interleaved) RSTAMP(5 + 3 * sgi);
   // ---- the segment's stream tiles (vector-input features)
   const int cnt = (B.ntiles == 0 || B.U == 0) ? 0 : (B.nsub > 1 ? B.U : (B.U + B.ups - 1) / B.ups);
-  if (cnt > 0) {
+  if (cnt > 0 && !interleaved) {
     for (int j = 0; j < cnt; ++j, ++t) {
       constexpr int KPP = NS / ROWS_NP, PIECE_Q = 2 * KPP * 64;
-      f32x16 am, ac = splat16(0.f);
+      f32x16 acc;
       rows_stream_step<NS, 0>(ring, wsh, t, RL.nts, wave, lane);
-      am = splat16(lbias[t * 32 + r]);
-      rows_piece_lds<NS, 0>(ring, ah, al, lane, am, ac);                      // (piece p of every tile sits in slot p)
+      acc = splat16(lbias[t * 32 + r]);
+      rows_piece_lds<NS, 0>(ring, ah, al, lane, acc);                      // (piece p of every tile sits in slot p)
       rows_stream_step<NS, 1>(ring, wsh, t, RL.nts, wave, lane);
-      rows_piece_lds<NS, KPP>(ring + PIECE_Q, ah, al, lane, am, ac);
+      rows_piece_lds<NS, KPP>(ring + PIECE_Q, ah, al, lane, acc);
       rows_stream_step<NS, 2>(ring, wsh, t, RL.nts, wave, lane);
-      rows_piece_lds<NS, 2 * KPP>(ring + 2 * PIECE_Q, ah, al, lane, am, ac);
+      rows_piece_lds<NS, 2 * KPP>(ring + 2 * PIECE_Q, ah, al, lane, acc);
       int u = (B.nsub > 1) ? j : j * B.ups + us;
       if (!(valid && u < B.U)) u = 0;
 #ifdef DDP_ROWS_ABL_NOEPI   // (timing-only ablation: the tile's feature contraction reduced to one add)
-      res[0] += am + ac;
+      res[0] += acc;
       (void)u;
 #else
-      rows_epilogue<C>(am, ac, F + (u * C) * ROWS_FS + 4 * hh, ROWS_FS, res);
+      rows_epilogue<C>(acc, F + (u * C) * ROWS_FS + 4 * hh, ROWS_FS, res);
 #endif
     }
   }
@@ -531,13 +747,8 @@ __global__ __launch_bounds__(ROWS_NT, 2) void ddp_conv_rows_kernel(const RowsLau
 #pragma unroll
     for (int ks = 0; ks < NS; ++ks) {
       h4 h0, l0, h1, l1;
-      split_h2(xv[ks][0], h0, l0);
-      split_h2(xv[ks][1], h1, l1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        h2_range_check(xv[ks][0][i], T.h2_range_flag);
-        h2_range_check(xv[ks][1][i], T.h2_range_flag);
-      }
+      rows_split(xv[ks][0], ROWS_SX, h0, l0, T.h2_range_flag);
+      rows_split(xv[ks][1], ROWS_SX, h1, l1, T.h2_range_flag);
       h8 lo;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -558,7 +769,7 @@ __global__ __launch_bounds__(ROWS_NT, 2) void ddp_conv_rows_kernel(const RowsLau
   int t = 0;
 #pragma unroll
   for (int ct = 0; ct < NCT1; ++ct, ++t) {
-    f32x16 am, ac = splat16(0.f);
+    f32x16 acc;
 #pragma unroll
     for (int pc = 0; pc < ROWS_NP; ++pc) {
       constexpr int KPP = NS / ROWS_NP, PIECE_Q = 2 * KPP * 64;
@@ -571,7 +782,7 @@ __global__ __launch_bounds__(ROWS_NT, 2) void ddp_conv_rows_kernel(const RowsLau
         for (int q4 = 0; q4 < 4; ++q4) {
           const f32x4 b = bp[2 * q4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) am[4 * q4 + q] = b[q];
+          for (int q = 0; q < 4; ++q) acc[4 * q4 + q] = b[q];
         }
       }
       const f32x4* slot = ring + pc * PIECE_Q;
@@ -586,18 +797,18 @@ __global__ __launch_bounds__(ROWS_NT, 2) void ddp_conv_rows_kernel(const RowsLau
           w1 = slot[(2 * k + 3) * 64 + lane];
           xl = xlo[(ks + 1) * 64 + lane];
         }
-        am = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[ks], am, 0, 0, 0);
-        ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xlk, ac, 0, 0, 0);
-        ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[ks], ac, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xlk, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[ks], acc, 0, 0, 0);
       }
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const float pre = am[j] + ac[j] * DDP_H2_INV;
+      const float pre = acc[j] * (ROWS_SH / (ROWS_SW * ROWS_SX));     // the h plane's scale over the accumulator's
       h2_range_check(pre, T.h2_range_flag);     // (before the relu: fmaxf drops a NaN)
       const float v = fmaxf(pre, 0.f);
       const _Float16 hi = (_Float16)v;
-      const _Float16 lo = (_Float16)((v - (float)hi) * DDP_H2_SCALE);
+      const _Float16 lo = (_Float16)(v - (float)hi);
       constexpr int dummy = 0;
       (void)dummy;
       if (2 * ct + (j >> 3) < NS) {
@@ -622,8 +833,10 @@ __global__ __launch_bounds__(ROWS_NT, 2) void ddp_conv_rows_kernel(const RowsLau
       aux->src[r] = src;
       aux->pos[r] = pos;
       aux->rid[r] = rowv ? (int)__popc(rmask & upto) - 1 : -1;
-      aux->sh[r][0] = shv[0]; aux->sh[r][1] = shv[1]; aux->sh[r][2] = shv[2]; aux->sh[r][3] = shv[3];
-      aux->shT[0][r] = shv[0]; aux->shT[1][r] = shv[1]; aux->shT[2][r] = shv[2]; aux->shT[3][r] = shv[3];
+      // the harmonics carry the inverse of the accumulators' scales: 1 / (SH SW) for the stream tiles' features, 1 / (SH SG) for G
+      constexpr float fs = 1.f / (ROWS_SH * ROWS_SW), gs = 1.f / (ROWS_SH * ROWS_SG);
+      aux->sh[r][0] = shv[0] * fs; aux->sh[r][1] = shv[1] * fs; aux->sh[r][2] = shv[2] * fs; aux->sh[r][3] = shv[3] * fs;
+      aux->shT[0][r] = shv[0] * gs; aux->shT[1][r] = shv[1] * gs; aux->shT[2][r] = shv[2] * gs; aux->shT[3][r] = shv[3] * gs;
     }
   }
 

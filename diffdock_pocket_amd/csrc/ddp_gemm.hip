@@ -584,7 +584,7 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
     const f32x4 a = *reinterpret_cast<const f32x4*>(&pt[pend_lds[p]]), b = *reinterpret_cast<const f32x4*>(&pt[pend_lds[p] + 4]);
     const f32x8 f = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     const h8 hi = __builtin_convertvector(f, h8);
-    const f32x8 rest = (f - __builtin_convertvector(hi, f32x8)) * 2048.f;
+    const f32x8 rest = f - __builtin_convertvector(hi, f32x8);     // (unified planes: lo at hi's scale, include/ddp_hip.h DDP_ROWS_S*)
     const h8 lo = __builtin_convertvector(rest, h8);
     const float m8 = fmaxf(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))), fmaxf(fmaxf(fabsf(f[4]), fabsf(f[5])), fmaxf(fabsf(f[6]), fabsf(f[7]))));
     gh_max = fmaxf(gh_max, pend_sp ? m8 : 0.f);

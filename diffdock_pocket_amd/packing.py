@@ -400,6 +400,8 @@ def _pack_tiles(Wcols: torch.Tensor, kp: int) -> torch.Tensor:
 
 
 H2_SCALE = 2048.0     # csrc/ddp_conv.hip DDP_H2_SCALE
+# plane scales of ddp_conv_rows' unified hi/lo planes (include/ddp_hip.h DDP_ROWS_S*): edge_attr_, weights, h, G
+ROWS_SX, ROWS_SW, ROWS_SH, ROWS_SG = 16.0, 256.0, 16.0, 32.0
 
 
 def h2_steps(spec: "ConvSpec") -> int:
@@ -410,19 +412,23 @@ def h2_steps(spec: "ConvSpec") -> int:
     return {180: 12, 96: 6, 72: 5, 48: 3}.get(spec.hid, 0)
 
 
-def _pack_tiles_h2(Wcols: torch.Tensor, ns16: int) -> torch.Tensor:
+def _pack_tiles_h2(Wcols: torch.Tensor, ns16: int, unified_scale: float = 0.0) -> torch.Tensor:
     """Wcols [ncols (multiple of 32), K] fp32 -> fp16 operand planes of v_mfma_f32_32x32x16_f16's B operand, v = hi + lo / 2048
     (hi = fp16(v), lo = fp16((v - hi) * 2048)):  [tile][ks][plane][hh][j][8] = plane(W)[tile*32 + j][16 ks + 8 hh + i], K zero-padded
-    to 16 * ns16 (include/ddp_hip.h, ddp_conv_task_t::w1h / w2h)."""
+    to 16 * ns16 (include/ddp_hip.h, ddp_conv_task_t::w1h / w2h).
+    unified_scale = S > 0: the UNIFIED planes of ddp_conv_rows instead, V = S v = hi + lo (lo = fp16(V - hi), both halves at one scale)."""
     ncols, K = Wcols.shape
     kp = 16 * ns16
     assert ncols % 32 == 0 and kp >= K
     W = torch.zeros(ncols, kp, dtype=torch.float32)
     W[:, :K] = Wcols
+    if unified_scale > 0.0:
+        W = W * unified_scale
     hi = W.to(torch.float16)
-    lo = ((W - hi.float()) * H2_SCALE).to(torch.float16)
+    lo = ((W - hi.float()) * (1.0 if unified_scale > 0.0 else H2_SCALE)).to(torch.float16)
     if not bool(torch.isfinite(hi).all()):
-        raise NotImplementedError("fc weight outside the fp16 range (|w| > 65504): the fp16 hi/lo form cannot represent it")
+        raise NotImplementedError("fc weight outside the fp16 range (|w| > 65504, ddp_conv_rows' planes: |w| > 255): the fp16 hi/lo form cannot "
+                                  "represent it")
     Pl = torch.stack([hi, lo], 0).reshape(2, ncols // 32, 32, ns16, 2, 8)      # [plane, tile, j, ks, hh, i]
     return Pl.permute(1, 3, 0, 4, 2, 5).contiguous().reshape(-1)
 
@@ -542,16 +548,17 @@ def rows_segments(spec: "ConvSpec"):
 
 def rows_stream(spec: "ConvSpec", w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor):
     """(wsh, bsp) of ddp_conv_task_t for ddp_conv_rows: fc.0's nct1 column tiles (natural k order: their K is edge_attr_), then the fc.3
-    tiles of `spec` (block scale folded in) segment by segment with the k index permuted by rows_kperm; fp16 hi/lo planes per tile as
-    in _pack_tiles_h2, the bias words fp32 [tiles, 32]."""
+    tiles of `spec` (block scale folded in) segment by segment with the k index permuted by rows_kperm; UNIFIED fp16 hi/lo planes of
+    ROWS_SW w per tile (_pack_tiles_h2), the bias words fp32 [tiles, 32] at the scale of their tile's accumulator (fc.0: ROWS_SW ROWS_SX,
+    fc.3: ROWS_SH ROWS_SW)."""
     ns16 = h2_steps(spec)
     assert ns16 > 0
     hid, f_in = w1.shape
     W1c = torch.zeros(spec.nct1 * 32, f_in)
     W1c[:hid] = w1.detach().float().cpu()
     b1c = torch.zeros(spec.nct1 * 32)
-    b1c[:hid] = b1.detach().float().cpu()
-    t1 = _pack_tiles_h2(W1c, ns16).reshape(spec.nct1, -1)
+    b1c[:hid] = b1.detach().float().cpu() * (ROWS_SW * ROWS_SX)
+    t1 = _pack_tiles_h2(W1c, ns16, ROWS_SW).reshape(spec.nct1, -1)
     w2 = w2.detach().float().cpu()
     b2 = b2.detach().float().cpu()
     cols, bcols = [], []
@@ -570,8 +577,8 @@ def rows_stream(spec: "ConvSpec", w1: torch.Tensor, b1: torch.Tensor, w2: torch.
         Wp = torch.zeros(Wall.shape[0], 16 * ns16)
         Wp[:, :spec.hid] = Wall
         Wp = Wp[:, rows_kperm(ns16)]                                # fragment slot -> permuted k
-        t2 = _pack_tiles_h2(Wp, ns16).reshape(Wall.shape[0] // 32, -1)[order]
-        bs2 = torch.cat(bcols, 0).reshape(-1, 32)[order]
+        t2 = _pack_tiles_h2(Wp, ns16, ROWS_SW).reshape(Wall.shape[0] // 32, -1)[order]
+        bs2 = torch.cat(bcols, 0).reshape(-1, 32)[order] * (ROWS_SH * ROWS_SW)
         return torch.cat([t1, t2], 0).reshape(-1).contiguous(), torch.cat([b1c.reshape(-1, 32), bs2], 0).contiguous()
     return t1.reshape(-1).contiguous(), b1c.reshape(-1, 32).contiguous()
 
@@ -600,7 +607,8 @@ def factor_weights_gh(spec: "ConvSpec", weight: torch.Tensor, bias: torch.Tensor
     """factor_weights for ddp_conv_rows: right-hand sides whose product columns are ordered [part][k8 group][column c of the part][8 k's
     of the group] (gh_parts; the k's of group g = 2 ks + hh are rows_kperm's slots (ks, hh, 0..7); h columns >= hid and the padding
     columns of a part are zero), then Gb per padded column, then zero padding to DDP_GH_LD.  ddp_stage_a_gh writes the groups of a row
-    as fp16 hi/lo planes, every part a contiguous tile [k8][plane][c][8] (ddp_conv_task_t::gh).
+    as unified fp16 hi/lo planes, every part a contiguous tile [k8][c][plane][8] (ddp_conv_task_t::gh): the plane scale ROWS_SG rides in
+    the G columns, the accumulator scale ROWS_SH ROWS_SG in the Gb columns.
     Returns ([Wg0, Wg1], [in_off0, in_off1], [part widths of slot 0, of slot 1])."""
     ns16 = h2_steps(spec)
     assert ns16 > 0
@@ -629,9 +637,9 @@ def factor_weights_gh(spec: "ConvSpec", weight: torch.Tensor, bias: torch.Tensor
         Wk = W[:, kp].reshape(n_in, n8, 8, gc)                                                       # [u, k8, i, column]
         for _, _, c0, w, wp, cum in parts:
             tile = torch.zeros(n_in, n8, wp, 8)
-            tile[:, :, :w] = Wk[:, :, :, c0:c0 + w].permute(0, 1, 3, 2)
+            tile[:, :, :w] = Wk[:, :, :, c0:c0 + w].permute(0, 1, 3, 2) * ROWS_SG
             Wfull[:, 8 * n8 * cum:8 * n8 * (cum + wp)] = tile.reshape(n_in, -1)
-            Wfull[:, 8 * n8 * gcp + cum:8 * n8 * gcp + cum + w] = Bm[:, c0:c0 + w]
+            Wfull[:, 8 * n8 * gcp + cum:8 * n8 * gcp + cum + w] = Bm[:, c0:c0 + w] * (ROWS_SH * ROWS_SG)
         Wg[slot], offs[slot], widths[slot] = Wfull.contiguous(), blks[0].g_in_off, [p[4] for p in parts]
     return Wg, offs, widths
 

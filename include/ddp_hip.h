@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DDP_ABI_VERSION 13
+#define DDP_ABI_VERSION 14
 #define DDP_EINVAL (-1)   /* bad argument (shape not supported, null pointer, ...) */
 #define DDP_ELIMIT (-2)   /* exceeds a compiled-in limit (see DDP_MAX_*) */
 
@@ -135,24 +135,35 @@ typedef struct {
    * h = relu(fc1) value) lies outside the fp16 range (|v| > 65504, or NaN): the result of that launch is then not to be trusted and
    * the caller should rerun with the fp32 form (w1h = w2h = NULL).  NULL: not reported. */
   int32_t* h2_range_flag;
-  /* Optional (ABI 13), for ddp_conv_rows (256-edge, row-stationary workgroups; csrc/ddp_conv_rows.hip):
-   *  wsh   the SAME fc.0 / fc.3 weights as w1h / w2h, as ONE stream of 32-column tiles in the order the kernel walks them: the nct1
-   *        tiles of fc.0, then for every block and every 32-column part of its n output columns the part's tiles in feature order
-   *        (packing.rows_stream).  Tile layout as w1h / w2h (2 NS fragments of 1 KiB), but the K index of the fc.3 tiles is
-   *        PERMUTED (DDP_ROWS_KPERM below): the kernel computes h = relu(fc1) as the transposed product, whose accumulator
+  /* Optional (ABI 13; plane form of ABI 14), for ddp_conv_rows (128-edge, row-stationary workgroups; csrc/ddp_conv_rows.hip).
+   * Its operands are UNIFIED fp16 hi/lo planes: V = v * S = hi + lo with hi = fp16(V), lo = fp16(V - hi) - both halves at the SAME
+   * power-of-two scale S (DDP_ROWS_S* below), so that the three split products of a k-step accumulate into ONE register tile (the form
+   * v = hi + lo / 2048 of w1h / w2h needs two and a multiply-add per element to join them).  22 significant bits while lo is a normal
+   * fp16 number (|V| >= 0.125), an absolute 2^-25 / S below; |V| must stay <= 65504 (h2_range_flag; the host-side packers refuse).
+   *  wsh   the SAME fc.0 / fc.3 weights as w1h / w2h, scaled by DDP_ROWS_SW, as ONE stream of 32-column tiles in the order the kernel
+   *        walks them: the nct1 tiles of fc.0, then for every block and every 32-column part of its n output columns the part's tiles
+   *        in feature order (packing.rows_stream).  Tile layout as w1h / w2h (2 NS fragments of 1 KiB), but the K index of the fc.3
+   *        tiles is PERMUTED (DDP_ROWS_KPERM below): the kernel computes h = relu(fc1) as the transposed product, whose accumulator
    *        registers then ARE the A-operand fragments of the fc.3 products in that k order (no transpose through LDS).
-   *  bsp   the tiles' bias words, fp32 [stream tiles][32]
-   *  gh    G[s] of a factorised conv as fp16 hi/lo operand planes (v = hi + lo / 2048), per source node DDP_GH_LD(hid, gcp) floats: the
+   *  bsp   the tiles' bias words, fp32 [stream tiles][32], AT THE SCALE OF THE TILE'S ACCUMULATOR: fc.0 tiles DDP_ROWS_SW DDP_ROWS_SX b,
+   *        fc.3 tiles DDP_ROWS_SH DDP_ROWS_SW b
+   *  gh    DDP_ROWS_SG G[s] of a factorised conv as unified planes, per source node DDP_GH_LD(hid, gcp) floats: the
  *        32-column parts of the slot's blocks (in block order, a block's parts in order) one after the other, part p a CONTIGUOUS tile
  *        [k8 < ceil(hid/8)][c < wp][plane][8 halves] with wp = the part's width rounded up to 4 (k8 group g holds the permuted k's
  *        DDP_ROWS_KPERM(g >> 1, g & 1, i), i < 8; padding columns are zero; hi and lo words of a column side by side, so that stage A
- *        fills whole 128-byte lines), then Gb per padded column as fp32 [gcp = sum of the wp],
- *        then padding to 128 bytes; written by ddp_stage_a_gh.
+ *        fills whole 128-byte lines), then DDP_ROWS_SH DDP_ROWS_SG Gb per padded column as fp32 [gcp = sum of the wp],
+ *        then padding to 128 bytes; written by ddp_stage_a_gh from right-hand sides that carry the scales (packing.factor_weights_gh).
  * NULL: the task can only run through ddp_conv_messages. */
   const void* wsh;
   const float* bsp;
   const void* gh[2];
 } ddp_conv_task_t;
+/* plane scales of ddp_conv_rows' operands: edge_attr_ (split in the kernel), fc.0 / fc.3 weights (task.wsh), h = relu(fc1) (split in
+ * the kernel), G (task.gh).  Ranges |edge_attr_|, |h| < 4094, |w| < 255, |G| < 2047; absolute floors 2^-29, 2^-33, 2^-30. */
+#define DDP_ROWS_SX 16
+#define DDP_ROWS_SW 256
+#define DDP_ROWS_SH 16
+#define DDP_ROWS_SG 32
 /* k index held by element i of the 8-k group (ks, hh) of an h / fc.3 / G operand fragment in ddp_conv_rows */
 #define DDP_ROWS_KPERM(ks, hh, i) (32 * ((ks) >> 1) + ((8 * ((ks) & 1) + (i)) & 3) + 8 * ((8 * ((ks) & 1) + (i)) >> 2) + 4 * (hh))
 #define DDP_GH_LD(hid, gcp) ((((((hid) + 7) / 8) * 8 + 1) * (gcp) + 31) / 32 * 32)   /* floats per node of a G array in plane form, gcp = padded columns */
