@@ -152,21 +152,27 @@ __device__ __forceinline__ void rows_apply_harmonics(const f32x16& tg, const flo
 #define ROWS_NP 3
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+// (the copies are BUFFER loads to LDS, not global_load_lds: hipcc books a global_load_lds as a flat access to both address spaces, and while
+// one is pending every wait for an ordinary load - the G fragments of the interleaved runs - becomes vmcnt(0))
+typedef __amdgpu_buffer_rsrc_t RowsStream;
+__device__ __forceinline__ RowsStream rows_stream_of(const void* wsh, int nts, int tile_bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wsh), 0, nts * tile_bytes, 0x00020000);
+}
 template <int NS>
-__device__ __forceinline__ void rows_request_piece(f32x4* ring, const f32x4* __restrict__ wsh, int jn, int npieces, int slot, int wave, int lane) {
+__device__ __forceinline__ void rows_request_piece(f32x4* ring, RowsStream wsh, int jn, int npieces, int slot, int wave, int lane) {
   constexpr int FPP = 2 * NS / ROWS_NP, FPW = FPP / ROWS_NW, PIECE_Q = FPP * 64;
   static_assert(NS % ROWS_NP == 0 && FPP % ROWS_NW == 0, "every wave moves the same number of fragments per piece");
   f32x4* nslot = ring + slot * PIECE_Q;
-  const f32x4* __restrict__ wn = wsh + (size_t)min(jn, npieces - 1) * PIECE_Q;
+  const int piece_off = min(jn, npieces - 1) * (PIECE_Q * 16);
 #pragma unroll
   for (int f = 0; f < FPW; ++f)
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)(wn + (wave + ROWS_NW * f) * 64 + lane), (lds_ptr_t)(nslot + (wave + ROWS_NW * f) * 64), 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wsh, (lds_ptr_t)(nslot + (wave + ROWS_NW * f) * 64), 16, ((wave + ROWS_NW * f) * 64 + lane) * 16, piece_off, 0, 0);
 }
 // GL = vector-memory operations a wave issues BETWEEN two piece requests besides them (the interleaved G steps of rows_segment: 4 fragment
 // loads per stream step); the literal must not exceed the operations younger than piece j's copies on ANY path that reaches the wait:
 // a smaller one only waits longer, a larger one lets the barrier pass with the copy in flight.
 template <int NS, int P, int GL = 0>
-__device__ __forceinline__ void rows_stream_step(f32x4* ring, const f32x4* __restrict__ wsh, int t, int nts, int wave, int lane) {
+__device__ __forceinline__ void rows_stream_step(f32x4* ring, RowsStream wsh, int t, int nts, int wave, int lane) {
   constexpr int FPW = 2 * NS / ROWS_NP / ROWS_NW;
   // (hipcc does NOT wait for an LDS-DMA in front of a barrier: without this a wave can pass while its part of the piece is in flight.
   // vmcnt counts in order: "at most FPW outstanding" = everything older than the copies of piece j + 1 has landed)
@@ -180,7 +186,13 @@ __device__ __forceinline__ void rows_stream_step(f32x4* ring, const f32x4* __res
   else
     asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
 #ifndef DDP_ROWS_ABL_NOBAR   // (timing-only ablation: no barrier - what do the four waves wait for each other?)
-  __syncthreads();
+  // the bare barrier, not __syncthreads(): its workgroup fence makes hipcc wait vmcnt(0) whenever an ordinary global load is in flight -
+  // the G fragments of the interleaved runs - and every stream step then waited for HBM.  What the barrier orders here is LDS only: this
+  // wave's reads of the slot that is requested next (and, once, the bias table's writes) are complete (lgkmcnt(0)), the copies it waits
+  // for are counted above; the asm statements keep the compiler from moving LDS accesses across it.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 #endif
   rows_request_piece<NS>(ring, wsh, ROWS_NP * t + P + 2, ROWS_NP * nts, (P + 2) % ROWS_NP, wave, lane);
 }
@@ -376,24 +388,33 @@ __device__ __forceinline__ f32x16 rows_g_runs(const ddp_conv_shape_t& S, const R
 // accumulators - 73 spilled registers); the last run's steps fetch the first run's fragments again instead of a next run's (nothing
 // reads them): every step issues its two loads, which is what rows_stream_step's wait literal counts on.
 struct RowsGSeq {        // (scalars only: the ring and the accumulators are separate locals, so that everything stays in registers)
-  const char* gp;        // node base of the current run's tile (wave-uniform)
-  const char* gpn;       // ... of the next run's
-  const char* gfirst;
+  // The fragments are BUFFER loads: descriptor of the node's tile (4 SGPRs, rebuilt per run) + the fragment's uniform offset (an SGPR) +
+  // ONE lane offset register - as global loads hipcc kept a 64-bit lane address per fragment of the run in registers (24 of them).
+  RowsStream rs;         // the current run's node
+  RowsStream rsn;        // the next run's
+  RowsStream rsfirst;
   const char* base;
   size_t gldb;
-  float bias, bias_n;
+  float bias;            // Gb of the current run's column (added when the run's product is added to the accumulator)
   unsigned m;            // runs not yet started (bit = first row)
   int run, nruns;
   unsigned lo_main, lo_last, lo_bias;
   int gc;
 };
-#define ROWS_GSEQ_FRAG(G, basep, kq, plane) \
-  (*reinterpret_cast<const f32x4*>((basep) + (((kq) == NS - 1) ? (size_t)(plane) * 16 : (size_t)(4 * (kq) * (G).gc + (plane)) * 16) + (((kq) == NS - 1) ? (G).lo_last : (G).lo_main)))
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define ROWS_GSEQ_FRAG(G, R, kq, plane)                                                                                              \
+  __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((R), (((kq) == NS - 1) ? (G).lo_last : (G).lo_main) + (plane) * 16, \
+                                                                  ((kq) == NS - 1) ? 0 : 4 * (kq) * (G).gc * 16, 0))
+__device__ __forceinline__ RowsStream rows_gseq_node(const RowsGSeq& G, int src_reg, int row) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(G.base + (size_t)__builtin_amdgcn_readlane(src_reg, row) * G.gldb), 0, (int)G.gldb, 0x00020000);
+}
+// a run starts: its bias word is requested now and read when the run's last k-step is done (a load whose value is needed at once is the
+// youngest operation in flight: waiting for it drains the whole in-order queue)
 __device__ __forceinline__ void rows_gseq_next(RowsGSeq& G, int src_reg, f32x16& gacc) {
   G.m &= G.m - 1u;
-  G.gpn = (G.m != 0u) ? G.base + (size_t)__builtin_amdgcn_readlane(src_reg, __builtin_ctz(G.m)) * G.gldb : G.gfirst;
-  G.bias_n = *reinterpret_cast<const float*>(G.gpn + G.lo_bias);
-  gacc = splat16(G.bias);
+  G.rsn = (G.m != 0u) ? rows_gseq_node(G, src_reg, __builtin_ctz(G.m)) : G.rsfirst;
+  G.bias = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(G.rs, G.lo_bias, 0, 0));
+  gacc = splat16(0.f);
 }
 template <int NS, int GR>
 __device__ __forceinline__ void rows_gseq_init(RowsGSeq& G, f32x4 (&gr)[GR], f32x16& gacc, const ddp_conv_shape_t& S, const RowsGPart& PA,
@@ -411,11 +432,10 @@ __device__ __forceinline__ void rows_gseq_init(RowsGSeq& G, f32x4 (&gr)[GR], f32
   G.m = rmask;
   G.nruns = __builtin_amdgcn_readfirstlane(__popc(rmask));
   G.run = 0;
-  G.gp = G.gfirst = PA.base + (size_t)__builtin_amdgcn_readlane(src_reg, __builtin_ctz(rmask)) * PA.gldb;
-  G.bias = *reinterpret_cast<const float*>(G.gp + G.lo_bias);
+  G.rs = G.rsfirst = rows_gseq_node(G, src_reg, __builtin_ctz(rmask));
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int k = 0; k < GR; ++k) gr[k] = ROWS_GSEQ_FRAG(G, G.gp, k >> 1, k & 1);
+  for (int k = 0; k < GR; ++k) gr[k] = ROWS_GSEQ_FRAG(G, G.rs, k >> 1, k & 1);
   __builtin_amdgcn_sched_barrier(0);
   rows_gseq_next(G, src_reg, gacc);
 }
@@ -431,7 +451,7 @@ __device__ __forceinline__ void rows_gseq_step(RowsGSeq& G, f32x4 (&gr)[GR], f32
     gacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[KS], bh, gacc, 0, 0, 0);
   }
   __builtin_amdgcn_sched_barrier(0);
-  const char* __restrict__ srcb = (q0 < NF) ? G.gp : G.gpn;
+  const RowsStream srcb = (q0 < NF) ? G.rs : G.rsn;
   gr[(2 * KS) % GR] = ROWS_GSEQ_FRAG(G, srcb, kq, 0);
   gr[(2 * KS + 1) % GR] = ROWS_GSEQ_FRAG(G, srcb, kq, 1);
   __builtin_amdgcn_sched_barrier(0);
@@ -447,11 +467,10 @@ __device__ __forceinline__ void rows_gseq_finish(RowsGSeq& G, f32x16& gacc, cons
       const i32x4 id = *reinterpret_cast<const i32x4*>(ridrow + 8 * q4);
       const f32x4 f = *reinterpret_cast<const f32x4*>(shrow + 8 * q4);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) res[4 * q4 + q] = (id[q] == sel) ? res[4 * q4 + q] + f[q] * gacc[4 * q4 + q] : res[4 * q4 + q];
+      for (int q = 0; q < 4; ++q) res[4 * q4 + q] = (id[q] == sel) ? res[4 * q4 + q] + f[q] * (gacc[4 * q4 + q] + G.bias) : res[4 * q4 + q];
     }
   }
-  G.gp = G.gpn;
-  G.bias = G.bias_n;
+  G.rs = G.rsn;
   ++G.run;
   rows_gseq_next(G, src_reg, gacc);
 }
@@ -479,7 +498,7 @@ __device__ __forceinline__ void rows_piece_lds_g(const f32x4* slot, const h8 (&a
 }
 // TPR stream tiles (tile TT of them) with one G run between their k-steps: 2 G k-steps per piece, NS = 2 ROWS_NP TPR
 template <int NS, int GR, int TT>
-__device__ __forceinline__ void rows_tile_g(f32x4* ring, const f32x4* __restrict__ wsh, const float* lbias, int t, int nts, const h8 (&ah)[NS],
+__device__ __forceinline__ void rows_tile_g(f32x4* ring, RowsStream wsh, const float* lbias, int t, int nts, const h8 (&ah)[NS],
                                             const h8 (&al)[NS], int wave, int lane, f32x16& acc, RowsGSeq& G, f32x4 (&gr)[GR], f32x16& gacc) {
   constexpr int KPP = NS / ROWS_NP, PIECE_Q = 2 * KPP * 64, G0 = 2 * ROWS_NP * TT;
   rows_stream_step<NS, 0, 4>(ring, wsh, t, nts, wave, lane);
@@ -503,7 +522,7 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
   (void)sgi;
   const ddp_conv_shape_t& S = RL.L.shape;
   const int r = lane & 31, hh = lane >> 5;
-  const f32x4* __restrict__ wsh = reinterpret_cast<const f32x4*>(T.wsh);
+  const RowsStream wsh = rows_stream_of(T.wsh, RL.nts, 2 * NS * 1024);
   // lane -> (output channel, feature slot) of the segment's tiles (tile_lane_map of ddp_conv.hip)
   int ncol, us;
   bool valid;
@@ -695,7 +714,7 @@ __global__ __launch_bounds__(ROWS_NT, 2) void ddp_conv_rows_kernel(const RowsLau
   f32x4* ring = reinterpret_cast<f32x4*>(lds);
   float* lbias = lds + RING_Q * 4;                                        // [nts][32] bias words of the stream tiles
   char* priv = reinterpret_cast<char*>(lds) + RING_Q * 16 + RL.bias_bytes + (size_t)wave * RL.priv_bytes;
-  const f32x4* __restrict__ wsh = reinterpret_cast<const f32x4*>(T.wsh);
+  const RowsStream wsh = rows_stream_of(T.wsh, RL.nts, 2 * NS * 1024);
   const int nvw = max(0, min(32, nvalid - 32 * wave));      // valid edges of this wave
   RSTAMP(0);
 
