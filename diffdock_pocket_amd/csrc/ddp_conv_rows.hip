@@ -176,11 +176,15 @@ __device__ __forceinline__ void rows_stream_step(f32x4* ring, RowsStream wsh, in
   constexpr int FPW = 2 * NS / ROWS_NP / ROWS_NW;
   // (hipcc does NOT wait for an LDS-DMA in front of a barrier: without this a wave can pass while its part of the piece is in flight.
   // vmcnt counts in order: "at most FPW outstanding" = everything older than the copies of piece j + 1 has landed)
-  static_assert((FPW == 2 || FPW == 1) && (GL == 0 || GL == 4), "the literals below");
+  static_assert((FPW == 2 || FPW == 1) && (GL == 0 || GL == 2 || GL == 4), "the literals below");
   if constexpr (FPW + 2 * GL == 2)
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   else if constexpr (FPW + 2 * GL == 1)
     asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (FPW + 2 * GL == 6)
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (FPW + 2 * GL == 5)
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
   else if constexpr (FPW + 2 * GL == 10)
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   else
@@ -475,9 +479,14 @@ __device__ __forceinline__ void rows_gseq_finish(RowsGSeq& G, f32x16& gacc, cons
   rows_gseq_next(G, src_reg, gacc);
 }
 
-// one piece of a stream tile with the G k-steps GK0, GK0 + 1 between its own: the first in front of the piece's first product (its
-// operands are in registers: it runs while the piece's first LDS reads are on their way), the second half-way
-template <int NS, int GR, int KS0, int GK0>
+// one piece of a stream tile with GKP G k-steps (GK0 ..) between its own: the first in front of the piece's first product (its operands
+// are in registers: it runs while the piece's first LDS reads are on their way), a second one half-way.
+// GKP = 1 (default): a run spans NS / ROWS_NP tiles and a fragment has GR / 2 stream steps to arrive (with 2 steps - GKP = 2 - the four
+// waves of a workgroup met the slowest wave's HBM latency at every barrier: 1.95 k ticks per step instead of 1.2 k)
+#ifndef DDP_ROWS_GKP
+#define DDP_ROWS_GKP 1
+#endif
+template <int NS, int GR, int KS0, int GK0, int GKP>
 __device__ __forceinline__ void rows_piece_lds_g(const f32x4* slot, const h8 (&ah)[NS], const h8 (&al)[NS], int lane, f32x16& acc, RowsGSeq& G,
                                                  f32x4 (&gr)[GR], f32x16& gacc) {
   constexpr int NK = NS / ROWS_NP;
@@ -493,21 +502,22 @@ __device__ __forceinline__ void rows_piece_lds_g(const f32x4* slot, const h8 (&a
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS0 + k], bh, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS0 + k], bl, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[KS0 + k], bh, acc, 0, 0, 0);
-    if (k == (NK - 1) / 2) rows_gseq_step<NS, GR, GK0 + 1>(G, gr, gacc, ah, al);
+    if constexpr (GKP == 2)
+      if (k == (NK - 1) / 2) rows_gseq_step<NS, GR, (GK0 + 1) % NS>(G, gr, gacc, ah, al);
   }
 }
-// TPR stream tiles (tile TT of them) with one G run between their k-steps: 2 G k-steps per piece, NS = 2 ROWS_NP TPR
-template <int NS, int GR, int TT>
+// TPR stream tiles (tile TT of them) with one G run between their k-steps: GKP G k-steps per piece, NS = GKP ROWS_NP TPR
+template <int NS, int GR, int TT, int GKP>
 __device__ __forceinline__ void rows_tile_g(f32x4* ring, RowsStream wsh, const float* lbias, int t, int nts, const h8 (&ah)[NS],
                                             const h8 (&al)[NS], int wave, int lane, f32x16& acc, RowsGSeq& G, f32x4 (&gr)[GR], f32x16& gacc) {
-  constexpr int KPP = NS / ROWS_NP, PIECE_Q = 2 * KPP * 64, G0 = 2 * ROWS_NP * TT;
-  rows_stream_step<NS, 0, 4>(ring, wsh, t, nts, wave, lane);
+  constexpr int KPP = NS / ROWS_NP, PIECE_Q = 2 * KPP * 64, G0 = GKP * ROWS_NP * TT;
+  rows_stream_step<NS, 0, 2 * GKP>(ring, wsh, t, nts, wave, lane);
   acc = splat16(lbias[t * 32 + (lane & 31)]);
-  rows_piece_lds_g<NS, GR, 0, G0>(ring, ah, al, lane, acc, G, gr, gacc);
-  rows_stream_step<NS, 1, 4>(ring, wsh, t, nts, wave, lane);
-  rows_piece_lds_g<NS, GR, KPP, G0 + 2>(ring + PIECE_Q, ah, al, lane, acc, G, gr, gacc);
-  rows_stream_step<NS, 2, 4>(ring, wsh, t, nts, wave, lane);
-  rows_piece_lds_g<NS, GR, 2 * KPP, G0 + 4>(ring + 2 * PIECE_Q, ah, al, lane, acc, G, gr, gacc);
+  rows_piece_lds_g<NS, GR, 0, G0 % NS, GKP>(ring, ah, al, lane, acc, G, gr, gacc);
+  rows_stream_step<NS, 1, 2 * GKP>(ring, wsh, t, nts, wave, lane);
+  rows_piece_lds_g<NS, GR, KPP, (G0 + GKP) % NS, GKP>(ring + PIECE_Q, ah, al, lane, acc, G, gr, gacc);
+  rows_stream_step<NS, 2, 2 * GKP>(ring, wsh, t, nts, wave, lane);
+  rows_piece_lds_g<NS, GR, 2 * KPP, (G0 + 2 * GKP) % NS, GKP>(ring + 2 * PIECE_Q, ah, al, lane, acc, G, gr, gacc);
 }
 
 // gmode: 0 = the segment runs its own G tiles; 1 = it runs the MERGED tiles of its block and the next one (block B's products are
@@ -543,8 +553,8 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
   bool interleaved = false;
   if constexpr (C == 1) {
     if (B.g_slot >= 0 && rmask != 0u && B.ntiles > 0 && B.U > 0) {
-      constexpr int TPR = NS / (2 * ROWS_NP);     // stream tiles per G run: 2 G k-steps per piece
-      static_assert(NS == 2 * ROWS_NP * TPR && (TPR == 1 || TPR == 2), "2 G k-steps per piece of the stream");
+      constexpr int GKP = DDP_ROWS_GKP, TPR = NS / (GKP * ROWS_NP);     // stream tiles per G run: GKP G k-steps per piece
+      static_assert(NS == GKP * ROWS_NP * TPR && TPR >= 1 && TPR <= 4, "GKP G k-steps per piece of the stream");
       const int cnt1 = B.nsub > 1 ? B.U : (B.U + B.ups - 1) / B.ups;
       const RowsGPart PA = rows_gpart_of(S, T, bi, part);
       RowsGSeq G;
@@ -557,14 +567,19 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
       RSTAMP(5 + 3 * sgi);
       int j = 0;
       for (; j + TPR <= cnt1 && G.run < G.nruns; j += TPR) {
-#pragma unroll
+        // (one tile per trip, its G k-steps chosen by a uniform branch: with the TPR tiles unrolled into one block hipcc gave every tile its
+        // own accumulator registers and spilled h inside the loop)
+#pragma nounroll
         for (int tt = 0; tt < TPR; ++tt, ++t) {
           f32x16 acc;
-          if (tt == 0) rows_tile_g<NS, GR, 0>(ring, wsh, lbias, t, RL.nts, ah, al, wave, lane, acc, G, gr, gacc);
-          else rows_tile_g<NS, GR, TPR - 1>(ring, wsh, lbias, t, RL.nts, ah, al, wave, lane, acc, G, gr, gacc);
+          if (tt == 0) rows_tile_g<NS, GR, 0, GKP>(ring, wsh, lbias, t, RL.nts, ah, al, wave, lane, acc, G, gr, gacc);
+          else if (tt == 1) rows_tile_g<NS, GR, 1 % TPR, GKP>(ring, wsh, lbias, t, RL.nts, ah, al, wave, lane, acc, G, gr, gacc);
+          else if (tt == 2) rows_tile_g<NS, GR, 2 % TPR, GKP>(ring, wsh, lbias, t, RL.nts, ah, al, wave, lane, acc, G, gr, gacc);
+          else rows_tile_g<NS, GR, 3 % TPR, GKP>(ring, wsh, lbias, t, RL.nts, ah, al, wave, lane, acc, G, gr, gacc);
           int u = (B.nsub > 1) ? j + tt : (j + tt) * B.ups + us;
           if (!(valid && u < B.U)) u = 0;
           rows_epilogue<1>(acc, F + u * ROWS_FS + 4 * hh, ROWS_FS, res);
+          __builtin_amdgcn_sched_barrier(0);     // (a tile's contraction is done before the next tile starts: one accumulator live)
         }
         rows_gseq_finish(G, gacc, ridrow, shrow, mine, src_reg, res[0]);
       }
