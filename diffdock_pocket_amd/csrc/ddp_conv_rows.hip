@@ -40,7 +40,7 @@
 #define ROWS_ET 128
 #define ROWS_FS 36     // floats per feature row F[u * C + c][edge]
 #ifndef DDP_ROWS_GRING1
-#define DDP_ROWS_GRING1 8
+#define DDP_ROWS_GRING1 12
 #endif
 #ifndef DDP_ROWS_GRING3
 #define DDP_ROWS_GRING3 8
@@ -153,7 +153,7 @@ __device__ __forceinline__ void rows_apply_harmonics(const f32x16& tg, const flo
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 // (the copies are BUFFER loads to LDS, not global_load_lds: hipcc books a global_load_lds as a flat access to both address spaces, and while
-// one is pending every wait for an ordinary load - the G fragments of the interleaved runs - becomes vmcnt(0))
+// one is pending every wait for an ordinary load becomes vmcnt(0))
 typedef __amdgpu_buffer_rsrc_t RowsStream;
 __device__ __forceinline__ RowsStream rows_stream_of(const void* wsh, int nts, int tile_bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wsh), 0, nts * tile_bytes, 0x00020000);
@@ -168,32 +168,21 @@ __device__ __forceinline__ void rows_request_piece(f32x4* ring, RowsStream wsh, 
   for (int f = 0; f < FPW; ++f)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(wsh, (lds_ptr_t)(nslot + (wave + ROWS_NW * f) * 64), 16, ((wave + ROWS_NW * f) * 64 + lane) * 16, piece_off, 0, 0);
 }
-// GL = vector-memory operations a wave issues BETWEEN two piece requests besides them (the interleaved G steps of rows_segment: 4 fragment
-// loads per stream step); the literal must not exceed the operations younger than piece j's copies on ANY path that reaches the wait:
-// a smaller one only waits longer, a larger one lets the barrier pass with the copy in flight.
-template <int NS, int P, int GL = 0>
+template <int NS, int P>
 __device__ __forceinline__ void rows_stream_step(f32x4* ring, RowsStream wsh, int t, int nts, int wave, int lane) {
   constexpr int FPW = 2 * NS / ROWS_NP / ROWS_NW;
   // (hipcc does NOT wait for an LDS-DMA in front of a barrier: without this a wave can pass while its part of the piece is in flight.
   // vmcnt counts in order: "at most FPW outstanding" = everything older than the copies of piece j + 1 has landed)
-  static_assert((FPW == 2 || FPW == 1) && (GL == 0 || GL == 2 || GL == 4), "the literals below");
-  if constexpr (FPW + 2 * GL == 2)
+  static_assert(FPW == 2 || FPW == 1, "the literals below");
+  if constexpr (FPW == 2)
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (FPW + 2 * GL == 1)
-    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  else if constexpr (FPW + 2 * GL == 6)
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (FPW + 2 * GL == 5)
-    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else if constexpr (FPW + 2 * GL == 10)
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   else
-    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
 #ifndef DDP_ROWS_ABL_NOBAR   // (timing-only ablation: no barrier - what do the four waves wait for each other?)
-  // the bare barrier, not __syncthreads(): its workgroup fence makes hipcc wait vmcnt(0) whenever an ordinary global load is in flight -
-  // the G fragments of the interleaved runs - and every stream step then waited for HBM.  What the barrier orders here is LDS only: this
-  // wave's reads of the slot that is requested next (and, once, the bias table's writes) are complete (lgkmcnt(0)), the copies it waits
-  // for are counted above; the asm statements keep the compiler from moving LDS accesses across it.
+  // the bare barrier, not __syncthreads(): its workgroup fence makes hipcc wait vmcnt(0) whenever an ordinary load is in flight.  What
+  // the barrier orders here is LDS only: this wave's reads of the slot that is requested next (and, once, the bias table's writes) are
+  // complete (lgkmcnt(0)), the copies it waits for are counted above; the asm statements keep the compiler from moving LDS accesses
+  // across it.
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -325,8 +314,8 @@ __device__ __forceinline__ f32x16 rows_g_runs(const ddp_conv_shape_t& S, const R
   const int k8l = min(2 * (NS - 1) + hh, n8 - 1);
   const unsigned lo_last = (unsigned)(2 * k8l * gc + 2 * cl) * 16u;                 // + plane * 16
   const unsigned lo_bias = (unsigned)((inb ? PB.bias_off : PA.bias_off) + 4 * cl);
-#ifdef DDP_ROWS_ABL_G0   // timing-only ablation: every run reads node 0's G (L2 hits): is the G phase bound by where G comes from?
-#define ROWS_NODE(a) 0
+#ifdef DDP_ROWS_ABL_G0   // timing-only ablation: the runs read the G of nodes 0 .. DDP_ROWS_ABL_G0 - 1 (L2 hits): is the G phase bound by where G comes from?
+#define ROWS_NODE(a) (__builtin_amdgcn_readlane(src_reg, (a)) & (DDP_ROWS_ABL_G0 - 1))
 #else
 #define ROWS_NODE(a) __builtin_amdgcn_readlane(src_reg, (a))
 #endif
@@ -383,20 +372,18 @@ __device__ __forceinline__ f32x16 rows_g_runs(const ddp_conv_shape_t& S, const R
   return tg;
 }
 
-// The G runs of a SCALAR segment as a resumable sequence of k-steps (round 5, second half): the runs' tile products are issued BETWEEN
-// the k-steps of the segment's stream tiles (rows_segment), so that the fragment loads of a run - 8 KiB in flight per wave against ~1 us of
-// loaded HBM latency: ~6 k ticks per tile product on their own - travel behind the stream tiles' MFMAs.  Same ring, same fragment order and
-// the same select as rows_g_runs; a run's product is added to the segment's accumulator when its last k-step is done (run by run, between
-// the stream tiles' contributions: the order is fixed by the segment's tile count alone, bitwise reproducible).
-// The interleaved tiles run while a run is left (no branch inside them: a branch around an MFMA chain made hipcc keep two copies of the
-// accumulators - 73 spilled registers); the last run's steps fetch the first run's fragments again instead of a next run's (nothing
-// reads them): every step issues its two loads, which is what rows_stream_step's wait literal counts on.
+// The G runs of a SCALAR segment (C = 1, one G array): like rows_g_runs, but
+//  * the fragments are BUFFER loads - descriptor of the node's tile (4 SGPRs, rebuilt per run) + the fragment's uniform offset (an SGPR) +
+//    ONE lane offset register; as global loads hipcc kept a 64-bit lane address per fragment of the run in registers (24 of them);
+//  * the register ring holds a WHOLE tile (DDP_ROWS_GRING1 = 2 NS fragments, 24 KiB in flight per wave: the unified planes freed an
+//    accumulator per product): while run i is multiplied, run i + 1 arrives in the slots its steps free - a run costs the larger of
+//    its 36 MFMAs and ONE memory round trip, not three;
+//  * the last run's steps load from an EMPTY buffer (num_records = 0: the loads return zeros without touching memory) instead of
+//    prefetching a tile nobody reads;
+//  * a run's product goes straight into the segment's accumulator (rows of the run selected, times the harmonic), no tg registers.
 struct RowsGSeq {        // (scalars only: the ring and the accumulators are separate locals, so that everything stays in registers)
-  // The fragments are BUFFER loads: descriptor of the node's tile (4 SGPRs, rebuilt per run) + the fragment's uniform offset (an SGPR) +
-  // ONE lane offset register - as global loads hipcc kept a 64-bit lane address per fragment of the run in registers (24 of them).
   RowsStream rs;         // the current run's node
-  RowsStream rsn;        // the next run's
-  RowsStream rsfirst;
+  RowsStream rsn;        // the next run's (behind the last run: an empty buffer)
   const char* base;
   size_t gldb;
   float bias;            // Gb of the current run's column (added when the run's product is added to the accumulator)
@@ -416,7 +403,7 @@ __device__ __forceinline__ RowsStream rows_gseq_node(const RowsGSeq& G, int src_
 // youngest operation in flight: waiting for it drains the whole in-order queue)
 __device__ __forceinline__ void rows_gseq_next(RowsGSeq& G, int src_reg, f32x16& gacc) {
   G.m &= G.m - 1u;
-  G.rsn = (G.m != 0u) ? rows_gseq_node(G, src_reg, __builtin_ctz(G.m)) : G.rsfirst;
+  G.rsn = (G.m != 0u) ? rows_gseq_node(G, src_reg, __builtin_ctz(G.m)) : __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(G.base), 0, 0, 0x00020000);
   G.bias = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(G.rs, G.lo_bias, 0, 0));
   gacc = splat16(0.f);
 }
@@ -436,7 +423,7 @@ __device__ __forceinline__ void rows_gseq_init(RowsGSeq& G, f32x4 (&gr)[GR], f32
   G.m = rmask;
   G.nruns = __builtin_amdgcn_readfirstlane(__popc(rmask));
   G.run = 0;
-  G.rs = G.rsfirst = rows_gseq_node(G, src_reg, __builtin_ctz(rmask));
+  G.rs = rows_gseq_node(G, src_reg, __builtin_ctz(rmask));
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < GR; ++k) gr[k] = ROWS_GSEQ_FRAG(G, G.rs, k >> 1, k & 1);
@@ -479,47 +466,6 @@ __device__ __forceinline__ void rows_gseq_finish(RowsGSeq& G, f32x16& gacc, cons
   rows_gseq_next(G, src_reg, gacc);
 }
 
-// one piece of a stream tile with GKP G k-steps (GK0 ..) between its own: the first in front of the piece's first product (its operands
-// are in registers: it runs while the piece's first LDS reads are on their way), a second one half-way.
-// GKP = 1 (default): a run spans NS / ROWS_NP tiles and a fragment has GR / 2 stream steps to arrive (with 2 steps - GKP = 2 - the four
-// waves of a workgroup met the slowest wave's HBM latency at every barrier: 1.95 k ticks per step instead of 1.2 k)
-#ifndef DDP_ROWS_GKP
-#define DDP_ROWS_GKP 1
-#endif
-template <int NS, int GR, int KS0, int GK0, int GKP>
-__device__ __forceinline__ void rows_piece_lds_g(const f32x4* slot, const h8 (&ah)[NS], const h8 (&al)[NS], int lane, f32x16& acc, RowsGSeq& G,
-                                                 f32x4 (&gr)[GR], f32x16& gacc) {
-  constexpr int NK = NS / ROWS_NP;
-  f32x4 b0 = slot[lane], b1 = slot[64 + lane];
-  rows_gseq_step<NS, GR, GK0>(G, gr, gacc, ah, al);
-#pragma unroll
-  for (int k = 0; k < NK; ++k) {
-    const h8 bh = __builtin_bit_cast(h8, b0), bl = __builtin_bit_cast(h8, b1);
-    if (k + 1 < NK) {
-      b0 = slot[(2 * k + 2) * 64 + lane];
-      b1 = slot[(2 * k + 3) * 64 + lane];
-    }
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS0 + k], bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS0 + k], bl, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[KS0 + k], bh, acc, 0, 0, 0);
-    if constexpr (GKP == 2)
-      if (k == (NK - 1) / 2) rows_gseq_step<NS, GR, (GK0 + 1) % NS>(G, gr, gacc, ah, al);
-  }
-}
-// TPR stream tiles (tile TT of them) with one G run between their k-steps: GKP G k-steps per piece, NS = GKP ROWS_NP TPR
-template <int NS, int GR, int TT, int GKP>
-__device__ __forceinline__ void rows_tile_g(f32x4* ring, RowsStream wsh, const float* lbias, int t, int nts, const h8 (&ah)[NS],
-                                            const h8 (&al)[NS], int wave, int lane, f32x16& acc, RowsGSeq& G, f32x4 (&gr)[GR], f32x16& gacc) {
-  constexpr int KPP = NS / ROWS_NP, PIECE_Q = 2 * KPP * 64, G0 = GKP * ROWS_NP * TT;
-  rows_stream_step<NS, 0, 2 * GKP>(ring, wsh, t, nts, wave, lane);
-  acc = splat16(lbias[t * 32 + (lane & 31)]);
-  rows_piece_lds_g<NS, GR, 0, G0 % NS, GKP>(ring, ah, al, lane, acc, G, gr, gacc);
-  rows_stream_step<NS, 1, 2 * GKP>(ring, wsh, t, nts, wave, lane);
-  rows_piece_lds_g<NS, GR, KPP, (G0 + GKP) % NS, GKP>(ring + PIECE_Q, ah, al, lane, acc, G, gr, gacc);
-  rows_stream_step<NS, 2, 2 * GKP>(ring, wsh, t, nts, wave, lane);
-  rows_piece_lds_g<NS, GR, 2 * KPP, (G0 + 2 * GKP) % NS, GKP>(ring + 2 * PIECE_Q, ah, al, lane, acc, G, gr, gacc);
-}
-
 // gmode: 0 = the segment runs its own G tiles; 1 = it runs the MERGED tiles of its block and the next one (block B's products are
 // parked behind the wave's per-edge tables); 2 = its G products were computed by the segment before (lanes [n, 2 n))
 template <int NS, int C>
@@ -549,80 +495,44 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
 #pragma unroll
   for (int c = 0; c < C; ++c) res[c] = splat16(0.f);
 
-  // ---- scalar segment with factorised features: the G runs travel between the k-steps of the stream tiles (RowsGSeq)
-  bool interleaved = false;
+  // ---- scalar segment with factorised features: whole-tile ring, buffer loads (RowsGSeq)
+  bool gdone = false;
   if constexpr (C == 1) {
-    if (B.g_slot >= 0 && rmask != 0u && B.ntiles > 0 && B.U > 0) {
-      constexpr int GKP = DDP_ROWS_GKP, TPR = NS / (GKP * ROWS_NP);     // stream tiles per G run: GKP G k-steps per piece
-      static_assert(NS == GKP * ROWS_NP * TPR && TPR >= 1 && TPR <= 4, "GKP G k-steps per piece of the stream");
-      const int cnt1 = B.nsub > 1 ? B.U : (B.U + B.ups - 1) / B.ups;
+    if (B.g_slot >= 0 && rmask != 0u) {
+      constexpr int GR1 = (DDP_ROWS_GRING1 >= NF) ? NF : GR;
       const RowsGPart PA = rows_gpart_of(S, T, bi, part);
       RowsGSeq G;
-      f32x4 gr[GR];
+      f32x4 gr[GR1];
       f32x16 gacc;
-      rows_gseq_init<NS, GR>(G, gr, gacc, S, PA, rmask, src_reg, lane);
+      rows_gseq_init<NS, GR1>(G, gr, gacc, S, PA, rmask, src_reg, lane);
       const int* ridrow = &aux->rid[4 * hh];
       const float* shrow = &aux->shT[0][4 * hh];
       const bool mine = r < PA.nmine;
-      RSTAMP(5 + 3 * sgi);
-      int j = 0;
-      for (; j + TPR <= cnt1 && G.run < G.nruns; j += TPR) {
-        // (one tile per trip, its G k-steps chosen by a uniform branch: with the TPR tiles unrolled into one block hipcc gave every tile its
-        // own accumulator registers and spilled h inside the loop)
-#pragma nounroll
-        for (int tt = 0; tt < TPR; ++tt, ++t) {
-          f32x16 acc;
-          if (tt == 0) rows_tile_g<NS, GR, 0, GKP>(ring, wsh, lbias, t, RL.nts, ah, al, wave, lane, acc, G, gr, gacc);
-          else if (tt == 1) rows_tile_g<NS, GR, 1 % TPR, GKP>(ring, wsh, lbias, t, RL.nts, ah, al, wave, lane, acc, G, gr, gacc);
-          else if (tt == 2) rows_tile_g<NS, GR, 2 % TPR, GKP>(ring, wsh, lbias, t, RL.nts, ah, al, wave, lane, acc, G, gr, gacc);
-          else rows_tile_g<NS, GR, 3 % TPR, GKP>(ring, wsh, lbias, t, RL.nts, ah, al, wave, lane, acc, G, gr, gacc);
-          int u = (B.nsub > 1) ? j + tt : (j + tt) * B.ups + us;
-          if (!(valid && u < B.U)) u = 0;
-          rows_epilogue<1>(acc, F + u * ROWS_FS + 4 * hh, ROWS_FS, res);
-          __builtin_amdgcn_sched_barrier(0);     // (a tile's contraction is done before the next tile starts: one accumulator live)
-        }
-        rows_gseq_finish(G, gacc, ridrow, shrow, mine, src_reg, res[0]);
-      }
-      // the runs the tiles did not cover, on their own (the same steps back to back), then the tiles left over
       while (G.run < G.nruns) {
 #pragma unroll
         for (int ks = 0; ks < NS; ++ks) {
-          // (static k-steps: the switch is resolved at compile time)
-          if (ks == 0) rows_gseq_step<NS, GR, 0>(G, gr, gacc, ah, al);
-          else if (ks == 1) rows_gseq_step<NS, GR, 1 % NS>(G, gr, gacc, ah, al);
-          else if (ks == 2) rows_gseq_step<NS, GR, 2 % NS>(G, gr, gacc, ah, al);
-          else if (ks == 3) rows_gseq_step<NS, GR, 3 % NS>(G, gr, gacc, ah, al);
-          else if (ks == 4) rows_gseq_step<NS, GR, 4 % NS>(G, gr, gacc, ah, al);
-          else if (ks == 5) rows_gseq_step<NS, GR, 5 % NS>(G, gr, gacc, ah, al);
-          else if (ks == 6) rows_gseq_step<NS, GR, 6 % NS>(G, gr, gacc, ah, al);
-          else if (ks == 7) rows_gseq_step<NS, GR, 7 % NS>(G, gr, gacc, ah, al);
-          else if (ks == 8) rows_gseq_step<NS, GR, 8 % NS>(G, gr, gacc, ah, al);
-          else if (ks == 9) rows_gseq_step<NS, GR, 9 % NS>(G, gr, gacc, ah, al);
-          else if (ks == 10) rows_gseq_step<NS, GR, 10 % NS>(G, gr, gacc, ah, al);
-          else rows_gseq_step<NS, GR, 11 % NS>(G, gr, gacc, ah, al);
+          // (static k-steps: the chain is resolved at compile time)
+          if (ks == 0) rows_gseq_step<NS, GR1, 0>(G, gr, gacc, ah, al);
+          else if (ks == 1) rows_gseq_step<NS, GR1, 1 % NS>(G, gr, gacc, ah, al);
+          else if (ks == 2) rows_gseq_step<NS, GR1, 2 % NS>(G, gr, gacc, ah, al);
+          else if (ks == 3) rows_gseq_step<NS, GR1, 3 % NS>(G, gr, gacc, ah, al);
+          else if (ks == 4) rows_gseq_step<NS, GR1, 4 % NS>(G, gr, gacc, ah, al);
+          else if (ks == 5) rows_gseq_step<NS, GR1, 5 % NS>(G, gr, gacc, ah, al);
+          else if (ks == 6) rows_gseq_step<NS, GR1, 6 % NS>(G, gr, gacc, ah, al);
+          else if (ks == 7) rows_gseq_step<NS, GR1, 7 % NS>(G, gr, gacc, ah, al);
+          else if (ks == 8) rows_gseq_step<NS, GR1, 8 % NS>(G, gr, gacc, ah, al);
+          else if (ks == 9) rows_gseq_step<NS, GR1, 9 % NS>(G, gr, gacc, ah, al);
+          else if (ks == 10) rows_gseq_step<NS, GR1, 10 % NS>(G, gr, gacc, ah, al);
+          else rows_gseq_step<NS, GR1, 11 % NS>(G, gr, gacc, ah, al);
         }
         rows_gseq_finish(G, gacc, ridrow, shrow, mine, src_reg, res[0]);
       }
-      for (; j < cnt1; ++j, ++t) {
-        constexpr int KPP = NS / ROWS_NP, PIECE_Q = 2 * KPP * 64;
-        f32x16 acc;
-        rows_stream_step<NS, 0>(ring, wsh, t, RL.nts, wave, lane);
-        acc = splat16(lbias[t * 32 + r]);
-        rows_piece_lds<NS, 0>(ring, ah, al, lane, acc);
-        rows_stream_step<NS, 1>(ring, wsh, t, RL.nts, wave, lane);
-        rows_piece_lds<NS, KPP>(ring + PIECE_Q, ah, al, lane, acc);
-        rows_stream_step<NS, 2>(ring, wsh, t, RL.nts, wave, lane);
-        rows_piece_lds<NS, 2 * KPP>(ring + 2 * PIECE_Q, ah, al, lane, acc);
-        int u = (B.nsub > 1) ? j : j * B.ups + us;
-        if (!(valid && u < B.U)) u = 0;
-        rows_epilogue<1>(acc, F + u * ROWS_FS + 4 * hh, ROWS_FS, res);
-      }
-      interleaved = true;
+      gdone = true;
     }
   }
 
   // ---- factorised features (G runs), multiplied by the harmonics once
-  if (!interleaved && B.g_slot >= 0 && rmask != 0u) {
+  if (!gdone && B.g_slot >= 0 && rmask != 0u) {
     const float* shrow = &aux->shT[(C == 1) ? 0 : 1][4 * hh];
     // (the pair's products of block B wait in the wave's private LDS area, not in 16 registers across block A's stream tiles)
     f32x4* pair = reinterpret_cast<f32x4*>(const_cast<RowsAux*>(aux) + 1) + (hh * 16 + min(max(r - B.n, 0), 15)) * 4;
@@ -654,10 +564,10 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
     }
   }
 
-  if (!interleaved) RSTAMP(5 + 3 * sgi);
+  RSTAMP(5 + 3 * sgi);
   // ---- the segment's stream tiles (vector-input features)
   const int cnt = (B.ntiles == 0 || B.U == 0) ? 0 : (B.nsub > 1 ? B.U : (B.U + B.ups - 1) / B.ups);
-  if (cnt > 0 && !interleaved) {
+  if (cnt > 0) {
     for (int j = 0; j < cnt; ++j, ++t) {
       constexpr int KPP = NS / ROWS_NP, PIECE_Q = 2 * KPP * 64;
       f32x16 acc;
@@ -732,6 +642,10 @@ __global__ __launch_bounds__(ROWS_NT, 2) void ddp_conv_rows_kernel(const RowsLau
   const RowsStream wsh = rows_stream_of(T.wsh, RL.nts, 2 * NS * 1024);
   const int nvw = max(0, min(32, nvalid - 32 * wave));      // valid edges of this wave
   RSTAMP(0);
+#ifdef DDP_ROWS_STAGGER   // experiment: are the two workgroups of a CU in the same phase all the time?  half of them start ~35 k clocks late
+  if (((int)blockIdx.x >> DDP_ROWS_STAGGER) & 1)
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
 
   // ---- the wave's edges (rows behind the last valid one repeat it: every load stays in bounds, nothing of theirs is stored)
   const int pr = p0 + min(32 * wave + r, nvalid - 1);

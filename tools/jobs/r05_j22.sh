@@ -1,0 +1,9 @@
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05_j22; mkdir -p $O; cd $R
+ulimit -c 0
+B="python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-workloads --no-roofline-pass"
+for v in "" noil noil12 noil12b; do
+  if [ -n "$v" ]; then export DDP_HIP_LIB=$R/diffdock_pocket_amd/libddp_hip_$v.so; fi
+  [ -n "$v" ] && [ ! -f "$DDP_HIP_LIB" ] && continue
+  timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "single_conv_layer or test_every_conv_output" 2>&1 | tail -1
+  for i in 1 2; do timeout 300 $B > $O/b.json 2>$O/b.err; echo "variant [$v]: $(grep -o '"ms_per_step": [0-9.]*' $O/b.json | head -1)"; done
+done

@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["DDP_HIP_LIB"] = os.path.join(ROOT, "diffdock_pocket_amd", "libddp_hip_rowstamps.so")
+os.environ["DDP_HIP_LIB"] = os.environ.get("STAMP_LIB", os.path.join(ROOT, "diffdock_pocket_amd", "libddp_hip_rowstamps.so"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
