@@ -190,18 +190,26 @@ __device__ __forceinline__ void rows_stream_step(f32x4* ring, RowsStream wsh, in
   rows_request_piece<NS>(ring, wsh, ROWS_NP * t + P + 2, ROWS_NP * nts, (P + 2) % ROWS_NP, wave, lane);
 }
 
-// acc += A(regs, k-steps KS0 ..) x B(piece in LDS): 3 split products per 16 k, B fragments read one k-step ahead
+// acc += A(regs, k-steps KS0 ..) x B(piece in LDS): 3 split products per 16 k, B fragments read DDP_ROWS_BDIST k-steps ahead
+#ifndef DDP_ROWS_BDIST
+#define DDP_ROWS_BDIST 2
+#endif
 template <int NS, int KS0>
 __device__ __forceinline__ void rows_piece_lds(const f32x4* slot, const h8 (&ah)[NS], const h8 (&al)[NS], int lane, f32x16& acc) {
-  constexpr int NK = NS / ROWS_NP;
-  f32x4 b0 = slot[lane], b1 = slot[64 + lane];
+  constexpr int NK = NS / ROWS_NP, D = (DDP_ROWS_BDIST < NK) ? DDP_ROWS_BDIST : NK;
+  f32x4 b[D + 1][2];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    b[k][0] = slot[(2 * k) * 64 + lane];
+    b[k][1] = slot[(2 * k + 1) * 64 + lane];
+  }
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
-    const h8 bh = __builtin_bit_cast(h8, b0), bl = __builtin_bit_cast(h8, b1);
-    if (k + 1 < NK) {
-      b0 = slot[(2 * k + 2) * 64 + lane];
-      b1 = slot[(2 * k + 3) * 64 + lane];
+    if (k + D < NK) {
+      b[(k + D) % (D + 1)][0] = slot[(2 * (k + D)) * 64 + lane];
+      b[(k + D) % (D + 1)][1] = slot[(2 * (k + D) + 1) * 64 + lane];
     }
+    const h8 bh = __builtin_bit_cast(h8, b[k % (D + 1)][0]), bl = __builtin_bit_cast(h8, b[k % (D + 1)][1]);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS0 + k], bh, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS0 + k], bl, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[KS0 + k], bh, acc, 0, 0, 0);
@@ -435,16 +443,22 @@ template <int NS, int GR, int KS>
 __device__ __forceinline__ void rows_gseq_step(RowsGSeq& G, f32x4 (&gr)[GR], f32x16& gacc, const h8 (&ah)[NS], const h8 (&al)[NS]) {
   constexpr int NF = 2 * NS, q0 = 2 * KS + GR, kq = (q0 < NF) ? (q0 >> 1) : ((q0 - NF) >> 1);
   __builtin_amdgcn_sched_barrier(0);
+#if !defined(DDP_ROWS_ABL_GSEQ) || DDP_ROWS_ABL_GSEQ != 2     // (timing-only ablations: 1 = no fragment loads behind the first ring fill, 2 = loads, no products)
   {
     const h8 bh = __builtin_bit_cast(h8, gr[(2 * KS) % GR]), bl = __builtin_bit_cast(h8, gr[(2 * KS + 1) % GR]);
     gacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS], bh, gacc, 0, 0, 0);
     gacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS], bl, gacc, 0, 0, 0);
     gacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[KS], bh, gacc, 0, 0, 0);
   }
+#else
+  gacc[0] += gr[(2 * KS) % GR][0] + gr[(2 * KS + 1) % GR][1];
+#endif
   __builtin_amdgcn_sched_barrier(0);
+#if !defined(DDP_ROWS_ABL_GSEQ) || DDP_ROWS_ABL_GSEQ != 1
   const RowsStream srcb = (q0 < NF) ? G.rs : G.rsn;
   gr[(2 * KS) % GR] = ROWS_GSEQ_FRAG(G, srcb, kq, 0);
   gr[(2 * KS + 1) % GR] = ROWS_GSEQ_FRAG(G, srcb, kq, 1);
+#endif
   __builtin_amdgcn_sched_barrier(0);
 }
 // the run's last k-step is done: res[row] += sh0[row] * product for the rows of THIS run (lanes behind the tile's last column: nothing)
@@ -642,10 +656,6 @@ __global__ __launch_bounds__(ROWS_NT, 2) void ddp_conv_rows_kernel(const RowsLau
   const RowsStream wsh = rows_stream_of(T.wsh, RL.nts, 2 * NS * 1024);
   const int nvw = max(0, min(32, nvalid - 32 * wave));      // valid edges of this wave
   RSTAMP(0);
-#ifdef DDP_ROWS_STAGGER   // experiment: are the two workgroups of a CU in the same phase all the time?  half of them start ~35 k clocks late
-  if (((int)blockIdx.x >> DDP_ROWS_STAGGER) & 1)
-    for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
 
   // ---- the wave's edges (rows behind the last valid one repeat it: every load stays in bounds, nothing of theirs is stored)
   const int pr = p0 + min(32 * wave + r, nvalid - 1);

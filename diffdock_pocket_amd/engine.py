@@ -138,6 +138,7 @@ class ForwardEngine:
         lig, rec, atom = data["ligand"], data["receptor"], data["atom"]
         dev = lig.pos.device
         m._refresh_weight_caches()
+        m.rows_all_or_none(dev)
         m.check_overflow(range_too=m.range_check_in_forward)
         K.CONV_H2 = m.conv_h2       # the form of the fc products this forward's tasks are built for (score_model.conv_h2)
         if dev in self._forks:      # (a forward that raised may have left streams marked as forked: the next fork waits for main again)

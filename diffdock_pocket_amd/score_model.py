@@ -187,11 +187,15 @@ class TensorProductConvLayer(nn.Module):
             # kernel's k order, and stage-A right-hand sides whose product ddp_stage_a_gh writes as fp16 hi/lo planes
             pk.wsh = pk.bsp = pk.wgh = pk.gh_groups = None
             if P.rows_supported(self.spec_g):
-                wsh, bsp = P.rows_stream(self.spec_g, self.fc[0].weight, self.fc[0].bias, self.fc[3].weight, self.fc[3].bias)
-                pk.wsh, pk.bsp = wsh.to(device), bsp.to(device)
-                wgh, _, widths = P.factor_weights_gh(self.spec_g, self.fc[3].weight, self.fc[3].bias)
-                pk.wgh = [w.to(device) if w is not None else None for w in wgh]
-                pk.gh_groups = widths          # (per slot: the padded widths of the G array's column parts)
+                try:
+                    wsh, bsp = P.rows_stream(self.spec_g, self.fc[0].weight, self.fc[0].bias, self.fc[3].weight, self.fc[3].bias)
+                except NotImplementedError:
+                    wsh = None      # a weight beyond the unified planes' range (|w| > 255): this conv keeps the 32-edge kernel
+                if wsh is not None:
+                    pk.wsh, pk.bsp = wsh.to(device), bsp.to(device)
+                    wgh, _, widths = P.factor_weights_gh(self.spec_g, self.fc[3].weight, self.fc[3].bias)
+                    pk.wgh = [w.to(device) if w is not None else None for w in wgh]
+                    pk.gh_groups = widths          # (per slot: the padded widths of the G array's column parts)
             self._packed_g = pk
         return self._packed_g
 
@@ -678,9 +682,24 @@ class TensorProductScoreModel(nn.Module):
             self.__dict__["_conv_h2"] = value
             self.__dict__["_packed_epoch"] = self.__dict__.get("_packed_epoch", 0) + 1
 
+    def rows_all_or_none(self, device):
+        """ddp_conv_rows runs either every factorised conv of its size class or none: stage A writes the G of several convs in one
+        launch, in ONE layout.  A conv whose weights the kernel's operand planes cannot hold (|w| > 255, packing.rows_stream) therefore
+        switches the model's factorised convs back to the 32-edge kernel.  Checked once per set of packed weights."""
+        if self.__dict__.get("_rows_checked_epoch") == self.__dict__.get("_packed_epoch", 0):
+            return
+        convs = [m for m in self.modules() if isinstance(m, TensorProductConvLayer) and getattr(m, "spec_g", None) is not None
+                 and P.rows_supported(m.spec_g)]
+        pks = [c.packed_g(device) for c in convs]
+        if any(pk.wsh is None for pk in pks):
+            for pk in pks:
+                pk.wsh = pk.bsp = pk.wgh = pk.gh_groups = None
+        self.__dict__["_rows_checked_epoch"] = self.__dict__.get("_packed_epoch", 0)
+
     def invalidate_packed(self):
         # (a captured step holds the ADDRESSES of what is dropped here: sampler.Sampler compares this counter before a replay)
         self.__dict__["_packed_epoch"] = self.__dict__.get("_packed_epoch", 0) + 1
+        self.__dict__["_rows_checked_epoch"] = None
         self._weights_seen = None
         self._weights_seen_fp = None
         self.__dict__["_weight_tensors_"] = None
