@@ -1,4 +1,4 @@
-// ddp_conv_rows.hip - the factorised conv (fc -> FasterTensorProduct -> message, csrc/ddp_conv.hip's contract) through 256-edge,
+// ddp_conv_rows.hip - the factorised conv (fc -> FasterTensorProduct -> message, csrc/ddp_conv.hip's contract) through 128-edge,
 // ROW-STATIONARY workgroups for gfx950 (round 5).
 //
 // Replaces, per conv (reference file:line):  edge_attr_ = cat(...)  models/all_atom_score_model.py:273-312;  w = fc(edge_attr_)
@@ -7,23 +7,27 @@
 // Why: the 32-edge kernel (ddp_conv32_kernel<60, h2>) streams the whole packed fc.3 weight set (1.47 MB) and ~0.5 MB of G rows
 // through every 32-edge workgroup: 278 M L2 requests of 128 B per 2.3-ms launch = 15.3 TB/s of L2 -> CU traffic, L2 busy 90 %
 // (profiles/r05_pmc_conv32_h2_l1_l2.json) against the 16.8 - 18.8 TB/s the chip delivers from its XCD L2s - the matrix pipe sat at
-// 31 %.  Here the weights leave L2 once per 256 edges:
+// 31 %.  Here the weights leave L2 once per 128 edges:
 //   workgroup = 4 waves (one per SIMD, 256 registers each), TWO per CU, 128 consecutive (source-ordered) edges of one conv: the two
 //     co-resident workgroups are independent, so one's memory-bound G runs overlap the other's matrix-bound stream tiles (one
 //     8-wave workgroup per CU ran every phase in lock-step behind its barriers: 480 k ticks per 256 edges, G runs 45 % of them);
 //   wave w owns the 32 edges [32 w, 32 w + 32) for the whole kernel and keeps h = relu(fc1) of them as the A-operand fragments
 //     of v_mfma_f32_32x32x16_f16 in REGISTERS (fp16 hi/lo planes: 8 NS registers);
+//   every operand is a pair of UNIFIED fp16 planes (V = v 2^s = hi + lo, both halves at one scale; DDP_ROWS_S* of include/ddp_hip.h):
+//     the three split products of a k-step accumulate into ONE register tile (the form v = hi + lo / 2048 of the other kernels needs
+//     two, and a multiply-add per element to join them);
 //   the weight tiles (task.wsh: the fc.0 tiles, then the fc.3 tiles segment by segment) are staged once per workgroup through a
-//     three-slot LDS ring of THIRD tiles (8 KiB each) by LDS-DMA - every wave moves 1/4 of the piece after next, one barrier per piece -
-//     and all four waves read their B operands from LDS (conflict-free lane-linear 16-byte reads);
+//     three-slot LDS ring of THIRD tiles (8 KiB each) by LDS-DMA (buffer loads to LDS) - every wave moves 1/4 of the piece after
+//     next, one BARE barrier per piece - and all four waves read their B operands from LDS (conflict-free lane-linear 16-byte reads);
 //   h comes from the TRANSPOSED fc1 product (A = fc.0 tile, B = edge_attr_ fragments gathered straight from the three row
 //     segments): the accumulator of column tile ct leaves lane (edge, hh) with 16 h values of its own edge, which ARE the k-groups
 //     (2 ct, hh) and (2 ct + 1, hh) of the next products in the permuted k order DDP_ROWS_KPERM (the host packs fc.3 and G in it);
 //   a segment = one 32-column part of one weight block's output columns: a wave accumulates EVERYTHING that lands there in
 //     registers - first the factorised features (one pass of the same tile product per run of edges with one source node, B = the
-//     node's G tile in plane form, task.gh, straight from memory through a 4-fragment register ring; rows outside the run are
-//     masked in the epilogue), then the segment's stream tiles (the vector-input features) - and stores the message columns;
-//     no message tile in LDS, no cross-wave reduction, no atomics.
+//     node's G tile in plane form, task.gh, straight from memory through a register ring: 12 fragments by buffer loads for the
+//     scalar segments, 8 by global loads for the merged pair of vector blocks; the rows of a run are selected from its product),
+//     then the segment's stream tiles (the vector-input features) - and stores the message columns; no message tile in LDS, no
+//     cross-wave reduction, no atomics.
 // Per 32 edges: 0.18 MB of weights + ~0.26 MB of G (whole runs: 2.5 per 32 edges at 3dpf) from L2 instead of 2.0 MB.
 // Summation order of a message element: G runs in edge order, then the stream tiles in feature order, then (blocks with several
 // features per tile) the lane groups in order: fixed, bitwise reproducible; within fp32 rounding of ddp_conv_messages.
@@ -190,26 +194,19 @@ __device__ __forceinline__ void rows_stream_step(f32x4* ring, RowsStream wsh, in
   rows_request_piece<NS>(ring, wsh, ROWS_NP * t + P + 2, ROWS_NP * nts, (P + 2) % ROWS_NP, wave, lane);
 }
 
-// acc += A(regs, k-steps KS0 ..) x B(piece in LDS): 3 split products per 16 k, B fragments read DDP_ROWS_BDIST k-steps ahead
-#ifndef DDP_ROWS_BDIST
-#define DDP_ROWS_BDIST 2
-#endif
+// acc += A(regs, k-steps KS0 ..) x B(piece in LDS): 3 split products per 16 k on ONE accumulator (unified planes), B fragments read one
+// k-step ahead (two or four k-steps ahead: the same step time, 18.15 ms)
 template <int NS, int KS0>
 __device__ __forceinline__ void rows_piece_lds(const f32x4* slot, const h8 (&ah)[NS], const h8 (&al)[NS], int lane, f32x16& acc) {
-  constexpr int NK = NS / ROWS_NP, D = (DDP_ROWS_BDIST < NK) ? DDP_ROWS_BDIST : NK;
-  f32x4 b[D + 1][2];
-#pragma unroll
-  for (int k = 0; k < D; ++k) {
-    b[k][0] = slot[(2 * k) * 64 + lane];
-    b[k][1] = slot[(2 * k + 1) * 64 + lane];
-  }
+  constexpr int NK = NS / ROWS_NP;
+  f32x4 b0 = slot[lane], b1 = slot[64 + lane];
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
-    if (k + D < NK) {
-      b[(k + D) % (D + 1)][0] = slot[(2 * (k + D)) * 64 + lane];
-      b[(k + D) % (D + 1)][1] = slot[(2 * (k + D) + 1) * 64 + lane];
+    const h8 bh = __builtin_bit_cast(h8, b0), bl = __builtin_bit_cast(h8, b1);
+    if (k + 1 < NK) {
+      b0 = slot[(2 * k + 2) * 64 + lane];
+      b1 = slot[(2 * k + 3) * 64 + lane];
     }
-    const h8 bh = __builtin_bit_cast(h8, b[k % (D + 1)][0]), bl = __builtin_bit_cast(h8, b[k % (D + 1)][1]);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS0 + k], bh, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS0 + k], bl, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[KS0 + k], bh, acc, 0, 0, 0);

@@ -1,0 +1,9 @@
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05_j30; mkdir -p $O; cd $R
+ulimit -c 0
+for rep in 1 2; do
+for v in new gp3 sp3; do
+  unset DDP_HIP_LIB
+  [ $v != new ] && export DDP_HIP_LIB=$R/diffdock_pocket_amd/libddp_hip_$v.so
+  timeout 300 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-workloads --no-roofline-pass > $O/b_$v.json 2>$O/b_$v.err; echo "variant [$v]: $(grep -o '"ms_per_step": [0-9.]*' $O/b_$v.json | head -1)"
+done
+done

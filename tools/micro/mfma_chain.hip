@@ -12,6 +12,8 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 template <int CH>
 __global__ __launch_bounds__(256, 2) void chain(float* out, unsigned long long* clk, int iters, int pad_regs) {
+  extern __shared__ float lds_pad[];     // (70 KiB per workgroup: at most two workgroups per CU, i.e. exactly W waves per SIMD)
+  if (pad_regs == 12345) lds_pad[threadIdx.x] = 1.f;
   const int lane = threadIdx.x & 63;
   h8 a[12], b[12];
 #pragma unroll
@@ -49,14 +51,16 @@ int main() {
   const int maxwg = 256 * 2;
   CK(hipMalloc(&out, sizeof(float) * maxwg * 256));
   CK(hipMalloc(&clk, sizeof(unsigned long long) * 2 * maxwg));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 70 * 1024));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(chain<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 70 * 1024));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int ch = 1; ch <= 2; ++ch)
     for (int wgs_per_cu = 1; wgs_per_cu <= 2; ++wgs_per_cu) {
       const int nwg = 256 * wgs_per_cu;
       for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0));
-        if (ch == 1) hipLaunchKernelGGL(chain<1>, dim3(nwg), dim3(256), 0, 0, out, clk, iters, 0);
-        else hipLaunchKernelGGL(chain<2>, dim3(nwg), dim3(256), 0, 0, out, clk, iters, 0);
+        if (ch == 1) hipLaunchKernelGGL(chain<1>, dim3(nwg), dim3(256), 70 * 1024, 0, out, clk, iters, 0);
+        else hipLaunchKernelGGL(chain<2>, dim3(nwg), dim3(256), 70 * 1024, 0, out, clk, iters, 0);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       }
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
