@@ -174,14 +174,16 @@ typedef struct {
  * concatenations (models/all_atom_score_model.py:273-312).  The [E, weight_numel] tensor never exists. */
 int ddp_conv_messages(const ddp_conv_shape_t* shape, const ddp_conv_task_t* tasks, int ntasks, void* stream);
 
-/* The same contract as ddp_conv_messages for FACTORISED shapes of the size classes with an h2 form (f_in = hid = 3 ns), through
- * 256-edge workgroups (8 waves, one workgroup per CU): every wave keeps h of ITS 32 edges as A-operand fragments in registers, the
- * weight tiles (task.wsh) are staged ONCE per workgroup through an LDS ring and read from there by all eight waves, the factorised
+/* The same contract as ddp_conv_messages for FACTORISED shapes of the size classes ns = 60 / 32 (f_in = hid = 3 ns), through
+ * 128-edge workgroups (4 waves, two workgroups per CU): every wave keeps h of ITS 32 edges as A-operand fragments in registers, the
+ * weight tiles (task.wsh) are staged ONCE per workgroup through an LDS ring and read from there by all four waves, the factorised
  * features are G tiles (task.gh: one pass of the same tile product per run of edges with one source node), and a wave accumulates
- * all contributions to its output columns in registers and stores message rows directly: the fc.3 weights leave L2 once per 256
+ * all contributions to its output columns in registers and stores message rows directly: the fc.3 weights leave L2 once per 128
  * edges instead of once per 32 (the 32-edge kernel was bound by that traffic: 15 TB/s of L2 -> CU reads, L2 90 % busy).
- * Every task needs wsh, bsp and - for shapes with g_cols != 0 - gh.  Results: within fp32 rounding of ddp_conv_messages (another
- * summation order), deterministic. */
+ * Every task needs wsh, bsp and - for shapes with g_cols != 0 - gh (unified fp16 hi/lo planes, DDP_ROWS_S* above).  A value beyond
+ * the planes' range (|edge_attr_| or |h| > 4094: h2_range_flag; |w| > 255: refused by packing.rows_stream; |G| > 2047: ddp_stage_a_gh's
+ * range flag) is reported, never saturated.  Results: within fp32 rounding of ddp_conv_messages (another summation order),
+ * deterministic. */
 int ddp_conv_rows(const ddp_conv_shape_t* shape, const ddp_conv_task_t* tasks, int ntasks, void* stream);
 
 /* Segmented mean over CSR rows + e3nn BatchNorm (eval) + residual accumulate:
@@ -379,9 +381,10 @@ int ddp_stage_a_h2(const float* x, int ldx, int nrows, const int32_t* rows, cons
 /* ... with every output row written in the plane form of ddp_conv_task_t::gh.  The host orders the product's columns [part][k8][c][8]
  * (packing.factor_weights_gh) and passes, per batch entry and per group of 8 columns, the float offsets inside the row of the group's two
  * 16-byte pieces: dest[b][g][0..1], device int32 [nbatch][ncols / 8][2]; bit 0 of dest[b][g][0] marks a plane group: the 8 k's of one
- * k8 group of one G column, whose values v = hi + lo / 2048 leave as 8 fp16 hi words at dest[..][0] & ~3 and 8 fp16 lo words at
- * dest[..][1] - the same bytes as the fp32 form, the same number of stores.  The other groups are 8 fp32 columns stored as they are (Gb,
- * padding).
+ * k8 group of one G column, whose values V leave as UNIFIED planes (ddp_conv_task_t, ABI 14): 8 fp16 hi words fp16(V) at
+ * dest[..][0] & ~3 and 8 fp16 lo words fp16(V - hi) at dest[..][1] - the same bytes as the fp32 form, the same number of stores; the
+ * plane scale DDP_ROWS_SG rides in the right-hand side's G columns (V = DDP_ROWS_SG G), |V| > 65504 raises range_flag.  The other groups
+ * are 8 fp32 columns stored as they are (Gb, padding).
  * Only on the h2 path (w_h2 given, k in {60, 32, 24, 16}, ncols % 32 == 0).  ABI 13. */
 int ddp_stage_a_gh(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows, const int32_t* offs,
                    int nbatch, const float* w, const void* w_h2, int k, int ncols, float* out, int ldo, int32_t* range_flag,
