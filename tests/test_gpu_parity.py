@@ -620,6 +620,48 @@ def test_single_conv_layer(ns, nv, layer, E, N, factorized):
     assert z.dim() == 0 and float(z) == 0.0
 
 
+@pytest.mark.parametrize("mag", [1.0, 1e-2, 1e-4])
+def test_rows_kernel_operand_planes_at_small_magnitudes(mag):
+    """ddp_conv_rows computes on UNIFIED fp16 hi/lo planes (V = v 2^s = hi + lo, both halves at one scale: include/ddp_hip.h DDP_ROWS_S*):
+    22 significant bits while lo is a normal fp16 number, an ABSOLUTE floor of 2^-25 / 2^s per operand element below that (2^-29 for
+    edge_attr_ and h, 2^-33 for the fc weights, 2^-30 for G).  Asserted here on a factorised ns = 60 conv whose edge_attr_ AND node
+    features are scaled down to 1e-2 and 1e-4 (the model's own operands are O(1e-2 ... 10)): the messages stay within
+    2e-5 max|message| + the floor's share, K 2^-29 max|w| per product, of the oracle's."""
+    from diffdock_pocket_amd import launch as K
+    from diffdock_pocket_amd import packing as P
+    from diffdock_pocket_amd.score_model import TensorProductConvLayer
+    ns, nv, layer, E, N = 60, 10, 3, 700, 60
+    torch.manual_seed(11)
+    mi, mo = P.irreps_muls(ns, nv, layer), P.irreps_muls(ns, nv, layer + 1)
+    spec = P.faster_tp_spec(mi, mo, 3 * ns)
+    blocks = [(m, d, s) for m, d, s in ((mo[0], 1, True), (mo[1], 3, False), (mo[2], 3, False), (mo[3], 1, False)) if m]
+    conv = TensorProductConvLayer(spec, blocks, batch_norm=False, spec_g=P.faster_tp_spec(mi, mo, 3 * ns, factorized=True))
+    x = torch.randn(N, P.irreps_dim(mi)) * mag
+    src = torch.sort(torch.randint(0, N, (E,)))[0]
+    ei = torch.stack([torch.randint(0, N, (E,)), src])
+    ea = torch.randn(E, 3 * ns) * mag
+    sh = tp.spherical_harmonics("1x0e+1x1o", torch.randn(E, 3))
+    cfg = OracleConfig(ns=ns, nv=nv, batch_norm=False)
+    sd = {"c." + k: v for k, v in conv.state_dict().items()}
+    want = OracleScoreModel(cfg, sd)._conv("c", cfg.irreps(layer), cfg.irreps(layer + 1), x, ei, ea, sh)
+    dev = _dev()
+    conv = conv.to(dev)
+    assert K.CONV_ROWS and K.rows_mode(conv.packed_g(dev))
+    got = conv(x.to(dev), ei.to(dev), ea.to(dev), sh.to(dev), factorized=True).cpu()
+    rows_was = K.CONV_ROWS
+    K.CONV_ROWS = False
+    try:
+        ref32 = conv(x.to(dev), ei.to(dev), ea.to(dev), sh.to(dev), factorized=True).cpu()     # the 32-edge kernel's 2048-scaled planes
+    finally:
+        K.CONV_ROWS = rows_was
+    base = want
+    wmax = float(max(conv.fc[0].weight.abs().max(), conv.fc[3].weight.abs().max()))
+    floor = 192 * 2.0 ** -29 * wmax * 4.0      # K products per output, a few outputs summed per message element
+    tol = 2e-5 * float(base.abs().max()) + floor
+    assert float((got - base).abs().max()) <= tol, (mag, float((got - base).abs().max()), tol)
+    assert float((got - ref32).abs().max()) <= tol, (mag, float((got - ref32).abs().max()), tol)
+
+
 def test_edge_featurize_and_torsion_sh():
     import ctypes as C
     from diffdock_pocket_amd import _lib as L
