@@ -11,7 +11,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 template <int CH>
-__global__ __launch_bounds__(256, 2) void chain(float* out, unsigned long long* clk, int iters, int pad_regs) {
+__global__ __launch_bounds__(256, 2) void chain(float* out, unsigned long long* clk, int iters, int pad_regs, const h8* __restrict__ rnd) {
   extern __shared__ float lds_pad[];     // (70 KiB per workgroup: at most two workgroups per CU, i.e. exactly W waves per SIMD)
   if (pad_regs == 12345) lds_pad[threadIdx.x] = 1.f;
   const int lane = threadIdx.x & 63;
@@ -20,6 +20,10 @@ __global__ __launch_bounds__(256, 2) void chain(float* out, unsigned long long* 
   for (int k = 0; k < 12; ++k)
 #pragma unroll
     for (int i = 0; i < 8; ++i) { a[k][i] = (_Float16)(0.001f * (lane + k + i)); b[k][i] = (_Float16)(0.002f * (lane - k + i)); }
+  if (rnd) {     // operands of random bits (what real data looks like to the multipliers)
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { a[k] = rnd[(2 * k) * 64 + lane]; b[k] = rnd[(2 * k + 1) * 64 + lane]; }
+  }
   f32x16 acc[CH];
 #pragma unroll
   for (int c = 0; c < CH; ++c)
@@ -54,13 +58,22 @@ int main() {
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 70 * 1024));
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(chain<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 70 * 1024));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  h8* rnd;
+  {
+    _Float16 hr[24 * 64 * 8];
+    srand(3);
+    for (auto& v : hr) v = (_Float16)((rand() / (float)RAND_MAX) * 4.f - 2.f);
+    CK(hipMalloc(&rnd, sizeof(hr)));
+    CK(hipMemcpy(rnd, hr, sizeof(hr), hipMemcpyHostToDevice));
+  }
+  for (int random = 0; random <= 1; ++random)
   for (int ch = 1; ch <= 2; ++ch)
     for (int wgs_per_cu = 1; wgs_per_cu <= 2; ++wgs_per_cu) {
       const int nwg = 256 * wgs_per_cu;
       for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0));
-        if (ch == 1) hipLaunchKernelGGL(chain<1>, dim3(nwg), dim3(256), 70 * 1024, 0, out, clk, iters, 0);
-        else hipLaunchKernelGGL(chain<2>, dim3(nwg), dim3(256), 70 * 1024, 0, out, clk, iters, 0);
+        if (ch == 1) hipLaunchKernelGGL(chain<1>, dim3(nwg), dim3(256), 70 * 1024, 0, out, clk, iters, 0, random ? rnd : nullptr);
+        else hipLaunchKernelGGL(chain<2>, dim3(nwg), dim3(256), 70 * 1024, 0, out, clk, iters, 0, random ? rnd : nullptr);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       }
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -68,7 +81,7 @@ int main() {
       double ticks = 0, real = 0; for (int i = 0; i < nwg; ++i) { ticks += h[2 * i]; real += h[2 * i + 1]; }
       ticks /= nwg; real /= nwg;
       const double nm = 36.0 * iters, fl = nm * 32768.0 * nwg * 4;
-      printf("chains %d, %d wave(s) per SIMD: %.3f ms, %.0f TFLOP/s fp16, %.1f ticks per MFMA and wave, clock %.0f MHz (ticks / realtime x 100 MHz)\n", ch, wgs_per_cu, ms,
+      printf("%s operands, chains %d, %d wave(s) per SIMD: %.3f ms, %.0f TFLOP/s fp16, %.1f ticks per MFMA and wave, clock %.0f MHz (ticks / realtime x 100 MHz)\n", random ? "random" : "smooth", ch, wgs_per_cu, ms,
              fl / ms * 1e-9, ticks / nm, ticks / real * 100.0);
     }
   return 0;
