@@ -62,6 +62,8 @@ def mixed_roofline(fc16, other, sec):
     t_min = 3.0 * fc16 / (F16_MFMA_PEAK_TFLOPS * 1e12) + other / (FP32_MFMA_PEAK_TFLOPS * 1e12)
     return issued / sec / 1e12, issued / t_min / 1e12, t_min / sec
 HBM_PEAK_GBS = 8000.0           # same guide: HBM3E ~8 TB/s
+SUSTAINED_F16_MFMA_TFLOPS = 1700.0     # measured: every SIMD issuing v_mfma_f32_32x32x16_f16 back to back (1.6 - 1.75 PFLOP/s at 1.55 - 1.75 GHz)
+SUSTAINED_TILE_LOOP_TFLOPS = 1160.0    # measured: the stream-tile loop of ddp_conv_rows alone (388 TFLOP/s fp32-equivalent x 3)
 PMC_FILE = os.path.join("profiles", "r05_pmc.json")
 
 
@@ -536,6 +538,16 @@ def main(argv=None):
                      "mfma_mix": {"fc_products_as_fp16_hi_lo_split_gflop_per_launch": fc16 / n_ / 1e9, "fp32_gflop_per_launch": oth / n_ / 1e9,
                                   "fp16_mfma_peak": F16_MFMA_PEAK_TFLOPS, "fp32_mfma_peak": FP32_MFMA_PEAK_TFLOPS,
                                   "instruction_flops_per_split_product_flop": 3},
+                     # what this chip SUSTAINS (profiles/r05_mfma_chain_micro.txt, r05_stream_wide_micro.txt): the
+                     # dense peak above is the guide's 2.5 PFLOP/s at 2.4 GHz; measured on the builder's boxes, not in this run
+                     "sustained_mfma": {"fp16_mfma_from_registers_tflops": SUSTAINED_F16_MFMA_TFLOPS,
+                                        "tile_loop_with_lds_operands_tflops": SUSTAINED_TILE_LOOP_TFLOPS,
+                                        "frac_of_mfma_from_registers": frac * F16_MFMA_PEAK_TFLOPS / SUSTAINED_F16_MFMA_TFLOPS,
+                                        "frac_of_tile_loop": frac * F16_MFMA_PEAK_TFLOPS / SUSTAINED_TILE_LOOP_TFLOPS,
+                                        "note": "back-to-back v_mfma_f32_32x32x16_f16 from registers on every SIMD run at 1.55 - 1.75 GHz "
+                                                "(tools/micro/mfma_chain.hip); the stripped stream-tile loop of ddp_conv_rows (operands from an "
+                                                "LDS ring, feature contraction) sustains 1.16 PFLOP/s of fp16 MFMA issue in the shipped "
+                                                "two-wave form and at one 512-register wave per SIMD alike (tools/micro/stream_wide.hip)"},
                      "fp32_equivalent_tflops": useful / sec / 1e12, "fp32_equivalent_vs_fp32_mfma_peak": useful / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                      "launches": n_, "avg_launch_ms": ms_ / n_, "useful_mfma_gflop_per_launch": useful / 1e9,
                      "tile_padded_mfma_gflop_per_launch": issued_model / 1e9,
