@@ -513,21 +513,23 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
   int cq[CT];
 #pragma unroll
   for (int t = 0; t < CT; ++t) cq[t] = max(0, min(4 * (lane & 7), ncols - 4 - (col0 + 32 * t)));
-  // GH: a store instruction writes 8 rows x 128 bytes like the fp32 form: lane (row 8 p + lane / 8, piece lane & 7) stores the hi
-  // (even piece) or lo (odd piece) words of column group (lane & 7) >> 1 of the block - two lanes convert the same 8 columns and keep one
-  // plane each.  gh_o[t]: float offset (inside a row) of this lane's piece; gh_sp[t]: a plane group (else 8 fp32 columns: the lane
-  // stores their first or second quad)
-  int gh_o[CT];
+  // GH: a lane owns ONE 8-column group of a row - lane (row 16 h + lane / 4, group lane & 3) for the two halves h of the tile -, converts
+  // it once and stores its hi words with one instruction and its lo words with the next (the two 16-byte pieces of a group are neighbours:
+  // the pair of instructions completes the 128-byte lines).  (Until the end of round 5 two lanes converted the same group and kept one
+  // plane each: twice the LDS reads and conversions per byte.)  gh_o[t][0 / 1]: float offsets (inside a row) of the group's two pieces;
+  // gh_sp[t]: a plane group (else 8 fp32 columns: first and second quad as they are)
+  int gh_o[CT][2];
   bool gh_sp[CT];
   float gh_max = 0.f;                   // GH: largest |G value| split (outside the fp16 range: reported through range_flag)
 #pragma unroll
   for (int t = 0; t < CT; ++t) {
-    gh_o[t] = 0;
+    gh_o[t][0] = gh_o[t][1] = 0;
     gh_sp[t] = false;
     if constexpr (GH) {
-      const int g = min(col0 + 32 * t + 8 * ((lane & 7) >> 1), ncols - 8) >> 3;
+      const int g = min(col0 + 32 * t + 8 * (lane & 3), ncols - 8) >> 3;
       const int32_t* __restrict__ d = gh_dest + ((size_t)z * (ncols >> 3) + g) * 2;
-      gh_o[t] = (lane & 1) ? d[1] : (d[0] & ~3);
+      gh_o[t][0] = d[0] & ~3;
+      gh_o[t][1] = d[1];
       gh_sp[t] = (d[0] & 1) != 0;
     }
   }
@@ -576,10 +578,15 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
   bool pend_sp = false;                 // GH: the pending block's groups are plane groups
   int pbuf = 0;
   f32x4 dv = {0.f, 0.f, 0.f, 0.f};
-  // GH: this lane's 16-byte piece of quarter p of the pending tile: the hi or lo words of the 8 columns at pend_lds[p] (or, for fp32
-  // groups, their first or second quad).  Packed conversions, the range check as one running max, no branch (a NaN needs an inf or a NaN
-  // in x, which the x split reports)
+  // GH: drain step p of the pending tile.  Even p: the 8 columns of this lane's group of half p / 2 are read and converted, dv = their hi
+  // words (fp32 groups: first quad), dv2 = the lo words (second quad); odd p: dv = dv2.  Packed conversions, the range check as one
+  // running max, no branch (a NaN needs an inf or a NaN in x, which the x split reports)
+  f32x4 dv2 = {0.f, 0.f, 0.f, 0.f};
   auto gh_read = [&](const float* pt, int p) {
+    if (p & 1) {
+      dv = dv2;
+      return;
+    }
     typedef float f32x8 __attribute__((ext_vector_type(8)));
     const f32x4 a = *reinterpret_cast<const f32x4*>(&pt[pend_lds[p]]), b = *reinterpret_cast<const f32x4*>(&pt[pend_lds[p] + 4]);
     const f32x8 f = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -589,9 +596,11 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
     const float m8 = fmaxf(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))), fmaxf(fmaxf(fabsf(f[4]), fabsf(f[5])), fmaxf(fabsf(f[6]), fabsf(f[7]))));
     gh_max = fmaxf(gh_max, pend_sp ? m8 : 0.f);
     const f32x4 vh = __builtin_bit_cast(f32x4, hi), vl = __builtin_bit_cast(f32x4, lo);
-    const bool odd = (lane & 1) != 0;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) dv[e] = pend_sp ? (odd ? vl[e] : vh[e]) : (odd ? b[e] : a[e]);
+    for (int e = 0; e < 4; ++e) {
+      dv[e] = pend_sp ? vh[e] : a[e];
+      dv2[e] = pend_sp ? vl[e] : b[e];
+    }
   };
   auto block = [&](auto drain_tag, int t, const h8 (&a)[2][NS], const int (&blk_ri)[4], int nr) {
     constexpr bool DRAIN = decltype(drain_tag)::value;
@@ -633,9 +642,9 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
 #endif
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        const int rr = min(8 * p + (lane >> 3), nr - 1);        // clamped row of the tile (blk_ri is clamped the same way)
-        pend_lds[p] = rr * TS + 8 * ((lane & 7) >> 1);
-        pend_off[p] = (size_t)blk_ri[p] * ldo + gh_o[t];
+        const int rr = min(16 * (p >> 1) + (lane >> 2), nr - 1);        // clamped row of the tile (blk_ri is clamped the same way)
+        pend_lds[p] = rr * TS + 8 * (lane & 3);
+        pend_off[p] = (size_t)blk_ri[p >> 1] * ldo + gh_o[t][p & 1];
       }
     } else {
 #pragma unroll
@@ -663,7 +672,8 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
     int blk_ri[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int ri = min(row0 + 8 * p + (lane >> 3), R1 - 1);
+      // (GH: entries 0, 1 = the lane's rows 16 h + lane / 4 of the tile's two halves)
+      const int ri = min(row0 + (GH ? 16 * (p & 1) + (lane >> 2) : 8 * p + (lane >> 3)), R1 - 1);
       blk_ri[p] = rows ? rows[ri] : ri;
     }
     const int nr = R1 - row0;

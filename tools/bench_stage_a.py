@@ -7,7 +7,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from diffdock_pocket_amd import _lib as L  # noqa: E402
-from diffdock_pocket_amd.packing import split_bf16x3, split_h2  # noqa: E402
+from diffdock_pocket_amd.packing import gh_dest_table, gh_ld, split_bf16x3, split_h2  # noqa: E402
 
 
 def timeit(fn, n=10):
@@ -39,6 +39,16 @@ def main():
         t_x3 = timeit(lambda: L.check(lib.ddp_stage_a(x.data_ptr(), ldx, N, None, None, N, offs, nb, w.data_ptr(), w3.data_ptr(), k, ncols, out.data_ptr(), ldo, st), "a"))
         wh = split_h2(w)
         t_h2 = timeit(lambda: L.check(lib.ddp_stage_a_h2(x.data_ptr(), ldx, N, None, None, N, offs, nb, w.data_ptr(), wh.data_ptr(), k, ncols, out.data_ptr(), ldo, None, st), "a"))
+        # the plane form ddp_conv_rows reads (ddp_stage_a_gh): a slot of 72 padded G columns (parts 32, 28, 12) at hid = 180
+        ncg = gh_ld(180, 72)
+        wg = torch.randn(nb, k, ncg, device=dev)
+        wgh = split_h2(wg)
+        outg = torch.empty(nb, N, ncg, device=dev)
+        dest = torch.stack([gh_dest_table([32, 28, 12], 23, ncg)] * nb).contiguous().to(dev)
+        t_gh = timeit(lambda: L.check(lib.ddp_stage_a_gh(x.data_ptr(), ldx, N, None, None, N, offs, nb, wg.data_ptr(), wgh.data_ptr(), k, ncg, outg.data_ptr(), ncg,
+                                                         None, dest.data_ptr(), st), "a"))
+        gbg = nb * N * ncg * 4 / 1e9
+        print(f"{name}: plane form (ddp_stage_a_gh) {gbg:.2f} GB out: {t_gh:.3f} ms ({gbg / t_gh:.2f} TB/s)")
         A = torch.stack([x[:, 120 * (i % 2):120 * (i % 2) + k] for i in range(nb)])
         t_bmm = timeit(lambda: torch.bmm(A, w))
         t_mm = timeit(lambda: [torch.mm(A[i], w[i]) for i in range(nb)])
