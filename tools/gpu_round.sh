@@ -34,6 +34,8 @@ cd $R
 python3 tools/pmc_raw.py $O/pmc_sq > $O/r05_pmc_wave_states.json 2>/dev/null
 python3 tools/pmc_collect.py $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/r05_pmc.json $O/pmc_l1l2 $O/pmc_lat > $O/pmc_collect.log 2>&1; echo "collect rc=$?"; tail -3 $O/pmc_collect.log
 fi
+# the default bench line once more with THIS run's counter file in place (the first line above read the tree's file: stale after a kernel edit)
+if [ -s $O/r05_pmc.json ]; then cp $O/r05_pmc.json $R/profiles/r05_pmc.json; timeout 900 python bench.py --steps 20 --warmup 3 --cpu-budget-s 30 > $O/bench_pmc.json 2>> $O/bench.err; echo "bench (fresh pmc) rc=$?"; fi
 cd $R
 for d in prof prof_flex prof_5 prof_cfg1; do echo "== $d"; python3 tools/gaps.py $O/$d 2>&1 | head -6; python3 tools/step_sequence.py $O/$d > $O/$d.sequence.txt 2>&1; tail -1 $O/$d.sequence.txt; done > $O/gaps.log 2>&1
 cat $O/gaps.log
