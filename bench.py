@@ -107,6 +107,9 @@ def parse_args(argv=None):
                     help="diagnostic: model.concurrent_max_atoms (batches with more pocket atoms take the large-batch launch order) for A/B runs")
     ap.add_argument("--no-fork-lists-flex", action="store_true", help="diagnostic: model.fork_lists_flex = False (A/B runs)")
     ap.add_argument("--no-fork-means", action="store_true", help="diagnostic: model.fork_small_means = False (A/B runs)")
+    ap.add_argument("--no-split-rows", action="store_true",
+                    help="diagnostic: the factorised convs of a layer as ONE launch behind all of stage A (model.split_rows_launch = False) "
+                         "for same-box A/B runs")
     ap.add_argument("--no-overlap-direct", action="store_true",
                     help="diagnostic: the serial launch order of the conv layers (model.overlap_direct_conv = False) for same-box A/B runs")
     ap.add_argument("--no-flex-sharing", action="store_true",
@@ -443,6 +446,8 @@ def main(argv=None):
         model.share_flex_layer0 = False
     if args.no_overlap_direct:
         model.overlap_direct_conv = False
+    if args.no_split_rows:
+        model.split_rows_launch = False
     if args.no_fork_front:
         model.fork_front = False
     if args.no_fork_lists_flex:
@@ -471,6 +476,10 @@ def main(argv=None):
             return
         sampler.restore(snap)
         sampler.graph_enabled = False
+        # (the instrumented steps launch a layer's factorised convs as ONE launch: its HIP-event time is then the kernel's, not its share of
+        # the chip beside stage A of the atom rows - the timed region starts the receptor- / ligand-sourced convs early, model.split_rows_launch)
+        split_was = getattr(model, "split_rows_launch", False)
+        model.split_rows_launch = False
         sm.set_conv_profiler(prof)
         for i in range(args.steps):
             sampler.step(i % 20, schedule)
@@ -482,6 +491,7 @@ def main(argv=None):
                 sampler.step(5 + 10 * i, schedule)
             torch.cuda.synchronize()
             sm.set_conv_profiler(None)
+        model.split_rows_launch = split_was
         sampler.graph_enabled = True
 
     elapsed, sampler, final_pos, gathered, schedule, info = timed_job(model, complex_graph, n_total, sl, device, args.flex, args.steps,
@@ -662,11 +672,14 @@ def main(argv=None):
                 def inst(smp_, snap_, sched_):
                     smp_.restore(snap_)
                     smp_.graph_enabled = False
+                    split_was_ = getattr(m_, "split_rows_launch", False)
+                    m_.split_rows_launch = False      # (as in roofline_pass)
                     sm.set_conv_profiler(pr)
                     for i in range(20):
                         smp_.step(i, sched_)
                     torch.cuda.synchronize()
                     sm.set_conv_profiler(None)
+                    m_.split_rows_launch = split_was_
                     smp_.graph_enabled = True
 
                 el_, s_, fp_, _, _, _ = timed_job(m_, g_, n_, slice(0, n_), device, flex_, 20, 3, on_timed=inst, cfg=cfg_)

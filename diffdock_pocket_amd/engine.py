@@ -961,12 +961,12 @@ class ForwardEngine:
         def launch_direct(P):
             K.launch_convs(P.spec, P.tasks, node_bytes=P.nb_d, tag=f"layer{P.l}")
 
-        def launch_factorised(P):
-            """The conv launch of all factorised convs of the layer."""
+        def launch_factorised(P, which="lar"):
+            """The conv launch of the layer's factorised convs whose SOURCE-node type is in `which` (and that have not been launched yet)."""
             l, spec, c1 = P.l, P.spec, P.c1
             tasks_g, nb_g = [], 0.0
             for k, (csr, so_k, x_src) in P.per.items():
-                if k in P.msgs:
+                if k in P.msgs or SRC_TYPE[k] not in which:
                     continue
                 x_recv, _, ek = arr[k]
                 conv = m.conv_layers[9 * l + k]
@@ -997,7 +997,8 @@ class ForwardEngine:
                 pkg = conv.packed_g(dev)
                 tasks_g.append(K.make_task(pkg, x_src, ldx, so_k, sh_k, segs, msg, g=[P.gmap.get((k, s_)) for s_ in (0, 1)], rows=K.rows_mode(pkg)))
             P.tasks_g = getattr(P, "tasks_g", []) + tasks_g
-            K.launch_convs(P.spec_g, tasks_g, flops_spec=spec, node_bytes=nb_g, tag=f"layer{l}")
+            if tasks_g:
+                K.launch_convs(P.spec_g, tasks_g, flops_spec=spec, node_bytes=nb_g, tag=f"layer{l}")
 
         def fix_rowmaps(P):
             if P.l == 0 and F.flex0 is not None:
@@ -1032,24 +1033,29 @@ class ForwardEngine:
             if P.tasks:
                 side.run(1, lambda P=P: launch_direct(P))
             stage_a(P, "lar")
+            split = bool(getattr(m, "split_rows_launch", False))
             for l in range(L_):
                 nxt = plan(l + 1) if l + 1 < L_ else None
-                launch_factorised(P)
+                launch_factorised(P)        # (split: the atom-sourced convs - the others were launched beside stage A{atom rows})
                 join_lists()
                 fix_rowmaps(P)
                 side.join(only=1)           # direct conv(l) is done: the means below update x in place
-                ev_r = torch.cuda.Event()
+                side.join(only=0)           # (split: the early conv launch of this layer)
+                ev_r, ev_l, ev_sr, ev_sl = (torch.cuda.Event() for _ in range(4))
 
-                def rec_chain(P=P, nxt=nxt, ev_r=ev_r):
+                def rec_chain(P=P, nxt=nxt, ev_r=ev_r, ev_sr=ev_sr):
                     means(P, "r")
                     ev_r.record()
                     if nxt is not None:
                         stage_a(nxt, "r")
+                        ev_sr.record()
 
-                def lig_chain(P=P, nxt=nxt):
+                def lig_chain(P=P, nxt=nxt, ev_l=ev_l, ev_sl=ev_sl):
                     means(P, "l")
+                    ev_l.record()
                     if nxt is not None:
                         stage_a(nxt, "l")
+                        ev_sl.record()
                 side.run(3, rec_chain)
                 side.run(2, lig_chain)
                 means(P, "a")
@@ -1060,6 +1066,15 @@ class ForwardEngine:
                             torch.cuda.current_stream(dev).wait_event(ev_r)
                             launch_direct(nxt)
                         side.run(1, direct_next)
+                    if split:
+                        # the convs with receptor / ligand sources need x(l + 1) of every node type (the three means) and their own G: they
+                        # start beside stage A of the atom rows (the largest product of the layer) instead of behind it
+                        def early(nxt=nxt, evs=(ev_r, ev_l, ev_sr, ev_sl)):
+                            st_ = torch.cuda.current_stream(dev)
+                            for ev in evs:
+                                st_.wait_event(ev)
+                            launch_factorised(nxt, "rl")
+                        side.run(0, early)
                     stage_a(nxt, "a")
                 side.join(only=2)
                 side.join(only=3)

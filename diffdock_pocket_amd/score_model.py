@@ -462,6 +462,11 @@ class TensorProductScoreModel(nn.Module):
         # layer l + 1 starts as soon as the atom and receptor means of layer l are queued; receptor / ligand / atom chains
         # [mean -> stage A] side by side); same kernels, same arguments, same bits as the serial order (False)
         self.overlap_direct_conv = True
+        # ... and the layer's factorised convs as TWO launches: the receptor- / ligand-sourced convs start as soon as the three means and their
+        # own stage A are done, beside stage A of the atom rows (the layer's largest product); the atom-sourced convs follow behind it.
+        # Same kernels, same tasks, same bits (a conv's workgroups do not depend on the launch it sits in); 17.5 -> 17.3 ms rigid,
+        # 21.8 -> 21.4 ms with flexible side chains (profiles/r05_conv32_ab.txt)
+        self.split_rows_launch = True
         # The front's independent chains side by side (parallel branches of the captured step; same kernels, same arguments, same bits):
         # [node encoders -> edge embeddings] beside [neighbour searches -> CSR / source-ordered views], and - rigid receptor - the index
         # lists of the work eliminations (first read by layer 1) beside stage A + the 32-edge conv launch of layer 0 (engine._front,

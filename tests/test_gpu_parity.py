@@ -373,7 +373,8 @@ def test_pipelined_layer_order_is_bitwise_the_serial_one(flex):
     the direct conv of layer l + 1 on a stream of its own from the moment the atom and receptor means of layer l are queued, the
     receptor / ligand / atom chains [mean -> stage A] side by side).  Same kernels, same per-edge arithmetic: the scores of forwards
     at two schedule positions, launch by launch and through a replayed hipGraph, and the poses must be bit for bit those of the serial
-    order (model.overlap_direct_conv = False).  Eight samples with the small-batch fork switched off (concurrent_max_atoms = 0: the
+    order (model.overlap_direct_conv = False) - with a layer's factorised convs as two launches (model.split_rows_launch, the default) and as
+    one.  Eight samples with the small-batch fork switched off (concurrent_max_atoms = 0: the
     large-batch path whatever the batch size) - a captured 40-sample step holds ~40 GB of device memory; the 40-sample batch runs
     this order in test_bench_batch_samples_match_oracle and in bench.py."""
     import bench
@@ -384,11 +385,13 @@ def test_pipelined_layer_order_is_bitwise_the_serial_one(flex):
     sched = get_t_schedule(20)
     g = make_3dpf_complex(seed=0, flexible_sidechains=flex)
     out = {}
-    orders = ("serial", "pipelined")
+    orders = ("serial", "pipelined", "pipelined, one conv launch per layer")
     for order in orders:
         model, kw = bench.build_model("cfg2", flex, dev)
         model.concurrent_max_atoms = 0
         model.overlap_direct_conv = order != "serial"
+        assert model.split_rows_launch          # (the default: receptor- / ligand-sourced convs beside stage A of the atom rows)
+        model.split_rows_launch = order == "pipelined"
         smp = Sampler(model, g, 8, dev, SamplerConfig(inference_steps=20, flexible_sidechains=flex), seed=0)
         smp.randomize()
         res = [[t.clone() for t in smp.scores(float(sched[0]))]]
