@@ -1033,7 +1033,16 @@ class ForwardEngine:
             if P.tasks:
                 side.run(1, lambda P=P: launch_direct(P))
             stage_a(P, "lar")
-            split = bool(getattr(m, "split_rows_launch", False))
+            def atom_g_bytes(Pn):
+                """Bytes of G that stage A writes for the atom-source rows of a layer (host-side capacities)."""
+                tot = 0
+                for (st_, _gid), (_x, rows_, convs_) in Pn.groups.items():
+                    if st_ != "a":
+                        continue
+                    for _k, conv_ in convs_:
+                        pk_ = conv_.packed_g(dev)
+                        tot += rows_[3] * 4 * sum(w.shape[1] for w in (getattr(pk_, "wgh", None) or []) if w is not None)
+                return tot
             for l in range(L_):
                 nxt = plan(l + 1) if l + 1 < L_ else None
                 launch_factorised(P)        # (split: the atom-sourced convs - the others were launched beside stage A{atom rows})
@@ -1066,7 +1075,9 @@ class ForwardEngine:
                             torch.cuda.current_stream(dev).wait_event(ev_r)
                             launch_direct(nxt)
                         side.run(1, direct_next)
-                    if split:
+                    # (worth a second launch only where the atom rows' product is long: 4.7 GB at 40 samples of cfg2; 20 samples, 2.4 GB, and the
+                    # README's small model, 1.4 GB, lost time with it: model.split_rows_min_g_bytes)
+                    if bool(getattr(m, "split_rows_launch", False)) and atom_g_bytes(nxt) >= m.split_rows_min_g_bytes:
                         # the convs with receptor / ligand sources need x(l + 1) of every node type (the three means) and their own G: they
                         # start beside stage A of the atom rows (the largest product of the layer) instead of behind it
                         def early(nxt=nxt, evs=(ev_r, ev_l, ev_sr, ev_sl)):

@@ -392,6 +392,7 @@ def test_pipelined_layer_order_is_bitwise_the_serial_one(flex):
         model.overlap_direct_conv = order != "serial"
         assert model.split_rows_launch          # (the default: receptor- / ligand-sourced convs beside stage A of the atom rows)
         model.split_rows_launch = order == "pipelined"
+        model.split_rows_min_g_bytes = 0       # (the default threshold, 4 GB of G for the atom rows, is the 40-sample batch)
         smp = Sampler(model, g, 8, dev, SamplerConfig(inference_steps=20, flexible_sidechains=flex), seed=0)
         smp.randomize()
         res = [[t.clone() for t in smp.scores(float(sched[0]))]]
