@@ -441,6 +441,72 @@ def test_h2_operand_planes_layout_and_precision():
     assert P.pack_fc2_h2(spec, w2).numel() == spec.ntiles * 2 * 12 * 64 * 8
 
 
+def test_rows_kernel_unified_planes_of_the_weight_stream_and_g():
+    """ddp_conv_rows' operands (include/ddp_hip.h DDP_ROWS_S*): UNIFIED planes V = S v = hi + lo, lo = fp16(V - hi) at hi's scale.
+    packing.rows_stream: the fc.0 tiles of the stream carry 256 w1 in natural k order, the fc.3 tiles 256 w2 (block scale folded in) with
+    k permuted by rows_kperm, the bias words sit at the scale of their tile's accumulator (fc.0: 256 x 16, fc.3: 16 x 256);
+    packing.factor_weights_gh: the G columns of stage A's right-hand sides carry 32, the Gb columns 16 x 32.  A weight beyond the planes'
+    range (|w| > 255) is refused."""
+    from diffdock_pocket_amd import packing as P
+    g = torch.Generator().manual_seed(1)
+    ns, nv, layer = 60, 10, 3
+    spec_g = P.faster_tp_spec(P.irreps_muls(ns, nv, layer), P.irreps_muls(ns, nv, layer + 1), 3 * ns, factorized=True)
+    assert P.rows_supported(spec_g) and P.h2_steps(spec_g) == 12
+    hid = 3 * ns
+    w1, b1 = torch.randn(hid, hid, generator=g) * 0.07, torch.randn(hid, generator=g) * 0.1
+    w2, b2 = torch.randn(spec_g.weight_numel, hid, generator=g) * 0.07, torch.randn(spec_g.weight_numel, generator=g) * 0.1
+    w1[3, 5], w2[7, 11] = 1e-5, 100.0                                       # a tiny and a large weight
+    wsh, bsp = P.rows_stream(spec_g, w1, b1, w2, b2)
+    nts = spec_g.nct1 + sum(len(t) for _, _, t in P.rows_segments(spec_g))
+    assert wsh.dtype == torch.float16 and wsh.numel() == nts * 2 * 12 * 64 * 8 and tuple(bsp.shape) == (nts, 32)
+    tiles = wsh.reshape(nts, 12, 2, 2, 32, 8).float()                       # [tile, ks, plane, hh, j, i]
+    rec = (tiles[:, :, 0] + tiles[:, :, 1]).permute(0, 3, 1, 2, 4).reshape(nts, 32, 192) / P.ROWS_SW     # [tile, column j, k]
+    # fc.0: tile ct, column j = h column 32 ct + j, natural k
+    W1 = torch.zeros(spec_g.nct1 * 32, 192)
+    W1[:hid, :hid] = w1
+    err1 = (rec[:spec_g.nct1].reshape(-1, 192).double() - W1.double()).abs()
+    assert float((err1 / W1.double().abs().clamp(min=0.125 / P.ROWS_SW)).max()) < 2.0 ** -20      # 22 bits above |V| = 0.125, an absolute 2^-25 / S below
+    assert torch.allclose(bsp[:spec_g.nct1].reshape(-1)[:hid], b1 * (P.ROWS_SW * P.ROWS_SX))
+    # fc.3: the first stream tile of the first segment = packed tile `order[0]`, k permuted
+    segs = P.rows_segments(spec_g)
+    first = next(t for _, _, t in segs if t)[0]
+    blk = next(b for b in spec_g.blocks if b.tile0 <= first < b.tile0 + max(b.ntiles, 1))
+    rows = blk.column_rows().reshape(-1, 32)[first - blk.tile0]
+    kp = P.rows_kperm(12)
+    for j in (0, 5, 31):
+        if int(rows[j]) < 0:
+            continue
+        want = torch.zeros(192)
+        want[:hid] = w2[int(rows[j])] * blk.scale
+        got = rec[spec_g.nct1, j]
+        assert float((got.double() - want[kp].double()).abs().max()) < 2.0 ** -20 * max(1.0, float(want.abs().max()))
+        assert abs(float(bsp[spec_g.nct1, j]) - float(b2[int(rows[j])]) * blk.scale * P.ROWS_SH * P.ROWS_SW) < 1e-3
+    # stage A's right-hand sides for the plane form
+    wgh, offs, widths = P.factor_weights_gh(spec_g, w2, b2)
+    wg, bg, _ = P.factor_weights(spec_g, w2, b2)
+    for slot in (0, 1):
+        if wgh[slot] is None:
+            continue
+        gcp, n8 = sum(widths[slot]), (hid + 7) // 8
+        assert wgh[slot].shape[1] == P.gh_ld(hid, gcp)
+        # Gb columns: the fp32 form's bias part x 16 x 32
+        gb = wgh[slot][:, 8 * n8 * gcp:8 * n8 * gcp + gcp]
+        cum = 0
+        for (_, _, c0, w, wp, _cum) in P.gh_parts(spec_g, slot):
+            assert torch.allclose(gb[:, cum:cum + w], bg[slot][:, c0:c0 + w] * (P.ROWS_SH * P.ROWS_SG))
+            cum += wp
+        # G columns: element (k8 = 0, column 0 of the slot's first part, i) of the tile = 32 x weight[(u, column)][h column kperm[i]] x scale
+        b0 = next(b for b in spec_g.blocks if b.g_slot == slot)
+        for u in (0, 7):
+            for i in (0, 3):
+                want = float(w2[b0.w_off + (b0.g_u0 + u) * b0.n + 0, int(kp[i])]) * b0.scale * P.ROWS_SG
+                assert abs(float(wgh[slot][u, i]) - want) <= 1e-6 * max(1.0, abs(want))
+    w2_big = w2.clone()
+    w2_big[int(rows[0]), 0] = 300.0 / blk.scale          # (a weight of the stream's first tile)
+    with pytest.raises(NotImplementedError):
+        P.rows_stream(spec_g, w1, b1, w2_big, b2)
+
+
 def test_lazy_stats_fresh_view_rereads_the_count_block():
     """LazyStats memoises its first read, but the count block of a CAPTURED forward is rewritten by every replay -
     Sampler installs `stats.fresh()` after each replay; a fresh view reads the block again."""
