@@ -456,7 +456,7 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_x3_kernel(con
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #ifndef DDP_SAH_CT_GH
-#define DDP_SAH_CT_GH 3
+#define DDP_SAH_CT_GH 4     // (round 5, end: the one-accumulator form of the GH path freed the registers of a fourth tile's weights: 253 VGPRs)
 #endif
 #ifndef DDP_SAH_CT
 #define DDP_SAH_CT 4   // column tiles per wave: 2 planes x 4 k-steps x 4 registers each = 32 weight registers per tile
@@ -478,7 +478,8 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
                                                                               const int32_t* __restrict__ gh_dest = nullptr) {
   if (nrows_dev) nrows = min(nrows, *nrows_dev);
   if ((int)blockIdx.y * mrows >= nrows) return;
-  // (GH: three column tiles per wave - the plane split of the drain needs the registers of the fourth tile's weights)
+  // (GH: four column tiles per wave since the block has ONE accumulator - 512 contiguous bytes per row and wave; with the 2048-scaled
+  // planes' two accumulators three tiles were what fitted)
   constexpr int KP = (KT + 15) / 16 * 16, NS = KP / 16, CT = GH ? DDP_SAH_CT_GH : DDP_SAH_CT;
   constexpr int XS = KP + 8;                                   // halves per LDS row of an x plane (16-byte aligned rows)
   constexpr int NV = (32 * KT / 4 + DDP_GEMM_THREADS - 1) / DDP_GEMM_THREADS;
@@ -559,10 +560,12 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
         h4 h, l;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float f = xv[v][e];
+          // GH: UNIFIED planes (hi and lo at one scale, DDP_GH_SX x: the weights carry 1 / DDP_GH_SX, so that the ONE accumulator of a
+          // block is the plane value itself - no second accumulator, no join); otherwise v = hi + lo / 2048
+          const float f = GH ? xv[v][e] * (float)DDP_GH_SX : xv[v][e];
           if (!(fabsf(f) <= 65504.f) && range_flag) *range_flag = 1;     // outside the fp16 range (or NaN): reported, not saturated
           h[e] = (_Float16)f;
-          l[e] = (_Float16)((f - (float)h[e]) * 2048.f);
+          l[e] = (_Float16)(GH ? f - (float)h[e] : (f - (float)h[e]) * 2048.f);
         }
         *reinterpret_cast<h4*>(&xt[buf][0][rr * XS + 4 * q]) = h;
         *reinterpret_cast<h4*>(&xt[buf][1][rr * XS + 4 * q]) = l;
@@ -616,9 +619,17 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
         else
           dv = *reinterpret_cast<const f32x4*>(&pt[pend_lds[s2]]);
       }
-      am = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][s2], wr[t][0][s2], am, 0, 0, 0);
-      ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][s2], wr[t][1][s2], ac, 0, 0, 0);
-      ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][s2], wr[t][0][s2], ac, 0, 0, 0);
+      if constexpr (GH) {
+        // the TRANSPOSED product (A = the weights' fragment, B = the rows'): lane (row r, hh) then holds 4 consecutive columns per group
+        // of accumulator registers - the tile is parked with four 16-byte LDS writes instead of sixteen 4-byte ones
+        am = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[t][0][s2], a[0][s2], am, 0, 0, 0);
+        am = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[t][1][s2], a[0][s2], am, 0, 0, 0);
+        am = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[t][0][s2], a[1][s2], am, 0, 0, 0);
+      } else {
+        am = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][s2], wr[t][0][s2], am, 0, 0, 0);
+        ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][s2], wr[t][1][s2], ac, 0, 0, 0);
+        ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][s2], wr[t][0][s2], ac, 0, 0, 0);
+      }
       if constexpr (DRAIN && NS == 4) *reinterpret_cast<f32x4*>(&ob[pend_off[s2]]) = dv;
     }
     if constexpr (DRAIN && NS != 4) {
@@ -632,8 +643,14 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
       }
     }
     float* tl = st[wave][pbuf];
+    if constexpr (GH) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) tl[((i & 3) + 8 * (i >> 2) + 4 * hh) * TS + r] = am[i] + ac[i] * (1.f / 2048.f);
+      for (int q4 = 0; q4 < 4; ++q4)
+        *reinterpret_cast<f32x4*>(&tl[r * TS + 8 * q4 + 4 * hh]) = f32x4{am[4 * q4], am[4 * q4 + 1], am[4 * q4 + 2], am[4 * q4 + 3]};
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) tl[((i & 3) + 8 * (i >> 2) + 4 * hh) * TS + r] = am[i] + ac[i] * (1.f / 2048.f);
+    }
     if constexpr (GH) {
 #if defined(DDP_GH_ABL) && DDP_GH_ABL == 1     // timing only: the plane destinations without the conversion
       pend_sp = false;

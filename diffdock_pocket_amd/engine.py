@@ -786,13 +786,13 @@ class ForwardEngine:
             Wst = torch.stack(Ws).contiguous()
             # (the bf16x3 split of the weights - 1.5 x their size and three copy kernels - only when that option is on)
             ent = (Wst, meta, (C.c_int32 * len(meta))(*[mm[2] for mm in meta]), P.split_bf16x3(Wst) if (m.stage_a_bf16x3 and not rows_k) else None,
-                   P.split_h2(Wst) if (m.stage_a_h2 or rows_k) else None,
+                   (P.split_h2(Wst, unified_scale=P.GH_SW) if rows_k else P.split_h2(Wst)) if (m.stage_a_h2 or rows_k) else None,
                    torch.stack([P.gh_dest_table(ws, (convs[0][1].spec_g.hid + 7) // 8, Wst.shape[2]) for ws in ghs]).contiguous().to(x.device) if rows_k else None)
             m._stage_a_stacks[key] = ent
         if m.stage_a_bf16x3 and ent[3] is None and not rows_k:
             ent = m._stage_a_stacks[key] = ent[:3] + (P.split_bf16x3(ent[0]),) + ent[4:]
         if m.stage_a_h2 and ent[4] is None:
-            ent = m._stage_a_stacks[key] = ent[:4] + (P.split_h2(ent[0]),) + ent[5:]
+            ent = m._stage_a_stacks[key] = ent[:4] + (P.split_h2(ent[0], unified_scale=P.GH_SW) if rows_k else P.split_h2(ent[0]),) + ent[5:]
         gh = ent[5]
         ent = ent[:5]
         Wst, meta, offs, W3, Wh = ent

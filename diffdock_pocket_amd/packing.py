@@ -351,16 +351,17 @@ def split_bf16x3(W: torch.Tensor) -> torch.Tensor:
     return planes.reshape(nb, 3, KP // 16, 2, 8, ncols).permute(0, 1, 2, 3, 5, 4).contiguous()
 
 
-def split_h2(W: torch.Tensor) -> torch.Tensor:
+def split_h2(W: torch.Tensor, unified_scale: float = 0.0) -> torch.Tensor:
     """Stage-A weights [nb, K, ncols] fp32 as two fp16 planes w = hi + lo / 2048 (hi = fp16(w), lo = fp16((w - hi) * 2048)) in the
     operand order of v_mfma_f32_32x32x16_f16: [nb][plane][k/16][k/8 % 2][ncols][8] (include/ddp_hip.h, ddp_stage_a_h2 `w_h2`), K
-    zero-padded to a multiple of 16."""
+    zero-padded to a multiple of 16.  unified_scale = S > 0: UNIFIED planes of S w instead (lo = fp16(S w - hi), both halves at one
+    scale): ddp_stage_a_gh's form, S = 1 / DDP_GH_SX (GH_SW below)."""
     nb, K, ncols = W.shape
     KP = (K + 15) // 16 * 16
     Wf = torch.zeros((nb, KP, ncols), dtype=torch.float32, device=W.device)
-    Wf[:, :K] = W.float()
+    Wf[:, :K] = W.float() * (unified_scale if unified_scale > 0.0 else 1.0)
     hi = Wf.to(torch.float16)
-    lo = ((Wf - hi.float()) * H2_SCALE).to(torch.float16)
+    lo = ((Wf - hi.float()) * (1.0 if unified_scale > 0.0 else H2_SCALE)).to(torch.float16)
     if not bool(torch.isfinite(hi).all()):
         raise NotImplementedError("stage-A weight outside the fp16 range (|w| > 65504): the fp16 hi/lo form cannot represent it")
     planes = torch.stack([hi, lo], dim=1)                                       # [nb, 2, KP, ncols]
@@ -402,6 +403,7 @@ def _pack_tiles(Wcols: torch.Tensor, kp: int) -> torch.Tensor:
 H2_SCALE = 2048.0     # csrc/ddp_conv.hip DDP_H2_SCALE
 # plane scales of ddp_conv_rows' unified hi/lo planes (include/ddp_hip.h DDP_ROWS_S*): edge_attr_, weights, h, G
 ROWS_SX, ROWS_SW, ROWS_SH, ROWS_SG = 16.0, 256.0, 16.0, 32.0
+GH_SW = 1.0 / 16.0      # ddp_stage_a_gh: planes of w / DDP_GH_SX (the kernel splits x at DDP_GH_SX = 16)
 
 
 def h2_steps(spec: "ConvSpec") -> int:

@@ -210,7 +210,7 @@ class TensorProductConvLayer(nn.Module):
                 if pk.wgh[slot] is None:
                     continue
                 w = pk.wgh[slot]
-                wh = P.split_h2(w.unsqueeze(0))
+                wh = P.split_h2(w.unsqueeze(0), unified_scale=P.GH_SW)
                 g[slot] = torch.empty((N, w.shape[1]), device=x_src.device, dtype=torch.float32)
                 offs = (C.c_int32 * 1)(pk.g_in_off[slot])
                 dest = P.gh_dest_table(pk.gh_groups[slot], (self.spec_g.hid + 7) // 8, w.shape[1]).to(x_src.device)

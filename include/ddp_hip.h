@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DDP_ABI_VERSION 14
+#define DDP_ABI_VERSION 15
 #define DDP_EINVAL (-1)   /* bad argument (shape not supported, null pointer, ...) */
 #define DDP_ELIMIT (-2)   /* exceeds a compiled-in limit (see DDP_MAX_*) */
 
@@ -389,6 +389,10 @@ int ddp_stage_a_h2(const float* x, int ldx, int nrows, const int32_t* rows, cons
 int ddp_stage_a_gh(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows, const int32_t* offs,
                    int nbatch, const float* w, const void* w_h2, int k, int ncols, float* out, int ldo, int32_t* range_flag,
                    const int32_t* dest, void* stream);
+
+/* ddp_stage_a_gh computes on unified planes too: x is split at DDP_GH_SX inside the kernel, w_h2 must hold the unified planes of
+ * w / DDP_GH_SX (packing.split_h2(w, unified_scale = 1 / DDP_GH_SX)): the block's one accumulator is then the value that leaves as planes. */
+#define DDP_GH_SX 16
 
 /* The pose update between two score-model calls, for all samples of a batch in one launch:
  * modify_conformer(pos, tr_update, rot_update, torsion_updates) of utils/diffusion_utils.py:37-60 = rigid move about the

@@ -42,7 +42,7 @@ def main():
         # the plane form ddp_conv_rows reads (ddp_stage_a_gh): a slot of 72 padded G columns (parts 32, 28, 12) at hid = 180
         ncg = gh_ld(180, 72)
         wg = torch.randn(nb, k, ncg, device=dev)
-        wgh = split_h2(wg)
+        wgh = split_h2(wg, unified_scale=1.0 / 16.0)
         outg = torch.empty(nb, N, ncg, device=dev)
         dest = torch.stack([gh_dest_table([32, 28, 12], 23, ncg)] * nb).contiguous().to(dev)
         t_gh = timeit(lambda: L.check(lib.ddp_stage_a_gh(x.data_ptr(), ldx, N, None, None, N, offs, nb, wg.data_ptr(), wgh.data_ptr(), k, ncg, outg.data_ptr(), ncg,
