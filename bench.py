@@ -574,7 +574,13 @@ def main(argv=None):
                 l2 = p.get("l2")
                 if l2:   # counter-derived L2 -> CU traffic of the kernel (128-byte requests) against what the chip delivers from its XCD L2s
                     cyc = l2.get("cycles_per_launch") or 0.0
-                    e["l2"] = {"request_bytes_per_launch": l2.get("l2_request_bytes_per_launch"), "hit_rate": l2.get("l2_hit_rate"),
+                    e["l2"] = {"request_bytes_per_launch": l2.get("l2_request_bytes_per_launch"),
+                               # the counter passes sample the timed region's SPLIT conv launches; avg_launch_ms above is per whole-layer
+                               # launch of the instrumented pass: the same bytes on that basis and per step
+                               "launches_per_step_in_the_counter_pass": l2.get("launches_per_step"),
+                               "request_bytes_per_step": l2.get("l2_request_bytes_per_step"),
+                               "request_bytes_per_layer_launch": l2.get("l2_request_bytes_per_layer_launch"),
+                               "hit_rate": l2.get("l2_hit_rate"),
                                "busy_frac": l2.get("l2_busy_frac"), "tcp_tcc_read_latency_cycles": l2.get("tcp_tcc_read_latency_cycles"),
                                "bytes_per_cycle_chip": l2.get("l2_bytes_per_cycle_chip"),
                                "tb_per_s_at_the_profiled_launch_time": (l2.get("l2_bytes_per_cycle_chip") or 0.0) * 2.1e9 / 1e12 if cyc else None,
@@ -620,7 +626,7 @@ def main(argv=None):
             roof["per_step"] = step
         line = {"metric": "ligand poses/sec (40 samples x 20 steps) on 3dpf", "value": poses / elapsed, "unit": "poses/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+                "higher_is_better": True, "scaling": scaling if world > 1 else None, "vs_baseline": None,
                 "dtype": "f32 (fc and G products: fp16 hi/lo split of both operands on v_mfma_f32_32x32x16_f16, fp32 accumulate; the exact fp32 MFMA form is timed in other_workloads)", "data": "synthetic",
                 "config": {"workload": f"3dpf ({sampler.n_l} lig atoms, 139 residues, {sampler.n_a} pocket atoms), "
                                        f"{n_total} samples over {world} GPU(s) ({n_local} on rank 0) x 20-step schedule, score model "
@@ -675,17 +681,21 @@ def main(argv=None):
                     split_was_ = getattr(m_, "split_rows_launch", False)
                     m_.split_rows_launch = False      # (as in roofline_pass)
                     sm.set_conv_profiler(pr)
-                    for i in range(20):
-                        smp_.step(i, sched_)
-                    torch.cuda.synchronize()
-                    sm.set_conv_profiler(None)
-                    m_.split_rows_launch = split_was_
-                    smp_.graph_enabled = True
+                    try:
+                        for i in range(20):
+                            smp_.step(i, sched_)
+                        torch.cuda.synchronize()
+                    finally:
+                        sm.set_conv_profiler(None)
+                        m_.split_rows_launch = split_was_
+                        smp_.graph_enabled = True
 
-                el_, s_, fp_, _, _, _ = timed_job(m_, g_, n_, slice(0, n_), device, flex_, 20, 3, on_timed=inst, cfg=cfg_)
-                assert torch.isfinite(fp_).all() and torch.isfinite(s_.atom_pos).all()
-                s_.close()
-                launch_.CONV_ROWS = rows_was
+                try:      # (the module-level switch is restored whatever a sub-record does: the records behind it must not inherit it)
+                    el_, s_, fp_, _, _, _ = timed_job(m_, g_, n_, slice(0, n_), device, flex_, 20, 3, on_timed=inst, cfg=cfg_)
+                    assert torch.isfinite(fp_).all() and torch.isfinite(s_.atom_pos).all()
+                    s_.close()
+                finally:
+                    launch_.CONV_ROWS = rows_was
                 return {"value": n_ / el_, "unit": "poses/s", "ms_per_step": el_ / 20 * 1e3, "steps": 20,
                         "edges_last_step": dict(m_.last_stats), "conv_kernels": conv_fracs(pr)}
 
@@ -704,6 +714,21 @@ def main(argv=None):
             s5.close()
             del s5
             line["other_workloads"] = others
+            # the figures a strict reader of `dtype` / `config` wants, as scalars inside `config` (the driver's record keeps `config` whole and
+            # only the tail of the rest): the exact-fp32 form of the headline, configs[2], configs[0], the README model, configs[3]'s shard
+            def pick(prefix):
+                for k_, v_ in others.items():
+                    if k_.startswith(prefix):
+                        return {"value": v_["value"], "ms_per_step": v_["ms_per_step"]}
+                return None
+            line["config"]["also_measured"] = {
+                "unit": "poses/s (per GPU for the shard)",
+                "exact_fp32_mfma_form": pick("configs[1] exact fp32"),
+                "round4_32_edge_kernel": pick("configs[1] fp16 hi/lo form through the 32-edge"),
+                "configs2_flexible_side_chains": pick("configs[2]"),
+                "configs0_cfg1_4_samples": pick("configs[0]"),
+                "readme_small_model": pick("README small"),
+                "configs3_shard_5_of_40_samples": pick("configs[3] shard")}
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (the other ranks must not wait for it)
             line["cpu_baseline"] = cpu_baseline(args, model, kw, complex_graph)
         print(json.dumps(line), flush=True)

@@ -17,9 +17,9 @@ F_SCALAR_S0, F_DOT, F_SCALAR_S1, F_VEC_S0, F_CROSS = range(5)
 FS = 68  # feature-buffer row stride of ddp_conv.hip
 
 DDP_MAX_GEMM_BATCH = 16
-EXPORTS = ["ddp_conv_messages", "ddp_conv_rows", "ddp_stage_a_gh", "ddp_segment_reduce", "ddp_edge_featurize", "ddp_edge_featurize_jobs", "ddp_torsion_sh", "ddp_stage_a", "ddp_stage_a_h2",
+EXPORTS = ["ddp_conv_messages", "ddp_conv_rows", "ddp_stage_a_gh", "ddp_stage_a_gh3", "ddp_segment_reduce", "ddp_edge_featurize", "ddp_edge_featurize_jobs", "ddp_torsion_sh", "ddp_stage_a", "ddp_stage_a_h2",
            "ddp_pose_update", "ddp_sidechain_update", "ddp_sde_update", "ddp_radius_count", "ddp_radius_fill", "ddp_knn", "ddp_group_by_key", "ddp_node_linear", "ddp_scan_jobs", "ddp_mark_jobs", "ddp_rowcopy_jobs", "ddp_select_jobs",
-           "ddp_gather_rows", "ddp_clean_pair_maps", "ddp_flex_mark", "ddp_fallback_rowmap", "ddp_step_prologue", "ddp_trrot_head", "ddp_tor_head", "ddp_radius_search_jobs", "ddp_group_by_key_jobs", "ddp_abi_version", "ddp_last_error", "ddp_source_hash"]
+           "ddp_gather_rows", "ddp_clean_pair_maps", "ddp_flex_mark", "ddp_fallback_rowmap", "ddp_step_prologue", "ddp_trrot_head", "ddp_tor_head", "ddp_radius_search_jobs", "ddp_group_by_key_jobs", "ddp_set_occupancy_shaping", "ddp_abi_version", "ddp_last_error", "ddp_source_hash"]
 
 
 class Seg(C.Structure):
@@ -53,7 +53,7 @@ class ConvTask(C.Structure):
                 ("seg_n", C.c_int32 * DDP_MAX_SEGS), ("w1p", C.c_void_p), ("b1p", C.c_void_p), ("w2p", C.c_void_p),
                 ("b2p", C.c_void_p), ("msg", C.c_void_p), ("g", C.c_void_p * 2),
                 ("pos", C.c_void_p), ("n_edges_dev", C.c_void_p), ("w1h", C.c_void_p), ("w2h", C.c_void_p), ("h2_range_flag", C.c_void_p),
-                ("wsh", C.c_void_p), ("bsp", C.c_void_p), ("gh", C.c_void_p * 2)]
+                ("wsh", C.c_void_p), ("bsp", C.c_void_p), ("gh", C.c_void_p * 2), ("gh_fmt", C.c_int32)]
 
 
 class ReduceSrc(C.Structure):
@@ -200,6 +200,10 @@ def load():
     lib.ddp_stage_a_h2.restype = C.c_int
     lib.ddp_stage_a_gh.argtypes = lib.ddp_stage_a_h2.argtypes[:-1] + [C.c_void_p, C.c_void_p]
     lib.ddp_stage_a_gh.restype = C.c_int
+    lib.ddp_stage_a_gh3.argtypes = lib.ddp_stage_a_gh.argtypes
+    lib.ddp_stage_a_gh3.restype = C.c_int
+    lib.ddp_set_occupancy_shaping.argtypes = [C.c_int, C.c_int]
+    lib.ddp_set_occupancy_shaping.restype = C.c_int
     lib.ddp_pose_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ddp_pose_update.restype = C.c_int
@@ -237,7 +241,7 @@ def load():
         getattr(lib, name).restype = C.c_int
     lib.ddp_node_linear.argtypes = [C.POINTER(NodeJob), C.c_int, C.c_void_p]
     lib.ddp_node_linear.restype = C.c_int
-    if lib.ddp_abi_version() != 15:
+    if lib.ddp_abi_version() != 16:
         raise DdpError("libddp_hip.so ABI version mismatch")
     lib.ddp_source_hash.restype = C.c_char_p
     if "DDP_HIP_LIB" not in os.environ:   # (diagnostic builds loaded through DDP_HIP_LIB carry extra -D flags, same sources)

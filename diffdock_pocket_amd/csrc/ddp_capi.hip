@@ -17,6 +17,19 @@ int ddp_fail_hip(hipError_t err, const char* where) {
   return (int)err;
 }
 
+int ddp_shape_rows_min_lds = 0;
+int ddp_shape_stage_a_pad = 0;
+// Launches enqueued after this call: ddp_conv_rows with at least `rows_min_lds_bytes` of dynamic LDS (> 80 KiB: ONE 4-wave workgroup per
+// CU, i.e. one 256-register wave per SIMD, instead of two), the MFMA forms of ddp_stage_a* with `stage_a_lds_pad_bytes` on top of their
+// static LDS (> 25 KiB: one workgroup per CU).  0 / 0 = the kernels' own occupancy.  Results do not depend on it.
+extern "C" int ddp_set_occupancy_shaping(int rows_min_lds_bytes, int stage_a_lds_pad_bytes) {
+  if (rows_min_lds_bytes < 0 || rows_min_lds_bytes > 160 * 1024 || stage_a_lds_pad_bytes < 0 || stage_a_lds_pad_bytes > 100 * 1024)
+    return ddp_fail(DDP_EINVAL, "ddp_set_occupancy_shaping: bytes out of range");
+  ddp_shape_rows_min_lds = rows_min_lds_bytes;
+  ddp_shape_stage_a_pad = stage_a_lds_pad_bytes;
+  return 0;
+}
+
 extern "C" int ddp_abi_version(void) { return DDP_ABI_VERSION; }
 extern "C" const char* ddp_last_error(void) { return g_err; }
 

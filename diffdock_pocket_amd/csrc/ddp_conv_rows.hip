@@ -290,35 +290,103 @@ __device__ __forceinline__ bool rows_gpart(const ddp_conv_shape_t& S, int bi, in
 struct RowsGPart {
   const char* base;      // the part's tile inside node 0's row of its G array
   size_t gldb;           // node stride in bytes
-  int wp, nmine, bias_off;   // padded width, columns, byte offset of Gb[column 0] from `base`
+  int wp, nmine, bias_off;   // padded width, columns, byte offset of Gb[column 0] (plane form 1: of the Gb region) from `base`
+  int cumw;              // padded columns of the slot in front of the part
 };
+// Plane form 1 of a G array (ddp_conv_task_t::gh_fmt = 1, round 6: "G3"): a part's tile is [k8][wp columns] 16-byte hi pieces (8 fp16 words),
+// then [k8][wp columns] 8-byte lo pieces (8 OCP e4m3 bytes of (V - hi) * DDP_GH3_LO_SCALE) - 24 bytes per 8 values instead of 32; Gb per
+// padded column c of the slot sits behind the tiles at 32 (c / 6) + 4 (c % 6) bytes (stage A stores 6 fp32 values per 8-column group).
+template <bool G3>
 __device__ __forceinline__ RowsGPart rows_gpart_of(const ddp_conv_shape_t& S, const ddp_conv_task_t& T, int bi, int part) {
   RowsGPart P;
   int wp, cumw, gcp;
   rows_gpart(S, bi, part, wp, cumw, gcp);
   const int n8 = (S.hid + 7) >> 3;
-  P.base = reinterpret_cast<const char*>(T.gh[S.blk[bi].g_slot]) + (size_t)(2 * n8 * cumw) * 16;
-  P.gldb = (size_t)DDP_GH_LD(S.hid, gcp) * 4;
+  if constexpr (G3) {
+    P.base = reinterpret_cast<const char*>(T.gh[S.blk[bi].g_slot]) + (size_t)(n8 * cumw) * 24;
+    P.gldb = (size_t)DDP_GH3_LD(S.hid, gcp) * 4;
+    P.bias_off = n8 * (gcp - cumw) * 24;
+  } else {
+    P.base = reinterpret_cast<const char*>(T.gh[S.blk[bi].g_slot]) + (size_t)(2 * n8 * cumw) * 16;
+    P.gldb = (size_t)DDP_GH_LD(S.hid, gcp) * 4;
+    P.bias_off = (8 * n8 * gcp + cumw) * 4 - (2 * n8 * cumw) * 16;
+  }
   P.wp = wp;
   P.nmine = min(32, S.blk[bi].n - 32 * part);
-  P.bias_off = (8 * n8 * gcp + cumw) * 4 - (2 * n8 * cumw) * 16;
+  P.cumw = cumw;
   return P;
 }
-template <int NS, int GR, bool MERGE>
+// per-lane byte offsets of a G part's fragments and of its Gb word (cl = the lane's column of the part)
+template <bool G3>
+struct RowsGLane {
+  unsigned h_main, h_last;    // hi (plane form 0: hi and lo) fragment of k-step kq < NS - 1: + fragment offset; of the last k-step
+  unsigned l_main, l_last;    // plane form 1: the 8-byte lo pieces
+  unsigned bias;
+};
+template <bool G3>
+__device__ __forceinline__ RowsGLane<G3> rows_glane(const RowsGPart& P, int n8, int NS, int hh, int cl) {
+  RowsGLane<G3> o;
+  const int gc = P.wp;
+  const int k8l = min(2 * (NS - 1) + hh, n8 - 1);
+  if constexpr (G3) {
+    o.h_main = (unsigned)(hh * gc + cl) * 16u;
+    o.h_last = (unsigned)(k8l * gc + cl) * 16u;
+    o.l_main = (unsigned)(n8 * gc) * 16u + (unsigned)(hh * gc + cl) * 8u;
+    o.l_last = (unsigned)(n8 * gc) * 16u + (unsigned)(k8l * gc + cl) * 8u;
+    const int c = P.cumw + cl;
+    o.bias = (unsigned)(P.bias_off + 32 * (c / 6) + 4 * (c % 6));
+  } else {
+    o.h_main = (unsigned)(2 * hh * gc + 2 * cl) * 16u;
+    o.h_last = (unsigned)(2 * k8l * gc + 2 * cl) * 16u;
+    o.l_main = o.h_main + 16u;
+    o.l_last = o.h_last + 16u;
+    o.bias = (unsigned)(P.bias_off + 4 * cl);
+  }
+  return o;
+}
+// uniform byte offset of k-step kq's fragments inside a part's tile (the last k-step is addressed by the lane offsets alone)
+template <bool G3>
+__device__ __forceinline__ constexpr unsigned rows_gfrag_hi(int kq, int NS, int gc) {
+  return (kq == NS - 1) ? 0u : (unsigned)((G3 ? 2 : 4) * kq * gc) * 16u;
+}
+template <bool G3>
+__device__ __forceinline__ constexpr unsigned rows_gfrag_lo(int kq, int NS, int gc) {
+  return (kq == NS - 1) ? 0u : (G3 ? (unsigned)(2 * kq * gc) * 8u : (unsigned)(4 * kq * gc) * 16u);
+}
+// the lo plane of a fragment as the B operand: plane form 0 holds the 8 fp16 words, plane form 1 eight e4m3 bytes at DDP_GH3_LO_SCALE
+typedef float f32x2r __attribute__((ext_vector_type(2)));
+template <bool G3>
+struct RowsLoT { typedef f32x4 type; };
+template <>
+struct RowsLoT<true> { typedef f32x2r type; };
+template <bool G3>
+__device__ __forceinline__ h8 rows_lo_operand(const typename RowsLoT<G3>::type v) {
+  if constexpr (G3) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const unsigned u0 = __builtin_bit_cast(unsigned, v[0]), u1 = __builtin_bit_cast(unsigned, v[1]);
+    constexpr float inv = 1.f / (float)DDP_GH3_LO_SCALE;
+    const h2 a = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(u0, inv, false), b = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(u0, inv, true);
+    const h2 c = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(u1, inv, false), d = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(u1, inv, true);
+    return h8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+  } else {
+    return __builtin_bit_cast(h8, v);
+  }
+}
+template <int NS, int GR, bool MERGE, bool G3>
 __device__ __forceinline__ f32x16 rows_g_runs(const ddp_conv_shape_t& S, const RowsGPart& PA, const RowsGPart& PB, const h8 (&ah)[NS], const h8 (&al)[NS],
                                               const RowsAux* aux, unsigned rmask, int src_reg, int lane) {
-  constexpr int NF = 2 * NS;
-  static_assert(NF % GR == 0, "fragment f of every G tile lives in ring slot f % GR");
+  constexpr int NF = 2 * NS, GK = GR / 2;      // the ring holds GK k-steps: a hi and a lo fragment each
+  static_assert(NF % GR == 0 && GR % 2 == 0, "k-step ks of every G tile lives in ring slot ks % (GR / 2)");
+  typedef typename RowsLoT<G3>::type lo_t;
   const int r = lane & 31, hh = lane >> 5;
   const int n8 = (S.hid + 7) >> 3;
   const int ncols = MERGE ? PA.nmine + PB.nmine : PA.nmine;
   const bool inb = MERGE && r >= PA.nmine;                                          // this lane reads block B's array
   const int cl = (r < ncols) ? (inb ? r - PA.nmine : r) : 0;
   const int gc = PA.wp;                                                             // (MERGE: the same for both parts)
-  const unsigned lo_main = (unsigned)(2 * hh * gc + 2 * cl) * 16u;                  // + (4 ks wp + plane) * 16
-  const int k8l = min(2 * (NS - 1) + hh, n8 - 1);
-  const unsigned lo_last = (unsigned)(2 * k8l * gc + 2 * cl) * 16u;                 // + plane * 16
-  const unsigned lo_bias = (unsigned)((inb ? PB.bias_off : PA.bias_off) + 4 * cl);
+  const RowsGLane<G3> LA = rows_glane<G3>(PA, n8, NS, hh, cl), LB = rows_glane<G3>(PB, n8, NS, hh, cl);
+  const unsigned lo_bias = inb ? LB.bias : LA.bias;
+  const unsigned h_main = LA.h_main, h_last = LA.h_last, l_main = LA.l_main, l_last = LA.l_last;     // (the same for both parts: one width)
 #ifdef DDP_ROWS_ABL_G0   // timing-only ablation: the runs read the G of nodes 0 .. DDP_ROWS_ABL_G0 - 1 (L2 hits): is the G phase bound by where G comes from?
 #define ROWS_NODE(a) (__builtin_amdgcn_readlane(src_reg, (a)) & (DDP_ROWS_ABL_G0 - 1))
 #else
@@ -326,16 +394,20 @@ __device__ __forceinline__ f32x16 rows_g_runs(const ddp_conv_shape_t& S, const R
 #endif
   // node base of this lane's array: wave-uniform without MERGE (SGPRs), a per-lane select of two uniform bases with it
 #define ROWS_GBASE(a) (inb ? PB.base + (size_t)ROWS_NODE(a) * PB.gldb : PA.base + (size_t)ROWS_NODE(a) * PA.gldb)
-#define ROWS_GFRAG(base, kq, plane) \
-  (*reinterpret_cast<const f32x4*>((base) + (((kq) == NS - 1) ? (size_t)(plane) * 16 : (size_t)(4 * (kq) * gc + (plane)) * 16) + (((kq) == NS - 1) ? lo_last : lo_main)))
+#define ROWS_GFRAG_HI(base, kq) (*reinterpret_cast<const f32x4*>((base) + rows_gfrag_hi<G3>((kq), NS, gc) + (((kq) == NS - 1) ? h_last : h_main)))
+#define ROWS_GFRAG_LO(base, kq) (*reinterpret_cast<const lo_t*>((base) + rows_gfrag_lo<G3>((kq), NS, gc) + (((kq) == NS - 1) ? l_last : l_main)))
   unsigned m = rmask;
   int a0 = __builtin_ctz(m);
   const char* __restrict__ gp = ROWS_GBASE(a0);
   float bias = *reinterpret_cast<const float*>(gp + lo_bias);
   __builtin_amdgcn_sched_barrier(0);
-  f32x4 gr[GR];
+  f32x4 grh[GK];
+  lo_t grl[GK];
 #pragma unroll
-  for (int k = 0; k < GR; ++k) gr[k] = ROWS_GFRAG(gp, k >> 1, k & 1);
+  for (int k = 0; k < GK; ++k) {
+    grh[k] = ROWS_GFRAG_HI(gp, k);
+    grl[k] = ROWS_GFRAG_LO(gp, k);
+  }
   __builtin_amdgcn_sched_barrier(0);
   int run = 0;
   const int* ridrow = &aux->rid[4 * hh];
@@ -348,15 +420,13 @@ __device__ __forceinline__ f32x16 rows_g_runs(const ddp_conv_shape_t& S, const R
     f32x16 acc = splat16(bias);
 #pragma unroll
     for (int ks = 0; ks < NS; ++ks) {
-      const h8 bh = __builtin_bit_cast(h8, gr[(2 * ks) % GR]), bl = __builtin_bit_cast(h8, gr[(2 * ks + 1) % GR]);
+      const h8 bh = __builtin_bit_cast(h8, grh[ks % GK]), bl = rows_lo_operand<G3>(grl[ks % GK]);
       {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int q0 = 2 * ks + GR;                      // the pair of fragments that takes the two slots this step frees
-        const int kq = (q0 < NF) ? (q0 >> 1) : ((q0 - NF) >> 1);
-        const char* __restrict__ srcb = (q0 < NF) ? gp : gpn;
-        gr[(2 * ks) % GR] = ROWS_GFRAG(srcb, kq, 0);
-        gr[(2 * ks + 1) % GR] = ROWS_GFRAG(srcb, kq, 1);
+        const int q0 = ks + GK;                          // the k-step that takes the slot this step frees
+        const int kq = (q0 < NS) ? q0 : q0 - NS;
+        const char* __restrict__ srcb = (q0 < NS) ? gp : gpn;
+        grh[ks % GK] = ROWS_GFRAG_HI(srcb, kq);
+        grl[ks % GK] = ROWS_GFRAG_LO(srcb, kq);
       }
       __builtin_amdgcn_sched_barrier(0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh, acc, 0, 0, 0);
@@ -371,7 +441,8 @@ __device__ __forceinline__ f32x16 rows_g_runs(const ddp_conv_shape_t& S, const R
     a0 = an;
     ++run;
   }
-#undef ROWS_GFRAG
+#undef ROWS_GFRAG_HI
+#undef ROWS_GFRAG_LO
 #undef ROWS_GBASE
 #undef ROWS_NODE
   return tg;
@@ -380,7 +451,7 @@ __device__ __forceinline__ f32x16 rows_g_runs(const ddp_conv_shape_t& S, const R
 // The G runs of a SCALAR segment (C = 1, one G array): like rows_g_runs, but
 //  * the fragments are BUFFER loads - descriptor of the node's tile (4 SGPRs, rebuilt per run) + the fragment's uniform offset (an SGPR) +
 //    ONE lane offset register; as global loads hipcc kept a 64-bit lane address per fragment of the run in registers (24 of them);
-//  * the register ring holds a WHOLE tile (DDP_ROWS_GRING1 = 2 NS fragments, 24 KiB in flight per wave: the unified planes freed an
+//  * the register ring holds half a tile (DDP_ROWS_GRING1 = 12 fragments = 6 k-steps, 12 KiB in flight per wave: the unified planes freed an
 //    accumulator per product): while run i is multiplied, run i + 1 arrives in the slots its steps free - a run costs the larger of
 //    its 36 MFMAs and ONE memory round trip, not three;
 //  * the last run's steps load from an EMPTY buffer (num_records = 0: the loads return zeros without touching memory) instead of
@@ -394,13 +465,22 @@ struct RowsGSeq {        // (scalars only: the ring and the accumulators are sep
   float bias;            // Gb of the current run's column (added when the run's product is added to the accumulator)
   unsigned m;            // runs not yet started (bit = first row)
   int run, nruns;
-  unsigned lo_main, lo_last, lo_bias;
+  unsigned h_main, h_last, l_main, l_last, lo_bias;
   int gc;
 };
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-#define ROWS_GSEQ_FRAG(G, R, kq, plane)                                                                                              \
-  __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((R), (((kq) == NS - 1) ? (G).lo_last : (G).lo_main) + (plane) * 16, \
-                                                                  ((kq) == NS - 1) ? 0 : 4 * (kq) * (G).gc * 16, 0))
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <bool G3, int NS>
+__device__ __forceinline__ f32x4 rows_gseq_hi(const RowsGSeq& G, RowsStream R, int kq) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(R, (kq == NS - 1) ? G.h_last : G.h_main, (int)rows_gfrag_hi<G3>(kq, NS, G.gc), 0));
+}
+template <bool G3, int NS>
+__device__ __forceinline__ typename RowsLoT<G3>::type rows_gseq_lo(const RowsGSeq& G, RowsStream R, int kq) {
+  if constexpr (G3)
+    return __builtin_bit_cast(f32x2r, __builtin_amdgcn_raw_buffer_load_b64(R, (kq == NS - 1) ? G.l_last : G.l_main, (int)rows_gfrag_lo<G3>(kq, NS, G.gc), 0));
+  else
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(R, (kq == NS - 1) ? G.l_last : G.l_main, (int)rows_gfrag_lo<G3>(kq, NS, G.gc), 0));
+}
 __device__ __forceinline__ RowsStream rows_gseq_node(const RowsGSeq& G, int src_reg, int row) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(G.base + (size_t)__builtin_amdgcn_readlane(src_reg, row) * G.gldb), 0, (int)G.gldb, 0x00020000);
 }
@@ -412,17 +492,19 @@ __device__ __forceinline__ void rows_gseq_next(RowsGSeq& G, int src_reg, f32x16&
   G.bias = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(G.rs, G.lo_bias, 0, 0));
   gacc = splat16(0.f);
 }
-template <int NS, int GR>
-__device__ __forceinline__ void rows_gseq_init(RowsGSeq& G, f32x4 (&gr)[GR], f32x16& gacc, const ddp_conv_shape_t& S, const RowsGPart& PA,
-                                               unsigned rmask, int src_reg, int lane) {
+template <int NS, int GK, bool G3>
+__device__ __forceinline__ void rows_gseq_init(RowsGSeq& G, f32x4 (&grh)[GK], typename RowsLoT<G3>::type (&grl)[GK], f32x16& gacc,
+                                               const ddp_conv_shape_t& S, const RowsGPart& PA, unsigned rmask, int src_reg, int lane) {
   const int r = lane & 31, hh = lane >> 5;
   const int n8 = (S.hid + 7) >> 3;
   const int cl = (r < PA.nmine) ? r : 0;
   G.gc = PA.wp;
-  G.lo_main = (unsigned)(2 * hh * G.gc + 2 * cl) * 16u;
-  const int k8l = min(2 * (NS - 1) + hh, n8 - 1);
-  G.lo_last = (unsigned)(2 * k8l * G.gc + 2 * cl) * 16u;
-  G.lo_bias = (unsigned)(PA.bias_off + 4 * cl);
+  const RowsGLane<G3> LA = rows_glane<G3>(PA, n8, NS, hh, cl);
+  G.h_main = LA.h_main;
+  G.h_last = LA.h_last;
+  G.l_main = LA.l_main;
+  G.l_last = LA.l_last;
+  G.lo_bias = LA.bias;
   G.base = PA.base;
   G.gldb = PA.gldb;
   G.m = rmask;
@@ -431,31 +513,29 @@ __device__ __forceinline__ void rows_gseq_init(RowsGSeq& G, f32x4 (&gr)[GR], f32
   G.rs = rows_gseq_node(G, src_reg, __builtin_ctz(rmask));
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int k = 0; k < GR; ++k) gr[k] = ROWS_GSEQ_FRAG(G, G.rs, k >> 1, k & 1);
+  for (int k = 0; k < GK; ++k) {
+    grh[k] = rows_gseq_hi<G3, NS>(G, G.rs, k);
+    grl[k] = rows_gseq_lo<G3, NS>(G, G.rs, k);
+  }
   __builtin_amdgcn_sched_barrier(0);
   rows_gseq_next(G, src_reg, gacc);
 }
-// k-step KS of the current run: three split products from ring slots (2 KS, 2 KS + 1) % GR, which then take the fragments GR / 2 k-steps on
-template <int NS, int GR, int KS>
-__device__ __forceinline__ void rows_gseq_step(RowsGSeq& G, f32x4 (&gr)[GR], f32x16& gacc, const h8 (&ah)[NS], const h8 (&al)[NS]) {
-  constexpr int NF = 2 * NS, q0 = 2 * KS + GR, kq = (q0 < NF) ? (q0 >> 1) : ((q0 - NF) >> 1);
+// k-step KS of the current run: three split products from ring slot KS % GK, which then takes the fragments GK k-steps on
+template <int NS, int GK, int KS, bool G3>
+__device__ __forceinline__ void rows_gseq_step(RowsGSeq& G, f32x4 (&grh)[GK], typename RowsLoT<G3>::type (&grl)[GK], f32x16& gacc, const h8 (&ah)[NS],
+                                               const h8 (&al)[NS]) {
+  constexpr int q0 = KS + GK, kq = (q0 < NS) ? q0 : q0 - NS;
   __builtin_amdgcn_sched_barrier(0);
-#if !defined(DDP_ROWS_ABL_GSEQ) || DDP_ROWS_ABL_GSEQ != 2     // (timing-only ablations: 1 = no fragment loads behind the first ring fill, 2 = loads, no products)
   {
-    const h8 bh = __builtin_bit_cast(h8, gr[(2 * KS) % GR]), bl = __builtin_bit_cast(h8, gr[(2 * KS + 1) % GR]);
+    const h8 bh = __builtin_bit_cast(h8, grh[KS % GK]), bl = rows_lo_operand<G3>(grl[KS % GK]);
     gacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS], bh, gacc, 0, 0, 0);
     gacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS], bl, gacc, 0, 0, 0);
     gacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[KS], bh, gacc, 0, 0, 0);
   }
-#else
-  gacc[0] += gr[(2 * KS) % GR][0] + gr[(2 * KS + 1) % GR][1];
-#endif
   __builtin_amdgcn_sched_barrier(0);
-#if !defined(DDP_ROWS_ABL_GSEQ) || DDP_ROWS_ABL_GSEQ != 1
-  const RowsStream srcb = (q0 < NF) ? G.rs : G.rsn;
-  gr[(2 * KS) % GR] = ROWS_GSEQ_FRAG(G, srcb, kq, 0);
-  gr[(2 * KS + 1) % GR] = ROWS_GSEQ_FRAG(G, srcb, kq, 1);
-#endif
+  const RowsStream srcb = (q0 < NS) ? G.rs : G.rsn;
+  grh[KS % GK] = rows_gseq_hi<G3, NS>(G, srcb, kq);
+  grl[KS % GK] = rows_gseq_lo<G3, NS>(G, srcb, kq);
   __builtin_amdgcn_sched_barrier(0);
 }
 // the run's last k-step is done: res[row] += sh0[row] * product for the rows of THIS run (lanes behind the tile's last column: nothing)
@@ -479,7 +559,7 @@ __device__ __forceinline__ void rows_gseq_finish(RowsGSeq& G, f32x16& gacc, cons
 
 // gmode: 0 = the segment runs its own G tiles; 1 = it runs the MERGED tiles of its block and the next one (block B's products are
 // parked behind the wave's per-edge tables); 2 = its G products were computed by the segment before (lanes [n, 2 n))
-template <int NS, int C>
+template <int NS, int C, bool G3>
 __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_block_t& B, int bi, int part, const ddp_conv_task_t& T, const h8 (&ah)[NS],
                                             const h8 (&al)[NS], f32x4* ring, const float* lbias, int t, const float* F,
                                             const RowsAux* aux, unsigned rmask, int src_reg, int nvw, int wave, int lane, int sgi,
@@ -510,12 +590,13 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
   bool gdone = false;
   if constexpr (C == 1) {
     if (B.g_slot >= 0 && rmask != 0u) {
-      constexpr int GR1 = (DDP_ROWS_GRING1 >= NF) ? NF : GR;
-      const RowsGPart PA = rows_gpart_of(S, T, bi, part);
+      constexpr int GK1 = ((DDP_ROWS_GRING1 >= NF) ? NF : GR) / 2;      // k-steps in the ring
+      const RowsGPart PA = rows_gpart_of<G3>(S, T, bi, part);
       RowsGSeq G;
-      f32x4 gr[GR1];
+      f32x4 grh[GK1];
+      typename RowsLoT<G3>::type grl[GK1];
       f32x16 gacc;
-      rows_gseq_init<NS, GR1>(G, gr, gacc, S, PA, rmask, src_reg, lane);
+      rows_gseq_init<NS, GK1, G3>(G, grh, grl, gacc, S, PA, rmask, src_reg, lane);
       const int* ridrow = &aux->rid[4 * hh];
       const float* shrow = &aux->shT[0][4 * hh];
       const bool mine = r < PA.nmine;
@@ -523,18 +604,18 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
 #pragma unroll
         for (int ks = 0; ks < NS; ++ks) {
           // (static k-steps: the chain is resolved at compile time)
-          if (ks == 0) rows_gseq_step<NS, GR1, 0>(G, gr, gacc, ah, al);
-          else if (ks == 1) rows_gseq_step<NS, GR1, 1 % NS>(G, gr, gacc, ah, al);
-          else if (ks == 2) rows_gseq_step<NS, GR1, 2 % NS>(G, gr, gacc, ah, al);
-          else if (ks == 3) rows_gseq_step<NS, GR1, 3 % NS>(G, gr, gacc, ah, al);
-          else if (ks == 4) rows_gseq_step<NS, GR1, 4 % NS>(G, gr, gacc, ah, al);
-          else if (ks == 5) rows_gseq_step<NS, GR1, 5 % NS>(G, gr, gacc, ah, al);
-          else if (ks == 6) rows_gseq_step<NS, GR1, 6 % NS>(G, gr, gacc, ah, al);
-          else if (ks == 7) rows_gseq_step<NS, GR1, 7 % NS>(G, gr, gacc, ah, al);
-          else if (ks == 8) rows_gseq_step<NS, GR1, 8 % NS>(G, gr, gacc, ah, al);
-          else if (ks == 9) rows_gseq_step<NS, GR1, 9 % NS>(G, gr, gacc, ah, al);
-          else if (ks == 10) rows_gseq_step<NS, GR1, 10 % NS>(G, gr, gacc, ah, al);
-          else rows_gseq_step<NS, GR1, 11 % NS>(G, gr, gacc, ah, al);
+          if (ks == 0) rows_gseq_step<NS, GK1, 0, G3>(G, grh, grl, gacc, ah, al);
+          else if (ks == 1) rows_gseq_step<NS, GK1, 1 % NS, G3>(G, grh, grl, gacc, ah, al);
+          else if (ks == 2) rows_gseq_step<NS, GK1, 2 % NS, G3>(G, grh, grl, gacc, ah, al);
+          else if (ks == 3) rows_gseq_step<NS, GK1, 3 % NS, G3>(G, grh, grl, gacc, ah, al);
+          else if (ks == 4) rows_gseq_step<NS, GK1, 4 % NS, G3>(G, grh, grl, gacc, ah, al);
+          else if (ks == 5) rows_gseq_step<NS, GK1, 5 % NS, G3>(G, grh, grl, gacc, ah, al);
+          else if (ks == 6) rows_gseq_step<NS, GK1, 6 % NS, G3>(G, grh, grl, gacc, ah, al);
+          else if (ks == 7) rows_gseq_step<NS, GK1, 7 % NS, G3>(G, grh, grl, gacc, ah, al);
+          else if (ks == 8) rows_gseq_step<NS, GK1, 8 % NS, G3>(G, grh, grl, gacc, ah, al);
+          else if (ks == 9) rows_gseq_step<NS, GK1, 9 % NS, G3>(G, grh, grl, gacc, ah, al);
+          else if (ks == 10) rows_gseq_step<NS, GK1, 10 % NS, G3>(G, grh, grl, gacc, ah, al);
+          else rows_gseq_step<NS, GK1, 11 % NS, G3>(G, grh, grl, gacc, ah, al);
         }
         rows_gseq_finish(G, gacc, ridrow, shrow, mine, src_reg, res[0]);
       }
@@ -558,8 +639,8 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
       }
       rows_apply_harmonics<C>(tsel, shrow, res);
     } else if (gmode == 1) {
-      const RowsGPart PA = rows_gpart_of(S, T, bi, part), PB = rows_gpart_of(S, T, bi + 1, 0);
-      const f32x16 tg = rows_g_runs<NS, GR, true>(S, PA, PB, ah, al, aux, rmask, src_reg, lane);
+      const RowsGPart PA = rows_gpart_of<G3>(S, T, bi, part), PB = rows_gpart_of<G3>(S, T, bi + 1, 0);
+      const f32x16 tg = rows_g_runs<NS, GR, true, G3>(S, PA, PB, ah, al, aux, rmask, src_reg, lane);
       if (in_b) {
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) pair[q4] = f32x4{tg[4 * q4], tg[4 * q4 + 1], tg[4 * q4 + 2], tg[4 * q4 + 3]};
@@ -569,8 +650,8 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
       for (int i = 0; i < 16; ++i) tsel[i] = (r < B.n) ? tg[i] : 0.f;
       rows_apply_harmonics<C>(tsel, shrow, res);
     } else {
-      const RowsGPart PA = rows_gpart_of(S, T, bi, part);
-      const f32x16 tg = rows_g_runs<NS, GR, false>(S, PA, PA, ah, al, aux, rmask, src_reg, lane);
+      const RowsGPart PA = rows_gpart_of<G3>(S, T, bi, part);
+      const f32x16 tg = rows_g_runs<NS, GR, false, G3>(S, PA, PA, ah, al, aux, rmask, src_reg, lane);
       rows_apply_harmonics<C>(tg, shrow, res);
     }
   }
@@ -634,7 +715,7 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
   return t;
 }
 
-template <int SZ>
+template <int SZ, bool G3>
 __global__ __launch_bounds__(ROWS_NT, 2) void ddp_conv_rows_kernel(const RowsLaunch RL) {
   constexpr int NS = H2Class<SZ>::NS, RING_Q = 2 * NS * 64;     // the ring holds one tile's worth of pieces
   constexpr int NCT1 = (3 * SZ + 31) / 32, NQ = SZ / 4;     // fc.0 column tiles; 16-byte quads per edge_attr_ segment (ns floats each)
@@ -824,9 +905,9 @@ __global__ __launch_bounds__(ROWS_NT, 2) void ddp_conv_rows_kernel(const RowsLau
         else if (with_next) gmode = 1;
       }
       if (B.C == 1)
-        t = rows_segment<NS, 1>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane, sgi, 0);
+        t = rows_segment<NS, 1, G3>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane, sgi, 0);
       else
-        t = rows_segment<NS, 3>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane, sgi, gmode);
+        t = rows_segment<NS, 3, G3>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane, sgi, gmode);
     }
   }
 }
@@ -863,10 +944,13 @@ extern "C" int ddp_conv_rows(const ddp_conv_shape_t* shape, const ddp_conv_task_
       if (B.U * B.C > frows) frows = B.U * B.C;
     }
   }
-  int tiles = 0;
+  int tiles = 0, gfmt = -1;
   for (int i = 0; i < ntasks; ++i) {
     const ddp_conv_task_t& T = tasks[i];
     if (T.n_edges <= 0) continue;  // an empty conv sends no message (models/score_model.py:109-111)
+    if (T.gh_fmt != 0 && T.gh_fmt != 1) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: task.gh_fmt must be 0 or 1");
+    if (gfmt >= 0 && T.gh_fmt != gfmt) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: the tasks of a launch carry G in ONE plane form");
+    gfmt = T.gh_fmt;
     if (T.n_edges_dev) L.dev_counts = 1;
     if (!T.wsh || !T.bsp || (reinterpret_cast<size_t>(T.wsh) & 15) || (reinterpret_cast<size_t>(T.bsp) & 15))
       return ddp_fail(DDP_EINVAL, "ddp_conv_rows: task.wsh / bsp missing (or not 16-byte aligned)");
@@ -894,19 +978,25 @@ extern "C" int ddp_conv_rows(const ddp_conv_shape_t* shape, const ddp_conv_task_
   priv = (priv + 127) / 128 * 128;
   RL.priv_bytes = priv;
   RL.bias_bytes = (nts * 128 + 127) / 128 * 128;
-  const size_t lds_bytes = (size_t)2 * (NS * 1024) + RL.bias_bytes + (size_t)ROWS_NW * priv;
+  size_t lds_bytes = (size_t)2 * (NS * 1024) + RL.bias_bytes + (size_t)ROWS_NW * priv;
   if (2 * lds_bytes > 160 * 1024) return ddp_fail(DDP_ELIMIT, "ddp_conv_rows: LDS budget of two workgroups per CU exceeded (too many vector features per block)");
-  static int lds_have[2] = {0, 0};
+  // occupancy shaping (ddp_set_occupancy_shaping): a launch that is to leave one 256-register wave slot per SIMD to another kernel asks
+  // for more LDS than two workgroups per CU can have
+  if ((size_t)ddp_shape_rows_min_lds > lds_bytes) lds_bytes = (size_t)ddp_shape_rows_min_lds;
+  static int lds_have[4] = {0, 0, 0, 0};
   hipError_t err;
-  if (sc == 60) {
-    err = ddp_need_lds(reinterpret_cast<const void*>(ddp_conv_rows_kernel<60>), (int)lds_bytes, &lds_have[0]);
-    if (err != hipSuccess) return ddp_fail_hip(err, "hipFuncSetAttribute(conv rows)");
-    hipLaunchKernelGGL(ddp_conv_rows_kernel<60>, dim3(tiles), dim3(ROWS_NT), lds_bytes, (hipStream_t)stream, RL);
-  } else {
-    err = ddp_need_lds(reinterpret_cast<const void*>(ddp_conv_rows_kernel<32>), (int)lds_bytes, &lds_have[1]);
-    if (err != hipSuccess) return ddp_fail_hip(err, "hipFuncSetAttribute(conv rows)");
-    hipLaunchKernelGGL(ddp_conv_rows_kernel<32>, dim3(tiles), dim3(ROWS_NT), lds_bytes, (hipStream_t)stream, RL);
+#define ROWS_LAUNCH(SZ_, G3_, I_)                                                                                                       \
+  {                                                                                                                                     \
+    err = ddp_need_lds(reinterpret_cast<const void*>(ddp_conv_rows_kernel<SZ_, G3_>), (int)lds_bytes, &lds_have[I_]);                  \
+    if (err != hipSuccess) return ddp_fail_hip(err, "hipFuncSetAttribute(conv rows)");                                                 \
+    hipLaunchKernelGGL((ddp_conv_rows_kernel<SZ_, G3_>), dim3(tiles), dim3(ROWS_NT), lds_bytes, (hipStream_t)stream, RL);               \
   }
+  if (sc == 60) {
+    if (gfmt == 1) ROWS_LAUNCH(60, true, 2) else ROWS_LAUNCH(60, false, 0)
+  } else {
+    if (gfmt == 1) ROWS_LAUNCH(32, true, 3) else ROWS_LAUNCH(32, false, 1)
+  }
+#undef ROWS_LAUNCH
   err = hipGetLastError();
   if (err != hipSuccess) return ddp_fail_hip(err, "ddp_conv_rows launch");
   return 0;

@@ -468,7 +468,11 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 // store instructions.  Where the two pieces of every 8-column group go is a table (gh_dest[batch][ncols / 8][2], float offsets inside
 // the row, built by the host from the parts of the G array; bit 0 of the first = a plane group): the drain has no arithmetic of its
 // own.  The other groups are fp32 columns (Gb, padding) and leave unconverted.  Needs ncols % 32 == 0.
-template <int KT, bool GH = false>
+// G3 (round 6, with GH): the lo plane of a plane group leaves as 8 OCP e4m3 bytes of (V - hi) * DDP_GH3_LO_SCALE instead of 8 fp16 words -
+// 24 bytes per 8 values instead of 32 (include/ddp_hip.h, ddp_conv_task_t::gh_fmt = 1): the second piece of EVERY group is then an
+// 8-byte store (fp32 groups - Gb - carry 6 values: the host leaves their last two product columns zero).  |V| must stay below 2048
+// (half an fp16 ulp times the scale stays inside e4m3's 448): range_flag otherwise.
+template <int KT, bool GH = false, bool G3 = false>
 __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(const float* __restrict__ x, int ldx, int nrows,
                                                                               const int32_t* __restrict__ rows,
                                                                               const int32_t* __restrict__ nrows_dev, int out_rows,
@@ -595,7 +599,18 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
     const f32x8 f = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     const h8 hi = __builtin_convertvector(f, h8);
     const f32x8 rest = f - __builtin_convertvector(hi, f32x8);     // (unified planes: lo at hi's scale, include/ddp_hip.h DDP_ROWS_S*)
-    const h8 lo = __builtin_convertvector(rest, h8);
+    h8 lo;
+    if constexpr (G3) {
+      // (the first two words of `lo` carry the 8 e4m3 bytes; v_cvt_pk_fp8_f32 rounds to nearest even like the fp16 conversion it replaces)
+      int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(rest[0] * (float)DDP_GH3_LO_SCALE, rest[1] * (float)DDP_GH3_LO_SCALE, 0, false);
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(rest[2] * (float)DDP_GH3_LO_SCALE, rest[3] * (float)DDP_GH3_LO_SCALE, w0, true);
+      int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(rest[4] * (float)DDP_GH3_LO_SCALE, rest[5] * (float)DDP_GH3_LO_SCALE, 0, false);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(rest[6] * (float)DDP_GH3_LO_SCALE, rest[7] * (float)DDP_GH3_LO_SCALE, w1, true);
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      lo = __builtin_bit_cast(h8, i32x4{w0, w1, 0, 0});
+    } else {
+      lo = __builtin_convertvector(rest, h8);
+    }
     const float m8 = fmaxf(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))), fmaxf(fmaxf(fabsf(f[4]), fabsf(f[5])), fmaxf(fabsf(f[6]), fabsf(f[7]))));
     gh_max = fmaxf(gh_max, pend_sp ? m8 : 0.f);
     const f32x4 vh = __builtin_bit_cast(f32x4, hi), vl = __builtin_bit_cast(f32x4, lo);
@@ -630,7 +645,16 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
         ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][s2], wr[t][1][s2], ac, 0, 0, 0);
         ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][s2], wr[t][0][s2], ac, 0, 0, 0);
       }
-      if constexpr (DRAIN && NS == 4) *reinterpret_cast<f32x4*>(&ob[pend_off[s2]]) = dv;
+      if constexpr (DRAIN && NS == 4) {
+        if constexpr (G3) {
+          if (s2 & 1)
+            *reinterpret_cast<f32x2*>(&ob[pend_off[s2]]) = f32x2{dv[0], dv[1]};
+          else
+            *reinterpret_cast<f32x4*>(&ob[pend_off[s2]]) = dv;
+        } else {
+          *reinterpret_cast<f32x4*>(&ob[pend_off[s2]]) = dv;
+        }
+      }
     }
     if constexpr (DRAIN && NS != 4) {
 #pragma unroll
@@ -639,7 +663,10 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
           gh_read(pt, p);
         else
           dv = *reinterpret_cast<const f32x4*>(&pt[pend_lds[p]]);
-        *reinterpret_cast<f32x4*>(&ob[pend_off[p]]) = dv;
+        if (G3 && (p & 1))
+          *reinterpret_cast<f32x2*>(&ob[pend_off[p]]) = f32x2{dv[0], dv[1]};
+        else
+          *reinterpret_cast<f32x4*>(&ob[pend_off[p]]) = dv;
       }
     }
     float* tl = st[wave][pbuf];
@@ -714,24 +741,30 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
         gh_read(pt, p);
       else
         dv = *reinterpret_cast<const f32x4*>(&pt[pend_lds[p]]);
-      *reinterpret_cast<f32x4*>(&ob[pend_off[p]]) = dv;
+      if (G3 && (p & 1))
+        *reinterpret_cast<f32x2*>(&ob[pend_off[p]]) = f32x2{dv[0], dv[1]};
+      else
+        *reinterpret_cast<f32x4*>(&ob[pend_off[p]]) = dv;
     }
   }
   __syncthreads();
   }
   if constexpr (GH) {
-    if (!(gh_max <= 65504.f) && range_flag) *range_flag = 1;
+    // (G3: the e4m3 lo plane holds half an fp16 ulp of V times DDP_GH3_LO_SCALE only below |V| = 2048)
+    if (!(gh_max <= (G3 ? 2047.f : 65504.f)) && range_flag) *range_flag = 1;
   }
 }
 
 static int stage_a_impl(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows,
                         const int32_t* offs, int nbatch, const float* w, const void* w_bf16x3, const void* w_h2, int k, int ncols, float* out,
-                        int ldo, int32_t* range_flag, void* stream, const int32_t* gh_dest = nullptr) {
+                        int ldo, int32_t* range_flag, void* stream, const int32_t* gh_dest = nullptr, int gh_fmt = 0) {
   if (!rows) out_rows = nrows;                       // dense: out[b] has one row per x row
   if (out_rows < 1 && nrows > 0) return ddp_fail(DDP_EINVAL, "ddp_stage_a: out_rows");
   if (nbatch < 0 || nbatch > DDP_MAX_GEMM_BATCH) return ddp_fail(DDP_ELIMIT, "ddp_stage_a: nbatch > DDP_MAX_GEMM_BATCH");
   if (k < 2 || k > 64 || (k & 1)) return ddp_fail(DDP_ELIMIT, "ddp_stage_a: K must be even and in [2, 64]");
-  if (ncols < 1 || nrows < 0 || ldo < ncols) return ddp_fail(DDP_EINVAL, "ddp_stage_a: ncols / nrows / ldo");
+  // (plane form 1 - fp16 hi + e4m3 lo - writes 24 bytes per 8 product columns: its rows are shorter than ncols floats)
+  if (ncols < 1 || nrows < 0 || (ldo < ncols && !(gh_dest && gh_fmt == 1 && ldo >= (ncols / 8) * 6)))
+    return ddp_fail(DDP_EINVAL, "ddp_stage_a: ncols / nrows / ldo");
   if (nbatch == 0 || nrows == 0) return 0;
   if (!x || !offs || !w || !out) return ddp_fail(DDP_EINVAL, "ddp_stage_a: null argument");
   if ((reinterpret_cast<size_t>(x) & 3) || (reinterpret_cast<size_t>(out) & 7))   // scalar loads: dword aligned
@@ -772,14 +805,28 @@ static int stage_a_impl(const float* x, int ldx, int nrows, const int32_t* rows,
           (reinterpret_cast<size_t>(gh_dest) & 7) == 0))
       return ddp_fail(DDP_EINVAL, "ddp_stage_a_gh: plane output needs the h2 path (w_h2, k in {60, 32, 24, 16}) and ncols % 32 == 0");
     const dim3 grid((ncols + 128 * DDP_SAH_CT_GH - 1) / (128 * DDP_SAH_CT_GH), gy, nbatch);
-#define DDP_GEMM_GH(KT)                                                                                          \
-    hipLaunchKernelGGL((ddp_stage_a_h2_kernel<KT, true>), grid, dim3(DDP_GEMM_THREADS), 0, s, x, ldx, nrows, rows, nrows_dev, out_rows, mrows, O, \
-                       reinterpret_cast<const _Float16*>(w_h2), ncols, out, ldo, range_flag, gh_dest)
+    // occupancy shaping (ddp_set_occupancy_shaping): extra dynamic LDS on top of the kernel's static 55 KB = one workgroup per CU
+    const int pad = ddp_shape_stage_a_pad;
+    static int pad_have[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define DDP_GEMM_GH(KT, I)                                                                                       \
+    {                                                                                                            \
+      if (pad > 0) {                                                                                             \
+        const hipError_t ep = (gh_fmt == 1) ? ddp_need_lds(reinterpret_cast<const void*>(ddp_stage_a_h2_kernel<KT, true, true>), pad, &pad_have[4 + I]) \
+                                            : ddp_need_lds(reinterpret_cast<const void*>(ddp_stage_a_h2_kernel<KT, true>), pad, &pad_have[I]); \
+        if (ep != hipSuccess) return ddp_fail_hip(ep, "hipFuncSetAttribute(stage A)");                           \
+      }                                                                                                          \
+      if (gh_fmt == 1)                                                                                           \
+        hipLaunchKernelGGL((ddp_stage_a_h2_kernel<KT, true, true>), grid, dim3(DDP_GEMM_THREADS), pad, s, x, ldx, nrows, rows, nrows_dev, out_rows, mrows, O, \
+                           reinterpret_cast<const _Float16*>(w_h2), ncols, out, ldo, range_flag, gh_dest);       \
+      else                                                                                                       \
+        hipLaunchKernelGGL((ddp_stage_a_h2_kernel<KT, true>), grid, dim3(DDP_GEMM_THREADS), pad, s, x, ldx, nrows, rows, nrows_dev, out_rows, mrows, O, \
+                           reinterpret_cast<const _Float16*>(w_h2), ncols, out, ldo, range_flag, gh_dest);       \
+    }
     switch (k) {
-      case 60: DDP_GEMM_GH(60); break;
-      case 32: DDP_GEMM_GH(32); break;
-      case 24: DDP_GEMM_GH(24); break;
-      default: DDP_GEMM_GH(16); break;
+      case 60: DDP_GEMM_GH(60, 0); break;
+      case 32: DDP_GEMM_GH(32, 1); break;
+      case 24: DDP_GEMM_GH(24, 2); break;
+      default: DDP_GEMM_GH(16, 3); break;
     }
 #undef DDP_GEMM_GH
     const hipError_t eg = hipGetLastError();
@@ -858,4 +905,13 @@ extern "C" int ddp_stage_a_gh(const float* x, int ldx, int nrows, const int32_t*
                               int32_t* range_flag, const int32_t* dest, void* stream) {
   if (!dest) return ddp_fail(DDP_EINVAL, "ddp_stage_a_gh: dest");
   return stage_a_impl(x, ldx, nrows, rows, nrows_dev, out_rows, offs, nbatch, w, nullptr, w_h2, k, ncols, out, ldo, range_flag, stream, dest);
+}
+
+// ddp_stage_a_gh with plane form 1 of ddp_conv_task_t::gh (fp16 hi + e4m3 lo: 24 bytes per 8 values; ABI 16).  `ldo` (floats per output row) is
+// then the row length of that form (packing.gh3_ld), smaller than ncols.
+extern "C" int ddp_stage_a_gh3(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows,
+                               const int32_t* offs, int nbatch, const float* w, const void* w_h2, int k, int ncols, float* out, int ldo,
+                               int32_t* range_flag, const int32_t* dest, void* stream) {
+  if (!dest) return ddp_fail(DDP_EINVAL, "ddp_stage_a_gh3: dest");
+  return stage_a_impl(x, ldx, nrows, rows, nrows_dev, out_rows, offs, nbatch, w, nullptr, w_h2, k, ncols, out, ldo, range_flag, stream, dest, 1);
 }

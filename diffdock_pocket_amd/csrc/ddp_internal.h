@@ -16,4 +16,9 @@ static inline hipError_t ddp_need_lds(const void* kernel, int bytes, int* have) 
   return err;
 }
 
+// Occupancy shaping (ddp_set_occupancy_shaping, include/ddp_hip.h): launch-time LDS floors that decide how many workgroups of a kernel
+// share a CU.  Plain ints read when a launch is enqueued.
+extern int ddp_shape_rows_min_lds;      // ddp_conv_rows: dynamic LDS of a launch is at least this many bytes
+extern int ddp_shape_stage_a_pad;       // ddp_stage_a*: dynamic LDS added to the kernels' static LDS
+
 #endif

@@ -774,7 +774,7 @@ class ForwardEngine:
         key = (l, tuple(k for k, _ in convs), rows_k)
         ent = m._stage_a_stacks.get(key)
         if ent is None or ent[0].device != x.device:
-            Ws, meta, ghs = [], [], []
+            Ws, meta, ghs, lds, fmts = [], [], [], [], set()
             for k, conv in convs:
                 pk = conv.packed_g(x.device)
                 for slot in (0, 1):
@@ -783,37 +783,42 @@ class ForwardEngine:
                         meta.append((k, slot, pk.g_in_off[slot]))
                         if rows_k:
                             ghs.append(pk.gh_groups[slot])
+                            lds.append(pk.gh_ld[slot])
+                            fmts.add(pk.gh_fmt)
+            assert len(fmts) <= 1 and len(set(lds)) <= 1, "the convs of one stage-A launch write G rows of one plane form and length"
+            gfmt = fmts.pop() if fmts else 0
             Wst = torch.stack(Ws).contiguous()
             # (the bf16x3 split of the weights - 1.5 x their size and three copy kernels - only when that option is on)
             ent = (Wst, meta, (C.c_int32 * len(meta))(*[mm[2] for mm in meta]), P.split_bf16x3(Wst) if (m.stage_a_bf16x3 and not rows_k) else None,
                    (P.split_h2(Wst, unified_scale=P.GH_SW) if rows_k else P.split_h2(Wst)) if (m.stage_a_h2 or rows_k) else None,
-                   torch.stack([P.gh_dest_table(ws, (convs[0][1].spec_g.hid + 7) // 8, Wst.shape[2]) for ws in ghs]).contiguous().to(x.device) if rows_k else None)
+                   torch.stack([P.gh_dest_table(ws, (convs[0][1].spec_g.hid + 7) // 8, Wst.shape[2], fmt=gfmt) for ws in ghs]).contiguous().to(x.device) if rows_k else None,
+                   (gfmt, lds[0] if lds else Wst.shape[2]))
             m._stage_a_stacks[key] = ent
         if m.stage_a_bf16x3 and ent[3] is None and not rows_k:
             ent = m._stage_a_stacks[key] = ent[:3] + (P.split_bf16x3(ent[0]),) + ent[4:]
         if m.stage_a_h2 and ent[4] is None:
             ent = m._stage_a_stacks[key] = ent[:4] + (P.split_h2(ent[0], unified_scale=P.GH_SW) if rows_k else P.split_h2(ent[0]),) + ent[5:]
-        gh = ent[5]
+        gh, (gfmt, g_ld) = ent[5], ent[6]
         ent = ent[:5]
         Wst, meta, offs, W3, Wh = ent
         nb = len(meta)
         if nb > L.DDP_MAX_GEMM_BATCH:
             raise L.DdpError("more (conv, slot) pairs per source array than DDP_MAX_GEMM_BATCH")
-        Gall = torch.empty((nb, n_rows, Wst.shape[2]), device=x.device, dtype=torch.float32)   # 128-byte aligned rows
+        Gall = torch.empty((nb, n_rows, g_ld), device=x.device, dtype=torch.float32)   # 128-byte aligned rows (plane form 1: 3 / 4 of the columns)
         prof = K.profiler(hbm=True)
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         n_list = n_rows if rows is None else int(rows.shape[0])
         if gh is not None:
-            K.stage_a(x, n_list, offs, nb, Wst, Gall, rows=rows, rows_cnt=rows_cnt, out_rows=n_rows, Wh=Wh, gh=gh)
+            K.stage_a(x, n_list, offs, nb, Wst, Gall, rows=rows, rows_cnt=rows_cnt, out_rows=n_rows, Wh=Wh, gh=gh, gh_fmt=gfmt, ldo=g_ld)
         else:
             K.stage_a(x, n_list, offs, nb, Wst, Gall, rows=rows, rows_cnt=rows_cnt, out_rows=n_rows, W3=W3 if m.stage_a_bf16x3 else None,
                       Wh=Wh if (m.stage_a_h2 and K.CONV_H2 and not m.stage_a_bf16x3) else None)
         if prof is not None:
             e1.record()
             # algorithmic bytes: the G rows written once + the scalar columns of x read once per product + the weights
-            row_bytes = 4.0 * nb * (Wst.shape[2] + Wst.shape[1])
+            row_bytes = 4.0 * nb * (g_ld + Wst.shape[1])
 
             def nbytes(n_list=n_list, rows_cnt=rows_cnt, row_bytes=row_bytes, wn=Wst.numel()):
                 n = n_list if rows_cnt is None else min(n_list, int(rows_cnt.item()))
@@ -1041,7 +1046,7 @@ class ForwardEngine:
                         continue
                     for _k, conv_ in convs_:
                         pk_ = conv_.packed_g(dev)
-                        tot += rows_[3] * 4 * sum(w.shape[1] for w in (getattr(pk_, "wgh", None) or []) if w is not None)
+                        tot += rows_[3] * 4 * sum(ld_ for ld_ in (getattr(pk_, "gh_ld", None) or []) if ld_ is not None)
                 return tot
             for l in range(L_):
                 nxt = plan(l + 1) if l + 1 < L_ else None
@@ -1084,6 +1089,15 @@ class ForwardEngine:
                             st_ = torch.cuda.current_stream(dev)
                             for ev in evs:
                                 st_.wait_event(ev)
+                            if getattr(m, "shape_early_rows", False):
+                                # one workgroup per CU (one 256-register wave per SIMD): stage A of the atom rows, queued beside this launch,
+                                # finds a wave slot and 78 KiB of LDS on every CU (measured: tools/overlap_ab.py, profiles/r06_overlap_ab.txt)
+                                K.occupancy_shaping(82 * 1024, 0)
+                                try:
+                                    launch_factorised(nxt, "rl")
+                                finally:
+                                    K.occupancy_shaping(0, 0)
+                                return
                             launch_factorised(nxt, "rl")
                         side.run(0, early)
                     stage_a(nxt, "a")

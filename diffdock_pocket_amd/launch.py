@@ -230,6 +230,12 @@ def set_range_flag(t):
 CONV_ROWS = os.environ.get("DDP_CONV_ROWS", "1") != "0"     # (environment: same-box A/B runs)
 
 
+def occupancy_shaping(rows_min_lds: int = 0, stage_a_pad: int = 0):
+    """ddp_set_occupancy_shaping (include/ddp_hip.h): launches enqueued from here on - ddp_conv_rows with at least `rows_min_lds` bytes of
+    dynamic LDS (> 80 KiB: one workgroup per CU), stage A's plane form with `stage_a_pad` extra bytes.  (0, 0): the kernels' own."""
+    L.check(L.load().ddp_set_occupancy_shaping(int(rows_min_lds), int(stage_a_pad)), "ddp_set_occupancy_shaping")
+
+
 def rows_mode(pk) -> bool:
     """Does a factorised conv with these packed weights run through ddp_conv_rows?  (Decided where stage A is planned: it writes G in
     the layout the conv kernel of the same layer reads.)"""
@@ -258,6 +264,7 @@ def make_task(pk, x_src, ldx_src, view: EdgeView, sh, segs, msg, g=None, rows=Fa
     for k in range(2):
         gk = g[k].data_ptr() if (g is not None and g[k] is not None) else 0
         t.g[k], t.gh[k] = (0, gk) if rows else (gk, 0)
+    t.gh_fmt = int(getattr(pk, "gh_fmt", 0)) if rows else 0
     t._rows = bool(rows)
     t.pos = _p(view.pos)
     t.n_edges_dev = _p(view.cnt)
@@ -391,7 +398,7 @@ def edge_featurize_jobs(calls):
     return outs
 
 
-def stage_a(x, n_rows, offs, nb, W, out, rows=None, rows_cnt=None, out_rows=None, W3=None, Wh=None, gh=None):
+def stage_a(x, n_rows, offs, nb, W, out, rows=None, rows_cnt=None, out_rows=None, W3=None, Wh=None, gh=None, gh_fmt=0, ldo=None):
     """ddp_stage_a: out[b][row] = x[row, offs[b]:offs[b]+k] @ W[b] for the listed rows (all n_rows rows if rows is None).
     Wh: the weights pre-split for the fp16 hi/lo form (packing.split_h2; ddp_stage_a_h2), W3: for the bf16x3 form
     (packing.split_bf16x3); neither: exact fp32 MFMA.  gh = the destination table of the plane form (int32 device tensor
@@ -399,6 +406,11 @@ def stage_a(x, n_rows, offs, nb, W, out, rows=None, rows_cnt=None, out_rows=None
     lib = L.load()
     n_in, ncols = W.shape[1], W.shape[2]
     if n_rows == 0:
+        return
+    if gh is not None and gh_fmt == 1:     # plane form 1 (fp16 hi + e4m3 lo pieces): rows of `ldo` floats (packing.gh3_ld), shorter than ncols
+        L.check(lib.ddp_stage_a_gh3(x.data_ptr(), x.stride(0), n_rows, ptr(rows), ptr(rows_cnt), out_rows if out_rows is not None else n_rows,
+                                    offs, nb, W.data_ptr(), ptr(Wh), n_in, ncols, out.data_ptr(), int(ldo), ptr(_RANGE_FLAG), gh.data_ptr(),
+                                    stream()), "ddp_stage_a_gh3")
         return
     if gh is not None:
         L.check(lib.ddp_stage_a_gh(x.data_ptr(), x.stride(0), n_rows, ptr(rows), ptr(rows_cnt), out_rows if out_rows is not None else n_rows,

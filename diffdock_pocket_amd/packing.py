@@ -403,7 +403,7 @@ def _pack_tiles(Wcols: torch.Tensor, kp: int) -> torch.Tensor:
 H2_SCALE = 2048.0     # csrc/ddp_conv.hip DDP_H2_SCALE
 # plane scales of ddp_conv_rows' unified hi/lo planes (include/ddp_hip.h DDP_ROWS_S*): edge_attr_, weights, h, G
 ROWS_SX, ROWS_SW, ROWS_SH, ROWS_SG = 16.0, 256.0, 16.0, 32.0
-GH_SW = 1.0 / 16.0      # ddp_stage_a_gh: planes of w / DDP_GH_SX (the kernel splits x at DDP_GH_SX = 16)
+GH_SW = 1.0 / 2.0       # ddp_stage_a_gh: planes of w / DDP_GH_SX (the kernel splits x at DDP_GH_SX = 2: typical |16 w| and |2 x| keep normal lo halves)
 
 
 def h2_steps(spec: "ConvSpec") -> int:
@@ -605,12 +605,24 @@ def gh_ld(hid: int, gcp: int) -> int:
     return (((hid + 7) // 8 * 8 + 1) * gcp + 31) // 32 * 32
 
 
-def factor_weights_gh(spec: "ConvSpec", weight: torch.Tensor, bias: torch.Tensor):
+GH3_LO_SCALE = 512.0     # include/ddp_hip.h DDP_GH3_LO_SCALE: the e4m3 lo bytes of plane form 1 hold (V - hi) * 512
+
+
+def gh3_ld(hid: int, gcp: int) -> int:
+    """DDP_GH3_LD: floats per node of a G array in plane form 1 (fp16 hi + e4m3 lo pieces: 24 bytes per 8 values; Gb as 6 fp32 values per
+    32-byte group; 32 bytes of scratch for the product's padding groups; 128-byte aligned rows)."""
+    n8 = (hid + 7) // 8
+    return (n8 * gcp * 24 + (gcp + 5) // 6 * 32 + 32 + 127) // 128 * 32
+
+
+def factor_weights_gh(spec: "ConvSpec", weight: torch.Tensor, bias: torch.Tensor, fmt: int = 0):
     """factor_weights for ddp_conv_rows: right-hand sides whose product columns are ordered [part][k8 group][column c of the part][8 k's
     of the group] (gh_parts; the k's of group g = 2 ks + hh are rows_kperm's slots (ks, hh, 0..7); h columns >= hid and the padding
     columns of a part are zero), then Gb per padded column, then zero padding to DDP_GH_LD.  ddp_stage_a_gh writes the groups of a row
     as unified fp16 hi/lo planes, every part a contiguous tile [k8][c][plane][8] (ddp_conv_task_t::gh): the plane scale ROWS_SG rides in
     the G columns, the accumulator scale ROWS_SH ROWS_SG in the Gb columns.
+    fmt = 1 (plane form 1, ddp_stage_a_gh3): the same plane groups, then Gb in groups of SIX values per 8 product columns (a group's second
+    piece is an 8-byte store; columns 6, 7 stay zero), then zero padding to a multiple of 32 columns; the output row is gh3_ld floats.
     Returns ([Wg0, Wg1], [in_off0, in_off1], [part widths of slot 0, of slot 1])."""
     ns16 = h2_steps(spec)
     assert ns16 > 0
@@ -634,19 +646,23 @@ def factor_weights_gh(spec: "ConvSpec", weight: torch.Tensor, bias: torch.Tensor
             Bm[:, b.g_col0:b.g_col0 + b.n] = bias[rows] * b.scale
         parts = gh_parts(spec, slot)
         gcp = sum(p[4] for p in parts)
-        ld = gh_ld(spec.hid, gcp)
+        ld = gh_ld(spec.hid, gcp) if fmt == 0 else (8 * (n8 * gcp + (gcp + 5) // 6) + 31) // 32 * 32
         Wfull = torch.zeros(n_in, ld)
         Wk = W[:, kp].reshape(n_in, n8, 8, gc)                                                       # [u, k8, i, column]
         for _, _, c0, w, wp, cum in parts:
             tile = torch.zeros(n_in, n8, wp, 8)
             tile[:, :, :w] = Wk[:, :, :, c0:c0 + w].permute(0, 1, 3, 2) * ROWS_SG
             Wfull[:, 8 * n8 * cum:8 * n8 * (cum + wp)] = tile.reshape(n_in, -1)
-            Wfull[:, 8 * n8 * gcp + cum:8 * n8 * gcp + cum + w] = Bm[:, c0:c0 + w] * (ROWS_SH * ROWS_SG)
+            if fmt == 0:
+                Wfull[:, 8 * n8 * gcp + cum:8 * n8 * gcp + cum + w] = Bm[:, c0:c0 + w] * (ROWS_SH * ROWS_SG)
+            else:
+                cpad = cum + torch.arange(w)                                                         # padded column of the slot
+                Wfull[:, 8 * n8 * gcp + 8 * (cpad // 6) + cpad % 6] = Bm[:, c0:c0 + w] * (ROWS_SH * ROWS_SG)
         Wg[slot], offs[slot], widths[slot] = Wfull.contiguous(), blks[0].g_in_off, [p[4] for p in parts]
     return Wg, offs, widths
 
 
-def gh_dest_table(widths: Sequence[int], n8: int, ncols: int) -> torch.Tensor:
+def gh_dest_table(widths: Sequence[int], n8: int, ncols: int, fmt: int = 0) -> torch.Tensor:
     """int32 [ncols / 8, 2] for ddp_stage_a_gh: float offsets inside a G row of the two 16-byte pieces of every 8-column group of the
     product factor_weights_gh sets up; bit 0 of entry [g][0] set = a plane group (its values leave as fp16 hi / lo words).  Group
     g = n8 cum_p + k8 w_p + c of part p (cum_p = the widths in front of it) is the k8 group of column c: its hi piece sits at 16-byte unit
@@ -655,6 +671,27 @@ def gh_dest_table(widths: Sequence[int], n8: int, ncols: int) -> torch.Tensor:
     ng = ncols // 8
     tab = torch.empty((ng, 2), dtype=torch.int32)
     g = torch.arange(ng, dtype=torch.int64)
+    if fmt == 1:
+        # plane form 1: part p's tile starts at byte 24 n8 cum_p: hi piece of group (k8, c) at + 16 (k8 w_p + c), lo piece (8 e4m3 bytes) at
+        # + 16 n8 w_p + 8 (k8 w_p + c); Gb group j (6 values) at byte 24 n8 gcp + 32 j; the product's padding groups go to the scratch slot
+        gcp = sum(widths)
+        ngb = (gcp + 5) // 6
+        gb0 = 24 * n8 * gcp
+        assert 8 * (n8 * gcp + ngb) <= ncols
+        tab[:, 0] = (gb0 + 32 * ngb) // 4
+        tab[:, 1] = (gb0 + 32 * ngb) // 4 + 4
+        cum = 0
+        for w in widths:
+            gs = n8 * cum
+            gl = torch.arange(n8 * w, dtype=torch.int64)
+            base = 24 * n8 * cum
+            tab[gs:gs + n8 * w, 0] = ((base + 16 * gl) // 4 + 1).int()
+            tab[gs:gs + n8 * w, 1] = ((base + 16 * n8 * w + 8 * gl) // 4).int()
+            cum += w
+        j = torch.arange(ngb, dtype=torch.int64)
+        tab[n8 * gcp:n8 * gcp + ngb, 0] = ((gb0 + 32 * j) // 4).int()
+        tab[n8 * gcp:n8 * gcp + ngb, 1] = ((gb0 + 32 * j) // 4 + 4).int()
+        return tab
     tab[:, 0] = (8 * g).int()
     tab[:, 1] = (8 * g + 4).int()
     cum = 0

@@ -685,9 +685,21 @@ class PipelinedSampler:
         torch.cuda.synchronize(device)
         self.n = hi - lo
         self.n_l, self.n_a = self.parts[0].n_l, self.parts[0].n_a
+        self.on_hip = torch.device(device).type == "cuda"
         self._stats: list = []
         self._warm = False
         self._done = None          # event after the most recent group step
+
+    def snapshot(self):
+        """One `Sampler.snapshot()` per group (poses, generator state), taken with the device idle."""
+        torch.cuda.synchronize(self.device)
+        return [p.snapshot() for p in self.parts]
+
+    def restore(self, snap):
+        """Puts every group back to its snapshot (on the group's own stream, behind whatever its last step queued)."""
+        snaps = iter(snap)
+        self._each(lambda p: p.restore(next(snaps)))
+        torch.cuda.synchronize(self.device)
 
     def _each(self, fn):
         stats = []

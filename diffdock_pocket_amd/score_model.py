@@ -149,6 +149,9 @@ class _PackedConv:
                  "wsh", "bsp", "wgh", "gh_groups")     # (the last four: ddp_conv_rows' weight stream and stage-A right-hand sides)
 
 
+G_PLANES3_DEFAULT = "0"      # model.g_planes3 unless DDP_G_PLANES3 says otherwise
+
+
 class TensorProductConvLayer(nn.Module):
     """Parameter layout of reference models/score_model.py:84-107; the arithmetic of its forward (:108-125) runs in
     the HIP kernels.  `forward` keeps the reference call signature for a single conv (used by the parity tests);
@@ -185,7 +188,8 @@ class TensorProductConvLayer(nn.Module):
             pk.g_in_off = offs
             # the 256-edge row-stationary kernel (ddp_conv_rows; size class ns = 60): the fc.0 / fc.3 tiles as one stream in the
             # kernel's k order, and stage-A right-hand sides whose product ddp_stage_a_gh writes as fp16 hi/lo planes
-            pk.wsh = pk.bsp = pk.wgh = pk.gh_groups = None
+            pk.wsh = pk.bsp = pk.wgh = pk.gh_groups = pk.gh_ld = None
+            pk.gh_fmt = int(getattr(self, "gh_fmt", 0))     # plane form of G (ddp_conv_task_t::gh_fmt; set by the model: g_planes3)
             if P.rows_supported(self.spec_g):
                 try:
                     wsh, bsp = P.rows_stream(self.spec_g, self.fc[0].weight, self.fc[0].bias, self.fc[3].weight, self.fc[3].bias)
@@ -193,9 +197,12 @@ class TensorProductConvLayer(nn.Module):
                     wsh = None      # a weight beyond the unified planes' range (|w| > 255): this conv keeps the 32-edge kernel
                 if wsh is not None:
                     pk.wsh, pk.bsp = wsh.to(device), bsp.to(device)
-                    wgh, _, widths = P.factor_weights_gh(self.spec_g, self.fc[3].weight, self.fc[3].bias)
+                    wgh, _, widths = P.factor_weights_gh(self.spec_g, self.fc[3].weight, self.fc[3].bias, fmt=pk.gh_fmt)
                     pk.wgh = [w.to(device) if w is not None else None for w in wgh]
                     pk.gh_groups = widths          # (per slot: the padded widths of the G array's column parts)
+                    # floats per node of the G array stage A writes (plane form 1: shorter than the product's columns)
+                    pk.gh_ld = [None if w is None else (P.gh3_ld(self.spec_g.hid, sum(ws)) if pk.gh_fmt == 1 else w.shape[1])
+                                for w, ws in zip(wgh, widths)]
             self._packed_g = pk
         return self._packed_g
 
@@ -211,11 +218,12 @@ class TensorProductConvLayer(nn.Module):
                     continue
                 w = pk.wgh[slot]
                 wh = P.split_h2(w.unsqueeze(0), unified_scale=P.GH_SW)
-                g[slot] = torch.empty((N, w.shape[1]), device=x_src.device, dtype=torch.float32)
+                g[slot] = torch.empty((N, pk.gh_ld[slot]), device=x_src.device, dtype=torch.float32)
                 offs = (C.c_int32 * 1)(pk.g_in_off[slot])
-                dest = P.gh_dest_table(pk.gh_groups[slot], (self.spec_g.hid + 7) // 8, w.shape[1]).to(x_src.device)
-                L.check(lib.ddp_stage_a_gh(x_src.data_ptr(), x_src.shape[1], N, None, None, N, offs, 1, w.data_ptr(), wh.data_ptr(), w.shape[0],
-                                           w.shape[1], g[slot].data_ptr(), w.shape[1], None, dest.data_ptr(), _stream()), "ddp_stage_a_gh")
+                dest = P.gh_dest_table(pk.gh_groups[slot], (self.spec_g.hid + 7) // 8, w.shape[1], fmt=pk.gh_fmt).to(x_src.device)
+                fn = lib.ddp_stage_a_gh3 if pk.gh_fmt == 1 else lib.ddp_stage_a_gh
+                L.check(fn(x_src.data_ptr(), x_src.shape[1], N, None, None, N, offs, 1, w.data_ptr(), wh.data_ptr(), w.shape[0],
+                           w.shape[1], g[slot].data_ptr(), pk.gh_ld[slot], None, dest.data_ptr(), _stream()), "ddp_stage_a_gh")
             return g
         for slot in (0, 1):
             if pk.wg[slot] is None:
@@ -467,7 +475,8 @@ class TensorProductScoreModel(nn.Module):
         # Same kernels, same tasks, same bits (a conv's workgroups do not depend on the launch it sits in); 17.5 -> 17.3 ms rigid,
         # 21.8 -> 21.4 ms with flexible side chains (profiles/r05_conv32_ab.txt)
         self.split_rows_launch = True
-        self.split_rows_min_g_bytes = 4.0e9     # ... where stage A of the atom rows writes at least this much (engine._layers): 4.7 GB at
+        self.shape_early_rows = False           # the early launch at ONE workgroup per CU beside stage A of the atom rows (measured: off)
+        self.split_rows_min_g_bytes = 3.0e9     # ... where stage A of the atom rows writes at least this much (engine._layers): 4.7 GB at
         # 40 samples of cfg2; at 20 samples (2.4 GB) the second launch cost 0.1 - 0.2 of 9.2 ms, on the README's small model (1.4 GB) 0.3 of 3.2
         # The front's independent chains side by side (parallel branches of the captured step; same kernels, same arguments, same bits):
         # [node encoders -> edge embeddings] beside [neighbour searches -> CSR / source-ordered views], and - rigid receptor - the index
@@ -539,6 +548,9 @@ class TensorProductScoreModel(nn.Module):
             self._torus_table = torch.from_numpy(z["torus_score_norm"]).float()
         self._edge_packs: Dict[str, _EdgeMLPPack] = {}
         self.last_stats: Dict[str, float] = {}
+        # plane form of the factorised convs' G (property g_planes3); DDP_G_PLANES3 = 0 / 1 in the environment sets the default of every model
+        # built in the process (the parity suites under the other form: profiles/r06_g3byte_parity.txt)
+        self.g_planes3 = os.environ.get("DDP_G_PLANES3", G_PLANES3_DEFAULT) == "1"
 
     # ---- checkpoint compatibility -------------------------------------------------------------
     _IGNORED_PREFIXES = ("final_tp_tor.", "final_tp_sc_tor.", "tor_bond_conv.tp.", "sc_tor_bond_conv.tp.")
@@ -689,6 +701,27 @@ class TensorProductScoreModel(nn.Module):
             self.__dict__["_conv_h2"] = value
             self.__dict__["_packed_epoch"] = self.__dict__.get("_packed_epoch", 0) + 1
 
+    @property
+    def g_planes3(self):
+        """Plane form of the factorised convs' G (ddp_conv_task_t::gh_fmt).  False: fp16 hi + fp16 lo words, 4 bytes per value, 22 significant
+        bits.  True: fp16 hi + OCP e4m3 lo bytes (ddp_stage_a_gh3), 3 bytes per value, 15 - 16 significant bits: a quarter less of the step's
+        G round trip through HBM (written by stage A, read once by ddp_conv_rows); |32 G| must stay below 2048 (range flag -> the fp32
+        form, like every other value the split forms cannot hold).  Changing it drops the packed weights and captured steps."""
+        return bool(self.__dict__.get("_g_planes3", False))
+
+    @g_planes3.setter
+    def g_planes3(self, value):
+        value = bool(value)
+        if value != self.g_planes3:
+            self.__dict__["_g_planes3"] = value
+            self._stage_a_stacks = {}
+            for m_ in self.modules():
+                if isinstance(m_, TensorProductConvLayer):
+                    m_.gh_fmt = 1 if value else 0
+                    m_._packed_g = None
+            self.__dict__["_rows_checked_epoch"] = None
+            self.__dict__["_packed_epoch"] = self.__dict__.get("_packed_epoch", 0) + 1
+
     def rows_all_or_none(self, device):
         """ddp_conv_rows runs either every factorised conv of its size class or none: stage A writes the G of several convs in one
         launch, in ONE layout.  A conv whose weights the kernel's operand planes cannot hold (|w| > 255, packing.rows_stream) therefore
@@ -700,7 +733,7 @@ class TensorProductScoreModel(nn.Module):
         pks = [c.packed_g(device) for c in convs]
         if any(pk.wsh is None for pk in pks):
             for pk in pks:
-                pk.wsh = pk.bsp = pk.wgh = pk.gh_groups = None
+                pk.wsh = pk.bsp = pk.wgh = pk.gh_groups = pk.gh_ld = None
         self.__dict__["_rows_checked_epoch"] = self.__dict__.get("_packed_epoch", 0)
 
     def invalidate_packed(self):

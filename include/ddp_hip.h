@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DDP_ABI_VERSION 15
+#define DDP_ABI_VERSION 16
 #define DDP_EINVAL (-1)   /* bad argument (shape not supported, null pointer, ...) */
 #define DDP_ELIMIT (-2)   /* exceeds a compiled-in limit (see DDP_MAX_*) */
 
@@ -157,6 +157,14 @@ typedef struct {
   const void* wsh;
   const float* bsp;
   const void* gh[2];
+  /* Plane form of gh (ABI 16; all tasks of a launch carry the same):
+   *  0  as above - hi and lo words of a column side by side, 32 bytes per 8 values, DDP_GH_LD floats per node;
+   *  1  "fp16 + e4m3": a part's tile is [k8][c < wp] 16-byte hi pieces (8 fp16 words fp16(V)), then [k8][c < wp] 8-byte lo pieces: 8 OCP
+   *     e4m3 bytes of (V - hi) * DDP_GH3_LO_SCALE - 24 bytes per 8 values, 15 - 16 significant bits (|err| <= 2^-16 |V|; below
+   *     |V| = 2^-3 the lo byte is an e4m3 subnormal: absolute 2^-19), |V| < 2048 or the range flag is raised; behind the tiles Gb per padded
+   *     column c of the slot as fp32 at byte 32 (c / 6) + 4 (c % 6) (stage A stores 6 values per 8-column group), 32 bytes of scratch,
+   *     padding to 128 bytes: DDP_GH3_LD floats per node.  Written by ddp_stage_a_gh3. */
+  int32_t gh_fmt;
 } ddp_conv_task_t;
 /* plane scales of ddp_conv_rows' operands: edge_attr_ (split in the kernel), fc.0 / fc.3 weights (task.wsh), h = relu(fc1) (split in
  * the kernel), G (task.gh).  Ranges |edge_attr_|, |h| < 4094, |w| < 255, |G| < 2047; absolute floors 2^-29, 2^-33, 2^-30. */
@@ -166,6 +174,8 @@ typedef struct {
 #define DDP_ROWS_SG 32
 /* k index held by element i of the 8-k group (ks, hh) of an h / fc.3 / G operand fragment in ddp_conv_rows */
 #define DDP_ROWS_KPERM(ks, hh, i) (32 * ((ks) >> 1) + ((8 * ((ks) & 1) + (i)) & 3) + 8 * ((8 * ((ks) & 1) + (i)) >> 2) + 4 * (hh))
+#define DDP_GH3_LO_SCALE 512
+#define DDP_GH3_LD(hid, gcp) ((((((hid) + 7) / 8) * (gcp) * 24 + (((gcp) + 5) / 6) * 32 + 32 + 127) / 128) * 32)   /* floats per node, plane form 1 */
 #define DDP_GH_LD(hid, gcp) ((((((hid) + 7) / 8) * 8 + 1) * (gcp) + 31) / 32 * 32)   /* floats per node of a G array in plane form, gcp = padded columns */
 /* Fused fc -> tensor product -> per-edge message for up to 9 convs that share one shape.
  * All tasks of one call share `shape` (factorised and plain convs therefore go in separate calls).
@@ -390,9 +400,28 @@ int ddp_stage_a_gh(const float* x, int ldx, int nrows, const int32_t* rows, cons
                    int nbatch, const float* w, const void* w_h2, int k, int ncols, float* out, int ldo, int32_t* range_flag,
                    const int32_t* dest, void* stream);
 
+/* ... in plane form 1 of ddp_conv_task_t::gh (gh_fmt = 1: fp16 hi + e4m3 lo pieces).  The product's columns are ordered as for
+ * ddp_stage_a_gh, but a group's second piece is 8 bytes: dest[b][g][1] is then the float offset (even) of the 8 e4m3 bytes of a plane group,
+ * or of values 4, 5 of an fp32 group (Gb: 6 values per group, the host leaves product columns 6, 7 of such a group zero); ldo = DDP_GH3_LD
+ * floats per row (shorter than ncols).  |V| >= 2048 raises range_flag.  ABI 16. */
+int ddp_stage_a_gh3(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows, const int32_t* offs,
+                    int nbatch, const float* w, const void* w_h2, int k, int ncols, float* out, int ldo, int32_t* range_flag,
+                    const int32_t* dest, void* stream);
+
 /* ddp_stage_a_gh computes on unified planes too: x is split at DDP_GH_SX inside the kernel, w_h2 must hold the unified planes of
  * w / DDP_GH_SX (packing.split_h2(w, unified_scale = 1 / DDP_GH_SX)): the block's one accumulator is then the value that leaves as planes. */
-#define DDP_GH_SX 16
+/* (DDP_GH_SX = 2 since ABI 16: the right-hand side's planes are then those of DDP_ROWS_SG / 2 = 16 w - fc.3 x block-scale weights of
+ * 1e-2 .. 5e-2 keep a NORMAL lo half (|V| >= 0.125; with 16 they were planes of 2 w: subnormal lo halves, an absolute 2^-26 on the
+ * weight, ~19 bits) - and node features |x| >= 0.0625 keep theirs; ranges |x| < 32752, |16 w| < 65504; absolute floors 2^-26 on x,
+ * 2^-29 on w.) */
+#define DDP_GH_SX 2
+
+/* Occupancy shaping (ABI 16).  Launches enqueued after this call: ddp_conv_rows asks for at least rows_min_lds_bytes of dynamic LDS - more
+ * than 80 KiB leaves ONE of its 4-wave workgroups per CU (one 256-register wave per SIMD) instead of two, so that a kernel launched
+ * beside it on another stream finds a free wave slot and LDS on every CU; the fp16 forms of ddp_stage_a_gh get stage_a_lds_pad_bytes of
+ * dynamic LDS on top of their static 55 KiB (more than 25 KiB: one workgroup per CU).  (0, 0) restores the kernels' own occupancy.
+ * Process-wide, read when a launch is enqueued (captured launches keep what they were captured with); results do not depend on it. */
+int ddp_set_occupancy_shaping(int rows_min_lds_bytes, int stage_a_lds_pad_bytes);
 
 /* The pose update between two score-model calls, for all samples of a batch in one launch:
  * modify_conformer(pos, tr_update, rot_update, torsion_updates) of utils/diffusion_utils.py:37-60 = rigid move about the

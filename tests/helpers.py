@@ -163,3 +163,46 @@ class PyGLikeBatch:
         for a, v in b._globals.items():
             setattr(out, a, mv(v))
         return out
+
+
+def decode_gh_rows(rows, widths, hid, fmt):
+    """Decodes G rows in the plane forms of ddp_conv_task_t::gh (include/ddp_hip.h) back to fp64: rows [N, ld] float32 (the bytes stage A
+    wrote) -> (V [N, n8, gcp, 8] = the plane values hi + lo per k8 group, padded column and k slot; Gb [N, gcp]).  fmt 0: hi / lo fp16 words
+    side by side; fmt 1: 16-byte hi pieces, then 8-byte pieces of OCP e4m3 bytes holding (V - hi) * 512.  Test infrastructure: written from
+    the header's description of the layouts, independently of packing.gh_dest_table."""
+    import numpy as np
+    import torch
+    n8, gcp = (hid + 7) // 8, sum(widths)
+    raw = rows.detach().cpu().contiguous().numpy().view(np.uint8)          # [N, 4 ld] bytes
+    N = raw.shape[0]
+    V = np.zeros((N, n8, gcp, 8), dtype=np.float64)
+    Gb = np.zeros((N, gcp), dtype=np.float64)
+
+    def e4m3(b):
+        b = b.astype(np.int64)
+        s, e, m = (b >> 7) & 1, (b >> 3) & 15, b & 7
+        v = np.where(e == 0, m / 8.0 * 2.0 ** -6, (1.0 + m / 8.0) * 2.0 ** (e.astype(np.float64) - 7.0))
+        v = np.where((e == 15) & (m == 7), np.nan, v)
+        return np.where(s == 1, -v, v)
+
+    cum = 0
+    for w in widths:
+        if fmt == 0:
+            base = 2 * n8 * cum * 16
+            t = raw[:, base:base + n8 * w * 32].reshape(N, n8, w, 2, 16)
+            hi = t[:, :, :, 0].copy().view(np.float16).astype(np.float64)
+            lo = t[:, :, :, 1].copy().view(np.float16).astype(np.float64)
+        else:
+            base = n8 * cum * 24
+            hi = raw[:, base:base + n8 * w * 16].reshape(N, n8, w, 16).copy().view(np.float16).astype(np.float64)
+            lo = e4m3(raw[:, base + n8 * w * 16:base + n8 * w * 24].reshape(N, n8, w, 8)) / 512.0
+        V[:, :, cum:cum + w] = hi + lo
+        cum += w
+    f32 = raw.view(np.float32)
+    if fmt == 0:
+        Gb[:] = f32[:, 8 * n8 * gcp:8 * n8 * gcp + gcp]
+    else:
+        g0 = 24 * n8 * gcp // 4
+        c = np.arange(gcp)
+        Gb[:] = f32[:, g0 + 8 * (c // 6) + c % 6]
+    return torch.from_numpy(V), torch.from_numpy(Gb)

@@ -984,6 +984,66 @@ def test_stage_a_h2_error_floor_for_small_operands(mag):
         assert float((err / scale).max()) > 2.0 ** -20
 
 
+@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("mag_w", [0.3, 0.02])
+def test_stage_a_plane_forms_against_fp64(fmt, mag_w):
+    """ddp_stage_a_gh / ddp_stage_a_gh3 by themselves: the G rows they write, decoded from the BYTES by the header's description of the two
+    plane forms (tests/helpers.decode_gh_rows), against an fp64 product of the same right-hand sides.
+      form 0 (hi + lo fp16 words): the unified planes of both operands carry 22 bits, the planes written carry 22: |err| <= 2^-20 sum|x w|
+        + the absolute floor 2^-25 of a subnormal lo word;
+      form 1 (hi fp16 + e4m3 lo byte at 2^9): |err| <= 2^-16 |V| (half an fp16 ulp resolved to 4 significant bits) + 2^-19 (e4m3 subnormals)
+        + the product's own 2^-20 sum|x w|.
+    mag_w = 0.02: the fc.3 x block-scale magnitudes of ADVICE round 5 (the right-hand side's planes are those of 16 w since DDP_GH_SX = 2:
+    lo words stay normal).  Values are V = DDP_ROWS_SG G; Gb columns are fp32 in both forms."""
+    import ctypes as C
+    from diffdock_pocket_amd import _lib as L
+    from diffdock_pocket_amd import packing as P
+    from diffdock_pocket_amd.score_model import _stream
+    from helpers import decode_gh_rows
+    torch.manual_seed(11 + fmt)
+    dev = _dev()
+    lib = L.load()
+    hid, widths, k, nrows, ldx = 180, [32, 28, 12], 60, 333, 184
+    n8, gcp = 23, sum(widths)
+    ncols = P.gh_ld(hid, gcp) if fmt == 0 else (8 * (n8 * gcp + (gcp + 5) // 6) + 31) // 32 * 32
+    ld = ncols if fmt == 0 else P.gh3_ld(hid, gcp)
+    # right-hand side in the product's column order: plane groups [part][k8][c][8], then the Gb columns (form 1: six per 8-column group)
+    Wv = torch.randn(k, n8, gcp, 8) * mag_w * 32.0                 # (the plane scale rides in the columns)
+    Wb = torch.randn(k, gcp) * mag_w * 512.0
+    W = torch.zeros(k, ncols)
+    cum = 0
+    for w_ in widths:
+        W[:, 8 * n8 * cum:8 * n8 * (cum + w_)] = Wv[:, :, cum:cum + w_].reshape(k, -1)
+        cum += w_
+    c = torch.arange(gcp)
+    W[:, (8 * n8 * gcp + c) if fmt == 0 else (8 * n8 * gcp + 8 * (c // 6) + c % 6)] = Wb
+    x = torch.randn(nrows, ldx)
+    xd, Wd = x.to(dev), W.unsqueeze(0).contiguous().to(dev)
+    wh = P.split_h2(Wd, unified_scale=P.GH_SW)
+    dest = P.gh_dest_table(widths, n8, ncols, fmt=fmt).unsqueeze(0).contiguous().to(dev)
+    out = torch.full((1, nrows, ld), float("nan"), device=dev)
+    offs_c = (C.c_int32 * 1)(60)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    fn = lib.ddp_stage_a_gh3 if fmt == 1 else lib.ddp_stage_a_gh
+    L.check(fn(xd.data_ptr(), ldx, nrows, None, None, nrows, offs_c, 1, Wd.data_ptr(), wh.data_ptr(), k, ncols, out.data_ptr(), ld, flag.data_ptr(),
+               dest.data_ptr(), _stream()), "ddp_stage_a_gh")
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    V, Gb = decode_gh_rows(out[0], widths, hid, fmt)
+    xs = x[:, 60:60 + k].double()
+    exactV = torch.einsum("nk,kgcs->ngcs", xs, Wv.double())
+    scaleV = torch.einsum("nk,kgcs->ngcs", xs.abs(), Wv.double().abs())
+    exactB, scaleB = xs @ Wb.double(), xs.abs() @ Wb.double().abs()
+    assert bool(torch.isfinite(V).all())
+    errV = (V - exactV).abs()
+    bound = 2.0 ** -20 * scaleV + (2.0 ** -25 if fmt == 0 else 2.0 ** -16 * exactV.abs() + 2.0 ** -19)
+    assert bool((errV <= bound).all()), (fmt, float((errV / bound).max()))
+    assert bool(((Gb - exactB).abs() <= 2.0 ** -20 * scaleB).all())
+    if fmt == 1:      # (the 8-bit lo plane is what it claims to be: clearly better than fp16 alone, clearly coarser than two fp16 words)
+        rel = float((errV / exactV.abs().clamp(min=1e-3)).max())
+        assert 2.0 ** -22 < rel < 2.0 ** -15, rel
+
+
 def test_forward_with_bf16x3_stage_a_agrees_with_the_exact_form():
     """model.stage_a_bf16x3 (an option, off by default): the same forward with stage A as bf16x3 products - scores within 2e-5
     of the exact-fp32 form's (parity tolerance of the path: 1e-4)."""
@@ -1380,6 +1440,39 @@ def test_sampler_end_to_end_on_device(flex):
     _, lig_b, atoms_b = run(4, slice(2, 4))
     assert torch.equal(lig_pipe, torch.cat([lig_a, lig_b])) and torch.equal(atoms_pipe, torch.cat([atoms_a, atoms_b]))
     assert model.cache_slot == 0
+    # ... and through run(): snapshot, all steps, one range check, the overflow check - the same poses; with the range flag forced once the
+    # job is put back to its snapshot and run again in the fp32 form (one recovery counted, every group restored: finite poses close to the
+    # split form's - one step's fp32-vs-split difference on a random-init network, not a restart from somewhere else)
+    pipe2 = PipelinedSampler(model, g, 4, dev, SamplerConfig(inference_steps=4, flexible_sidechains=flex), seed=3, ways=2)
+    pipe2.randomize()
+    lig_run, atoms_run = pipe2.run(sched)
+    assert torch.equal(lig_run, lig_pipe) and torch.equal(atoms_run, atoms_pipe)
+    if model.conv_h2:
+        pipe3 = PipelinedSampler(model, g, 4, dev, SamplerConfig(inference_steps=4, flexible_sidechains=flex), seed=3, ways=2)
+        pipe3.randomize()
+        start = pipe3.snapshot()
+        real = model.range_flag_raised
+        fired = []
+
+        def once(clear=True):
+            if not fired:
+                fired.append(1)
+                return True
+            return real(clear)
+        model.range_flag_raised = once
+        before = model.__dict__.get("h2_recoveries", 0)
+        try:
+            lig_rec, atoms_rec = pipe3.run(sched)
+        finally:
+            del model.__dict__["range_flag_raised"]
+        assert model.__dict__.get("h2_recoveries", 0) == before + 1 and model.conv_h2
+        assert torch.isfinite(lig_rec).all() and torch.isfinite(atoms_rec).all()
+        # the rerun started from the snapshot: its first step from there reproduces, in the fp32 form, what a fresh sampler's first step gives
+        pipe3.restore(start)
+        pipe3.step(0, sched)
+        _, lig_one_a, _ = run(4, slice(0, 2), steps=1)
+        _, lig_one_b, _ = run(4, slice(2, 4), steps=1)
+        assert torch.equal(pipe3.lig_pos, torch.cat([lig_one_a, lig_one_b]))
     if flex:
         assert float((atoms_all - g["atom"].pos.to(dev)).abs().max()) > 1e-3      # side chains moved
 

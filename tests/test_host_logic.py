@@ -242,7 +242,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.ddp_abi_version.restype = ctypes.c_int
-    assert lib.ddp_abi_version() == L.load().ddp_abi_version() == 15
+    assert lib.ddp_abi_version() == L.load().ddp_abi_version() == 16
     assert ctypes.sizeof(L.ConvShape) == 11 * 4 + 4 * (11 * 4 + 3 * 12) + 4 + 4 * 4 + 4 * 2 * 20
 
 

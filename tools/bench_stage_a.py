@@ -7,7 +7,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from diffdock_pocket_amd import _lib as L  # noqa: E402
-from diffdock_pocket_amd.packing import gh_dest_table, gh_ld, split_bf16x3, split_h2  # noqa: E402
+from diffdock_pocket_amd.packing import gh3_ld, gh_dest_table, gh_ld, split_bf16x3, split_h2  # noqa: E402
 
 
 def timeit(fn, n=10):
@@ -42,13 +42,23 @@ def main():
         # the plane form ddp_conv_rows reads (ddp_stage_a_gh): a slot of 72 padded G columns (parts 32, 28, 12) at hid = 180
         ncg = gh_ld(180, 72)
         wg = torch.randn(nb, k, ncg, device=dev)
-        wgh = split_h2(wg, unified_scale=1.0 / 16.0)
+        wgh = split_h2(wg, unified_scale=0.5)
         outg = torch.empty(nb, N, ncg, device=dev)
         dest = torch.stack([gh_dest_table([32, 28, 12], 23, ncg)] * nb).contiguous().to(dev)
         t_gh = timeit(lambda: L.check(lib.ddp_stage_a_gh(x.data_ptr(), ldx, N, None, None, N, offs, nb, wg.data_ptr(), wgh.data_ptr(), k, ncg, outg.data_ptr(), ncg,
                                                          None, dest.data_ptr(), st), "a"))
         gbg = nb * N * ncg * 4 / 1e9
         print(f"{name}: plane form (ddp_stage_a_gh) {gbg:.2f} GB out: {t_gh:.3f} ms ({gbg / t_gh:.2f} TB/s)")
+        # plane form 1 (fp16 hi + e4m3 lo pieces, ddp_stage_a_gh3): 24 bytes per 8 values
+        nc3, ld3 = (8 * (23 * 72 + 12) + 31) // 32 * 32, gh3_ld(180, 72)
+        wg3 = torch.randn(nb, k, nc3, device=dev)
+        wgh3 = split_h2(wg3, unified_scale=0.5)
+        outg3 = torch.empty(nb, N, ld3, device=dev)
+        dest3 = torch.stack([gh_dest_table([32, 28, 12], 23, nc3, fmt=1)] * nb).contiguous().to(dev)
+        t_g3 = timeit(lambda: L.check(lib.ddp_stage_a_gh3(x.data_ptr(), ldx, N, None, None, N, offs, nb, wg3.data_ptr(), wgh3.data_ptr(), k, nc3, outg3.data_ptr(), ld3,
+                                                          None, dest3.data_ptr(), st), "a"))
+        gb3 = nb * N * ld3 * 4 / 1e9
+        print(f"{name}: plane form 1 (ddp_stage_a_gh3) {gb3:.2f} GB out: {t_g3:.3f} ms ({gb3 / t_g3:.2f} TB/s) = x{t_g3 / t_gh:.2f} of the 4-byte form's time")
         A = torch.stack([x[:, 120 * (i % 2):120 * (i % 2) + k] for i in range(nb)])
         t_bmm = timeit(lambda: torch.bmm(A, w))
         t_mm = timeit(lambda: [torch.mm(A[i], w[i]) for i in range(nb)])

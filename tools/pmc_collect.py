@@ -159,7 +159,22 @@ def main():
                         "fetch_bytes_per_step": 2.0 * fe_all * 1024.0 / steps, "write_bytes_per_step": wr_all * 1024.0 / steps,
                         "window": "all dispatches from the first to the last logged conv launch (the last step's pose update falls outside)"}
     if len(sys.argv) >= 7:      # optional: the L1 / L2 passes
+        # those passes carry no launch log and count every step of their run (warm-up + timed, the SPLIT launches of the timed region's
+        # layer order) while the main passes sample the instrumented pass (one launch per layer): every figure is therefore also given per
+        # STEP and per whole-layer launch of the main passes (`*_per_layer_launch`: the basis of `avg_launch_ms` in bench.py's line)
+        pass_steps = int(lf.get("warmup_steps", 0)) + int(lf.get("steps", 0))
         for k, e in l2_block(sys.argv[5], sys.argv[6]).items():
+            main_per_step = (res["kernels"].get(k, {}).get("launches_sampled") or 0) / steps if steps else 0
+            if pass_steps and e.get("launches_sampled"):
+                lps = e["launches_sampled"] / pass_steps
+                e["steps_in_pass"] = pass_steps
+                e["launches_per_step"] = lps
+                e["l2_request_bytes_per_step"] = e["l2_request_bytes_per_launch"] * lps
+                if e.get("hbm_read_bytes_per_launch_ea") is not None:
+                    e["hbm_read_bytes_per_step_ea"] = e["hbm_read_bytes_per_launch_ea"] * lps
+                if main_per_step:
+                    e["main_pass_launches_per_step"] = main_per_step
+                    e["l2_request_bytes_per_layer_launch"] = e["l2_request_bytes_per_step"] / main_per_step
             res["kernels"].setdefault(k, {})["l2"] = e
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1)
