@@ -31,7 +31,7 @@ The JSON line also carries
                 `l2` carries the counter-derived L2 -> CU traffic of the kernel against the rate the guide measures for rows shared
                 through the XCD L2s.  The reference formulation's FLOPs, most of which the source-node
                 factorisation removes, are reported separately as `algorithmic_vs_fp32_peak`.  PMC-derived fields come from
-                profiles/r05_pmc.json (collected on the builder's box, see `pmc_source`) and are dropped when that file was taken from
+                profiles/r06_pmc.json (collected on the builder's box, see `pmc_source`) and are dropped when that file was taken from
                 other kernel sources than the ones loaded (source hash).
   cpu_baseline  the CPU oracle (reference-equivalent restatement, kind "port") on a bounded sample of the same workload
   other_workloads  BASELINE configs[2] (flexible side chains) and configs[0] (cfg1, 4 samples) measured in the same run.
@@ -64,7 +64,7 @@ def mixed_roofline(fc16, other, sec):
 HBM_PEAK_GBS = 8000.0           # same guide: HBM3E ~8 TB/s
 SUSTAINED_F16_MFMA_TFLOPS = 1700.0     # measured: every SIMD issuing v_mfma_f32_32x32x16_f16 back to back (1.6 - 1.75 PFLOP/s at 1.55 - 1.75 GHz)
 SUSTAINED_TILE_LOOP_TFLOPS = 1160.0    # measured: the stream-tile loop of ddp_conv_rows alone (388 TFLOP/s fp32-equivalent x 3)
-PMC_FILE = os.path.join("profiles", "r05_pmc.json")
+PMC_FILE = os.environ.get("DDP_PMC_FILE", os.path.join("profiles", "r06_pmc.json"))     # (DDP_PMC_FILE: a counter file of this very run, tools/gpu_round.sh)
 
 
 def parse_args(argv=None):

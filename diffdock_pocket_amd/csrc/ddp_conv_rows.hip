@@ -182,7 +182,6 @@ __device__ __forceinline__ void rows_stream_step(f32x4* ring, RowsStream wsh, in
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   else
     asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-#ifndef DDP_ROWS_ABL_NOBAR   // (timing-only ablation: no barrier - what do the four waves wait for each other?)
   // the bare barrier, not __syncthreads(): its workgroup fence makes hipcc wait vmcnt(0) whenever an ordinary load is in flight.  What
   // the barrier orders here is LDS only: this wave's reads of the slot that is requested next (and, once, the bias table's writes) are
   // complete (lgkmcnt(0)), the copies it waits for are counted above; the asm statements keep the compiler from moving LDS accesses
@@ -190,7 +189,6 @@ __device__ __forceinline__ void rows_stream_step(f32x4* ring, RowsStream wsh, in
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-#endif
   rows_request_piece<NS>(ring, wsh, ROWS_NP * t + P + 2, ROWS_NP * nts, (P + 2) % ROWS_NP, wave, lane);
 }
 
@@ -230,7 +228,7 @@ __device__ __forceinline__ void rows_build_features(const ddp_block_t& B, const 
     float ax[MAXI], ay[MAXI], az[MAXI];
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
-      const int ul = min(half + 2 * i, cnt - 1);
+      const int ul = max(min(half + 2 * i, cnt - 1), 0);      // (an empty segment: the load stays inside the row, nothing is stored)
       ax[i] = xrow[off + 3 * ul];
       ay[i] = xrow[off + 3 * ul + 1];
       az[i] = xrow[off + 3 * ul + 2];
@@ -296,13 +294,13 @@ struct RowsGPart {
 // Plane form 1 of a G array (ddp_conv_task_t::gh_fmt = 1, round 6: "G3"): a part's tile is [k8][wp columns] 16-byte hi pieces (8 fp16 words),
 // then [k8][wp columns] 8-byte lo pieces (8 OCP e4m3 bytes of (V - hi) * DDP_GH3_LO_SCALE) - 24 bytes per 8 values instead of 32; Gb per
 // padded column c of the slot sits behind the tiles at 32 (c / 6) + 4 (c % 6) bytes (stage A stores 6 fp32 values per 8-column group).
-template <bool G3>
+template <int GF>
 __device__ __forceinline__ RowsGPart rows_gpart_of(const ddp_conv_shape_t& S, const ddp_conv_task_t& T, int bi, int part) {
   RowsGPart P;
   int wp, cumw, gcp;
   rows_gpart(S, bi, part, wp, cumw, gcp);
   const int n8 = (S.hid + 7) >> 3;
-  if constexpr (G3) {
+  if constexpr (GF == 1) {
     P.base = reinterpret_cast<const char*>(T.gh[S.blk[bi].g_slot]) + (size_t)(n8 * cumw) * 24;
     P.gldb = (size_t)DDP_GH3_LD(S.hid, gcp) * 4;
     P.bias_off = n8 * (gcp - cumw) * 24;
@@ -317,18 +315,24 @@ __device__ __forceinline__ RowsGPart rows_gpart_of(const ddp_conv_shape_t& S, co
   return P;
 }
 // per-lane byte offsets of a G part's fragments and of its Gb word (cl = the lane's column of the part)
-template <bool G3>
+template <int GF>
 struct RowsGLane {
   unsigned h_main, h_last;    // hi (plane form 0: hi and lo) fragment of k-step kq < NS - 1: + fragment offset; of the last k-step
   unsigned l_main, l_last;    // plane form 1: the 8-byte lo pieces
   unsigned bias;
 };
-template <bool G3>
-__device__ __forceinline__ RowsGLane<G3> rows_glane(const RowsGPart& P, int n8, int NS, int hh, int cl) {
-  RowsGLane<G3> o;
+template <int GF>
+__device__ __forceinline__ RowsGLane<GF> rows_glane(const RowsGPart& P, int n8, int NS, int hh, int cl) {
+  RowsGLane<GF> o;
   const int gc = P.wp;
   const int k8l = min(2 * (NS - 1) + hh, n8 - 1);
-  if constexpr (G3) {
+  if constexpr (GF == 2) {       // plane form 2: [k8][c] 16-byte hi pieces, then [k8][c] 16-byte lo pieces; Gb as in form 0
+    o.h_main = (unsigned)(hh * gc + cl) * 16u;
+    o.h_last = (unsigned)(k8l * gc + cl) * 16u;
+    o.l_main = (unsigned)(n8 * gc) * 16u + o.h_main;
+    o.l_last = (unsigned)(n8 * gc) * 16u + o.h_last;
+    o.bias = (unsigned)(P.bias_off + 4 * cl);
+  } else if constexpr (GF == 1) {
     o.h_main = (unsigned)(hh * gc + cl) * 16u;
     o.h_last = (unsigned)(k8l * gc + cl) * 16u;
     o.l_main = (unsigned)(n8 * gc) * 16u + (unsigned)(hh * gc + cl) * 8u;
@@ -345,23 +349,23 @@ __device__ __forceinline__ RowsGLane<G3> rows_glane(const RowsGPart& P, int n8, 
   return o;
 }
 // uniform byte offset of k-step kq's fragments inside a part's tile (the last k-step is addressed by the lane offsets alone)
-template <bool G3>
+template <int GF>
 __device__ __forceinline__ constexpr unsigned rows_gfrag_hi(int kq, int NS, int gc) {
-  return (kq == NS - 1) ? 0u : (unsigned)((G3 ? 2 : 4) * kq * gc) * 16u;
+  return (kq == NS - 1) ? 0u : (unsigned)((GF != 0 ? 2 : 4) * kq * gc) * 16u;
 }
-template <bool G3>
+template <int GF>
 __device__ __forceinline__ constexpr unsigned rows_gfrag_lo(int kq, int NS, int gc) {
-  return (kq == NS - 1) ? 0u : (G3 ? (unsigned)(2 * kq * gc) * 8u : (unsigned)(4 * kq * gc) * 16u);
+  return (kq == NS - 1) ? 0u : (GF == 1 ? (unsigned)(2 * kq * gc) * 8u : (unsigned)((GF == 2 ? 2 : 4) * kq * gc) * 16u);
 }
 // the lo plane of a fragment as the B operand: plane form 0 holds the 8 fp16 words, plane form 1 eight e4m3 bytes at DDP_GH3_LO_SCALE
 typedef float f32x2r __attribute__((ext_vector_type(2)));
-template <bool G3>
+template <int GF>
 struct RowsLoT { typedef f32x4 type; };
 template <>
-struct RowsLoT<true> { typedef f32x2r type; };
-template <bool G3>
-__device__ __forceinline__ h8 rows_lo_operand(const typename RowsLoT<G3>::type v) {
-  if constexpr (G3) {
+struct RowsLoT<1> { typedef f32x2r type; };
+template <int GF>
+__device__ __forceinline__ h8 rows_lo_operand(const typename RowsLoT<GF>::type v) {
+  if constexpr (GF == 1) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const unsigned u0 = __builtin_bit_cast(unsigned, v[0]), u1 = __builtin_bit_cast(unsigned, v[1]);
     constexpr float inv = 1.f / (float)DDP_GH3_LO_SCALE;
@@ -372,7 +376,7 @@ __device__ __forceinline__ h8 rows_lo_operand(const typename RowsLoT<G3>::type v
     return __builtin_bit_cast(h8, v);
   }
 }
-template <int NS, int GR, bool MERGE, bool G3>
+template <int NS, int GR, bool MERGE, int G3>
 __device__ __forceinline__ f32x16 rows_g_runs(const ddp_conv_shape_t& S, const RowsGPart& PA, const RowsGPart& PB, const h8 (&ah)[NS], const h8 (&al)[NS],
                                               const RowsAux* aux, unsigned rmask, int src_reg, int lane) {
   constexpr int NF = 2 * NS, GK = GR / 2;      // the ring holds GK k-steps: a hi and a lo fragment each
@@ -387,11 +391,7 @@ __device__ __forceinline__ f32x16 rows_g_runs(const ddp_conv_shape_t& S, const R
   const RowsGLane<G3> LA = rows_glane<G3>(PA, n8, NS, hh, cl), LB = rows_glane<G3>(PB, n8, NS, hh, cl);
   const unsigned lo_bias = inb ? LB.bias : LA.bias;
   const unsigned h_main = LA.h_main, h_last = LA.h_last, l_main = LA.l_main, l_last = LA.l_last;     // (the same for both parts: one width)
-#ifdef DDP_ROWS_ABL_G0   // timing-only ablation: the runs read the G of nodes 0 .. DDP_ROWS_ABL_G0 - 1 (L2 hits): is the G phase bound by where G comes from?
-#define ROWS_NODE(a) (__builtin_amdgcn_readlane(src_reg, (a)) & (DDP_ROWS_ABL_G0 - 1))
-#else
 #define ROWS_NODE(a) __builtin_amdgcn_readlane(src_reg, (a))
-#endif
   // node base of this lane's array: wave-uniform without MERGE (SGPRs), a per-lane select of two uniform bases with it
 #define ROWS_GBASE(a) (inb ? PB.base + (size_t)ROWS_NODE(a) * PB.gldb : PA.base + (size_t)ROWS_NODE(a) * PA.gldb)
 #define ROWS_GFRAG_HI(base, kq) (*reinterpret_cast<const f32x4*>((base) + rows_gfrag_hi<G3>((kq), NS, gc) + (((kq) == NS - 1) ? h_last : h_main)))
@@ -470,13 +470,13 @@ struct RowsGSeq {        // (scalars only: the ring and the accumulators are sep
 };
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-template <bool G3, int NS>
+template <int G3, int NS>
 __device__ __forceinline__ f32x4 rows_gseq_hi(const RowsGSeq& G, RowsStream R, int kq) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(R, (kq == NS - 1) ? G.h_last : G.h_main, (int)rows_gfrag_hi<G3>(kq, NS, G.gc), 0));
 }
-template <bool G3, int NS>
+template <int G3, int NS>
 __device__ __forceinline__ typename RowsLoT<G3>::type rows_gseq_lo(const RowsGSeq& G, RowsStream R, int kq) {
-  if constexpr (G3)
+  if constexpr (G3 == 1)
     return __builtin_bit_cast(f32x2r, __builtin_amdgcn_raw_buffer_load_b64(R, (kq == NS - 1) ? G.l_last : G.l_main, (int)rows_gfrag_lo<G3>(kq, NS, G.gc), 0));
   else
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(R, (kq == NS - 1) ? G.l_last : G.l_main, (int)rows_gfrag_lo<G3>(kq, NS, G.gc), 0));
@@ -492,7 +492,7 @@ __device__ __forceinline__ void rows_gseq_next(RowsGSeq& G, int src_reg, f32x16&
   G.bias = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(G.rs, G.lo_bias, 0, 0));
   gacc = splat16(0.f);
 }
-template <int NS, int GK, bool G3>
+template <int NS, int GK, int G3>
 __device__ __forceinline__ void rows_gseq_init(RowsGSeq& G, f32x4 (&grh)[GK], typename RowsLoT<G3>::type (&grl)[GK], f32x16& gacc,
                                                const ddp_conv_shape_t& S, const RowsGPart& PA, unsigned rmask, int src_reg, int lane) {
   const int r = lane & 31, hh = lane >> 5;
@@ -521,7 +521,7 @@ __device__ __forceinline__ void rows_gseq_init(RowsGSeq& G, f32x4 (&grh)[GK], ty
   rows_gseq_next(G, src_reg, gacc);
 }
 // k-step KS of the current run: three split products from ring slot KS % GK, which then takes the fragments GK k-steps on
-template <int NS, int GK, int KS, bool G3>
+template <int NS, int GK, int KS, int G3>
 __device__ __forceinline__ void rows_gseq_step(RowsGSeq& G, f32x4 (&grh)[GK], typename RowsLoT<G3>::type (&grl)[GK], f32x16& gacc, const h8 (&ah)[NS],
                                                const h8 (&al)[NS]) {
   constexpr int q0 = KS + GK, kq = (q0 < NS) ? q0 : q0 - NS;
@@ -559,7 +559,7 @@ __device__ __forceinline__ void rows_gseq_finish(RowsGSeq& G, f32x16& gacc, cons
 
 // gmode: 0 = the segment runs its own G tiles; 1 = it runs the MERGED tiles of its block and the next one (block B's products are
 // parked behind the wave's per-edge tables); 2 = its G products were computed by the segment before (lanes [n, 2 n))
-template <int NS, int C, bool G3>
+template <int NS, int C, int G3>
 __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_block_t& B, int bi, int part, const ddp_conv_task_t& T, const h8 (&ah)[NS],
                                             const h8 (&al)[NS], f32x4* ring, const float* lbias, int t, const float* F,
                                             const RowsAux* aux, unsigned rmask, int src_reg, int nvw, int wave, int lane, int sgi,
@@ -672,12 +672,7 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
       rows_piece_lds<NS, 2 * KPP>(ring + 2 * PIECE_Q, ah, al, lane, acc);
       int u = (B.nsub > 1) ? j : j * B.ups + us;
       if (!(valid && u < B.U)) u = 0;
-#ifdef DDP_ROWS_ABL_NOEPI   // (timing-only ablation: the tile's feature contraction reduced to one add)
-      res[0] += acc;
-      (void)u;
-#else
       rows_epilogue<C>(acc, F + (u * C) * ROWS_FS + 4 * hh, ROWS_FS, res);
-#endif
     }
   }
 
@@ -715,7 +710,7 @@ __device__ __forceinline__ int rows_segment(const RowsLaunch& RL, const ddp_bloc
   return t;
 }
 
-template <int SZ, bool G3>
+template <int SZ, int G3>
 __global__ __launch_bounds__(ROWS_NT, 2) void ddp_conv_rows_kernel(const RowsLaunch RL) {
   constexpr int NS = H2Class<SZ>::NS, RING_Q = 2 * NS * 64;     // the ring holds one tile's worth of pieces
   constexpr int NCT1 = (3 * SZ + 31) / 32, NQ = SZ / 4;     // fc.0 column tiles; 16-byte quads per edge_attr_ segment (ns floats each)
@@ -948,7 +943,7 @@ extern "C" int ddp_conv_rows(const ddp_conv_shape_t* shape, const ddp_conv_task_
   for (int i = 0; i < ntasks; ++i) {
     const ddp_conv_task_t& T = tasks[i];
     if (T.n_edges <= 0) continue;  // an empty conv sends no message (models/score_model.py:109-111)
-    if (T.gh_fmt != 0 && T.gh_fmt != 1) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: task.gh_fmt must be 0 or 1");
+    if (T.gh_fmt < 0 || T.gh_fmt > 2) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: task.gh_fmt must be 0, 1 or 2");
     if (gfmt >= 0 && T.gh_fmt != gfmt) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: the tasks of a launch carry G in ONE plane form");
     gfmt = T.gh_fmt;
     if (T.n_edges_dev) L.dev_counts = 1;
@@ -983,7 +978,7 @@ extern "C" int ddp_conv_rows(const ddp_conv_shape_t* shape, const ddp_conv_task_
   // occupancy shaping (ddp_set_occupancy_shaping): a launch that is to leave one 256-register wave slot per SIMD to another kernel asks
   // for more LDS than two workgroups per CU can have
   if ((size_t)ddp_shape_rows_min_lds > lds_bytes) lds_bytes = (size_t)ddp_shape_rows_min_lds;
-  static int lds_have[4] = {0, 0, 0, 0};
+  static int lds_have[6] = {0, 0, 0, 0, 0, 0};
   hipError_t err;
 #define ROWS_LAUNCH(SZ_, G3_, I_)                                                                                                       \
   {                                                                                                                                     \
@@ -992,9 +987,9 @@ extern "C" int ddp_conv_rows(const ddp_conv_shape_t* shape, const ddp_conv_task_
     hipLaunchKernelGGL((ddp_conv_rows_kernel<SZ_, G3_>), dim3(tiles), dim3(ROWS_NT), lds_bytes, (hipStream_t)stream, RL);               \
   }
   if (sc == 60) {
-    if (gfmt == 1) ROWS_LAUNCH(60, true, 2) else ROWS_LAUNCH(60, false, 0)
+    if (gfmt == 1) ROWS_LAUNCH(60, 1, 2) else if (gfmt == 2) ROWS_LAUNCH(60, 2, 4) else ROWS_LAUNCH(60, 0, 0)
   } else {
-    if (gfmt == 1) ROWS_LAUNCH(32, true, 3) else ROWS_LAUNCH(32, false, 1)
+    if (gfmt == 1) ROWS_LAUNCH(32, 1, 3) else if (gfmt == 2) ROWS_LAUNCH(32, 2, 5) else ROWS_LAUNCH(32, 0, 1)
   }
 #undef ROWS_LAUNCH
   err = hipGetLastError();

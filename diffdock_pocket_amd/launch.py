@@ -225,7 +225,7 @@ def set_range_flag(t):
     _RANGE_FLAG = t
 
 
-# Factorised convs of the size class ns = 60 through the 256-edge row-stationary kernel (ddp_conv_rows, csrc/ddp_conv_rows.hip; needs
+# Factorised convs of the size classes ns = 60 / 32 through the 128-edge row-stationary kernel (ddp_conv_rows, csrc/ddp_conv_rows.hip; needs
 # CONV_H2).  False: the 32-edge kernel of rounds 2 - 4 (A/B runs).  The two read G in different layouts: a task carries one of them.
 CONV_ROWS = os.environ.get("DDP_CONV_ROWS", "1") != "0"     # (environment: same-box A/B runs)
 

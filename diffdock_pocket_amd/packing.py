@@ -511,6 +511,13 @@ def rows_supported(spec: "ConvSpec") -> bool:
     ns16 = h2_steps(spec)
     if not spec.factorized or ns16 not in (12, 6):
         return False
+    # the host entry's block checks (csrc/ddp_conv_rows.hip, ddp_conv_rows): shapes it would refuse keep the 32-edge kernel instead of
+    # failing at launch
+    for b in spec.blocks:
+        if b.C not in (1, 3) or b.n < 1 or b.n > 64 or (b.C == 3 and b.n > 32):
+            return False
+        if b.nsub < 1 or b.nsub > 2 or b.ups < 1 or (b.nsub > 1) != (b.n > 32) or (b.nsub == 1 and b.ups != 32 // b.n):
+            return False
     frows = max([b.U * b.C for b in spec.blocks if b.U > 0] + [0])
     priv = max((frows * 36 * 4 + 127) // 128 * 128 + 1408 + 2048, ns16 * 1024)
     nts = spec.nct1 + sum(len(t) for _, _, t in rows_segments(spec))
@@ -646,14 +653,14 @@ def factor_weights_gh(spec: "ConvSpec", weight: torch.Tensor, bias: torch.Tensor
             Bm[:, b.g_col0:b.g_col0 + b.n] = bias[rows] * b.scale
         parts = gh_parts(spec, slot)
         gcp = sum(p[4] for p in parts)
-        ld = gh_ld(spec.hid, gcp) if fmt == 0 else (8 * (n8 * gcp + (gcp + 5) // 6) + 31) // 32 * 32
+        ld = gh_ld(spec.hid, gcp) if fmt != 1 else (8 * (n8 * gcp + (gcp + 5) // 6) + 31) // 32 * 32
         Wfull = torch.zeros(n_in, ld)
         Wk = W[:, kp].reshape(n_in, n8, 8, gc)                                                       # [u, k8, i, column]
         for _, _, c0, w, wp, cum in parts:
             tile = torch.zeros(n_in, n8, wp, 8)
             tile[:, :, :w] = Wk[:, :, :, c0:c0 + w].permute(0, 1, 3, 2) * ROWS_SG
             Wfull[:, 8 * n8 * cum:8 * n8 * (cum + wp)] = tile.reshape(n_in, -1)
-            if fmt == 0:
+            if fmt != 1:
                 Wfull[:, 8 * n8 * gcp + cum:8 * n8 * gcp + cum + w] = Bm[:, c0:c0 + w] * (ROWS_SH * ROWS_SG)
             else:
                 cpad = cum + torch.arange(w)                                                         # padded column of the slot
@@ -671,6 +678,21 @@ def gh_dest_table(widths: Sequence[int], n8: int, ncols: int, fmt: int = 0) -> t
     ng = ncols // 8
     tab = torch.empty((ng, 2), dtype=torch.int32)
     g = torch.arange(ng, dtype=torch.int64)
+    if fmt == 2:
+        # plane form 2: the bytes of form 0, but a part's tile is its [k8][c] hi pieces (16 bytes each) followed by its [k8][c] lo pieces:
+        # ddp_conv_rows then loads every fragment as ONE contiguous KiB; Gb and the padding groups stay where form 0 has them
+        tab[:, 0] = (8 * g).int()
+        tab[:, 1] = (8 * g + 4).int()
+        cum = 0
+        for w in widths:
+            gs = n8 * cum
+            gl = torch.arange(n8 * w, dtype=torch.int64)
+            base = 32 * n8 * cum
+            tab[gs:gs + n8 * w, 0] = ((base + 16 * gl) // 4 + 1).int()
+            tab[gs:gs + n8 * w, 1] = ((base + 16 * n8 * w + 16 * gl) // 4).int()
+            cum += w
+        assert 8 * n8 * cum + cum <= ncols
+        return tab
     if fmt == 1:
         # plane form 1: part p's tile starts at byte 24 n8 cum_p: hi piece of group (k8, c) at + 16 (k8 w_p + c), lo piece (8 e4m3 bytes) at
         # + 16 n8 w_p + 8 (k8 w_p + c); Gb group j (6 values) at byte 24 n8 gcp + 32 j; the product's padding groups go to the scratch slot

@@ -367,6 +367,40 @@ def test_values_outside_the_fp16_range_are_recovered_in_the_same_call(name):
     assert torch.isfinite(poses[True]).all() and torch.equal(poses[True], poses[False])
 
 
+def test_rows_kernel_range_flag_is_raised_and_recovered():
+    """the recovery test above scales fc.0 by 3e5, which puts |w| beyond the row-stationary kernel's weight planes (255) and
+    moves the whole model to the 32-edge kernel - ddp_conv_rows' own flag site never ran.  Here the weights stay inside the planes
+    (launch.rows_mode stays on for every factorised conv) and a VALUE leaves the kernel's range: fc.0 (weight and bias) x 3000 and
+    fc.3 / 3000 on one conv: |w| <= 3000 x 0.075 < 255, h = relu(fc1) of many edges beyond the h plane's 4094 (65504 / DDP_ROWS_SH) but
+    far inside the 65504 of the 32-edge kernel's 2048-scaled planes.  The forward returns the fp32 form's scores (1e-4 of the oracle),
+    counts one recovery, and the next forward does the same.  (Stage A's flag - a plane value |32 G| beyond the range - is raised at unit
+    level: test_stage_a_plane_forms_report_values_outside_their_range.)"""
+    from diffdock_pocket_amd import launch as K
+    case, gold, batch, sd = case_inputs("cfg2_small")
+    sd = dict(sd)
+    conv = "conv_layers.12"       # (layer 1, atom<-atom: a factorised conv of the rows kernel)
+    sd[conv + ".fc.0.weight"] = sd[conv + ".fc.0.weight"] * 3000.0
+    sd[conv + ".fc.0.bias"] = sd[conv + ".fc.0.bias"] * 3000.0
+    sd[conv + ".fc.3.weight"] = sd[conv + ".fc.3.weight"] / 3000.0
+    assert float(sd[conv + ".fc.0.weight"].abs().max()) < 255.0 and float(sd[conv + ".fc.3.weight"].abs().max()) < 255.0
+    want = OracleScoreModel(case.oracle_config(), sd)(case.make_batch())
+    assert all(torch.isfinite(w).all() for w in want)
+    model = _model_for(case, sd)
+    dev = _dev()
+    assert all(K.rows_mode(c.packed_g(dev)) for c in model.conv_layers if getattr(c, "spec_g", None) is not None and c.spec_g.factorized)
+    b = case.make_batch().to(dev)
+    got = model(b)
+    assert model.__dict__.get("h2_recoveries", 0) == 1
+    for g, w, k in zip(got, want, ("tr", "rot", "tor", "sc_tor")):
+        if w.numel():
+            assert rel_err(g.float().cpu(), w) < TOL, (k, rel_err(g.float().cpu(), w))
+    model.check_overflow()
+    got2 = model(b)
+    assert model.__dict__["h2_recoveries"] == 2
+    for g, g2 in zip(got, got2):
+        assert torch.equal(g, g2)
+
+
 @pytest.mark.parametrize("flex", [False, True])
 def test_pipelined_layer_order_is_bitwise_the_serial_one(flex):
     """For large batches the launches of a conv layer run as parallel branches of the captured step (engine._layers, "pipelined":
@@ -984,12 +1018,12 @@ def test_stage_a_h2_error_floor_for_small_operands(mag):
         assert float((err / scale).max()) > 2.0 ** -20
 
 
-@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("fmt", [0, 1, 2])
 @pytest.mark.parametrize("mag_w", [0.3, 0.02])
 def test_stage_a_plane_forms_against_fp64(fmt, mag_w):
     """ddp_stage_a_gh / ddp_stage_a_gh3 by themselves: the G rows they write, decoded from the BYTES by the header's description of the two
     plane forms (tests/helpers.decode_gh_rows), against an fp64 product of the same right-hand sides.
-      form 0 (hi + lo fp16 words): the unified planes of both operands carry 22 bits, the planes written carry 22: |err| <= 2^-20 sum|x w|
+      forms 0 and 2 (hi + lo fp16 words, side by side / in two regions of a part's tile): the unified planes of both operands carry 22 bits, the planes written carry 22: |err| <= 2^-20 sum|x w|
         + the absolute floor 2^-25 of a subnormal lo word;
       form 1 (hi fp16 + e4m3 lo byte at 2^9): |err| <= 2^-16 |V| (half an fp16 ulp resolved to 4 significant bits) + 2^-19 (e4m3 subnormals)
         + the product's own 2^-20 sum|x w|.
@@ -1005,8 +1039,8 @@ def test_stage_a_plane_forms_against_fp64(fmt, mag_w):
     lib = L.load()
     hid, widths, k, nrows, ldx = 180, [32, 28, 12], 60, 333, 184
     n8, gcp = 23, sum(widths)
-    ncols = P.gh_ld(hid, gcp) if fmt == 0 else (8 * (n8 * gcp + (gcp + 5) // 6) + 31) // 32 * 32
-    ld = ncols if fmt == 0 else P.gh3_ld(hid, gcp)
+    ncols = P.gh_ld(hid, gcp) if fmt != 1 else (8 * (n8 * gcp + (gcp + 5) // 6) + 31) // 32 * 32
+    ld = ncols if fmt != 1 else P.gh3_ld(hid, gcp)
     # right-hand side in the product's column order: plane groups [part][k8][c][8], then the Gb columns (form 1: six per 8-column group)
     Wv = torch.randn(k, n8, gcp, 8) * mag_w * 32.0                 # (the plane scale rides in the columns)
     Wb = torch.randn(k, gcp) * mag_w * 512.0
@@ -1016,7 +1050,7 @@ def test_stage_a_plane_forms_against_fp64(fmt, mag_w):
         W[:, 8 * n8 * cum:8 * n8 * (cum + w_)] = Wv[:, :, cum:cum + w_].reshape(k, -1)
         cum += w_
     c = torch.arange(gcp)
-    W[:, (8 * n8 * gcp + c) if fmt == 0 else (8 * n8 * gcp + 8 * (c // 6) + c % 6)] = Wb
+    W[:, (8 * n8 * gcp + c) if fmt != 1 else (8 * n8 * gcp + 8 * (c // 6) + c % 6)] = Wb
     x = torch.randn(nrows, ldx)
     xd, Wd = x.to(dev), W.unsqueeze(0).contiguous().to(dev)
     wh = P.split_h2(Wd, unified_scale=P.GH_SW)
@@ -1036,12 +1070,68 @@ def test_stage_a_plane_forms_against_fp64(fmt, mag_w):
     exactB, scaleB = xs @ Wb.double(), xs.abs() @ Wb.double().abs()
     assert bool(torch.isfinite(V).all())
     errV = (V - exactV).abs()
-    bound = 2.0 ** -20 * scaleV + (2.0 ** -25 if fmt == 0 else 2.0 ** -16 * exactV.abs() + 2.0 ** -19)
+    bound = 2.0 ** -20 * scaleV + (2.0 ** -25 if fmt != 1 else 2.0 ** -16 * exactV.abs() + 2.0 ** -19)
     assert bool((errV <= bound).all()), (fmt, float((errV / bound).max()))
     assert bool(((Gb - exactB).abs() <= 2.0 ** -20 * scaleB).all())
     if fmt == 1:      # (the 8-bit lo plane is what it claims to be: clearly better than fp16 alone, clearly coarser than two fp16 words)
-        rel = float((errV / exactV.abs().clamp(min=1e-3)).max())
-        assert 2.0 ** -22 < rel < 2.0 ** -15, rel
+        big = exactV.abs() > 1.0
+        rel = float((errV[big] / exactV.abs()[big]).max())
+        assert 2.0 ** -21 < rel < 2.0 ** -15, rel
+
+
+
+@pytest.mark.parametrize("fmt,limit", [(0, 65504.0), (2, 65504.0), (1, 2047.0)])
+def test_stage_a_plane_forms_report_values_outside_their_range(fmt, limit):
+    """A plane value the form cannot hold - |V| > 65504 for the fp16 + fp16 forms, |V| >= 2048 for fp16 + e4m3 (half an fp16 ulp times 512
+    leaves e4m3's 448) - raises range_flag (pinned host memory in the product: the forward then reruns in the fp32 form); just inside
+    the limit it stays 0."""
+    import ctypes as C
+    from diffdock_pocket_amd import _lib as L
+    from diffdock_pocket_amd import packing as P
+    from diffdock_pocket_amd.score_model import _stream
+    dev = _dev()
+    lib = L.load()
+    hid, widths, k, nrows, ldx = 180, [32, 28, 12], 60, 64, 64
+    n8, gcp = 23, sum(widths)
+    ncols = P.gh_ld(hid, gcp) if fmt != 1 else (8 * (n8 * gcp + (gcp + 5) // 6) + 31) // 32 * 32
+    ld = ncols if fmt != 1 else P.gh3_ld(hid, gcp)
+    W = torch.zeros(1, k, ncols)
+    W[0, 0, :8 * n8 * gcp] = 4.0                       # V = 4 x[:, 0] in every plane group (x itself stays inside ITS split's range)
+    Wd = W.to(dev)
+    wh = P.split_h2(Wd, unified_scale=P.GH_SW)
+    dest = P.gh_dest_table(widths, n8, ncols, fmt=fmt).unsqueeze(0).contiguous().to(dev)
+    fn = lib.ddp_stage_a_gh3 if fmt == 1 else lib.ddp_stage_a_gh
+    for value, want in ((0.97 * limit, 0), (1.03 * limit, 1)):
+        x = torch.zeros(nrows, ldx)
+        x[5, 0] = value / 4.0
+        xd = x.to(dev)
+        out = torch.empty((1, nrows, ld), device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        L.check(fn(xd.data_ptr(), ldx, nrows, None, None, nrows, (C.c_int32 * 1)(0), 1, Wd.data_ptr(), wh.data_ptr(), k, ncols, out.data_ptr(), ld,
+                   flag.data_ptr(), dest.data_ptr(), _stream()), "ddp_stage_a_gh")
+        torch.cuda.synchronize()
+        assert int(flag.item()) == want, (fmt, value, int(flag.item()))
+
+
+def test_occupancy_shaping_changes_no_bit():
+    """ddp_set_occupancy_shaping (ABI 16) only changes how many workgroups of ddp_conv_rows / stage A share a CU (launch-time LDS floors,
+    profiles/r06_overlap_ab.txt): the same kernels with the same arguments - the forward's scores are bit for bit the unshaped ones, and
+    (0, 0) restores the kernels' own occupancy."""
+    from diffdock_pocket_amd import launch as K
+    case, gold, batch, sd = case_inputs("cfg2_noflex")
+    model = _model_for(case, sd)
+    b = batch.to(_dev())
+    base = [t.clone() for t in model(b)]
+    K.occupancy_shaping(82 * 1024, 30 * 1024)
+    try:
+        shaped = [t.clone() for t in model(b)]
+    finally:
+        K.occupancy_shaping(0, 0)
+    again = [t.clone() for t in model(b)]
+    for a, s_, c in zip(base, shaped, again):
+        assert torch.equal(a, s_) and torch.equal(a, c)
+    with pytest.raises(Exception):
+        K.occupancy_shaping(-1, 0)
 
 
 def test_forward_with_bf16x3_stage_a_agrees_with_the_exact_form():

@@ -1,0 +1,91 @@
+"""Round 6, VERDICT item 3: the 3-byte G plane (model.g_planes3: fp16 hi + e4m3 lo, 15 - 16 significant bits) MEASURED against the path's
+1e-4 bar instead of argued away.  For every golden case whose factorised convs run through ddp_conv_rows (size classes ns = 60 / 32):
+forward scores against the CPU oracle in both plane forms (tests/test_gpu_parity.py::test_forward_matches_oracle_and_golden's measure:
+max |d| / max |ref| per output); the cfg2 job of 2 samples x 20 steps
+against the oracle-driven CPU sampler (test_cfg2_job_end_to_end_against_the_cpu_sampler's measure).  Prints profiles/r06_g3byte_parity.txt.
+Reads no reference file; imports oracle/ as the checker (a tool, not the product)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import bench  # noqa: E402
+from helpers import case_inputs, rel_err  # noqa: E402
+from oracle.cases import CASES  # noqa: E402
+from oracle.ref_model import OracleConfig, OracleScoreModel  # noqa: E402
+from diffdock_pocket_amd import launch as K  # noqa: E402
+from diffdock_pocket_amd.diffusion import get_t_schedule  # noqa: E402
+from diffdock_pocket_amd.sampler import Sampler, SamplerConfig  # noqa: E402
+from diffdock_pocket_amd.score_model import TensorProductScoreModel  # noqa: E402
+from diffdock_pocket_amd.synthetic import make_3dpf_complex  # noqa: E402
+
+TOL = 1e-4
+
+
+def main():
+    dev = torch.device("cuda:0")
+    worst = {0: 0.0, 1: 0.0}
+    print("# forward scores against the CPU oracle, max |d| / max |ref| per output; plane form 0 (fp16 + fp16, shipped) | form 1 (fp16 + e4m3)")
+    for name, case in CASES.items():
+        _, gold, batch, sd = case_inputs(name)
+        kw = dict(case.model_kwargs())
+        kw.update(case.ctor_extras())
+        kw["device"] = dev
+        model = TensorProductScoreModel(**kw)
+        model.load_state_dict(sd, strict=True)
+        model = model.to(dev).eval()
+        if not any(K.rows_mode(c.packed_g(dev)) for c in model.conv_layers if getattr(c, "spec_g", None) is not None):
+            continue
+        want = OracleScoreModel(case.oracle_config(), sd)(case.make_batch())
+        keys = ("tr", "rot", "tor", "sc_tor")
+        if case.confidence_mode:
+            want, keys = (want,), ("confidence",)
+        row = []
+        for fmt in (0, 1):
+            model.g_planes3 = bool(fmt)
+            got = model(batch.to(dev))
+            torch.cuda.synchronize()
+            if case.confidence_mode:
+                got = (got,)
+            errs = {k: rel_err(g.float().cpu(), w) for g, w, k in zip(got, want, keys) if w.numel()}
+            worst[fmt] = max([worst[fmt]] + list(errs.values()))
+            wmax = max(errs.values())      # (of the last form run: form 1)
+            row.append(" ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+        flag = "  <-- above 1e-4" if wmax >= TOL else ""
+        print(f"{name:18s} form 0: {row[0]:58s} | form 1: {row[1]}{flag}")
+    print(f"worst over the cases: form 0 {worst[0]:.2e} ({TOL / max(worst[0], 1e-30):.1f} x inside 1e-4), form 1 {worst[1]:.2e} "
+          f"({'%.2f x OUTSIDE' % (worst[1] / TOL) if worst[1] >= TOL else '%.1f x inside' % (TOL / worst[1])} 1e-4)")
+
+    model, kw = bench.build_model("cfg2", False, dev)
+    ocfg = OracleConfig(ns=kw["ns"], nv=kw["nv"], num_conv_layers=kw["num_conv_layers"], sigma_embed_dim=kw["sigma_embed_dim"],
+                        distance_embed_dim=kw["distance_embed_dim"], cross_distance_embed_dim=kw["cross_distance_embed_dim"],
+                        flexible_sidechains=kw["flexible_sidechains"], embedding_scale=1000.0)
+    cg = make_3dpf_complex(seed=0, flexible_sidechains=False)
+    sched = get_t_schedule(20)
+    # ---- the cfg2 job end to end: 2 samples x 20 steps against the oracle-driven CPU sampler
+    print("# cfg2 job, 2 samples x 20 steps (rigid), HIP sampler against the oracle-driven CPU sampler: max |ligand pose diff| (A) per step; bound of the test 2e-3")
+    for fmt in (0, 1):
+        model, kw = bench.build_model("cfg2", False, dev)
+        model.g_planes3 = bool(fmt)
+        oracle = OracleScoreModel(ocfg, {k: v.detach().cpu() for k, v in model.state_dict().items()})
+        cfg = SamplerConfig(inference_steps=20, flexible_sidechains=False)
+        s_gpu = Sampler(model, cg, 2, dev, cfg, seed=5)
+        s_cpu = Sampler(lambda b: oracle(b), cg, 2, torch.device("cpu"), cfg, seed=5)
+        s_gpu.randomize()
+        s_cpu.randomize()
+        out = []
+        with torch.no_grad():
+            for i in range(20):
+                s_gpu.step(i, sched)
+                s_cpu.step(i, sched)
+                out.append(float((s_gpu.lig_pos.cpu() - s_cpu.lig_pos).abs().max()))
+        print(f"form {fmt}: " + " ".join(f"{v:.1e}" for v in out) + f"   max {max(out):.2e} A")
+        s_gpu.close()
+
+
+if __name__ == "__main__":
+    main()

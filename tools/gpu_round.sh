@@ -31,11 +31,11 @@ timeout 600 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_HIT_sum TCC_MIS
 timeout 600 rocprofv3 --pmc TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum TCC_BUSY_avr GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_lat -- $P --no-roofline-pass > $O/pmc_lat.log 2>&1; echo "lat rc=$?"
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES --kernel-trace --output-format csv -d $O/pmc_sq -- $P --no-roofline-pass > $O/pmc_sq.log 2>&1; echo "sq rc=$?"
 cd $R
-python3 tools/pmc_raw.py $O/pmc_sq > $O/r05_pmc_wave_states.json 2>/dev/null
-python3 tools/pmc_collect.py $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/r05_pmc.json $O/pmc_l1l2 $O/pmc_lat > $O/pmc_collect.log 2>&1; echo "collect rc=$?"; tail -3 $O/pmc_collect.log
+python3 tools/pmc_raw.py $O/pmc_sq > $O/r06_pmc_wave_states.json 2>/dev/null
+python3 tools/pmc_collect.py $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/r06_pmc.json $O/pmc_l1l2 $O/pmc_lat > $O/pmc_collect.log 2>&1; echo "collect rc=$?"; tail -3 $O/pmc_collect.log
 fi
-# the default bench line once more with THIS run's counter file in place (the first line above read the tree's file: stale after a kernel edit)
-if [ -s $O/r05_pmc.json ]; then cp $O/r05_pmc.json $R/profiles/r05_pmc.json; timeout 900 python bench.py --steps 20 --warmup 3 --cpu-budget-s 30 > $O/bench_pmc.json 2>> $O/bench.err; echo "bench (fresh pmc) rc=$?"; fi
+# the default bench line once more with THIS run's counter file (DDP_PMC_FILE; the tree's profiles/r06_pmc.json is only replaced by hand, from gpurun_out)
+if [ -s $O/r06_pmc.json ]; then DDP_PMC_FILE=$O/r06_pmc.json timeout 900 python bench.py --steps 20 --warmup 3 --cpu-budget-s 30 > $O/bench_pmc.json 2>> $O/bench.err; echo "bench (fresh pmc) rc=$?"; fi
 cd $R
 for d in prof prof_flex prof_5 prof_cfg1; do echo "== $d"; python3 tools/gaps.py $O/$d 2>&1 | head -6; python3 tools/step_sequence.py $O/$d > $O/$d.sequence.txt 2>&1; tail -1 $O/$d.sequence.txt; done > $O/gaps.log 2>&1
 cat $O/gaps.log

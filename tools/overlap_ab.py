@@ -107,6 +107,15 @@ def main():
         torch.cuda.synchronize()
         rows = lambda: real_launch(spec, tasks, flops_spec=flops_spec, node_bytes=node_bytes, tag=tag)      # noqa: E731
         sa = last_sa["call"]
+        if "--pair-only" in sys.argv:      # under rocprofv3 --kernel-trace: one unshaped and one shaped pair, marked by a tiny fill in front of each
+            res["rows2"] = 0.0
+            for shaped in (0, ROWS_ONE):
+                torch.cuda.synchronize()
+                torch.zeros(1, device=dev).fill_(1.0)
+                shaping(shaped, 0)
+                time_pair(rows, sa, s1, s2, reps=1)
+            shaping(0, 0)
+            return
         res["edges"] = sum(t.n_edges for t in tasks)
         res["sa_gb"] = last_sa["gb"]
         shaping(0, 0)
@@ -133,6 +142,8 @@ def main():
         K.stage_a, K.launch_convs = real_stage_a, real_launch
         shaping(0, 0)
     smp.close()
+    if "--pair-only" in sys.argv:
+        return
     print(f"# layer 3 of a 40-sample cfg2 step (schedule position 3): {res['edges']} edges in the conv launch, {res['sa_gb']:.2f} GB of G from the atom rows' stage A")
     print(f"rows alone      two workgroups per CU {res['rows2']:.3f} ms | one per CU (dynamic LDS {ROWS_ONE // 1024} KiB) {res['rows1']:.3f} ms = x{res['rows1'] / res['rows2']:.2f}")
     print(f"stage A alone   two workgroups per CU {res['sa2']:.3f} ms ({res['sa_gb'] / res['sa2']:.2f} TB/s) | one per CU (+{SA_ONE // 1024} KiB) {res['sa1']:.3f} ms "
