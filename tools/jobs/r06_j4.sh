@@ -1,6 +1,16 @@
-# round 6: the 3-byte G plane's parity margins (tools/g3_parity.py), the pair's start / end offsets under rocprofv3, the whole GPU suite (default form) with durations
+# round 6: the 3-byte G plane's parity margins (tools/g3_parity.py), the pair's start / end offsets under rocprofv3, plane form 2 against
+# form 0 (same-box bench pairs), the whole GPU suite (default form) with durations
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06_j4; mkdir -p $O; cd $R; ulimit -c 0
 python -m diffdock_pocket_amd.build > $O/build.log 2>&1; echo "build rc=$?"
+for f in 0 2 0 2; do
+  DDP_GH_FMT=$f timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-workloads > $O/bench_f$f.json 2>> $O/bench.err
+  python - <<PY
+import json
+d=json.loads(open("$O/bench_f$f.json").read().strip().splitlines()[-1])
+r=d["roofline"]
+print("gh_fmt=$f", round(d["value"],2), "poses/s", round(d["ms_per_step"],3), "ms/step; rows launch", round(r["avg_launch_ms"],3), "ms; frac", round(r["frac"],4), [ (k["kernel"], round(k["avg_launch_ms"],3), round(k.get("ms_per_step",0),3)) for k in r["other_kernels"]])
+PY
+done
 timeout 1200 python tools/g3_parity.py > $O/g3_parity.txt 2> $O/g3_parity.err; echo "g3 parity rc=$?"; cat $O/g3_parity.txt; tail -3 $O/g3_parity.err
 cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/pair_trace -- python3 $R/tools/overlap_ab.py --pair-only > $O/pair_trace.log 2>&1; echo "pair trace rc=$?"
