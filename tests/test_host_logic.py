@@ -551,3 +551,66 @@ def test_smooth_edge_weight_matches_the_oracle_and_tolerates_unfilled_list_entri
     assert torch.equal(got[:150], ForwardEngine._smooth_weight(pa, ia, pb, ib, 5.0)[:150]) and torch.isfinite(got).all()
     orc.cfg = OracleConfig(smooth_edges=False)
     assert orc._edge_weight(vec, 5.0) == 1.0
+
+
+@pytest.mark.parametrize("fmt", [0, 1, 2])
+def test_g_plane_forms_host_side_against_the_decoder(fmt):
+    """The three plane forms of a factorised conv's G (ddp_conv_task_t::gh_fmt; include/ddp_hip.h): packing.factor_weights_gh orders the
+    product's columns, packing.gh_dest_table says where the two pieces of every 8-column group go, the kernel's drain is one conversion
+    per group.  Emulated here on the CPU exactly as csrc/ddp_gemm.hip drains (a plane group: 8 fp16 hi words + the lo piece - 8 fp16 words,
+    or 8 e4m3 bytes of (V - hi) x 512 in form 1; any other group: its first 4, and second 4 - form 1: 2 - fp32 values), and read back with
+    tests/helpers.decode_gh_rows, which is written from the header's description of the BYTES alone: the decoded planes must be the fp64
+    product (to the forms' precision), the Gb columns exact, and the row lengths DDP_GH_LD / DDP_GH3_LD."""
+    import numpy as np
+    from diffdock_pocket_amd import packing as P
+    from helpers import decode_gh_rows
+    g = torch.Generator().manual_seed(5 + fmt)
+    ns, nv, layer = 60, 10, 3
+    spec_g = P.faster_tp_spec(P.irreps_muls(ns, nv, layer), P.irreps_muls(ns, nv, layer + 1), 3 * ns, factorized=True)
+    hid = 3 * ns
+    w2, b2 = torch.randn(spec_g.weight_numel, hid, generator=g) * 0.07, torch.randn(spec_g.weight_numel, generator=g) * 0.1
+    wgh, offs, widths = P.factor_weights_gh(spec_g, w2, b2, fmt=fmt)
+    wg0, _, _ = P.factor_weights_gh(spec_g, w2, b2, fmt=0)
+    n8 = (hid + 7) // 8
+    for slot in (0, 1):
+        if wgh[slot] is None:
+            continue
+        W = wgh[slot]
+        gcp = sum(widths[slot])
+        ncols = W.shape[1]
+        ld = P.gh3_ld(hid, gcp) if fmt == 1 else P.gh_ld(hid, gcp)
+        assert ncols % 32 == 0 and (ncols == ld if fmt != 1 else (ld * 4) % 128 == 0 and ld < ncols)
+        tab = P.gh_dest_table(widths[slot], n8, ncols, fmt=fmt)
+        x = torch.randn(7, W.shape[0], generator=g)
+        prod = (x.double() @ W.double()).float()                              # what the block's accumulator holds (fp32)
+        raw = np.zeros((7, ld * 4), dtype=np.uint8)
+        for gi in range(ncols // 8):
+            v = prod[:, 8 * gi:8 * gi + 8]
+            o0, o1, plane = int(tab[gi, 0]) & ~3, int(tab[gi, 1]), int(tab[gi, 0]) & 1
+            if plane:
+                hi = v.to(torch.float16)
+                rest = v - hi.float()
+                raw[:, 4 * o0:4 * o0 + 16] = hi.numpy().view(np.uint8).reshape(7, 16)
+                if fmt == 1:
+                    raw[:, 4 * o1:4 * o1 + 8] = (rest * P.GH3_LO_SCALE).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+                else:
+                    raw[:, 4 * o1:4 * o1 + 16] = rest.to(torch.float16).numpy().view(np.uint8).reshape(7, 16)
+            else:
+                raw[:, 4 * o0:4 * o0 + 16] = v[:, :4].contiguous().numpy().view(np.uint8).reshape(7, 16)
+                n2 = 2 if fmt == 1 else 4
+                raw[:, 4 * o1:4 * o1 + 4 * n2] = v[:, 4:4 + n2].contiguous().numpy().view(np.uint8).reshape(7, 4 * n2)
+        rows = torch.from_numpy(raw.view(np.float32).copy())
+        V, Gb = decode_gh_rows(rows, widths[slot], hid, fmt)
+        # the same planes and bias columns as form 0's right-hand side gives (its column order is the documented one)
+        W0 = wg0[slot]
+        want = (x.double() @ W0.double())
+        wantV = torch.zeros(7, n8, gcp, 8, dtype=torch.float64)
+        cum = 0
+        for w in widths[slot]:
+            wantV[:, :, cum:cum + w] = want[:, 8 * n8 * cum:8 * n8 * (cum + w)].reshape(7, n8, w, 8)
+            cum += w
+        wantB = want[:, 8 * n8 * gcp:8 * n8 * gcp + gcp]
+        tolV = 2.0 ** -21 * wantV.abs() + 2.0 ** -24 if fmt != 1 else 2.0 ** -15 * wantV.abs() + 2.0 ** -18
+        assert bool(((V - wantV).abs() <= tolV + 1e-6 * wantV.abs()).all()), (fmt, slot, float((V - wantV).abs().max()))
+        # (the Gb columns of the padded parts only: the others are zero on both sides)
+        assert bool(((Gb - wantB).abs() <= 1e-6 * wantB.abs() + 1e-9).all()), (fmt, slot)
