@@ -1,5 +1,5 @@
-# round 6: the 3-byte G plane's parity margins (tools/g3_parity.py), the pair's start / end offsets under rocprofv3, plane form 2 against
-# form 0 (same-box bench pairs), the whole GPU suite (default form) with durations
+# round 6: plane form 2 against form 0 (same-box bench pairs), the whole GPU suite (default form) with durations, the 3-byte G plane's
+# parity margins (tools/g3_parity.py), the pair's start / end offsets under rocprofv3
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06_j4; mkdir -p $O; cd $R; ulimit -c 0
 python -m diffdock_pocket_amd.build > $O/build.log 2>&1; echo "build rc=$?"
 for f in 0 2 0 2; do
@@ -11,10 +11,10 @@ r=d["roofline"]
 print("gh_fmt=$f", round(d["value"],2), "poses/s", round(d["ms_per_step"],3), "ms/step; rows launch", round(r["avg_launch_ms"],3), "ms; frac", round(r["frac"],4), [ (k["kernel"], round(k["avg_launch_ms"],3), round(k.get("ms_per_step",0),3)) for k in r["other_kernels"]])
 PY
 done
+timeout 2400 python -m pytest tests -m gpu -q --durations=30 > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -45 $O/pytest.log
 timeout 1200 python tools/g3_parity.py > $O/g3_parity.txt 2> $O/g3_parity.err; echo "g3 parity rc=$?"; cat $O/g3_parity.txt; tail -3 $O/g3_parity.err
 cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/pair_trace -- python3 $R/tools/overlap_ab.py --pair-only > $O/pair_trace.log 2>&1; echo "pair trace rc=$?"
 cd $R
 python3 tools/pair_offsets.py $O/pair_trace > $O/pair_offsets.txt 2>&1; cat $O/pair_offsets.txt
 find $O/pair_trace -name "*.csv" -size +1M -delete
-timeout 2400 python -m pytest tests -m gpu -q --durations=30 > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -45 $O/pytest.log
