@@ -30,6 +30,10 @@ SA_ONE = 30 * 1024
 REPS = 6
 
 
+class _PairsDone(Exception):
+    pass
+
+
 def shaping(rows=0, sa=0):
     L.check(L.load().ddp_set_occupancy_shaping(rows, sa), "shaping")
 
@@ -115,7 +119,7 @@ def main():
                 shaping(shaped, 0)
                 time_pair(rows, sa, s1, s2, reps=1)
             shaping(0, 0)
-            return
+            raise _PairsDone()      # (the pairs stay the LAST dispatches of the trace: tools/pair_offsets.py reads them from its end)
         res["edges"] = sum(t.n_edges for t in tasks)
         res["sa_gb"] = last_sa["gb"]
         shaping(0, 0)
@@ -137,6 +141,8 @@ def main():
     K.stage_a, K.launch_convs = stage_a, launch_convs
     try:
         smp.step(3, sched)
+        torch.cuda.synchronize()
+    except _PairsDone:
         torch.cuda.synchronize()
     finally:
         K.stage_a, K.launch_convs = real_stage_a, real_launch
