@@ -326,13 +326,7 @@ __device__ __forceinline__ RowsGLane<GF> rows_glane(const RowsGPart& P, int n8, 
   RowsGLane<GF> o;
   const int gc = P.wp;
   const int k8l = min(2 * (NS - 1) + hh, n8 - 1);
-  if constexpr (GF == 2) {       // plane form 2: [k8][c] 16-byte hi pieces, then [k8][c] 16-byte lo pieces; Gb as in form 0
-    o.h_main = (unsigned)(hh * gc + cl) * 16u;
-    o.h_last = (unsigned)(k8l * gc + cl) * 16u;
-    o.l_main = (unsigned)(n8 * gc) * 16u + o.h_main;
-    o.l_last = (unsigned)(n8 * gc) * 16u + o.h_last;
-    o.bias = (unsigned)(P.bias_off + 4 * cl);
-  } else if constexpr (GF == 1) {
+  if constexpr (GF == 1) {
     o.h_main = (unsigned)(hh * gc + cl) * 16u;
     o.h_last = (unsigned)(k8l * gc + cl) * 16u;
     o.l_main = (unsigned)(n8 * gc) * 16u + (unsigned)(hh * gc + cl) * 8u;
@@ -351,11 +345,11 @@ __device__ __forceinline__ RowsGLane<GF> rows_glane(const RowsGPart& P, int n8, 
 // uniform byte offset of k-step kq's fragments inside a part's tile (the last k-step is addressed by the lane offsets alone)
 template <int GF>
 __device__ __forceinline__ constexpr unsigned rows_gfrag_hi(int kq, int NS, int gc) {
-  return (kq == NS - 1) ? 0u : (unsigned)((GF != 0 ? 2 : 4) * kq * gc) * 16u;
+  return (kq == NS - 1) ? 0u : (unsigned)((GF == 1 ? 2 : 4) * kq * gc) * 16u;
 }
 template <int GF>
 __device__ __forceinline__ constexpr unsigned rows_gfrag_lo(int kq, int NS, int gc) {
-  return (kq == NS - 1) ? 0u : (GF == 1 ? (unsigned)(2 * kq * gc) * 8u : (unsigned)((GF == 2 ? 2 : 4) * kq * gc) * 16u);
+  return (kq == NS - 1) ? 0u : (GF == 1 ? (unsigned)(2 * kq * gc) * 8u : (unsigned)(4 * kq * gc) * 16u);
 }
 // the lo plane of a fragment as the B operand: plane form 0 holds the 8 fp16 words, plane form 1 eight e4m3 bytes at DDP_GH3_LO_SCALE
 typedef float f32x2r __attribute__((ext_vector_type(2)));
@@ -943,7 +937,7 @@ extern "C" int ddp_conv_rows(const ddp_conv_shape_t* shape, const ddp_conv_task_
   for (int i = 0; i < ntasks; ++i) {
     const ddp_conv_task_t& T = tasks[i];
     if (T.n_edges <= 0) continue;  // an empty conv sends no message (models/score_model.py:109-111)
-    if (T.gh_fmt < 0 || T.gh_fmt > 2) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: task.gh_fmt must be 0, 1 or 2");
+    if (T.gh_fmt != 0 && T.gh_fmt != 1) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: task.gh_fmt must be 0 or 1");
     if (gfmt >= 0 && T.gh_fmt != gfmt) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: the tasks of a launch carry G in ONE plane form");
     gfmt = T.gh_fmt;
     if (T.n_edges_dev) L.dev_counts = 1;
@@ -978,7 +972,7 @@ extern "C" int ddp_conv_rows(const ddp_conv_shape_t* shape, const ddp_conv_task_
   // occupancy shaping (ddp_set_occupancy_shaping): a launch that is to leave one 256-register wave slot per SIMD to another kernel asks
   // for more LDS than two workgroups per CU can have
   if ((size_t)ddp_shape_rows_min_lds > lds_bytes) lds_bytes = (size_t)ddp_shape_rows_min_lds;
-  static int lds_have[6] = {0, 0, 0, 0, 0, 0};
+  static int lds_have[4] = {0, 0, 0, 0};
   hipError_t err;
 #define ROWS_LAUNCH(SZ_, G3_, I_)                                                                                                       \
   {                                                                                                                                     \
@@ -987,9 +981,9 @@ extern "C" int ddp_conv_rows(const ddp_conv_shape_t* shape, const ddp_conv_task_
     hipLaunchKernelGGL((ddp_conv_rows_kernel<SZ_, G3_>), dim3(tiles), dim3(ROWS_NT), lds_bytes, (hipStream_t)stream, RL);               \
   }
   if (sc == 60) {
-    if (gfmt == 1) ROWS_LAUNCH(60, 1, 2) else if (gfmt == 2) ROWS_LAUNCH(60, 2, 4) else ROWS_LAUNCH(60, 0, 0)
+    if (gfmt == 1) ROWS_LAUNCH(60, 1, 2) else ROWS_LAUNCH(60, 0, 0)
   } else {
-    if (gfmt == 1) ROWS_LAUNCH(32, 1, 3) else if (gfmt == 2) ROWS_LAUNCH(32, 2, 5) else ROWS_LAUNCH(32, 0, 1)
+    if (gfmt == 1) ROWS_LAUNCH(32, 1, 3) else ROWS_LAUNCH(32, 0, 1)
   }
 #undef ROWS_LAUNCH
   err = hipGetLastError();

@@ -678,21 +678,6 @@ def gh_dest_table(widths: Sequence[int], n8: int, ncols: int, fmt: int = 0) -> t
     ng = ncols // 8
     tab = torch.empty((ng, 2), dtype=torch.int32)
     g = torch.arange(ng, dtype=torch.int64)
-    if fmt == 2:
-        # plane form 2: the bytes of form 0, but a part's tile is its [k8][c] hi pieces (16 bytes each) followed by its [k8][c] lo pieces:
-        # ddp_conv_rows then loads every fragment as ONE contiguous KiB; Gb and the padding groups stay where form 0 has them
-        tab[:, 0] = (8 * g).int()
-        tab[:, 1] = (8 * g + 4).int()
-        cum = 0
-        for w in widths:
-            gs = n8 * cum
-            gl = torch.arange(n8 * w, dtype=torch.int64)
-            base = 32 * n8 * cum
-            tab[gs:gs + n8 * w, 0] = ((base + 16 * gl) // 4 + 1).int()
-            tab[gs:gs + n8 * w, 1] = ((base + 16 * n8 * w + 16 * gl) // 4).int()
-            cum += w
-        assert 8 * n8 * cum + cum <= ncols
-        return tab
     if fmt == 1:
         # plane form 1: part p's tile starts at byte 24 n8 cum_p: hi piece of group (k8, c) at + 16 (k8 w_p + c), lo piece (8 e4m3 bytes) at
         # + 16 n8 w_p + 8 (k8 w_p + c); Gb group j (6 values) at byte 24 n8 gcp + 32 j; the product's padding groups go to the scratch slot

@@ -150,7 +150,6 @@ class _PackedConv:
 
 
 G_PLANES3_DEFAULT = "0"      # model.g_planes3 unless DDP_G_PLANES3 says otherwise
-GH_FMT_DEFAULT = int(os.environ.get("DDP_GH_FMT", "0"))     # plane form of the 4-byte planes: 0 = hi / lo words side by side, 2 = hi region + lo region
 
 
 class TensorProductConvLayer(nn.Module):
@@ -190,7 +189,7 @@ class TensorProductConvLayer(nn.Module):
             # the 128-edge row-stationary kernel (ddp_conv_rows; size classes ns = 60 / 32): the fc.0 / fc.3 tiles as one stream in the
             # kernel's k order, and stage-A right-hand sides whose product ddp_stage_a_gh writes as fp16 hi/lo planes
             pk.wsh = pk.bsp = pk.wgh = pk.gh_groups = pk.gh_ld = None
-            pk.gh_fmt = int(getattr(self, "gh_fmt", GH_FMT_DEFAULT))     # plane form of G (ddp_conv_task_t::gh_fmt; set by the model: g_plane_form)
+            pk.gh_fmt = int(getattr(self, "gh_fmt", 0))     # plane form of G (ddp_conv_task_t::gh_fmt; set by the model: g_planes3)
             if P.rows_supported(self.spec_g):
                 try:
                     wsh, bsp = P.rows_stream(self.spec_g, self.fc[0].weight, self.fc[0].bias, self.fc[3].weight, self.fc[3].bias)
@@ -718,7 +717,7 @@ class TensorProductScoreModel(nn.Module):
             self._stage_a_stacks = {}
             for m_ in self.modules():
                 if isinstance(m_, TensorProductConvLayer):
-                    m_.gh_fmt = 1 if value else GH_FMT_DEFAULT
+                    m_.gh_fmt = 1 if value else 0
                     m_._packed_g = None
             self.__dict__["_rows_checked_epoch"] = None
             self.__dict__["_packed_epoch"] = self.__dict__.get("_packed_epoch", 0) + 1

@@ -168,8 +168,7 @@ class PyGLikeBatch:
 def decode_gh_rows(rows, widths, hid, fmt):
     """Decodes G rows in the plane forms of ddp_conv_task_t::gh (include/ddp_hip.h) back to fp64: rows [N, ld] float32 (the bytes stage A
     wrote) -> (V [N, n8, gcp, 8] = the plane values hi + lo per k8 group, padded column and k slot; Gb [N, gcp]).  fmt 0: hi / lo fp16 words
-    side by side; fmt 2: a part's 16-byte hi pieces, then its 16-byte lo pieces; fmt 1: 16-byte hi pieces, then 8-byte pieces of OCP e4m3 bytes
-    holding (V - hi) * 512.  Test infrastructure: written from
+    side by side; fmt 1: 16-byte hi pieces, then 8-byte pieces of OCP e4m3 bytes holding (V - hi) * 512.  Test infrastructure: written from
     the header's description of the layouts, independently of packing.gh_dest_table."""
     import numpy as np
     import torch
@@ -193,10 +192,6 @@ def decode_gh_rows(rows, widths, hid, fmt):
             t = raw[:, base:base + n8 * w * 32].reshape(N, n8, w, 2, 16)
             hi = t[:, :, :, 0].copy().view(np.float16).astype(np.float64)
             lo = t[:, :, :, 1].copy().view(np.float16).astype(np.float64)
-        elif fmt == 2:
-            base = 2 * n8 * cum * 16
-            hi = raw[:, base:base + n8 * w * 16].reshape(N, n8, w, 16).copy().view(np.float16).astype(np.float64)
-            lo = raw[:, base + n8 * w * 16:base + n8 * w * 32].reshape(N, n8, w, 16).copy().view(np.float16).astype(np.float64)
         else:
             base = n8 * cum * 24
             hi = raw[:, base:base + n8 * w * 16].reshape(N, n8, w, 16).copy().view(np.float16).astype(np.float64)

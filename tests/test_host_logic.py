@@ -553,9 +553,9 @@ def test_smooth_edge_weight_matches_the_oracle_and_tolerates_unfilled_list_entri
     assert orc._edge_weight(vec, 5.0) == 1.0
 
 
-@pytest.mark.parametrize("fmt", [0, 1, 2])
+@pytest.mark.parametrize("fmt", [0, 1])
 def test_g_plane_forms_host_side_against_the_decoder(fmt):
-    """The three plane forms of a factorised conv's G (ddp_conv_task_t::gh_fmt; include/ddp_hip.h): packing.factor_weights_gh orders the
+    """The two plane forms of a factorised conv's G (ddp_conv_task_t::gh_fmt; include/ddp_hip.h): packing.factor_weights_gh orders the
     product's columns, packing.gh_dest_table says where the two pieces of every 8-column group go, the kernel's drain is one conversion
     per group.  Emulated here on the CPU exactly as csrc/ddp_gemm.hip drains (a plane group: 8 fp16 hi words + the lo piece - 8 fp16 words,
     or 8 e4m3 bytes of (V - hi) x 512 in form 1; any other group: its first 4, and second 4 - form 1: 2 - fp32 values), and read back with
