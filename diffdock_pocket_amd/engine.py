@@ -85,9 +85,10 @@ class _Fork:
     kernel instead of running behind it - at 5 samples of 3dpf the kernels of a layer do not fill the chip one by one; at
     40 samples they do, and sharing the CUs was measured without gain."""
 
-    def __init__(self, dev, n):
+    def __init__(self, dev, n, priorities=None):
         self.main = torch.cuda.current_stream(dev)
-        self.side = [torch.cuda.Stream(device=dev) for _ in range(n)]
+        # (priorities: {slot: stream priority}; lower = served first.  Only an experiment uses it: model.direct_conv_priority)
+        self.side = [torch.cuda.Stream(device=dev, priority=int((priorities or {}).get(i, 0))) for i in range(n)]
         self.used = []
 
     def run(self, i, fn):
@@ -121,7 +122,10 @@ class ForwardEngine:
         """Side streams of the current stream for a layer's independent launches."""
         f = self._forks.get(dev)     # (created by the first ordinary step: no stream is created during a capture)
         if f is None:
-            f = self._forks[dev] = _Fork(dev, 5)     # slots 0 - 2: stage-A groups / front, 3: direct conv, 4: index lists
+            # slots 0 - 2: stage-A groups / front, 3: direct conv, 4: index lists (pipelined order: 0 = the early conv launch, 1 = the direct
+            # conv, 2 / 3 = the ligand / receptor chains)
+            prio = getattr(self.m, "direct_conv_priority", None)
+            f = self._forks[dev] = _Fork(dev, 5, {1: prio} if prio is not None else None)
         f.main = torch.cuda.current_stream(dev)
         return f
 
