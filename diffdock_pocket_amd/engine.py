@@ -124,8 +124,12 @@ class ForwardEngine:
         if f is None:
             # slots 0 - 2: stage-A groups / front, 3: direct conv, 4: index lists (pipelined order: 0 = the early conv launch, 1 = the direct
             # conv, 2 / 3 = the ligand / receptor chains)
-            prio = getattr(self.m, "direct_conv_priority", None)
-            f = self._forks[dev] = _Fork(dev, 5, {1: prio} if prio is not None else None)
+            prio = {}
+            if getattr(self.m, "direct_conv_priority", None) is not None:
+                prio[1] = self.m.direct_conv_priority
+            if getattr(self.m, "rows_priority", None) is not None:      # the layer's factorised conv launches (both of a split layer)
+                prio[0] = self.m.rows_priority
+            f = self._forks[dev] = _Fork(dev, 5, prio or None)
         f.main = torch.cuda.current_stream(dev)
         return f
 
@@ -1052,9 +1056,17 @@ class ForwardEngine:
                         pk_ = conv_.packed_g(dev)
                         tot += rows_[3] * 4 * sum(ld_ for ld_ in (getattr(pk_, "gh_ld", None) or []) if ld_ is not None)
                 return tot
+            rows_side = getattr(m, "rows_priority", None) is not None
             for l in range(L_):
                 nxt = plan(l + 1) if l + 1 < L_ else None
-                launch_factorised(P)        # (split: the atom-sourced convs - the others were launched beside stage A{atom rows})
+                if rows_side:
+                    # (experiment, model.rows_priority: the conv launch on the prioritised side stream of the early launch, behind everything
+                    # the main stream has queued - stage A of the atom rows; joined with it below)
+                    if side.side[0] in side.used:
+                        side.resync(0)
+                    side.run(0, lambda P=P: launch_factorised(P))
+                else:
+                    launch_factorised(P)        # (split: the atom-sourced convs - the others were launched beside stage A{atom rows})
                 join_lists()
                 fix_rowmaps(P)
                 side.join(only=1)           # direct conv(l) is done: the means below update x in place

@@ -477,6 +477,7 @@ class TensorProductScoreModel(nn.Module):
         self.split_rows_launch = True
         # experiment (profiles/r06_direct_conv_priority.txt): stream priority of the direct conv's side stream in the pipelined order (None: default)
         self.direct_conv_priority = (int(os.environ["DDP_DIRECT_PRIO"]) if os.environ.get("DDP_DIRECT_PRIO") else None)
+        self.rows_priority = (int(os.environ["DDP_ROWS_PRIO"]) if os.environ.get("DDP_ROWS_PRIO") else None)     # experiment, same file
         self.shape_early_rows = False           # the early launch at ONE workgroup per CU beside stage A of the atom rows (measured: off)
         self.split_rows_min_g_bytes = 3.0e9     # ... where stage A of the atom rows writes at least this much (engine._layers): 4.7 GB at
         # 40 samples of cfg2; at 20 samples (2.4 GB) the second launch cost 0.1 - 0.2 of 9.2 ms, on the README's small model (1.4 GB) 0.3 of 3.2
@@ -952,6 +953,27 @@ class TensorProductScoreModel(nn.Module):
             return out
         self.__dict__["h2_recoveries"] = self.__dict__.get("h2_recoveries", 0) + 1
         return self.forward_fp32(data)
+
+    def split_form_error(self, data):
+        """How far the fp16 hi/lo split form of the fc products (what `forward` runs) is from the exact fp32 MFMA form ON THIS BATCH AND
+        THESE WEIGHTS: {output name: max |split - fp32| / max |fp32|}.  The split operands carry 22 significant bits only while their lo
+        halves are normal fp16 numbers (include/ddp_hip.h, DDP_ROWS_S*: absolute floors below |V| = 0.125); the parity suites run on
+        seeded random weights with O(1) BatchNorm-ed activations, so a user with a trained checkpoint whose magnitudes differ can ask here
+        instead of trusting them (two forwards; typical values 1e-6 .. 1e-5, the path's tolerance is 1e-4).  A batch the split form cannot
+        represent at all (range flag) reports {"recovered": True}: `forward` then returns the fp32 form by itself."""
+        before = self.__dict__.get("h2_recoveries", 0)
+        a = self.forward(data)
+        if self.__dict__.get("h2_recoveries", 0) != before:
+            return {"recovered": True}
+        b = self.forward_fp32(data)
+        if not isinstance(a, (tuple, list)):
+            a, b = (a,), (b,)
+        names = ("tr", "rot", "tor", "sc_tor") if len(a) == 4 else ("confidence",)
+        out = {}
+        for n_, x, y in zip(names, a, b):
+            if y.numel():
+                out[n_] = float((x.double() - y.double()).abs().max() / y.double().abs().max().clamp(min=1e-30))
+        return out
 
     def forward_fp32(self, data):
         """This forward with every fc product in the exact fp32 MFMA form (launch.CONV_H2 off for the tasks it builds), whatever conv_h2

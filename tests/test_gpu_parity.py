@@ -304,6 +304,9 @@ def test_fp16_split_products_against_the_fp32_mfma_form(name):
         out[h2] = [t.double().cpu() for t in got]
     assert model.__dict__.get("h2_recoveries", 0) == 0                            # (no forward fell back to the fp32 form)
     assert any(not torch.equal(a, b) for a, b in zip(out[True], out[False]))      # (the switch does switch)
+    model.conv_h2 = True
+    rep = model.split_form_error(case.make_batch().to(_dev()))                    # (the user-facing form of this comparison)
+    assert rep and "recovered" not in rep and all(v < 1e-5 for v in rep.values()), rep
     for a, b, w, k in zip(out[True], out[False], want, ("tr", "rot", "tor", "sc_tor")):
         if w.numel() == 0:
             continue
@@ -371,7 +374,7 @@ def test_rows_kernel_range_flag_is_raised_and_recovered():
     """the recovery test above scales fc.0 by 3e5, which puts |w| beyond the row-stationary kernel's weight planes (255) and
     moves the whole model to the 32-edge kernel - ddp_conv_rows' own flag site never ran.  Here the weights stay inside the planes
     (launch.rows_mode stays on for every factorised conv) and a VALUE leaves the kernel's range: fc.0 (weight and bias) x 3000 and
-    fc.3 / 3000 on one conv (and its edge embeddings x 10): |w| <= 3000 x 0.075 < 255, h = relu(fc1) of many edges beyond the h plane's 4094 (65504 / DDP_ROWS_SH) but
+    fc.3 / 3000 on one conv (and its edge embeddings x 100): |w| <= 3000 x 0.075 < 255, h = relu(fc1) of many edges beyond the h plane's 4094 (65504 / DDP_ROWS_SH) but
     far inside the 65504 of the 32-edge kernel's 2048-scaled planes.  The forward returns the fp32 form's scores (1e-4 of the oracle),
     counts one recovery, and the next forward does the same.  (Stage A's flag - a plane value |32 G| beyond the range - is raised at unit
     level: test_stage_a_plane_forms_report_values_outside_their_range.)"""
@@ -382,10 +385,10 @@ def test_rows_kernel_range_flag_is_raised_and_recovered():
     sd[conv + ".fc.0.weight"] = sd[conv + ".fc.0.weight"] * 3000.0
     sd[conv + ".fc.0.bias"] = sd[conv + ".fc.0.bias"] * 3000.0
     sd[conv + ".fc.3.weight"] = sd[conv + ".fc.3.weight"] / 3000.0
-    # (... and the atom-atom edge embeddings x 10: a third of edge_attr_'s columns, so that h = relu(fc1) passes 4094 on many edges with room
+    # (... and the atom-atom edge embeddings x 100: a third of edge_attr_'s columns, so that h = relu(fc1) passes 4094 on many edges with room
     # to spare - the weights alone stop at 255 / 0.075 = 3400)
-    sd["atom_edge_embedding.3.weight"] = sd["atom_edge_embedding.3.weight"] * 10.0
-    sd["atom_edge_embedding.3.bias"] = sd["atom_edge_embedding.3.bias"] * 10.0
+    sd["atom_edge_embedding.3.weight"] = sd["atom_edge_embedding.3.weight"] * 100.0
+    sd["atom_edge_embedding.3.bias"] = sd["atom_edge_embedding.3.bias"] * 100.0
     assert float(sd[conv + ".fc.0.weight"].abs().max()) < 255.0 and float(sd[conv + ".fc.3.weight"].abs().max()) < 255.0
     want = OracleScoreModel(case.oracle_config(), sd)(case.make_batch())
     assert all(torch.isfinite(w).all() for w in want)
