@@ -85,10 +85,11 @@ class _Fork:
     kernel instead of running behind it - at 5 samples of 3dpf the kernels of a layer do not fill the chip one by one; at
     40 samples they do, and sharing the CUs was measured without gain."""
 
-    def __init__(self, dev, n, priorities=None):
+    def __init__(self, dev, n):
         self.main = torch.cuda.current_stream(dev)
-        # (priorities: {slot: stream priority}; lower = served first.  Only an experiment uses it: model.direct_conv_priority)
-        self.side = [torch.cuda.Stream(device=dev, priority=int((priorities or {}).get(i, 0))) for i in range(n)]
+        # (all at the default priority: a high-priority branch - the direct conv, or the conv launches - cost 1.9 - 2.2 ms of a 16-ms step,
+        # profiles/r06_direct_conv_priority.txt)
+        self.side = [torch.cuda.Stream(device=dev) for _ in range(n)]
         self.used = []
 
     def run(self, i, fn):
@@ -124,12 +125,7 @@ class ForwardEngine:
         if f is None:
             # slots 0 - 2: stage-A groups / front, 3: direct conv, 4: index lists (pipelined order: 0 = the early conv launch, 1 = the direct
             # conv, 2 / 3 = the ligand / receptor chains)
-            prio = {}
-            if getattr(self.m, "direct_conv_priority", None) is not None:
-                prio[1] = self.m.direct_conv_priority
-            if getattr(self.m, "rows_priority", None) is not None:      # the layer's factorised conv launches (both of a split layer)
-                prio[0] = self.m.rows_priority
-            f = self._forks[dev] = _Fork(dev, 5, prio or None)
+            f = self._forks[dev] = _Fork(dev, 5)
         f.main = torch.cuda.current_stream(dev)
         return f
 
@@ -1056,17 +1052,9 @@ class ForwardEngine:
                         pk_ = conv_.packed_g(dev)
                         tot += rows_[3] * 4 * sum(ld_ for ld_ in (getattr(pk_, "gh_ld", None) or []) if ld_ is not None)
                 return tot
-            rows_side = getattr(m, "rows_priority", None) is not None
             for l in range(L_):
                 nxt = plan(l + 1) if l + 1 < L_ else None
-                if rows_side:
-                    # (experiment, model.rows_priority: the conv launch on the prioritised side stream of the early launch, behind everything
-                    # the main stream has queued - stage A of the atom rows; joined with it below)
-                    if side.side[0] in side.used:
-                        side.resync(0)
-                    side.run(0, lambda P=P: launch_factorised(P))
-                else:
-                    launch_factorised(P)        # (split: the atom-sourced convs - the others were launched beside stage A{atom rows})
+                launch_factorised(P)        # (split: the atom-sourced convs - the others were launched beside stage A{atom rows})
                 join_lists()
                 fix_rowmaps(P)
                 side.join(only=1)           # direct conv(l) is done: the means below update x in place

@@ -475,9 +475,6 @@ class TensorProductScoreModel(nn.Module):
         # Same kernels, same tasks, same bits (a conv's workgroups do not depend on the launch it sits in); 17.5 -> 17.3 ms rigid,
         # 21.8 -> 21.4 ms with flexible side chains (profiles/r05_conv32_ab.txt)
         self.split_rows_launch = True
-        # experiment (profiles/r06_direct_conv_priority.txt): stream priority of the direct conv's side stream in the pipelined order (None: default)
-        self.direct_conv_priority = (int(os.environ["DDP_DIRECT_PRIO"]) if os.environ.get("DDP_DIRECT_PRIO") else None)
-        self.rows_priority = (int(os.environ["DDP_ROWS_PRIO"]) if os.environ.get("DDP_ROWS_PRIO") else None)     # experiment, same file
         self.shape_early_rows = False           # the early launch at ONE workgroup per CU beside stage A of the atom rows (measured: off)
         self.split_rows_min_g_bytes = 3.0e9     # ... where stage A of the atom rows writes at least this much (engine._layers): 4.7 GB at
         # 40 samples of cfg2; at 20 samples (2.4 GB) the second launch cost 0.1 - 0.2 of 9.2 ms, on the README's small model (1.4 GB) 0.3 of 3.2

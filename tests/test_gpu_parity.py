@@ -394,7 +394,8 @@ def test_rows_kernel_range_flag_is_raised_and_recovered():
     assert all(torch.isfinite(w).all() for w in want)
     model = _model_for(case, sd)
     dev = _dev()
-    assert all(K.rows_mode(c.packed_g(dev)) for c in model.conv_layers if getattr(c, "spec_g", None) is not None and c.spec_g.factorized)
+    # (every factorised conv carries the row-stationary kernel's weight stream: none was pushed back to the 32-edge kernel by its weights)
+    assert all(c.packed_g(dev).wsh is not None for c in model.conv_layers if getattr(c, "spec_g", None) is not None and c.spec_g.factorized)
     b = case.make_batch().to(dev)
     got = model(b)
     assert model.__dict__.get("h2_recoveries", 0) == 1
