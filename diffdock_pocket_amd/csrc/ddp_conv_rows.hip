@@ -933,13 +933,16 @@ extern "C" int ddp_conv_rows(const ddp_conv_shape_t* shape, const ddp_conv_task_
       if (B.U * B.C > frows) frows = B.U * B.C;
     }
   }
-  int tiles = 0, gfmt = -1;
+  int tiles = 0, gfmt = -1, form = -1;
   for (int i = 0; i < ntasks; ++i) {
     const ddp_conv_task_t& T = tasks[i];
     if (T.n_edges <= 0) continue;  // an empty conv sends no message (models/score_model.py:109-111)
     if (T.gh_fmt != 0 && T.gh_fmt != 1) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: task.gh_fmt must be 0 or 1");
     if (gfmt >= 0 && T.gh_fmt != gfmt) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: the tasks of a launch carry G in ONE plane form");
     gfmt = T.gh_fmt;
+    if (T.rows_form != 0 && T.rows_form != 1) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: task.rows_form must be 0 or 1");
+    if (form >= 0 && T.rows_form != form) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: the tasks of a launch carry ONE form of operand images");
+    form = T.rows_form;
     if (T.n_edges_dev) L.dev_counts = 1;
     if (!T.wsh || !T.bsp || (reinterpret_cast<size_t>(T.wsh) & 15) || (reinterpret_cast<size_t>(T.bsp) & 15))
       return ddp_fail(DDP_EINVAL, "ddp_conv_rows: task.wsh / bsp missing (or not 16-byte aligned)");
@@ -958,6 +961,7 @@ extern "C" int ddp_conv_rows(const ddp_conv_shape_t* shape, const ddp_conv_task_
   }
   L.tile_start[L.ntasks] = tiles;
   if (tiles == 0) return 0;
+  if (form == 1) return ddp_conv_rows16_launch(shape, tasks, ntasks, sc, stream);     // operand images of v_mfma_f32_16x16x32_f16
   RL.nts = nts;
   int fbytes = frows * ROWS_FS * 4;
   fbytes = (fbytes + 127) / 128 * 128;

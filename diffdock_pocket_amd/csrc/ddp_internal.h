@@ -3,6 +3,8 @@
 #define DDP_INTERNAL_H
 #include <hip/hip_runtime.h>
 
+#include "ddp_hip.h"
+
 int ddp_fail(int code, const char* msg);
 int ddp_fail_hip(hipError_t err, const char* where);
 
@@ -15,6 +17,9 @@ static inline hipError_t ddp_need_lds(const void* kernel, int bytes, int* have) 
   if (err == hipSuccess) *have = bytes;
   return err;
 }
+
+// csrc/ddp_conv_rows16.hip: the launch of ddp_conv_rows for tasks with rows_form = 1 (arguments validated by ddp_conv_rows; sc = size class)
+int ddp_conv_rows16_launch(const ddp_conv_shape_t* shape, const ddp_conv_task_t* tasks, int ntasks, int sc, void* stream);
 
 // Occupancy shaping (ddp_set_occupancy_shaping, include/ddp_hip.h): launch-time LDS floors that decide how many workgroups of a kernel
 // share a CU.  Plain ints read when a launch is enqueued.

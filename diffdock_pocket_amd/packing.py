@@ -435,6 +435,33 @@ def _pack_tiles_h2(Wcols: torch.Tensor, ns16: int, unified_scale: float = 0.0) -
     return Pl.permute(1, 3, 0, 4, 2, 5).contiguous().reshape(-1)
 
 
+def rows16_pos(ncols: int) -> torch.Tensor:
+    """LongTensor [ncols] (ncols a multiple of 32): DDP_ROWS16_POS per 32-column tile - where column c = 32 t + j of fc.0's output sits in the
+    stream of ddp_conv_rows' 16x16x32 form (rows_form 1): position 32 t + 16 ((j & 7) >> 2) + 4 (j >> 3) + (j & 3).  The transposed fc1
+    product then leaves lane (edge, g) with the h columns 32 t + 8 g + i, i < 8, as its A fragment of k32 step t: natural k order."""
+    c = torch.arange(ncols)
+    j = c % 32
+    return (c - j) + 16 * ((j & 7) >> 2) + 4 * (j >> 3) + (j & 3)
+
+
+def _pack_tiles_16(Wcols: torch.Tensor, ns16: int, unified_scale: float) -> torch.Tensor:
+    """Wcols [ncols (multiple of 32), K] fp32 -> unified fp16 hi/lo planes of S w in the operand images of v_mfma_f32_16x16x32_f16
+    (ddp_conv_task_t::rows_form = 1): per 32-column tile 2 ns16 fragments of 1 KiB ordered [k32 step s][column tile ct][plane], each
+    [k group g < 4][column n < 16][8 halves] = plane(W)[column 16 ct + n][k = 32 s + 8 g + i], K zero-padded to 16 ns16."""
+    ncols, K = Wcols.shape
+    kp = 16 * ns16
+    assert ncols % 32 == 0 and kp >= K and ns16 % 2 == 0
+    W = torch.zeros(ncols, kp, dtype=torch.float32)
+    W[:, :K] = Wcols
+    W = W * unified_scale
+    hi = W.to(torch.float16)
+    lo = (W - hi.float()).to(torch.float16)
+    if not bool(torch.isfinite(hi).all()):
+        raise NotImplementedError("fc weight outside the fp16 range of ddp_conv_rows' planes (|w| > 255): the fp16 hi/lo form cannot represent it")
+    Pl = torch.stack([hi, lo], 0).reshape(2, ncols // 32, 2, 16, ns16 // 2, 4, 8)      # [plane, tile, ct, n, s, g, i]
+    return Pl.permute(1, 4, 2, 0, 5, 3, 6).contiguous().reshape(-1)                    # [tile, s, ct, plane, g, n, i]
+
+
 def pack_fc1_h2(spec: ConvSpec, weight: torch.Tensor):
     """fc.0 weight [hid, f_in] as fp16 hi/lo planes per 32-column tile (bias: pack_fc1's)."""
     hid, f_in = weight.shape
@@ -555,11 +582,14 @@ def rows_segments(spec: "ConvSpec"):
     return segs
 
 
-def rows_stream(spec: "ConvSpec", w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor):
+def rows_stream(spec: "ConvSpec", w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, form: int = 0):
     """(wsh, bsp) of ddp_conv_task_t for ddp_conv_rows: fc.0's nct1 column tiles (natural k order: their K is edge_attr_), then the fc.3
     tiles of `spec` (block scale folded in) segment by segment with the k index permuted by rows_kperm; UNIFIED fp16 hi/lo planes of
     ROWS_SW w per tile (_pack_tiles_h2), the bias words fp32 [tiles, 32] at the scale of their tile's accumulator (fc.0: ROWS_SW ROWS_SX,
-    fc.3: ROWS_SH ROWS_SW)."""
+    fc.3: ROWS_SH ROWS_SW).
+    form = 1 (ddp_conv_task_t::rows_form, csrc/ddp_conv_rows16.hip): the same stream in the operand images of v_mfma_f32_16x16x32_f16
+    (_pack_tiles_16): fc.0's output columns placed by rows16_pos inside every 32-column tile (bias words in the same positions), the k of
+    the fc.3 tiles in natural order."""
     ns16 = h2_steps(spec)
     assert ns16 > 0
     hid, f_in = w1.shape
@@ -567,7 +597,15 @@ def rows_stream(spec: "ConvSpec", w1: torch.Tensor, b1: torch.Tensor, w2: torch.
     W1c[:hid] = w1.detach().float().cpu()
     b1c = torch.zeros(spec.nct1 * 32)
     b1c[:hid] = b1.detach().float().cpu() * (ROWS_SW * ROWS_SX)
-    t1 = _pack_tiles_h2(W1c, ns16, ROWS_SW).reshape(spec.nct1, -1)
+    if form == 1:
+        pos = rows16_pos(spec.nct1 * 32)
+        W1p, b1p = torch.zeros_like(W1c), torch.zeros_like(b1c)
+        W1p[pos] = W1c
+        b1p[pos] = b1c
+        W1c, b1c = W1p, b1p
+        t1 = _pack_tiles_16(W1c, ns16, ROWS_SW).reshape(spec.nct1, -1)
+    else:
+        t1 = _pack_tiles_h2(W1c, ns16, ROWS_SW).reshape(spec.nct1, -1)
     w2 = w2.detach().float().cpu()
     b2 = b2.detach().float().cpu()
     cols, bcols = [], []
@@ -585,8 +623,11 @@ def rows_stream(spec: "ConvSpec", w1: torch.Tensor, b1: torch.Tensor, w2: torch.
         Wall = torch.cat(cols, 0)                                   # [ntiles * 32, hid]
         Wp = torch.zeros(Wall.shape[0], 16 * ns16)
         Wp[:, :spec.hid] = Wall
-        Wp = Wp[:, rows_kperm(ns16)]                                # fragment slot -> permuted k
-        t2 = _pack_tiles_h2(Wp, ns16, ROWS_SW).reshape(Wall.shape[0] // 32, -1)[order]
+        if form == 1:
+            t2 = _pack_tiles_16(Wp, ns16, ROWS_SW).reshape(Wall.shape[0] // 32, -1)[order]      # (natural k)
+        else:
+            Wp = Wp[:, rows_kperm(ns16)]                                # fragment slot -> permuted k
+            t2 = _pack_tiles_h2(Wp, ns16, ROWS_SW).reshape(Wall.shape[0] // 32, -1)[order]
         bs2 = torch.cat(bcols, 0).reshape(-1, 32)[order] * (ROWS_SH * ROWS_SW)
         return torch.cat([t1, t2], 0).reshape(-1).contiguous(), torch.cat([b1c.reshape(-1, 32), bs2], 0).contiguous()
     return t1.reshape(-1).contiguous(), b1c.reshape(-1, 32).contiguous()
@@ -622,7 +663,7 @@ def gh3_ld(hid: int, gcp: int) -> int:
     return (n8 * gcp * 24 + (gcp + 5) // 6 * 32 + 32 + 127) // 128 * 32
 
 
-def factor_weights_gh(spec: "ConvSpec", weight: torch.Tensor, bias: torch.Tensor, fmt: int = 0):
+def factor_weights_gh(spec: "ConvSpec", weight: torch.Tensor, bias: torch.Tensor, fmt: int = 0, form: int = 0):
     """factor_weights for ddp_conv_rows: right-hand sides whose product columns are ordered [part][k8 group][column c of the part][8 k's
     of the group] (gh_parts; the k's of group g = 2 ks + hh are rows_kperm's slots (ks, hh, 0..7); h columns >= hid and the padding
     columns of a part are zero), then Gb per padded column, then zero padding to DDP_GH_LD.  ddp_stage_a_gh writes the groups of a row
@@ -636,7 +677,8 @@ def factor_weights_gh(spec: "ConvSpec", weight: torch.Tensor, bias: torch.Tensor
     weight = weight.detach().float().cpu()
     bias = bias.detach().float().cpu()
     n8 = (spec.hid + 7) // 8
-    kp = rows_kperm(ns16)[:8 * n8]
+    # (rows_form 1: h, and with it G's k, is in natural order - the same bytes per node, other k's in the groups)
+    kp = torch.arange(8 * n8) if form == 1 else rows_kperm(ns16)[:8 * n8]
     Wg, offs, widths = [None, None], [0, 0], [None, None]
     for slot in (0, 1):
         blks = [b for b in spec.blocks if b.g_slot == slot]

@@ -146,10 +146,11 @@ def _mlp(n_in, n_hidden, n_out, dropout):
 
 class _PackedConv:
     __slots__ = ("w1p", "b1p", "w2p", "b2p", "bn_scale", "bn_shift", "wg", "bg", "g_in_off", "w1h", "w2h",
-                 "wsh", "bsp", "wgh", "gh_groups", "gh_ld", "gh_fmt")     # (the last six: ddp_conv_rows' weight stream and stage-A right-hand sides)
+                 "wsh", "bsp", "wgh", "gh_groups", "gh_ld", "gh_fmt", "rows_form")     # (the last six: ddp_conv_rows' weight stream and stage-A right-hand sides)
 
 
 G_PLANES3_DEFAULT = "0"      # model.g_planes3 unless DDP_G_PLANES3 says otherwise
+ROWS_MFMA16_DEFAULT = "0"    # model.rows_mfma16 unless DDP_ROWS_MFMA16 says otherwise
 
 
 class TensorProductConvLayer(nn.Module):
@@ -190,14 +191,15 @@ class TensorProductConvLayer(nn.Module):
             # kernel's k order, and stage-A right-hand sides whose product ddp_stage_a_gh writes as fp16 hi/lo planes
             pk.wsh = pk.bsp = pk.wgh = pk.gh_groups = pk.gh_ld = None
             pk.gh_fmt = int(getattr(self, "gh_fmt", 0))     # plane form of G (ddp_conv_task_t::gh_fmt; set by the model: g_planes3)
+            pk.rows_form = int(getattr(self, "rows_form", 0))   # operand images of the rows kernel (ddp_conv_task_t::rows_form: rows_mfma16)
             if P.rows_supported(self.spec_g):
                 try:
-                    wsh, bsp = P.rows_stream(self.spec_g, self.fc[0].weight, self.fc[0].bias, self.fc[3].weight, self.fc[3].bias)
+                    wsh, bsp = P.rows_stream(self.spec_g, self.fc[0].weight, self.fc[0].bias, self.fc[3].weight, self.fc[3].bias, form=pk.rows_form)
                 except NotImplementedError:
                     wsh = None      # a weight beyond the unified planes' range (|w| > 255): this conv keeps the 32-edge kernel
                 if wsh is not None:
                     pk.wsh, pk.bsp = wsh.to(device), bsp.to(device)
-                    wgh, _, widths = P.factor_weights_gh(self.spec_g, self.fc[3].weight, self.fc[3].bias, fmt=pk.gh_fmt)
+                    wgh, _, widths = P.factor_weights_gh(self.spec_g, self.fc[3].weight, self.fc[3].bias, fmt=pk.gh_fmt, form=pk.rows_form)
                     pk.wgh = [w.to(device) if w is not None else None for w in wgh]
                     pk.gh_groups = widths          # (per slot: the padded widths of the G array's column parts)
                     # floats per node of the G array stage A writes (plane form 1: shorter than the product's columns)
@@ -551,6 +553,7 @@ class TensorProductScoreModel(nn.Module):
         # plane form of the factorised convs' G (property g_planes3); DDP_G_PLANES3 = 0 / 1 in the environment sets the default of every model
         # built in the process (the parity suites under the other form: profiles/r06_g3byte_parity.txt)
         self.g_planes3 = os.environ.get("DDP_G_PLANES3", G_PLANES3_DEFAULT) == "1"
+        self.rows_mfma16 = os.environ.get("DDP_ROWS_MFMA16", ROWS_MFMA16_DEFAULT) == "1"
 
     # ---- checkpoint compatibility -------------------------------------------------------------
     _IGNORED_PREFIXES = ("final_tp_tor.", "final_tp_sc_tor.", "tor_bond_conv.tp.", "sc_tor_bond_conv.tp.")
@@ -718,6 +721,29 @@ class TensorProductScoreModel(nn.Module):
             for m_ in self.modules():
                 if isinstance(m_, TensorProductConvLayer):
                     m_.gh_fmt = 1 if value else 0
+                    m_._packed_g = None
+            self.__dict__["_rows_checked_epoch"] = None
+            self.__dict__["_packed_epoch"] = self.__dict__.get("_packed_epoch", 0) + 1
+
+    @property
+    def rows_mfma16(self):
+        """Operand images of the row-stationary conv kernel (ddp_conv_task_t::rows_form).  True: every tile product on
+        v_mfma_f32_16x16x32_f16 (csrc/ddp_conv_rows16.hip); False: v_mfma_f32_32x32x16_f16 (csrc/ddp_conv_rows.hip).  Same arithmetic per
+        product (unified fp16 hi/lo planes, fp32 accumulation), other summation order inside a k-step: results agree to fp32 rounding, not
+        bit for bit.  Changing it drops the packed weights and captured steps.  Excludes g_planes3."""
+        return bool(self.__dict__.get("_rows_mfma16", False))
+
+    @rows_mfma16.setter
+    def rows_mfma16(self, value):
+        value = bool(value)
+        if value != self.rows_mfma16:
+            if value and self.g_planes3:
+                raise NotImplementedError("rows_mfma16 reads G in plane form 0 (g_planes3 must be off)")
+            self.__dict__["_rows_mfma16"] = value
+            self._stage_a_stacks = {}
+            for m_ in self.modules():
+                if isinstance(m_, TensorProductConvLayer):
+                    m_.rows_form = 1 if value else 0
                     m_._packed_g = None
             self.__dict__["_rows_checked_epoch"] = None
             self.__dict__["_packed_epoch"] = self.__dict__.get("_packed_epoch", 0) + 1

@@ -165,6 +165,15 @@ typedef struct {
    *     column c of the slot as fp32 at byte 32 (c / 6) + 4 (c % 6) (stage A stores 6 values per 8-column group), 32 bytes of scratch,
    *     padding to 128 bytes: DDP_GH3_LD floats per node.  Written by ddp_stage_a_gh3. */
   int32_t gh_fmt;
+  /* Operand images of wsh / gh / the kernel's h (ABI 16; all tasks of a launch carry the same):
+   *  0  v_mfma_f32_32x32x16_f16 (csrc/ddp_conv_rows.hip): wsh fragments [ks][plane] of [hh][column 32][8 halves], k of the fc.3 tiles and of gh
+   *     permuted by DDP_ROWS_KPERM;
+   *  1  v_mfma_f32_16x16x32_f16 (csrc/ddp_conv_rows16.hip): a 32-column tile = 2 NS fragments of 1 KiB ordered [k32 step s][column tile ct]
+   *     [plane], each [k group g < 4][column n < 16][8 halves] = plane(W)[column 16 ct + n][k = 32 s + 8 g + i]; the k order of the fc.3 tiles and
+   *     of gh is the NATURAL one (gh: the same bytes per node as form 0, k8 group = k / 8), and fc.0's OUTPUT columns are placed inside every
+   *     32-column stream tile t so that the transposed fc1 product leaves h in that k order: h column 32 t + 8 g + i sits at position
+   *     16 (i / 4) + 4 g + i % 4 of the tile (DDP_ROWS16_POS; bias words in position order).  gh_fmt must be 0. */
+  int32_t rows_form;
 } ddp_conv_task_t;
 /* plane scales of ddp_conv_rows' operands: edge_attr_ (split in the kernel), fc.0 / fc.3 weights (task.wsh), h = relu(fc1) (split in
  * the kernel), G (task.gh).  Ranges |edge_attr_|, |h| < 4094, |w| < 255, |G| < 2047; absolute floors 2^-29, 2^-33, 2^-30. */
@@ -174,6 +183,8 @@ typedef struct {
 #define DDP_ROWS_SG 32
 /* k index held by element i of the 8-k group (ks, hh) of an h / fc.3 / G operand fragment in ddp_conv_rows */
 #define DDP_ROWS_KPERM(ks, hh, i) (32 * ((ks) >> 1) + ((8 * ((ks) & 1) + (i)) & 3) + 8 * ((8 * ((ks) & 1) + (i)) >> 2) + 4 * (hh))
+/* position inside a 32-column fc.0 stream tile of the h column with in-tile index j = 8 g + i (rows_form 1) */
+#define DDP_ROWS16_POS(j) (16 * (((j) & 7) >> 2) + 4 * ((j) >> 3) + ((j) & 3))
 #define DDP_GH3_LO_SCALE 512
 #define DDP_GH3_LD(hid, gcp) ((((((hid) + 7) / 8) * (gcp) * 24 + (((gcp) + 5) / 6) * 32 + 32 + 127) / 128) * 32)   /* floats per node, plane form 1 */
 #define DDP_GH_LD(hid, gcp) ((((((hid) + 7) / 8) * 8 + 1) * (gcp) + 31) / 32 * 32)   /* floats per node of a G array in plane form, gcp = padded columns */
