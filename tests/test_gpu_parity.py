@@ -692,7 +692,7 @@ def test_rows_kernel_operand_planes_at_small_magnitudes(mag):
     want = OracleScoreModel(cfg, sd)._conv("c", cfg.irreps(layer), cfg.irreps(layer + 1), x, ei, ea, sh)
     dev = _dev()
     conv = conv.to(dev)
-    assert K.CONV_ROWS and K.rows_mode(conv.packed_g(dev))
+    assert K.CONV_ROWS and conv.packed_g(dev).wsh is not None      # (the row-stationary kernel's weight stream exists: this conv runs through it)
     got = conv(x.to(dev), ei.to(dev), ea.to(dev), sh.to(dev), factorized=True).cpu()
     rows_was = K.CONV_ROWS
     K.CONV_ROWS = False
