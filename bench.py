@@ -23,7 +23,7 @@ Synthetic data: real 3dpf geometry + random categorical features / ESM block, ra
 checkpoints).  Inputs are resident in HBM before the timed region.
 
 The JSON line also carries
-  roofline      the dominant kernel (ddp_conv_rows_kernel since round 5; matrix-core bound by its instruction mix).  `achieved` =
+  roofline      the dominant kernel (ddp_conv_rows16_kernel since round 6, ddp_conv_rows_kernel in round 5; matrix-core bound by its instruction mix).  `achieved` =
                 matrix-core instruction FLOPs of the kernel's own formulation without padding - the two fc products and (rows kernel) the
                 per-edge G contraction as fp16 hi/lo split products = three fp16 MFMA FLOPs per product FLOP, the rest fp32 - / mean
                 launch time from HIP events on the launch stream over the instrumented steps behind the timed region; `peak` = the same
@@ -627,7 +627,7 @@ def main(argv=None):
         line = {"metric": "ligand poses/sec (40 samples x 20 steps) on 3dpf", "value": poses / elapsed, "unit": "poses/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                 "higher_is_better": True, "scaling": scaling if world > 1 else None, "vs_baseline": None,
-                "dtype": "f32 (fc and G products: fp16 hi/lo split of both operands on v_mfma_f32_32x32x16_f16, fp32 accumulate; the exact fp32 MFMA form is timed in other_workloads)", "data": "synthetic",
+                "dtype": "f32 (fc and G products: fp16 hi/lo split of both operands on v_mfma_f32_16x16x32_f16 - the row-stationary conv kernel - and v_mfma_f32_32x32x16_f16, fp32 accumulate; the exact fp32 MFMA form is timed in other_workloads)", "data": "synthetic",
                 "config": {"workload": f"3dpf ({sampler.n_l} lig atoms, 139 residues, {sampler.n_a} pocket atoms), "
                                        f"{n_total} samples over {world} GPU(s) ({n_local} on rank 0) x 20-step schedule, score model "
                                        f"{args.cfg} (ns={kw['ns']} nv={kw['nv']} L={kw['num_conv_layers']}), "
@@ -665,10 +665,12 @@ def main(argv=None):
             if hasattr(sampler, "close"):
                 sampler.close()     # the main job's captured step goes back to the shared graph memory pool before the sub-records
 
-            def sub_job(cfg_, flex_, n_, conv_h2=True, conv_rows=True):   # a timed job + its instrumented pass
+            def sub_job(cfg_, flex_, n_, conv_h2=True, conv_rows=True, rows16=None):   # a timed job + its instrumented pass
                 m_, kw_ = build_model(cfg_, flex_, device)
                 m_.fork_front = model.fork_front
                 m_.conv_h2 = conv_h2
+                if rows16 is not None:
+                    m_.rows_mfma16 = rows16
                 from diffdock_pocket_amd import launch as launch_
                 rows_was = launch_.CONV_ROWS
                 launch_.CONV_ROWS = rows_was and conv_rows
@@ -703,6 +705,8 @@ def main(argv=None):
             # in the h2 form through the 32-edge kernel of round 4 (launch.CONV_ROWS = False): driver-timed beside the headline
             others["configs[1] exact fp32 MFMA form (model.conv_h2 = False), 40 samples, cfg2, rigid"] = sub_job("cfg2", False, 40, conv_h2=False)
             others["configs[1] fp16 hi/lo form through the 32-edge kernel of round 4 (launch.CONV_ROWS = False)"] = sub_job("cfg2", False, 40, conv_rows=False)
+            others["configs[1] through the row-stationary kernel of round 5 on v_mfma_f32_32x32x16_f16 (model.rows_mfma16 = False)"] = \
+                sub_job("cfg2", False, 40, rows16=False)
             others["configs[2] 3dpf flexible side chains, 40 samples, cfg2"] = sub_job("cfg2", True, 40)
             others["configs[0] 3dpf 4 samples, cfg1 (ns=16 nv=4 L=2), flexible side chains"] = sub_job("cfg1", True, 4)
             others["README small score model (README.md:82: ns=32 nv=6 L=5, atom_max_neighbors=12, tr_sigma_max=15), 40 samples, rigid receptor"] = \
@@ -725,6 +729,7 @@ def main(argv=None):
                 "unit": "poses/s (per GPU for the shard)",
                 "exact_fp32_mfma_form": pick("configs[1] exact fp32"),
                 "round4_32_edge_kernel": pick("configs[1] fp16 hi/lo form through the 32-edge"),
+                "round5_rows_kernel_32x32x16": pick("configs[1] through the row-stationary kernel of round 5"),
                 "configs2_flexible_side_chains": pick("configs[2]"),
                 "configs0_cfg1_4_samples": pick("configs[0]"),
                 "readme_small_model": pick("README small"),

@@ -39,12 +39,6 @@
 #define R16_ET 128
 #define R16_FS 36     // floats per feature row F[u * C + c][edge]
 #define R16_NP 3      // pieces per stream tile (one ring slot each)
-#ifndef R16_GK2
-#define R16_GK2 2     // k32 steps in the G ring of a scalar segment with two column tiles (8 fragments; 3 = 12 fragments spills 31 registers)
-#endif
-#ifndef R16_RT_SKIP
-#define R16_RT_SKIP 1 // a G run that lies inside one 16-row tile multiplies that row tile only
-#endif
 #define R16_SX ((float)DDP_ROWS_SX)
 #define R16_SW ((float)DDP_ROWS_SW)
 #define R16_SH ((float)DDP_ROWS_SH)
@@ -222,7 +216,6 @@ struct R16GSeq {
   float bias[NCT];       // Gb of the current run's columns
   unsigned m;            // runs not yet started (bit = first row)
   int run, nruns;
-  int a0;                // first row of the current run
   unsigned l_main[NCT], l_last[NCT], l_bias[NCT];
   int gc;
 };
@@ -232,7 +225,6 @@ __device__ __forceinline__ R16Stream r16_gseq_node(const R16GSeq<NCT>& G, int sr
 }
 template <int NCT>
 __device__ __forceinline__ void r16_gseq_next(R16GSeq<NCT>& G, int src_reg, f32x4 (&gacc)[4]) {
-  G.a0 = (G.m != 0u) ? __builtin_ctz(G.m) : 0;      // (the run that becomes the current one)
   G.m &= G.m - 1u;
   G.rsn = (G.m != 0u) ? r16_gseq_node(G, src_reg, __builtin_ctz(G.m)) : __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(G.base), 0, 0, 0x00020000);
 #pragma unroll
@@ -278,9 +270,11 @@ __device__ __forceinline__ void r16_gseq_init(R16GSeq<NCT>& G, f32x4 (&gh)[GK][N
   __builtin_amdgcn_sched_barrier(0);
   r16_gseq_next(G, src_reg, gacc);
 }
-// k32 step KS of the current run: the split products of the run's row tile(s) - RTM = 0 / 1: the run lies inside row tile 0 / 1 (a run of at
-// most 16 edges that does not straddle: half the matrix work), 2: both - against ring slot KS % GK, which then takes the fragments GK steps on
-template <int NS, int NCT, int GK, int KS, int RTM>
+// k32 step KS of the current run: the split products of both row tiles against ring slot KS % GK, which then takes the fragments GK steps on.
+// (Multiplying only the row tile a run lies in - a run of at most 16 edges that does not straddle: half the matrix work of its product - was
+// built and measured: three straight-line variants of the chain cost the 12-fragment ring its registers, and the step got 0.3 ms LONGER,
+// 15.75 - 15.88 against 15.47 - 15.50 ms; the runs are bound by their loads, not by their MFMAs.  profiles/r06_rows16_ab.txt)
+template <int NS, int NCT, int GK, int KS>
 __device__ __forceinline__ void r16_gseq_step(R16GSeq<NCT>& G, f32x4 (&gh)[GK][NCT], f32x4 (&gl)[GK][NCT], f32x4 (&gacc)[4], const h8 (&ah)[NS],
                                               const h8 (&al)[NS]) {
   constexpr int NS2 = NS / 2, q0 = KS + GK, kq = (q0 < NS2) ? q0 : q0 - NS2;
@@ -289,7 +283,7 @@ __device__ __forceinline__ void r16_gseq_step(R16GSeq<NCT>& G, f32x4 (&gh)[GK][N
   for (int ct = 0; ct < NCT; ++ct) {
     const h8 bh = __builtin_bit_cast(h8, gh[KS % GK][ct]), bl = __builtin_bit_cast(h8, gl[KS % GK][ct]);
 #pragma unroll
-    for (int rt = (RTM == 1 ? 1 : 0); rt < (RTM == 0 ? 1 : 2); ++rt) {
+    for (int rt = 0; rt < 2; ++rt) {
       f32x4 d = gacc[2 * rt + ct];
       d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[2 * KS + rt], bh, d, 0, 0, 0);
       d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[2 * KS + rt], bl, d, 0, 0, 0);
@@ -333,11 +327,11 @@ __device__ __forceinline__ void r16_gseq_finish(R16GSeq<NCT>& G, f32x4 (&gacc)[4
 }
 template <int NS, int C, int NCT>
 __device__ __forceinline__ void r16_g_runs(const ddp_conv_shape_t& S, const R16GPart& PA, const h8 (&ah)[NS], const h8 (&al)[NS], const R16Aux* aux,
-                                           unsigned rmask, int src_reg, int nvw, int lane, f32x16 (&res)[C]) {
+                                           unsigned rmask, int src_reg, int lane, f32x16 (&res)[C]) {
   // k32 steps in the ring: half a tile at NS = 12 (the whole tile at NS = 6) for the scalar segments - 12 fragments at two column tiles, like
   // ddp_conv_rows.hip -; a vector segment holds three accumulator sets, so its ring is 6 fragments at one column tile (n <= 16: the shapes
   // of nv <= 16) and one k32 step at two
-  constexpr int NS2 = NS / 2, GK = (C == 3) ? ((NCT == 2) ? 1 : ((NS2 % 3 == 0) ? 3 : 1)) : (NCT == 2 && NS2 % R16_GK2 == 0) ? R16_GK2 : ((NS2 % 3 == 0) ? 3 : 1);
+  constexpr int NS2 = NS / 2, GK = (C == 3 && NCT == 2) ? 1 : ((NS2 % 3 == 0) ? 3 : 1);
   const int n = lane & 15, g = lane >> 4;
   R16GSeq<NCT> G;
   f32x4 gh[GK][NCT], gl[GK][NCT], gacc[4];
@@ -346,26 +340,16 @@ __device__ __forceinline__ void r16_g_runs(const ddp_conv_shape_t& S, const R16G
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) mine[ct] = 16 * ct + n < PA.nmine;
   while (G.run < G.nruns) {
-    // rows of the current run: [a0, next run's first row) (the last run: up to the wave's last valid edge) - wave-uniform
-    const int nxt = (G.m != 0u) ? __builtin_ctz(G.m) : nvw;
-    const int rt_lo = G.a0 >> 4, rt_hi = (nxt - 1) >> 4;
-#define R16_GCHAIN(RTM)                                                                                    \
-    _Pragma("unroll") for (int ks = 0; ks < NS2; ++ks) {                                                   \
-      if (ks == 0) r16_gseq_step<NS, NCT, GK, 0, RTM>(G, gh, gl, gacc, ah, al);                            \
-      else if (ks == 1) r16_gseq_step<NS, NCT, GK, 1 % NS2, RTM>(G, gh, gl, gacc, ah, al);                 \
-      else if (ks == 2) r16_gseq_step<NS, NCT, GK, 2 % NS2, RTM>(G, gh, gl, gacc, ah, al);                 \
-      else if (ks == 3) r16_gseq_step<NS, NCT, GK, 3 % NS2, RTM>(G, gh, gl, gacc, ah, al);                 \
-      else if (ks == 4) r16_gseq_step<NS, NCT, GK, 4 % NS2, RTM>(G, gh, gl, gacc, ah, al);                 \
-      else r16_gseq_step<NS, NCT, GK, 5 % NS2, RTM>(G, gh, gl, gacc, ah, al);                              \
+#pragma unroll
+    for (int ks = 0; ks < NS2; ++ks) {
+      // (static k-steps: the chain is resolved at compile time)
+      if (ks == 0) r16_gseq_step<NS, NCT, GK, 0>(G, gh, gl, gacc, ah, al);
+      else if (ks == 1) r16_gseq_step<NS, NCT, GK, 1 % NS2>(G, gh, gl, gacc, ah, al);
+      else if (ks == 2) r16_gseq_step<NS, NCT, GK, 2 % NS2>(G, gh, gl, gacc, ah, al);
+      else if (ks == 3) r16_gseq_step<NS, NCT, GK, 3 % NS2>(G, gh, gl, gacc, ah, al);
+      else if (ks == 4) r16_gseq_step<NS, NCT, GK, 4 % NS2>(G, gh, gl, gacc, ah, al);
+      else r16_gseq_step<NS, NCT, GK, 5 % NS2>(G, gh, gl, gacc, ah, al);
     }
-    if (rt_lo != rt_hi || !R16_RT_SKIP) {
-      R16_GCHAIN(2)
-    } else if (rt_lo == 0) {
-      R16_GCHAIN(0)
-    } else {
-      R16_GCHAIN(1)
-    }
-#undef R16_GCHAIN
     r16_gseq_finish<C, NCT>(G, gacc, aux, g, mine, src_reg, res);
   }
 }
@@ -403,9 +387,9 @@ __device__ __forceinline__ int r16_segment(const R16Launch& RL, const ddp_block_
   if (B.g_slot >= 0 && rmask != 0u) {
     const R16GPart PA = r16_gpart_of(S, T, bi, part);
     if (PA.nmine > 16)
-      r16_g_runs<NS, C, 2>(S, PA, ah, al, aux, rmask, src_reg, nvw, lane, res);
+      r16_g_runs<NS, C, 2>(S, PA, ah, al, aux, rmask, src_reg, lane, res);
     else
-      r16_g_runs<NS, C, 1>(S, PA, ah, al, aux, rmask, src_reg, nvw, lane, res);
+      r16_g_runs<NS, C, 1>(S, PA, ah, al, aux, rmask, src_reg, lane, res);
   }
 
   // ---- the segment's stream tiles (vector-input features)

@@ -88,7 +88,9 @@ class ConvProfiler:
         self.events.append((e0, e1))
         self.tags.append(tag)
         self.h2.append(bool(h2))     # the launch ran the fp16 hi/lo split form of the fc products
-        self.kernel.append("ddp_conv_rows_kernel" if rows else "ddp_conv32_kernel" if spec.factorized else "ddp_conv_messages_kernel")
+        # (rows: 1 = ddp_conv_rows_kernel, the v_mfma_f32_32x32x16_f16 form; 2 = ddp_conv_rows16_kernel, the 16x16x32 form)
+        self.kernel.append(("ddp_conv_rows16_kernel" if int(rows) == 2 else "ddp_conv_rows_kernel") if rows else
+                           "ddp_conv32_kernel" if spec.factorized else "ddp_conv_messages_kernel")
         self.specs.append((spec, flops_spec or spec))
         self.counts.append(tasks_counts)
         self.node_bytes.append(node_bytes)
@@ -114,7 +116,7 @@ class ConvProfiler:
             self.useful = [s.useful_flops_per_edge() * n for (s, fs), n in zip(self.specs, ne)]
             # product FLOPs that run as fp16 hi/lo split products: the two fc products; ddp_conv_rows also runs the per-edge G contraction
             # (h @ G[src]: 2 hid g_cols per edge) as tile products of the same form
-            self.fc = [(s.fc_flops_per_edge() + (2 * s.hid * sum(s.g_cols) if k == "ddp_conv_rows_kernel" else 0)) * n
+            self.fc = [(s.fc_flops_per_edge() + (2 * s.hid * sum(s.g_cols) if k.startswith("ddp_conv_rows") else 0)) * n
                        for (s, fs), n, k in zip(self.specs, ne, self.kernel)]
             self.boundary = [n * (4.0 * fs.f_in + 32.0) + nb for (s, fs), n, nb in zip(self.specs, ne, self.node_bytes)]
             self._resolved = True
@@ -293,7 +295,8 @@ def launch_convs(spec: P.ConvSpec, tasks: List[L.ConvTask], flops_spec: Optional
     if prof is not None:
         e1.record()
         h2 = P.h2_steps(spec) > 0 and all(t.w1h and t.w2h for t in tasks)
-        prof.record_conv(e0, e1, spec, flops_spec, [t._count for t in tasks], node_bytes, tag, h2, rows=rows)
+        prof.record_conv(e0, e1, spec, flops_spec, [t._count for t in tasks], node_bytes, tag, h2,
+                         rows=(2 if all(t.rows_form == 1 for t in tasks) else 1) if rows else 0)
 
 
 def launch_reduce(x, ldx, n_nodes, d_out, sources, accumulate=True, n_rep=1, rep_stride=0):

@@ -150,7 +150,7 @@ class _PackedConv:
 
 
 G_PLANES3_DEFAULT = "0"      # model.g_planes3 unless DDP_G_PLANES3 says otherwise
-ROWS_MFMA16_DEFAULT = "0"    # model.rows_mfma16 unless DDP_ROWS_MFMA16 says otherwise
+ROWS_MFMA16_DEFAULT = "1"    # model.rows_mfma16 unless DDP_ROWS_MFMA16 says otherwise (round 6: 15.5 against 16.1 ms per 40-sample step)
 
 
 class TensorProductConvLayer(nn.Module):

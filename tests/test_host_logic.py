@@ -614,3 +614,64 @@ def test_g_plane_forms_host_side_against_the_decoder(fmt):
         assert bool(((V - wantV).abs() <= tolV + 1e-6 * wantV.abs()).all()), (fmt, slot, float((V - wantV).abs().max()))
         # (the Gb columns of the padded parts only: the others are zero on both sides)
         assert bool(((Gb - wantB).abs() <= 1e-6 * wantB.abs() + 1e-9).all()), (fmt, slot)
+
+
+def test_rows_kernel_operand_images_of_the_16x16x32_form():
+    """ddp_conv_task_t::rows_form = 1 (csrc/ddp_conv_rows16.hip, include/ddp_hip.h): the weight stream in the operand images of
+    v_mfma_f32_16x16x32_f16 - per 32-column tile 2 NS fragments [k32 step s][column tile ct][plane] of [k group g][column n][8 halves] =
+    plane(256 w)[column 16 ct + n][k = 32 s + 8 g + i] - with the k of the fc.3 tiles in NATURAL order, and fc.0's output columns placed
+    inside every 32-column tile at DDP_ROWS16_POS (h column 32 t + 8 g + i at position 16 (i / 4) + 4 g + i % 4, bias words with them): the
+    transposed fc1 product then leaves a lane's accumulator registers as its A fragment of the later products in natural k order.  The
+    stage-A right-hand sides keep form 0's columns with the k's of every 8-group un-permuted."""
+    from diffdock_pocket_amd import packing as P
+    g = torch.Generator().manual_seed(2)
+    ns, nv, layer = 60, 10, 3
+    spec_g = P.faster_tp_spec(P.irreps_muls(ns, nv, layer), P.irreps_muls(ns, nv, layer + 1), 3 * ns, factorized=True)
+    hid = 3 * ns
+    w1, b1 = torch.randn(hid, hid, generator=g) * 0.07, torch.randn(hid, generator=g) * 0.1
+    w2, b2 = torch.randn(spec_g.weight_numel, hid, generator=g) * 0.07, torch.randn(spec_g.weight_numel, generator=g) * 0.1
+    wsh, bsp = P.rows_stream(spec_g, w1, b1, w2, b2, form=1)
+    wsh0, bsp0 = P.rows_stream(spec_g, w1, b1, w2, b2, form=0)
+    assert wsh.shape == wsh0.shape and bsp.shape == bsp0.shape
+    nts = bsp.shape[0]
+    tiles = wsh.reshape(nts, 6, 2, 2, 4, 16, 8).float()                     # [tile, s, ct, plane, g, n, i]
+    rec = (tiles[:, :, :, 0] + tiles[:, :, :, 1]) / P.ROWS_SW               # [tile, s, ct, g, n, i]
+    rec = rec.permute(0, 2, 4, 1, 3, 5).reshape(nts, 32, 192)               # [tile, column 16 ct + n, k = 32 s + 8 g + i]
+    pos = P.rows16_pos(192)
+    assert sorted(pos.tolist()) == list(range(192)) and int(pos[8 * 1 + 5]) == 16 * 1 + 4 * 1 + 1      # (g = 1, i = 5 -> position 21)
+    # fc.0: position pos[c] of the stream holds h column c (natural k = edge_attr_ column)
+    W1 = torch.zeros(192, 192)
+    W1[:hid, :hid] = w1
+    got1 = rec[:spec_g.nct1].reshape(192, 192)
+    assert float((got1[pos] - W1).abs().max()) < 2.0 ** -20
+    bias1 = torch.zeros(192)
+    bias1[:hid] = b1 * (P.ROWS_SW * P.ROWS_SX)
+    assert torch.allclose(bsp[:spec_g.nct1].reshape(-1)[pos], bias1)
+    # fc.3: the same tiles as form 0 in the same stream order, natural k: form 0's tile is this one with its k permuted by rows_kperm
+    t0 = wsh0.reshape(nts, 12, 2, 2, 32, 8).float()                          # [tile, ks, plane, hh, j, i]
+    rec0 = ((t0[:, :, 0] + t0[:, :, 1]).permute(0, 3, 1, 2, 4).reshape(nts, 32, 192)) / P.ROWS_SW
+    kp = P.rows_kperm(12)
+    nat0 = torch.zeros_like(rec0)
+    nat0[:, :, kp] = rec0                                                    # slot -> natural k
+    assert float((rec[spec_g.nct1:] - nat0[spec_g.nct1:]).abs().max()) < 2.0 ** -20
+    assert torch.equal(bsp[spec_g.nct1:], bsp0[spec_g.nct1:])
+    # stage A's right-hand sides: identity k order inside the groups
+    wg1, _, widths1 = P.factor_weights_gh(spec_g, w2, b2, form=1)
+    wg0, _, widths0 = P.factor_weights_gh(spec_g, w2, b2, form=0)
+    assert widths1 == widths0
+    n8 = (hid + 7) // 8
+    for slot in (0, 1):
+        if wg1[slot] is None:
+            continue
+        gcp = sum(widths1[slot])
+        a = wg1[slot][:, :8 * n8 * gcp]
+        b = wg0[slot][:, :8 * n8 * gcp]
+        assert torch.equal(wg1[slot][:, 8 * n8 * gcp:], wg0[slot][:, 8 * n8 * gcp:])     # Gb columns: the same
+        cum = 0
+        for w in widths1[slot]:
+            A = a[:, 8 * n8 * cum:8 * n8 * (cum + w)].reshape(-1, n8, w, 8).permute(0, 2, 1, 3).reshape(-1, w, 8 * n8)      # [u, column, k slot]
+            B = b[:, 8 * n8 * cum:8 * n8 * (cum + w)].reshape(-1, n8, w, 8).permute(0, 2, 1, 3).reshape(-1, w, 8 * n8)
+            nat = torch.zeros(A.shape[0], w, 192)
+            nat[:, :, kp[:8 * n8]] = B                                        # form 0: slot -> natural k
+            assert torch.equal(A, nat[:, :, :8 * n8])
+            cum += w
