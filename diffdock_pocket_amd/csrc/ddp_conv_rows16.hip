@@ -354,135 +354,12 @@ __device__ __forceinline__ void r16_g_runs(const ddp_conv_shape_t& S, const R16G
   }
 }
 
-// The G runs of a PAIR of vector blocks of one width n <= 16 with a single G part each (1o and 1e at nv = 10; ddp_conv_rows.hip's merged
-// pair): ONE pass over the runs for both - column tile 0 = block A's columns (its G array), column tile 1 = block B's (another array, the
-// same source node) - instead of two latency-bound passes.  Returns the selected products tg[2 rt + ct] (+ Gb) BEFORE the harmonics: block
-// A applies them at once, block B's are parked in the wave's private area until its own segment.
-struct R16GPair {
-  R16Stream rs[2], rsn[2];
-  const char* base[2];
-  size_t gldb[2];
-  float bias[2];
-  unsigned m;
-  int run, nruns;
-  unsigned l_main[2], l_last[2], l_bias[2];
-  int gc[2];
-};
-__device__ __forceinline__ R16Stream r16_gpair_node(const R16GPair& G, int ct, int src_reg, int row) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(G.base[ct] + (size_t)__builtin_amdgcn_readlane(src_reg, row) * G.gldb[ct]), 0, (int)G.gldb[ct],
-                                           0x00020000);
-}
-__device__ __forceinline__ void r16_gpair_next(R16GPair& G, int src_reg, f32x4 (&gacc)[4]) {
-  G.m &= G.m - 1u;
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    G.rsn[ct] = (G.m != 0u) ? r16_gpair_node(G, ct, src_reg, __builtin_ctz(G.m)) : __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(G.base[ct]), 0, 0, 0x00020000);
-    G.bias[ct] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(G.rs[ct], G.l_bias[ct], 0, 0));
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) gacc[i] = r16_splat4(0.f);
-}
-template <int NS2>
-__device__ __forceinline__ f32x4 r16_gpair_frag(const R16GPair& G, R16Stream R, int kq, int ct, int plane) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(R, ((kq == NS2 - 1) ? G.l_last[ct] : G.l_main[ct]) + plane * 16,
-                                                                          (kq == NS2 - 1) ? 0 : 4 * kq * G.gc[ct] * 32, 0));
-}
-template <int NS, int GK, int KS>
-__device__ __forceinline__ void r16_gpair_step(R16GPair& G, f32x4 (&gh)[GK][2], f32x4 (&gl)[GK][2], f32x4 (&gacc)[4], const h8 (&ah)[NS], const h8 (&al)[NS]) {
-  constexpr int NS2 = NS / 2, q0 = KS + GK, kq = (q0 < NS2) ? q0 : q0 - NS2;
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    const h8 bh = __builtin_bit_cast(h8, gh[KS % GK][ct]), bl = __builtin_bit_cast(h8, gl[KS % GK][ct]);
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      f32x4 d = gacc[2 * rt + ct];
-      d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[2 * KS + rt], bh, d, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[2 * KS + rt], bl, d, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[2 * KS + rt], bh, d, 0, 0, 0);
-      gacc[2 * rt + ct] = d;
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    const R16Stream srcb = (q0 < NS2) ? G.rs[ct] : G.rsn[ct];
-    gh[KS % GK][ct] = r16_gpair_frag<NS2>(G, srcb, kq, ct, 0);
-    gl[KS % GK][ct] = r16_gpair_frag<NS2>(G, srcb, kq, ct, 1);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-}
-template <int NS>
-__device__ __forceinline__ void r16_g_runs_pair(const ddp_conv_shape_t& S, const R16GPart& PA, const R16GPart& PB, const h8 (&ah)[NS], const h8 (&al)[NS],
-                                                const R16Aux* aux, unsigned rmask, int src_reg, int lane, f32x4 (&tg)[4]) {
-  constexpr int NS2 = NS / 2, GK = (NS2 % 3 == 0) ? 3 : 1;
-  const int n = lane & 15, g = lane >> 4;
-  const int n8 = (S.hid + 7) >> 3;
-  const int k8l = min(4 * (NS2 - 1) + g, n8 - 1);
-  R16GPair G;
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    const R16GPart& P = ct ? PB : PA;
-    const int cl = min(n, P.nmine - 1);
-    G.gc[ct] = P.wp;
-    G.l_main[ct] = (unsigned)(g * P.wp + cl) * 32u;
-    G.l_last[ct] = (unsigned)(k8l * P.wp + cl) * 32u;
-    G.l_bias[ct] = (unsigned)(P.bias_off + 4 * cl);
-    G.base[ct] = P.base;
-    G.gldb[ct] = P.gldb;
-  }
-  G.m = rmask;
-  G.nruns = __builtin_amdgcn_readfirstlane(__popc(rmask));
-  G.run = 0;
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) G.rs[ct] = r16_gpair_node(G, ct, src_reg, __builtin_ctz(rmask));
-  f32x4 gh[GK][2], gl[GK][2], gacc[4];
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int k = 0; k < GK; ++k)
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      gh[k][ct] = r16_gpair_frag<NS2>(G, G.rs[ct], k, ct, 0);
-      gl[k][ct] = r16_gpair_frag<NS2>(G, G.rs[ct], k, ct, 1);
-    }
-  __builtin_amdgcn_sched_barrier(0);
-  r16_gpair_next(G, src_reg, gacc);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) tg[i] = r16_splat4(0.f);
-  const bool mine[2] = {n < PA.nmine, n < PB.nmine};
-  while (G.run < G.nruns) {
-#pragma unroll
-    for (int ks = 0; ks < NS2; ++ks) {
-      if (ks == 0) r16_gpair_step<NS, GK, 0>(G, gh, gl, gacc, ah, al);
-      else if (ks == 1) r16_gpair_step<NS, GK, 1 % NS2>(G, gh, gl, gacc, ah, al);
-      else if (ks == 2) r16_gpair_step<NS, GK, 2 % NS2>(G, gh, gl, gacc, ah, al);
-      else if (ks == 3) r16_gpair_step<NS, GK, 3 % NS2>(G, gh, gl, gacc, ah, al);
-      else if (ks == 4) r16_gpair_step<NS, GK, 4 % NS2>(G, gh, gl, gacc, ah, al);
-      else r16_gpair_step<NS, GK, 5 % NS2>(G, gh, gl, gacc, ah, al);
-    }
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      const i32x4 id = *reinterpret_cast<const i32x4*>(&aux->rid[16 * rt + 4 * g]);
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const int sel = mine[ct] ? G.run : -2;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) tg[2 * rt + ct][j] = (id[j] == sel) ? gacc[2 * rt + ct][j] + G.bias[ct] : tg[2 * rt + ct][j];
-      }
-    }
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) G.rs[ct] = G.rsn[ct];
-    ++G.run;
-    r16_gpair_next(G, src_reg, gacc);
-  }
-}
-
 // One segment = one 32-column part of one weight block's output columns: the factorised features (G runs), then the segment's stream
 // tiles (vector-input features), then the message columns
 template <int NS, int C>
 __device__ __forceinline__ int r16_segment(const R16Launch& RL, const ddp_block_t& B, int bi, int part, const ddp_conv_task_t& T, const h8 (&ah)[NS],
                                            const h8 (&al)[NS], f32x4* ring, const float* lbias, int t, const float* F, const R16Aux* aux, unsigned rmask,
-                                           int src_reg, int nvw, int wave, int lane, int gmode) {
+                                           int src_reg, int nvw, int wave, int lane) {
   const ddp_conv_shape_t& S = RL.L.shape;
   const int n = lane & 15, g = lane >> 4;
   const R16Stream wsh = r16_stream_of(T.wsh, RL.nts, 2 * NS * 1024);
@@ -506,33 +383,8 @@ __device__ __forceinline__ int r16_segment(const R16Launch& RL, const ddp_block_
 #pragma unroll
   for (int c = 0; c < C; ++c) res[c] = splat16(0.f);
 
-  // ---- factorised features.  gmode 1: this vector block and the next one run their G tiles as a pair (block B's selected products wait
-  // behind the wave's per-edge tables); gmode 2: this block's products were computed by the block before it
-  if (C == 3 && gmode != 0 && B.g_slot >= 0 && rmask != 0u) {
-    float* stash = reinterpret_cast<float*>(const_cast<R16Aux*>(aux) + 1);      // [rt][lane][4]
-    f32x4 tga[2];
-    if (gmode == 1) {
-      const R16GPart PA = r16_gpart_of(S, T, bi, part), PB = r16_gpart_of(S, T, bi + 1, 0);
-      f32x4 tg[4];
-      r16_g_runs_pair<NS>(S, PA, PB, ah, al, aux, rmask, src_reg, lane, tg);
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        tga[rt] = tg[2 * rt];
-        *reinterpret_cast<f32x4*>(stash + (rt * 64 + lane) * 4) = tg[2 * rt + 1];
-      }
-    } else {
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) tga[rt] = *reinterpret_cast<const f32x4*>(stash + (rt * 64 + lane) * 4);
-    }
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const f32x4 f = *reinterpret_cast<const f32x4*>(&aux->shT[(C == 1) ? 0 : 1 + c][16 * rt + 4 * g]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) res[c][4 * (2 * rt) + j] = f[j] * tga[rt][j];
-      }
-  } else if (B.g_slot >= 0 && rmask != 0u) {
+  // ---- factorised features
+  if (B.g_slot >= 0 && rmask != 0u) {
     const R16GPart PA = r16_gpart_of(S, T, bi, part);
     if (PA.nmine > 16)
       r16_g_runs<NS, C, 2>(S, PA, ah, al, aux, rmask, src_reg, lane, res);
@@ -793,20 +645,10 @@ __global__ __launch_bounds__(R16_NT, 2) void ddp_conv_rows16_kernel(const R16Lau
     }
     const int nparts = (B.n + 31) >> 5;
     for (int part = 0; part < nparts; ++part) {
-      // two neighbouring vector blocks of one width n <= 16 with a single G part each (1o, 1e): their G runs as one pass (r16_g_runs_pair)
-      int gmode = 0;
-      if (B.C == 3 && B.g_slot >= 0 && nparts == 1 && B.n <= 16) {
-        const bool with_next = bi + 1 < S.nblocks && S.blk[bi + 1].C == 3 && S.blk[bi + 1].g_slot >= 0 && S.blk[bi + 1].n == B.n;
-        const bool with_prev = bi > 0 && S.blk[bi - 1].C == 3 && S.blk[bi - 1].g_slot >= 0 && S.blk[bi - 1].n == B.n;
-        // (pairs are (1, 2): a block that is the second of a pair is never the first of another)
-        const bool prev_is_second = with_prev && bi > 1 && S.blk[bi - 2].C == 3 && S.blk[bi - 2].g_slot >= 0 && S.blk[bi - 2].n == B.n;
-        if (with_prev && !prev_is_second) gmode = 2;
-        else if (with_next) gmode = 1;
-      }
       if (B.C == 1)
-        t = r16_segment<NS, 1>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane, 0);
+        t = r16_segment<NS, 1>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane);
       else
-        t = r16_segment<NS, 3>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane, gmode);
+        t = r16_segment<NS, 3>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane);
     }
   }
 }
@@ -846,7 +688,7 @@ int ddp_conv_rows16_launch(const ddp_conv_shape_t* shape, const ddp_conv_task_t*
   int fbytes = frows * R16_FS * 4;
   fbytes = (fbytes + 127) / 128 * 128;
   RL.aux_off = fbytes;
-  int priv = fbytes + (int)sizeof(R16Aux) + 2048;      // (+ the parked G products of a pair of vector blocks: 2 row tiles x 64 lanes x 16 bytes)
+  int priv = fbytes + (int)sizeof(R16Aux);
   if (priv < NS * 1024) priv = NS * 1024;          // the lo plane of edge_attr_ during fc1
   priv = (priv + 127) / 128 * 128;
   RL.priv_bytes = priv;
