@@ -552,8 +552,8 @@ class TensorProductScoreModel(nn.Module):
         self.last_stats: Dict[str, float] = {}
         # plane form of the factorised convs' G (property g_planes3); DDP_G_PLANES3 = 0 / 1 in the environment sets the default of every model
         # built in the process (the parity suites under the other form: profiles/r06_g3byte_parity.txt)
-        self.g_planes3 = os.environ.get("DDP_G_PLANES3", G_PLANES3_DEFAULT) == "1"
         self.rows_mfma16 = os.environ.get("DDP_ROWS_MFMA16", ROWS_MFMA16_DEFAULT) == "1"
+        self.g_planes3 = os.environ.get("DDP_G_PLANES3", G_PLANES3_DEFAULT) == "1"      # (switches rows_mfma16 off: see the property)
 
     # ---- checkpoint compatibility -------------------------------------------------------------
     _IGNORED_PREFIXES = ("final_tp_tor.", "final_tp_sc_tor.", "tor_bond_conv.tp.", "sc_tor_bond_conv.tp.")
@@ -709,13 +709,17 @@ class TensorProductScoreModel(nn.Module):
         """Plane form of the factorised convs' G (ddp_conv_task_t::gh_fmt).  False: fp16 hi + fp16 lo words, 4 bytes per value, 22 significant
         bits.  True: fp16 hi + OCP e4m3 lo bytes (ddp_stage_a_gh3), 3 bytes per value, 15 - 16 significant bits: a quarter less of the step's
         G round trip through HBM (written by stage A, read once by ddp_conv_rows); |32 G| must stay below 2048 (range flag -> the fp32
-        form, like every other value the split forms cannot hold).  Changing it drops the packed weights and captured steps."""
+        form, like every other value the split forms cannot hold).  Changing it drops the packed weights and captured steps; switching it ON
+        also switches rows_mfma16 off (only the round-5 kernel reads this form).  Measured in round 6: FAILS the 1e-4 bar
+        (profiles/r06_g3byte_parity.txt) - for experiments only."""
         return bool(self.__dict__.get("_g_planes3", False))
 
     @g_planes3.setter
     def g_planes3(self, value):
         value = bool(value)
         if value != self.g_planes3:
+            if value and self.rows_mfma16:
+                self.rows_mfma16 = False      # (the e4m3 form is read by the round-5 kernel only: csrc/ddp_conv_rows.hip)
             self.__dict__["_g_planes3"] = value
             self._stage_a_stacks = {}
             for m_ in self.modules():

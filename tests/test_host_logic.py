@@ -675,3 +675,35 @@ def test_rows_kernel_operand_images_of_the_16x16x32_form():
             nat[:, :, kp[:8 * n8]] = B                                        # form 0: slot -> natural k
             assert torch.equal(A, nat[:, :, :8 * n8])
             cum += w
+
+
+def test_rows_kernel_options_are_consistent(monkeypatch):
+    """model.rows_mfma16 (the row-stationary conv kernel on v_mfma_f32_16x16x32_f16: the default) and model.g_planes3 (G in three bytes: only
+    the round-5 kernel reads it): switching the second on switches the first off, the first refuses to come on beside the second, both
+    setters drop the packed weights (epoch) and tell the conv layers; the environment sets the defaults."""
+    from diffdock_pocket_amd.score_model import TensorProductConvLayer, TensorProductScoreModel
+    from oracle.cases import CASES
+    case = CASES["cfg2_small"]
+    kw = dict(case.model_kwargs())
+    kw.update(case.ctor_extras())
+    kw["device"] = torch.device("cpu")
+    monkeypatch.delenv("DDP_ROWS_MFMA16", raising=False)
+    monkeypatch.delenv("DDP_G_PLANES3", raising=False)
+    m = TensorProductScoreModel(**kw)
+    convs = [c for c in m.modules() if isinstance(c, TensorProductConvLayer)]
+    assert m.rows_mfma16 and not m.g_planes3 and all(getattr(c, "rows_form", 0) == 1 and getattr(c, "gh_fmt", 0) == 0 for c in convs)
+    e0 = m.__dict__.get("_packed_epoch", 0)
+    m.g_planes3 = True
+    assert m.g_planes3 and not m.rows_mfma16 and all(c.rows_form == 0 and c.gh_fmt == 1 for c in convs)
+    assert m.__dict__["_packed_epoch"] > e0
+    with pytest.raises(NotImplementedError):
+        m.rows_mfma16 = True
+    m.g_planes3 = False
+    m.rows_mfma16 = True
+    assert all(c.rows_form == 1 and c.gh_fmt == 0 for c in convs)
+    monkeypatch.setenv("DDP_ROWS_MFMA16", "0")
+    assert not TensorProductScoreModel(**kw).rows_mfma16
+    monkeypatch.setenv("DDP_G_PLANES3", "1")
+    monkeypatch.setenv("DDP_ROWS_MFMA16", "1")
+    m2 = TensorProductScoreModel(**kw)
+    assert m2.g_planes3 and not m2.rows_mfma16
