@@ -632,7 +632,10 @@ def test_forward_is_deterministic():
 
 @pytest.mark.parametrize("ns,nv,layer,E,N", [(16, 4, 0, 1, 3), (16, 4, 1, 63, 10), (16, 4, 2, 64, 10), (24, 6, 3, 65, 7),
                                               (60, 10, 3, 200, 23), (60, 10, 0, 129, 5), (32, 6, 3, 500, 40),
-                                              (64, 32, 3, 70, 9)])
+                                              (64, 32, 3, 70, 9),
+                                              # vector blocks wider than one 16-column tile of the row-stationary kernel (nv > 16): two column tiles in
+                                              # their G runs, layer 0 without and layer 1 with stream tiles (24 features: the general feature path)
+                                              (60, 20, 0, 150, 9), (32, 24, 1, 170, 11)])
 @pytest.mark.parametrize("factorized", [False, True])
 def test_single_conv_layer(ns, nv, layer, E, N, factorized):
     """TensorProductConvLayer.forward with the reference call signature (models/score_model.py:108) on ragged
