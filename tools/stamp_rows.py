@@ -23,6 +23,7 @@ from diffdock_pocket_amd.synthetic import make_3dpf_complex  # noqa: E402
 dev = torch.device("cuda:0")
 model, kw = bench.build_model("cfg2", False, dev)
 model.overlap_direct_conv = False
+model.rows_mfma16 = False      # (the stamps sit in ddp_conv_rows.hip, the round-5 kernel on v_mfma_f32_32x32x16_f16; the 16x16x32 kernel has none)
 g = make_3dpf_complex(seed=0, flexible_sidechains=False)
 smp = Sampler(model, g, 40, dev, SamplerConfig(flexible_sidechains=False, hip_graph=False), seed=0)
 smp.randomize()
