@@ -24,6 +24,8 @@ from diffdock_pocket_amd.score_model import TensorProductScoreModel  # noqa: E40
 from diffdock_pocket_amd.synthetic import make_3dpf_complex  # noqa: E402
 
 TOL = 1e-4
+# --forms 0 : only the shipped plane form (e.g. under a variant library through DDP_HIP_LIB: tools/jobs/r06_j15.sh); default both
+FORMS = tuple(int(v) for v in (sys.argv[sys.argv.index("--forms") + 1] if "--forms" in sys.argv else "0,1").split(","))
 
 
 def main():
@@ -45,7 +47,7 @@ def main():
         if case.confidence_mode:
             want, keys = (want,), ("confidence",)
         row = []
-        for fmt in (0, 1):
+        for fmt in FORMS:
             model.g_planes3 = bool(fmt)
             got = model(batch.to(dev))
             torch.cuda.synchronize()
@@ -56,9 +58,9 @@ def main():
             wmax = max(errs.values())      # (of the last form run: form 1)
             row.append(" ".join(f"{k} {v:.2e}" for k, v in errs.items()))
         flag = "  <-- above 1e-4" if wmax >= TOL else ""
-        print(f"{name:18s} form 0: {row[0]:58s} | form 1: {row[1]}{flag}")
-    print(f"worst over the cases: form 0 {worst[0]:.2e} ({TOL / max(worst[0], 1e-30):.1f} x inside 1e-4), form 1 {worst[1]:.2e} "
-          f"({'%.2f x OUTSIDE' % (worst[1] / TOL) if worst[1] >= TOL else '%.1f x inside' % (TOL / worst[1])} 1e-4)")
+        print(f"{name:18s} " + " | ".join(f"form {f}: {r:58s}" for f, r in zip(FORMS, row)) + flag)
+    print("worst over the cases: " + ", ".join(
+        f"form {f} {worst[f]:.2e} ({'%.2f x OUTSIDE' % (worst[f] / TOL) if worst[f] >= TOL else '%.1f x inside' % (TOL / max(worst[f], 1e-30))} 1e-4)" for f in FORMS))
 
     model, kw = bench.build_model("cfg2", False, dev)
     ocfg = OracleConfig(ns=kw["ns"], nv=kw["nv"], num_conv_layers=kw["num_conv_layers"], sigma_embed_dim=kw["sigma_embed_dim"],
@@ -68,7 +70,7 @@ def main():
     sched = get_t_schedule(20)
     # ---- the cfg2 job end to end: 2 samples x 20 steps against the oracle-driven CPU sampler
     print("# cfg2 job, 2 samples x 20 steps (rigid), HIP sampler against the oracle-driven CPU sampler: max |ligand pose diff| (A) per step; bound of the test 2e-3")
-    for fmt in (0, 1):
+    for fmt in FORMS:
         model, kw = bench.build_model("cfg2", False, dev)
         model.g_planes3 = bool(fmt)
         oracle = OracleScoreModel(ocfg, {k: v.detach().cpu() for k, v in model.state_dict().items()})
