@@ -291,9 +291,9 @@ struct RowsGPart {
   int wp, nmine, bias_off;   // padded width, columns, byte offset of Gb[column 0] (plane form 1: of the Gb region) from `base`
   int cumw;              // padded columns of the slot in front of the part
 };
-// Plane form 1 of a G array (ddp_conv_task_t::gh_fmt = 1, round 6: "G3"): a part's tile is [k8][wp columns] 16-byte hi pieces (8 fp16 words),
-// then [k8][wp columns] 8-byte lo pieces (8 OCP e4m3 bytes of (V - hi) * DDP_GH3_LO_SCALE) - 24 bytes per 8 values instead of 32; Gb per
-// padded column c of the slot sits behind the tiles at 32 (c / 6) + 4 (c % 6) bytes (stage A stores 6 fp32 values per 8-column group).
+// Plane form 1 of a G array (ddp_conv_task_t::gh_fmt = 1, round 6: "G3"; ABI 17): the unit (k8, c) of a part's tile is 24 bytes - 8 fp16 hi
+// words (V truncated), then 8 continuation bytes (19 significant bits; include/ddp_hip.h) - instead of 32; Gb per padded column c of the
+// slot sits behind the units of all parts in 24-byte groups of six fp32: 24 (c / 6) + 4 (c % 6) bytes.
 template <int GF>
 __device__ __forceinline__ RowsGPart rows_gpart_of(const ddp_conv_shape_t& S, const ddp_conv_task_t& T, int bi, int part) {
   RowsGPart P;
@@ -327,12 +327,12 @@ __device__ __forceinline__ RowsGLane<GF> rows_glane(const RowsGPart& P, int n8, 
   const int gc = P.wp;
   const int k8l = min(2 * (NS - 1) + hh, n8 - 1);
   if constexpr (GF == 1) {
-    o.h_main = (unsigned)(hh * gc + cl) * 16u;
-    o.h_last = (unsigned)(k8l * gc + cl) * 16u;
-    o.l_main = (unsigned)(n8 * gc) * 16u + (unsigned)(hh * gc + cl) * 8u;
-    o.l_last = (unsigned)(n8 * gc) * 16u + (unsigned)(k8l * gc + cl) * 8u;
+    o.h_main = (unsigned)(hh * gc + cl) * 24u;
+    o.h_last = (unsigned)(k8l * gc + cl) * 24u;
+    o.l_main = o.h_main + 16u;
+    o.l_last = o.h_last + 16u;
     const int c = P.cumw + cl;
-    o.bias = (unsigned)(P.bias_off + 32 * (c / 6) + 4 * (c % 6));
+    o.bias = (unsigned)(P.bias_off + 24 * (c / 6) + 4 * (c % 6));
   } else {
     o.h_main = (unsigned)(2 * hh * gc + 2 * cl) * 16u;
     o.h_last = (unsigned)(2 * k8l * gc + 2 * cl) * 16u;
@@ -345,27 +345,35 @@ __device__ __forceinline__ RowsGLane<GF> rows_glane(const RowsGPart& P, int n8, 
 // uniform byte offset of k-step kq's fragments inside a part's tile (the last k-step is addressed by the lane offsets alone)
 template <int GF>
 __device__ __forceinline__ constexpr unsigned rows_gfrag_hi(int kq, int NS, int gc) {
-  return (kq == NS - 1) ? 0u : (unsigned)((GF == 1 ? 2 : 4) * kq * gc) * 16u;
+  return (kq == NS - 1) ? 0u : (GF == 1 ? (unsigned)(2 * kq * gc) * 24u : (unsigned)(4 * kq * gc) * 16u);
 }
 template <int GF>
 __device__ __forceinline__ constexpr unsigned rows_gfrag_lo(int kq, int NS, int gc) {
-  return (kq == NS - 1) ? 0u : (GF == 1 ? (unsigned)(2 * kq * gc) * 8u : (unsigned)(4 * kq * gc) * 16u);
+  return (kq == NS - 1) ? 0u : (GF == 1 ? (unsigned)(2 * kq * gc) * 24u : (unsigned)(4 * kq * gc) * 16u);
 }
-// the lo plane of a fragment as the B operand: plane form 0 holds the 8 fp16 words, plane form 1 eight e4m3 bytes at DDP_GH3_LO_SCALE
+// the lo plane of a fragment as the B operand: plane form 0 holds the 8 fp16 words, plane form 1 eight continuation bytes - lo = sign(hi)
+// 2^E(hi) u8 / 2^18: the byte in the mantissa of 2^-8 (0x1C00 | u8), minus 2^-8, times the hi word's sign-and-exponent bits; four packed
+// instructions per pair of values (csrc/ddp_conv_rows16.hip, r16_lo_of: the same)
 typedef float f32x2r __attribute__((ext_vector_type(2)));
 template <int GF>
 struct RowsLoT { typedef f32x4 type; };
 template <>
 struct RowsLoT<1> { typedef f32x2r type; };
 template <int GF>
-__device__ __forceinline__ h8 rows_lo_operand(const typename RowsLoT<GF>::type v) {
+__device__ __forceinline__ h8 rows_lo_operand(const typename RowsLoT<GF>::type v, const f32x4 hi) {
   if constexpr (GF == 1) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    const unsigned u0 = __builtin_bit_cast(unsigned, v[0]), u1 = __builtin_bit_cast(unsigned, v[1]);
-    constexpr float inv = 1.f / (float)DDP_GH3_LO_SCALE;
-    const h2 a = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(u0, inv, false), b = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(u0, inv, true);
-    const h2 c = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(u1, inv, false), d = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(u1, inv, true);
-    return h8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+    typedef unsigned u32x4r __attribute__((ext_vector_type(4)));
+    const u32x4r hw = __builtin_bit_cast(u32x4r, hi);
+    const h2 c = {(_Float16)0.00390625f, (_Float16)0.00390625f};
+    u32x4r out;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned x = __builtin_amdgcn_perm(0x1c1c1c1cu, __builtin_bit_cast(unsigned, v[i >> 1]), (i & 1) ? 0x07030602u : 0x05010400u);
+      const h2 y = __builtin_bit_cast(h2, x) - c;
+      out[i] = __builtin_bit_cast(unsigned, y * __builtin_bit_cast(h2, hw[i] & 0xfc00fc00u));
+    }
+    return __builtin_bit_cast(h8, out);
   } else {
     return __builtin_bit_cast(h8, v);
   }
@@ -414,7 +422,7 @@ __device__ __forceinline__ f32x16 rows_g_runs(const ddp_conv_shape_t& S, const R
     f32x16 acc = splat16(bias);
 #pragma unroll
     for (int ks = 0; ks < NS; ++ks) {
-      const h8 bh = __builtin_bit_cast(h8, grh[ks % GK]), bl = rows_lo_operand<G3>(grl[ks % GK]);
+      const h8 bh = __builtin_bit_cast(h8, grh[ks % GK]), bl = rows_lo_operand<G3>(grl[ks % GK], grh[ks % GK]);
       {
         const int q0 = ks + GK;                          // the k-step that takes the slot this step frees
         const int kq = (q0 < NS) ? q0 : q0 - NS;
@@ -521,7 +529,7 @@ __device__ __forceinline__ void rows_gseq_step(RowsGSeq& G, f32x4 (&grh)[GK], ty
   constexpr int q0 = KS + GK, kq = (q0 < NS) ? q0 : q0 - NS;
   __builtin_amdgcn_sched_barrier(0);
   {
-    const h8 bh = __builtin_bit_cast(h8, grh[KS % GK]), bl = rows_lo_operand<G3>(grl[KS % GK]);
+    const h8 bh = __builtin_bit_cast(h8, grh[KS % GK]), bl = rows_lo_operand<G3>(grl[KS % GK], grh[KS % GK]);
     gacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS], bh, gacc, 0, 0, 0);
     gacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[KS], bl, gacc, 0, 0, 0);
     gacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[KS], bh, gacc, 0, 0, 0);

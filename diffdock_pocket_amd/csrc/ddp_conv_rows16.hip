@@ -178,8 +178,12 @@ __device__ __forceinline__ void r16_build_features(const ddp_block_t& B, const d
 struct R16GPart {
   const char* base;      // the part's tile inside node 0's row of its G array
   size_t gldb;           // node stride in bytes
-  int wp, nmine, bias_off;   // padded width, columns, byte offset of Gb[column 0] from `base`
+  int wp, nmine, bias_off;   // padded width, columns, byte offset of Gb[column 0] from `base` (plane form 1: of Gb's first group)
+  int cumw;                  // padded columns of the slot in front of the part
 };
+// Plane form GF (ddp_conv_task_t::gh_fmt): 0 = [k8][c][plane][8 halves], 32 bytes per unit (k8, c); 1 = 24-byte units [8 hi halves | 8
+// continuation bytes], Gb in 24-byte groups of six fp32 behind the units of all parts
+template <int GF>
 __device__ __forceinline__ R16GPart r16_gpart_of(const ddp_conv_shape_t& S, const ddp_conv_task_t& T, int bi, int part) {
   const ddp_block_t& B = S.blk[bi];
   int wp = 0, cumw = 0, gcp = 0;
@@ -195,9 +199,16 @@ __device__ __forceinline__ R16GPart r16_gpart_of(const ddp_conv_shape_t& S, cons
   }
   const int n8 = (S.hid + 7) >> 3;
   R16GPart P;
-  P.base = reinterpret_cast<const char*>(T.gh[B.g_slot]) + (size_t)(2 * n8 * cumw) * 16;
-  P.gldb = (size_t)DDP_GH_LD(S.hid, gcp) * 4;
-  P.bias_off = (8 * n8 * gcp + cumw) * 4 - (2 * n8 * cumw) * 16;
+  if constexpr (GF == 1) {
+    P.base = reinterpret_cast<const char*>(T.gh[B.g_slot]) + (size_t)(n8 * cumw) * 24;
+    P.gldb = (size_t)DDP_GH3_LD(S.hid, gcp) * 4;
+    P.bias_off = 24 * n8 * gcp - 24 * n8 * cumw;
+  } else {
+    P.base = reinterpret_cast<const char*>(T.gh[B.g_slot]) + (size_t)(2 * n8 * cumw) * 16;
+    P.gldb = (size_t)DDP_GH_LD(S.hid, gcp) * 4;
+    P.bias_off = (8 * n8 * gcp + cumw) * 4 - (2 * n8 * cumw) * 16;
+  }
+  P.cumw = cumw;
   P.wp = wp;
   P.nmine = min(32, B.n - 32 * part);
   return P;
@@ -233,14 +244,51 @@ __device__ __forceinline__ void r16_gseq_next(R16GSeq<NCT>& G, int src_reg, f32x
   for (int i = 0; i < 4; ++i) gacc[i] = r16_splat4(0.f);
 }
 // fragment (k32 step kq, column tile ct, plane) of the tile behind descriptor R: k8 group 4 kq + g (the last step: clamped to the row's last group)
-template <int NCT, int NS2>
-__device__ __forceinline__ f32x4 r16_gfrag(const R16GSeq<NCT>& G, R16Stream R, int kq, int ct, int plane) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(R, ((kq == NS2 - 1) ? G.l_last[ct] : G.l_main[ct]) + plane * 16,
-                                                                          (kq == NS2 - 1) ? 0 : 4 * kq * G.gc * 32, 0));
+template <int GF>
+struct R16Lo {      // what a lane keeps of a fragment's lo plane in the ring: 8 fp16 words, or 8 continuation bytes (decoded when the step multiplies)
+  typedef f32x4 T;
+};
+typedef uint32_t r16_u32x2 __attribute__((ext_vector_type(2)));
+template <>
+struct R16Lo<1> {
+  typedef r16_u32x2 T;
+};
+template <int NCT, int NS2, int GF>
+__device__ __forceinline__ f32x4 r16_gfrag_hi(const R16GSeq<NCT>& G, R16Stream R, int kq, int ct) {
+  constexpr int UB = GF == 1 ? 24 : 32;
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(R, ((kq == NS2 - 1) ? G.l_last[ct] : G.l_main[ct]),
+                                                                          (kq == NS2 - 1) ? 0 : 4 * kq * G.gc * UB, 0));
 }
-template <int NS, int NCT, int GK>
-__device__ __forceinline__ void r16_gseq_init(R16GSeq<NCT>& G, f32x4 (&gh)[GK][NCT], f32x4 (&gl)[GK][NCT], f32x4 (&gacc)[4], const ddp_conv_shape_t& S,
-                                              const R16GPart& PA, unsigned rmask, int src_reg, int lane) {
+template <int NCT, int NS2, int GF>
+__device__ __forceinline__ typename R16Lo<GF>::T r16_gfrag_lo(const R16GSeq<NCT>& G, R16Stream R, int kq, int ct) {
+  if constexpr (GF == 1)
+    return __builtin_bit_cast(r16_u32x2, __builtin_amdgcn_raw_buffer_load_b64(R, ((kq == NS2 - 1) ? G.l_last[ct] : G.l_main[ct]) + 16,
+                                                                               (kq == NS2 - 1) ? 0 : 4 * kq * G.gc * 24, 0));
+  else
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(R, ((kq == NS2 - 1) ? G.l_last[ct] : G.l_main[ct]) + 16,
+                                                                            (kq == NS2 - 1) ? 0 : 4 * kq * G.gc * 32, 0));
+}
+// plane form 1: the lo words of a fragment from its hi words and continuation bytes.  V = hi + sign(hi) 2^E u8 / 2^18 (E = hi's exponent;
+// hi = V truncated): the byte lands in the mantissa of 2^-8 (0x1C00 | u8 = 2^-8 + u8 2^-18), minus 2^-8, times hi's sign-and-exponent
+// word - four packed instructions per pair of values; a zero exponent (|V| < 2^-14) gives lo = 0
+__device__ __forceinline__ h8 r16_lo_of(const f32x4 hi, const r16_u32x2 by) {
+  typedef _Float16 r16_h2 __attribute__((ext_vector_type(2)));
+  typedef uint32_t r16_u32x4 __attribute__((ext_vector_type(4)));
+  const r16_u32x4 hw = __builtin_bit_cast(r16_u32x4, hi);
+  const r16_h2 c = {(_Float16)0.00390625f, (_Float16)0.00390625f};
+  r16_u32x4 out;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t x = __builtin_amdgcn_perm(0x1c1c1c1cu, by[i >> 1], (i & 1) ? 0x07030602u : 0x05010400u);
+    const r16_h2 y = __builtin_bit_cast(r16_h2, x) - c;
+    const r16_h2 pw = __builtin_bit_cast(r16_h2, hw[i] & 0xfc00fc00u);
+    out[i] = __builtin_bit_cast(uint32_t, y * pw);
+  }
+  return __builtin_bit_cast(h8, out);
+}
+template <int NS, int NCT, int GK, int GF>
+__device__ __forceinline__ void r16_gseq_init(R16GSeq<NCT>& G, f32x4 (&gh)[GK][NCT], typename R16Lo<GF>::T (&gl)[GK][NCT], f32x4 (&gacc)[4],
+                                              const ddp_conv_shape_t& S, const R16GPart& PA, unsigned rmask, int src_reg, int lane) {
   constexpr int NS2 = NS / 2;
   const int n = lane & 15, g = lane >> 4;
   const int n8 = (S.hid + 7) >> 3;
@@ -249,9 +297,13 @@ __device__ __forceinline__ void r16_gseq_init(R16GSeq<NCT>& G, f32x4 (&gh)[GK][N
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) {
     const int cl = min(16 * ct + n, PA.nmine - 1);       // (lanes behind the part's last column read a valid one: they select nothing)
-    G.l_main[ct] = (unsigned)(g * G.gc + cl) * 32u;
-    G.l_last[ct] = (unsigned)(k8l * G.gc + cl) * 32u;
-    G.l_bias[ct] = (unsigned)(PA.bias_off + 4 * cl);
+    constexpr unsigned UB = GF == 1 ? 24u : 32u;
+    G.l_main[ct] = (unsigned)(g * G.gc + cl) * UB;
+    G.l_last[ct] = (unsigned)(k8l * G.gc + cl) * UB;
+    if constexpr (GF == 1)
+      G.l_bias[ct] = (unsigned)(PA.bias_off + 24 * ((PA.cumw + cl) / 6) + 4 * ((PA.cumw + cl) % 6));
+    else
+      G.l_bias[ct] = (unsigned)(PA.bias_off + 4 * cl);
   }
   G.base = PA.base;
   G.gldb = PA.gldb;
@@ -264,8 +316,8 @@ __device__ __forceinline__ void r16_gseq_init(R16GSeq<NCT>& G, f32x4 (&gh)[GK][N
   for (int k = 0; k < GK; ++k)
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
-      gh[k][ct] = r16_gfrag<NCT, NS2>(G, G.rs, k, ct, 0);
-      gl[k][ct] = r16_gfrag<NCT, NS2>(G, G.rs, k, ct, 1);
+      gh[k][ct] = r16_gfrag_hi<NCT, NS2, GF>(G, G.rs, k, ct);
+      gl[k][ct] = r16_gfrag_lo<NCT, NS2, GF>(G, G.rs, k, ct);
     }
   __builtin_amdgcn_sched_barrier(0);
   r16_gseq_next(G, src_reg, gacc);
@@ -274,14 +326,19 @@ __device__ __forceinline__ void r16_gseq_init(R16GSeq<NCT>& G, f32x4 (&gh)[GK][N
 // (Multiplying only the row tile a run lies in - a run of at most 16 edges that does not straddle: half the matrix work of its product - was
 // built and measured: three straight-line variants of the chain cost the 12-fragment ring its registers, and the step got 0.3 ms LONGER,
 // 15.75 - 15.88 against 15.47 - 15.50 ms; the runs are bound by their loads, not by their MFMAs.  profiles/r06_rows16_ab.txt)
-template <int NS, int NCT, int GK, int KS>
-__device__ __forceinline__ void r16_gseq_step(R16GSeq<NCT>& G, f32x4 (&gh)[GK][NCT], f32x4 (&gl)[GK][NCT], f32x4 (&gacc)[4], const h8 (&ah)[NS],
-                                              const h8 (&al)[NS]) {
+template <int NS, int NCT, int GK, int KS, int GF>
+__device__ __forceinline__ void r16_gseq_step(R16GSeq<NCT>& G, f32x4 (&gh)[GK][NCT], typename R16Lo<GF>::T (&gl)[GK][NCT], f32x4 (&gacc)[4],
+                                              const h8 (&ah)[NS], const h8 (&al)[NS]) {
   constexpr int NS2 = NS / 2, q0 = KS + GK, kq = (q0 < NS2) ? q0 : q0 - NS2;
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) {
-    const h8 bh = __builtin_bit_cast(h8, gh[KS % GK][ct]), bl = __builtin_bit_cast(h8, gl[KS % GK][ct]);
+    const h8 bh = __builtin_bit_cast(h8, gh[KS % GK][ct]);
+    h8 bl;
+    if constexpr (GF == 1)
+      bl = r16_lo_of(gh[KS % GK][ct], gl[KS % GK][ct]);
+    else
+      bl = __builtin_bit_cast(h8, gl[KS % GK][ct]);
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       f32x4 d = gacc[2 * rt + ct];
@@ -295,8 +352,8 @@ __device__ __forceinline__ void r16_gseq_step(R16GSeq<NCT>& G, f32x4 (&gh)[GK][N
   const R16Stream srcb = (q0 < NS2) ? G.rs : G.rsn;
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) {
-    gh[KS % GK][ct] = r16_gfrag<NCT, NS2>(G, srcb, kq, ct, 0);
-    gl[KS % GK][ct] = r16_gfrag<NCT, NS2>(G, srcb, kq, ct, 1);
+    gh[KS % GK][ct] = r16_gfrag_hi<NCT, NS2, GF>(G, srcb, kq, ct);
+    gl[KS % GK][ct] = r16_gfrag_lo<NCT, NS2, GF>(G, srcb, kq, ct);
   }
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -325,7 +382,7 @@ __device__ __forceinline__ void r16_gseq_finish(R16GSeq<NCT>& G, f32x4 (&gacc)[4
   ++G.run;
   r16_gseq_next(G, src_reg, gacc);
 }
-template <int NS, int C, int NCT>
+template <int NS, int C, int NCT, int GF>
 __device__ __forceinline__ void r16_g_runs(const ddp_conv_shape_t& S, const R16GPart& PA, const h8 (&ah)[NS], const h8 (&al)[NS], const R16Aux* aux,
                                            unsigned rmask, int src_reg, int lane, f32x16 (&res)[C]) {
   // k32 steps in the ring: half a tile at NS = 12 (the whole tile at NS = 6) for the scalar segments - 12 fragments at two column tiles, like
@@ -334,8 +391,9 @@ __device__ __forceinline__ void r16_g_runs(const ddp_conv_shape_t& S, const R16G
   constexpr int NS2 = NS / 2, GK = (C == 3 && NCT == 2) ? 1 : ((NS2 % 3 == 0) ? 3 : 1);
   const int n = lane & 15, g = lane >> 4;
   R16GSeq<NCT> G;
-  f32x4 gh[GK][NCT], gl[GK][NCT], gacc[4];
-  r16_gseq_init<NS, NCT, GK>(G, gh, gl, gacc, S, PA, rmask, src_reg, lane);
+  f32x4 gh[GK][NCT], gacc[4];
+  typename R16Lo<GF>::T gl[GK][NCT];
+  r16_gseq_init<NS, NCT, GK, GF>(G, gh, gl, gacc, S, PA, rmask, src_reg, lane);
   bool mine[NCT];
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) mine[ct] = 16 * ct + n < PA.nmine;
@@ -343,12 +401,12 @@ __device__ __forceinline__ void r16_g_runs(const ddp_conv_shape_t& S, const R16G
 #pragma unroll
     for (int ks = 0; ks < NS2; ++ks) {
       // (static k-steps: the chain is resolved at compile time)
-      if (ks == 0) r16_gseq_step<NS, NCT, GK, 0>(G, gh, gl, gacc, ah, al);
-      else if (ks == 1) r16_gseq_step<NS, NCT, GK, 1 % NS2>(G, gh, gl, gacc, ah, al);
-      else if (ks == 2) r16_gseq_step<NS, NCT, GK, 2 % NS2>(G, gh, gl, gacc, ah, al);
-      else if (ks == 3) r16_gseq_step<NS, NCT, GK, 3 % NS2>(G, gh, gl, gacc, ah, al);
-      else if (ks == 4) r16_gseq_step<NS, NCT, GK, 4 % NS2>(G, gh, gl, gacc, ah, al);
-      else r16_gseq_step<NS, NCT, GK, 5 % NS2>(G, gh, gl, gacc, ah, al);
+      if (ks == 0) r16_gseq_step<NS, NCT, GK, 0, GF>(G, gh, gl, gacc, ah, al);
+      else if (ks == 1) r16_gseq_step<NS, NCT, GK, 1 % NS2, GF>(G, gh, gl, gacc, ah, al);
+      else if (ks == 2) r16_gseq_step<NS, NCT, GK, 2 % NS2, GF>(G, gh, gl, gacc, ah, al);
+      else if (ks == 3) r16_gseq_step<NS, NCT, GK, 3 % NS2, GF>(G, gh, gl, gacc, ah, al);
+      else if (ks == 4) r16_gseq_step<NS, NCT, GK, 4 % NS2, GF>(G, gh, gl, gacc, ah, al);
+      else r16_gseq_step<NS, NCT, GK, 5 % NS2, GF>(G, gh, gl, gacc, ah, al);
     }
     r16_gseq_finish<C, NCT>(G, gacc, aux, g, mine, src_reg, res);
   }
@@ -356,7 +414,7 @@ __device__ __forceinline__ void r16_g_runs(const ddp_conv_shape_t& S, const R16G
 
 // One segment = one 32-column part of one weight block's output columns: the factorised features (G runs), then the segment's stream
 // tiles (vector-input features), then the message columns
-template <int NS, int C>
+template <int NS, int C, int GF>
 __device__ __forceinline__ int r16_segment(const R16Launch& RL, const ddp_block_t& B, int bi, int part, const ddp_conv_task_t& T, const h8 (&ah)[NS],
                                            const h8 (&al)[NS], f32x4* ring, const float* lbias, int t, const float* F, const R16Aux* aux, unsigned rmask,
                                            int src_reg, int nvw, int wave, int lane) {
@@ -385,11 +443,11 @@ __device__ __forceinline__ int r16_segment(const R16Launch& RL, const ddp_block_
 
   // ---- factorised features
   if (B.g_slot >= 0 && rmask != 0u) {
-    const R16GPart PA = r16_gpart_of(S, T, bi, part);
+    const R16GPart PA = r16_gpart_of<GF>(S, T, bi, part);
     if (PA.nmine > 16)
-      r16_g_runs<NS, C, 2>(S, PA, ah, al, aux, rmask, src_reg, lane, res);
+      r16_g_runs<NS, C, 2, GF>(S, PA, ah, al, aux, rmask, src_reg, lane, res);
     else
-      r16_g_runs<NS, C, 1>(S, PA, ah, al, aux, rmask, src_reg, lane, res);
+      r16_g_runs<NS, C, 1, GF>(S, PA, ah, al, aux, rmask, src_reg, lane, res);
   }
 
   // ---- the segment's stream tiles (vector-input features)
@@ -465,7 +523,7 @@ __device__ __forceinline__ int r16_segment(const R16Launch& RL, const ddp_block_
   return t;
 }
 
-template <int SZ>
+template <int SZ, int GF>
 __global__ __launch_bounds__(R16_NT, 2) void ddp_conv_rows16_kernel(const R16Launch RL) {
   constexpr int NS = H2Class<SZ>::NS, NS2 = NS / 2, RING_Q = 2 * NS * 64;     // the ring holds one tile's worth of pieces
   constexpr int NQ = SZ / 4;     // 16-byte quads per edge_attr_ segment (ns floats each)
@@ -646,9 +704,9 @@ __global__ __launch_bounds__(R16_NT, 2) void ddp_conv_rows16_kernel(const R16Lau
     const int nparts = (B.n + 31) >> 5;
     for (int part = 0; part < nparts; ++part) {
       if (B.C == 1)
-        t = r16_segment<NS, 1>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane);
+        t = r16_segment<NS, 1, GF>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane);
       else
-        t = r16_segment<NS, 3>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane);
+        t = r16_segment<NS, 3, GF>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane);
     }
   }
 }
@@ -675,7 +733,7 @@ int ddp_conv_rows16_launch(const ddp_conv_shape_t* shape, const ddp_conv_task_t*
   for (int i = 0; i < ntasks; ++i) {
     const ddp_conv_task_t& T = tasks[i];
     if (T.n_edges <= 0) continue;
-    if (T.gh_fmt != 0) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: the 16x16x32 form reads G in plane form 0 only");
+    if (T.gh_fmt != tasks[0].gh_fmt || (unsigned)T.gh_fmt > 1u) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: the tasks of a launch carry one plane form of G (gh_fmt 0 or 1)");
     if (T.n_edges_dev) L.dev_counts = 1;
     L.tile_start[L.ntasks] = tiles;
     L.task[L.ntasks] = T;
@@ -696,17 +754,21 @@ int ddp_conv_rows16_launch(const ddp_conv_shape_t* shape, const ddp_conv_task_t*
   size_t lds_bytes = (size_t)2 * (NS * 1024) + RL.bias_bytes + (size_t)R16_NW * priv;
   if (2 * lds_bytes > 160 * 1024) return ddp_fail(DDP_ELIMIT, "ddp_conv_rows: LDS budget of two workgroups per CU exceeded (too many vector features per block)");
   if ((size_t)ddp_shape_rows_min_lds > lds_bytes) lds_bytes = (size_t)ddp_shape_rows_min_lds;
-  static int lds_have[2] = {0, 0};
+  static int lds_have[4] = {0, 0, 0, 0};
   hipError_t err;
-  if (sc == 60) {
-    err = ddp_need_lds(reinterpret_cast<const void*>(ddp_conv_rows16_kernel<60>), (int)lds_bytes, &lds_have[0]);
-    if (err != hipSuccess) return ddp_fail_hip(err, "hipFuncSetAttribute(conv rows16)");
-    hipLaunchKernelGGL(ddp_conv_rows16_kernel<60>, dim3(tiles), dim3(R16_NT), lds_bytes, (hipStream_t)stream, RL);
-  } else {
-    err = ddp_need_lds(reinterpret_cast<const void*>(ddp_conv_rows16_kernel<32>), (int)lds_bytes, &lds_have[1]);
-    if (err != hipSuccess) return ddp_fail_hip(err, "hipFuncSetAttribute(conv rows16)");
-    hipLaunchKernelGGL(ddp_conv_rows16_kernel<32>, dim3(tiles), dim3(R16_NT), lds_bytes, (hipStream_t)stream, RL);
+  const int gf = tasks[0].gh_fmt;
+#define R16_LAUNCH(SZ_, GF_, I_)                                                                                             \
+  {                                                                                                                          \
+    err = ddp_need_lds(reinterpret_cast<const void*>(ddp_conv_rows16_kernel<SZ_, GF_>), (int)lds_bytes, &lds_have[I_]);      \
+    if (err != hipSuccess) return ddp_fail_hip(err, "hipFuncSetAttribute(conv rows16)");                                    \
+    hipLaunchKernelGGL((ddp_conv_rows16_kernel<SZ_, GF_>), dim3(tiles), dim3(R16_NT), lds_bytes, (hipStream_t)stream, RL);   \
   }
+  if (sc == 60) {
+    if (gf == 1) R16_LAUNCH(60, 1, 2) else R16_LAUNCH(60, 0, 0)
+  } else {
+    if (gf == 1) R16_LAUNCH(32, 1, 3) else R16_LAUNCH(32, 0, 1)
+  }
+#undef R16_LAUNCH
   err = hipGetLastError();
   if (err != hipSuccess) return ddp_fail_hip(err, "ddp_conv_rows (16x16x32 form) launch");
   return 0;

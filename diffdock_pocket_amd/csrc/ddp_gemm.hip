@@ -468,10 +468,15 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 // store instructions.  Where the two pieces of every 8-column group go is a table (gh_dest[batch][ncols / 8][2], float offsets inside
 // the row, built by the host from the parts of the G array; bit 0 of the first = a plane group): the drain has no arithmetic of its
 // own.  The other groups are fp32 columns (Gb, padding) and leave unconverted.  Needs ncols % 32 == 0.
-// G3 (round 6, with GH): the lo plane of a plane group leaves as 8 OCP e4m3 bytes of (V - hi) * DDP_GH3_LO_SCALE instead of 8 fp16 words -
-// 24 bytes per 8 values instead of 32 (include/ddp_hip.h, ddp_conv_task_t::gh_fmt = 1): the second piece of EVERY group is then an
-// 8-byte store (fp32 groups - Gb - carry 6 values: the host leaves their last two product columns zero).  |V| must stay below 2048
-// (half an fp16 ulp times the scale stays inside e4m3's 448): range_flag otherwise.
+// G3 (round 6, with GH; plane form 1 of include/ddp_hip.h, ddp_conv_task_t::gh_fmt = 1): a plane group leaves as 24 bytes - 8 fp16 hi words =
+// V TRUNCATED to fp16 after rounding V to 19 significant bits, then 8 bytes = the next 8 mantissa bits of each value - and EVERY 8-column
+// group g of the product sits at byte 24 g of the row (fp32 groups - Gb, padding - carry 6 values: product columns 0, 1, 4, 5, 2, 6 of the
+// group in that order, columns 3 and 7 are not stored).  The drain is a different one (profiles/r06_store_g3_micro.txt: partial lines that
+// complete a block later cost a quarter of the rate, a row group's bytes written by consecutive instructions do not): a lane converts its
+// accumulator quads - 4 consecutive columns of its row, the transposed product - straight out of the registers into the wave's image of
+// the row tile in LDS (32 rows x the 384 bytes of the wave's 16 groups: no fp32 park, no re-read for the conversion), and behind the row
+// tile's fourth block the wave copies the image out with twelve 16-byte store instructions of WHOLE 128-byte lines (8 rows x 384 bytes per
+// three instructions).  Needs ncols % 128 == 0 (a wave's four blocks are all there or none is) and ldo = 6 ncols / 8.
 template <int KT, bool GH = false, bool G3 = false>
 __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(const float* __restrict__ x, int ldx, int nrows,
                                                                               const int32_t* __restrict__ rows,
@@ -488,8 +493,10 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
   constexpr int XS = KP + 8;                                   // halves per LDS row of an x plane (16-byte aligned rows)
   constexpr int NV = (32 * KT / 4 + DDP_GEMM_THREADS - 1) / DDP_GEMM_THREADS;
   constexpr int TS = 36;
+  constexpr int RS3 = 392;                                     // G3: bytes per row of a wave's row-tile image (384 + 8: 98 words, two-way banks at most)
   __shared__ __attribute__((aligned(16))) _Float16 xt[2][2][32 * XS];
-  __shared__ __attribute__((aligned(16))) float st[4][2][32 * TS];
+  __shared__ __attribute__((aligned(16))) float st[G3 ? 1 : 4][2][G3 ? 4 : 32 * TS];
+  __shared__ __attribute__((aligned(16))) char g3t[G3 ? 4 : 1][G3 ? 32 * RS3 : 16];
   const int z = (int)blockIdx.z, tid = (int)threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int col0 = ((int)blockIdx.x * 4 + wave) * (32 * CT);
@@ -536,6 +543,19 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
       gh_o[t][0] = d[0] & ~3;
       gh_o[t][1] = d[1];
       gh_sp[t] = (d[0] & 1) != 0;
+    }
+  }
+  // G3: which of the wave's 16 groups are plane groups (bit 4 t + q), and where lane i = 64 j + lane of a drain instruction j < 3 reads /
+  // writes: 8 rows x 24 16-byte pieces per three instructions
+  unsigned sp3 = 0u;
+  int g3_rr[3] = {0, 0, 0}, g3_pc[3] = {0, 0, 0};
+  if constexpr (G3) {
+    const int g = min(col0 + 8 * (lane & 15), ncols - 8) >> 3;
+    sp3 = (unsigned)__ballot((gh_dest[((size_t)z * (ncols >> 3) + g) * 2] & 1) != 0) & 0xffffu;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      g3_rr[j] = (64 * j + lane) / 24;
+      g3_pc[j] = (64 * j + lane) % 24;
     }
   }
   for (int R0 = (int)blockIdx.y * mrows; R0 < nrows; R0 += (int)gridDim.y * mrows) {
@@ -599,18 +619,7 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
     const f32x8 f = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     const h8 hi = __builtin_convertvector(f, h8);
     const f32x8 rest = f - __builtin_convertvector(hi, f32x8);     // (unified planes: lo at hi's scale, include/ddp_hip.h DDP_ROWS_S*)
-    h8 lo;
-    if constexpr (G3) {
-      // (the first two words of `lo` carry the 8 e4m3 bytes; v_cvt_pk_fp8_f32 rounds to nearest even like the fp16 conversion it replaces)
-      int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(rest[0] * (float)DDP_GH3_LO_SCALE, rest[1] * (float)DDP_GH3_LO_SCALE, 0, false);
-      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(rest[2] * (float)DDP_GH3_LO_SCALE, rest[3] * (float)DDP_GH3_LO_SCALE, w0, true);
-      int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(rest[4] * (float)DDP_GH3_LO_SCALE, rest[5] * (float)DDP_GH3_LO_SCALE, 0, false);
-      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(rest[6] * (float)DDP_GH3_LO_SCALE, rest[7] * (float)DDP_GH3_LO_SCALE, w1, true);
-      typedef int i32x4 __attribute__((ext_vector_type(4)));
-      lo = __builtin_bit_cast(h8, i32x4{w0, w1, 0, 0});
-    } else {
-      lo = __builtin_convertvector(rest, h8);
-    }
+    const h8 lo = __builtin_convertvector(rest, h8);
     const float m8 = fmaxf(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))), fmaxf(fmaxf(fabsf(f[4]), fabsf(f[5])), fmaxf(fabsf(f[6]), fabsf(f[7]))));
     gh_max = fmaxf(gh_max, pend_sp ? m8 : 0.f);
     const f32x4 vh = __builtin_bit_cast(f32x4, hi), vl = __builtin_bit_cast(f32x4, lo);
@@ -646,12 +655,7 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
         ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][s2], wr[t][0][s2], ac, 0, 0, 0);
       }
       if constexpr (DRAIN && NS == 4) {
-        if constexpr (G3) {
-          if (s2 & 1)
-            *reinterpret_cast<f32x2*>(&ob[pend_off[s2]]) = f32x2{dv[0], dv[1]};
-          else
-            *reinterpret_cast<f32x4*>(&ob[pend_off[s2]]) = dv;
-        } else {
+        {
           // (the hi and the lo store of a group leave one k-step apart and complete whole 128-byte lines together; as CONSECUTIVE
           // instructions behind the odd k-step - measured, round 6 - the atom stack takes 1.20 - 1.23 ms against 1.22: no difference)
           *reinterpret_cast<f32x4*>(&ob[pend_off[s2]]) = dv;
@@ -665,10 +669,7 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
           gh_read(pt, p);
         else
           dv = *reinterpret_cast<const f32x4*>(&pt[pend_lds[p]]);
-        if (G3 && (p & 1))
-          *reinterpret_cast<f32x2*>(&ob[pend_off[p]]) = f32x2{dv[0], dv[1]};
-        else
-          *reinterpret_cast<f32x4*>(&ob[pend_off[p]]) = dv;
+        *reinterpret_cast<f32x4*>(&ob[pend_off[p]]) = dv;
       }
     }
     float* tl = st[wave][pbuf];
@@ -702,6 +703,61 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
     }
     pbuf ^= 1;
   };
+  // G3: block t of the row tile - the transposed product, then this lane's four accumulator quads (row r, product columns 32 t + 8 q + 4 hh
+  // + 0..3: half of group q) into the wave's image: 8 bytes of hi words at 24 (4 t + q) + 8 hh, 4 continuation bytes at + 16 + 4 hh
+  auto block3 = [&](int t, const h8 (&a)[2][NS]) {
+    f32x16 am;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) am[i] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+      am = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[t][0][s2], a[0][s2], am, 0, 0, 0);
+      am = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[t][1][s2], a[0][s2], am, 0, 0, 0);
+      am = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[t][0][s2], a[1][s2], am, 0, 0, 0);
+    }
+    char* tl = g3t[G3 ? wave : 0] + r * RS3 + 96 * t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool sp = ((sp3 >> (4 * t + q)) & 1u) != 0u;      // (wave-uniform)
+      const float v0 = am[4 * q], v1 = am[4 * q + 1], v2 = am[4 * q + 2], v3 = am[4 * q + 3];
+      gh_max = fmaxf(gh_max, sp ? fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))) : 0.f);
+      // V rounded to 19 significant bits (half of bit 5 of the fp32 mantissa added to the bit pattern: magnitude rounding, carries into the
+      // exponent where it must), hi = its truncation to fp16, byte = mantissa bits 12 .. 5 (below the fp16 normal range the byte means
+      // nothing and the reader multiplies it by the hi word's zero exponent)
+      const uint32_t b0 = __builtin_bit_cast(uint32_t, v0) + 0x10u, b1 = __builtin_bit_cast(uint32_t, v1) + 0x10u;
+      const uint32_t b2 = __builtin_bit_cast(uint32_t, v2) + 0x10u, b3 = __builtin_bit_cast(uint32_t, v3) + 0x10u;
+      typedef __fp16 pk2 __attribute__((ext_vector_type(2)));
+      const pk2 h01 = __builtin_amdgcn_cvt_pkrtz(__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1));
+      const pk2 h23 = __builtin_amdgcn_cvt_pkrtz(__builtin_bit_cast(float, b2), __builtin_bit_cast(float, b3));
+      const uint32_t lo = ((b0 >> 5) & 0xffu) | (((b1 >> 5) & 0xffu) << 8) | (((b2 >> 5) & 0xffu) << 16) | ((b3 >> 5) << 24);
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      u32x2 w8;
+      w8[0] = sp ? __builtin_bit_cast(uint32_t, h01) : __builtin_bit_cast(uint32_t, v0);
+      w8[1] = sp ? __builtin_bit_cast(uint32_t, h23) : __builtin_bit_cast(uint32_t, v1);
+      *reinterpret_cast<u32x2*>(tl + 24 * q + 8 * hh) = w8;
+      *reinterpret_cast<uint32_t*>(tl + 24 * q + 16 + 4 * hh) = sp ? lo : __builtin_bit_cast(uint32_t, v2);
+    }
+  };
+  // G3: the row tile's image leaves - twelve 16-byte stores of whole lines; rows behind the tile's last repeat it (identical data)
+  auto drain3 = [&](int myrow, int nr) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const char* img = g3t[G3 ? wave : 0];
+    float* __restrict__ oc = ob + 6 * (col0 >> 3);
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int rl = min(8 * p + g3_rr[j], nr - 1);
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 lo8 = *reinterpret_cast<const u32x2*>(img + rl * RS3 + 16 * g3_pc[j]);
+        const u32x2 hi8 = *reinterpret_cast<const u32x2*>(img + rl * RS3 + 16 * g3_pc[j] + 8);
+        const int ri = __shfl(myrow, rl);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<u32x4*>(oc + (size_t)ri * ldo + 4 * g3_pc[j]) = u32x4{lo8[0], lo8[1], hi8[0], hi8[1]};
+      }
+    __builtin_amdgcn_wave_barrier();
+  };
   fetch(R0);
   park(0);
   __syncthreads();
@@ -723,6 +779,18 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
       blk_ri[p] = rows ? rows[ri] : ri;
     }
     const int nr = R1 - row0;
+    if constexpr (G3) {
+      if (col0 < ncols) {                              // (wave-uniform; ncols % 128 == 0: all four blocks or none)
+        const int ri = min(row0 + r, R1 - 1);
+        const int myrow = rows ? rows[ri] : ri;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) block3(t, a);
+        drain3(myrow, nr);
+      }
+      if (more) park(buf ^ 1);
+      __syncthreads();
+      continue;
+    }
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
       if (col0 + 32 * t >= ncols) continue;           // (wave-uniform: a column block beyond the array)
@@ -743,17 +811,13 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
         gh_read(pt, p);
       else
         dv = *reinterpret_cast<const f32x4*>(&pt[pend_lds[p]]);
-      if (G3 && (p & 1))
-        *reinterpret_cast<f32x2*>(&ob[pend_off[p]]) = f32x2{dv[0], dv[1]};
-      else
-        *reinterpret_cast<f32x4*>(&ob[pend_off[p]]) = dv;
+      *reinterpret_cast<f32x4*>(&ob[pend_off[p]]) = dv;
     }
   }
   __syncthreads();
   }
   if constexpr (GH) {
-    // (G3: the e4m3 lo plane holds half an fp16 ulp of V times DDP_GH3_LO_SCALE only below |V| = 2048)
-    if (!(gh_max <= (G3 ? 2047.f : 65504.f)) && range_flag) *range_flag = 1;
+    if (!(gh_max <= 65504.f) && range_flag) *range_flag = 1;
   }
 }
 
@@ -764,9 +828,11 @@ static int stage_a_impl(const float* x, int ldx, int nrows, const int32_t* rows,
   if (out_rows < 1 && nrows > 0) return ddp_fail(DDP_EINVAL, "ddp_stage_a: out_rows");
   if (nbatch < 0 || nbatch > DDP_MAX_GEMM_BATCH) return ddp_fail(DDP_ELIMIT, "ddp_stage_a: nbatch > DDP_MAX_GEMM_BATCH");
   if (k < 2 || k > 64 || (k & 1)) return ddp_fail(DDP_ELIMIT, "ddp_stage_a: K must be even and in [2, 64]");
-  // (plane form 1 - fp16 hi + e4m3 lo - writes 24 bytes per 8 product columns: its rows are shorter than ncols floats)
+  // (plane form 1 - fp16 hi + a continuation byte - writes 24 bytes per 8 product columns: its rows are shorter than ncols floats)
   if (ncols < 1 || nrows < 0 || (ldo < ncols && !(gh_dest && gh_fmt == 1 && ldo >= (ncols / 8) * 6)))
     return ddp_fail(DDP_EINVAL, "ddp_stage_a: ncols / nrows / ldo");
+  if (gh_dest && gh_fmt == 1 && ((ncols & 127) != 0 || (ldo & 31) != 0))
+    return ddp_fail(DDP_EINVAL, "ddp_stage_a_gh3: ncols % 128 == 0 (a wave's four column blocks), ldo % 32 == 0 (whole 128-byte lines)");
   if (nbatch == 0 || nrows == 0) return 0;
   if (!x || !offs || !w || !out) return ddp_fail(DDP_EINVAL, "ddp_stage_a: null argument");
   if ((reinterpret_cast<size_t>(x) & 3) || (reinterpret_cast<size_t>(out) & 7))   // scalar loads: dword aligned
@@ -909,8 +975,9 @@ extern "C" int ddp_stage_a_gh(const float* x, int ldx, int nrows, const int32_t*
   return stage_a_impl(x, ldx, nrows, rows, nrows_dev, out_rows, offs, nbatch, w, nullptr, w_h2, k, ncols, out, ldo, range_flag, stream, dest);
 }
 
-// ddp_stage_a_gh with plane form 1 of ddp_conv_task_t::gh (fp16 hi + e4m3 lo: 24 bytes per 8 values; ABI 16).  `ldo` (floats per output row) is
-// then the row length of that form (packing.gh3_ld), smaller than ncols.
+// ddp_stage_a_gh with plane form 1 of ddp_conv_task_t::gh (fp16 hi + a continuation byte: 24 bytes per 8 values, 19 significant bits; ABI 17).
+// `ldo` (floats per output row) is then the row length of that form (packing.gh3_ld = 6 ncols / 8), smaller than ncols; of `dest` only bit 0 of
+// entry [group][0] is read (a plane group or an fp32 group): every group sits at byte 24 g of the row.
 extern "C" int ddp_stage_a_gh3(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows,
                                const int32_t* offs, int nbatch, const float* w, const void* w_h2, int k, int ncols, float* out, int ldo,
                                int32_t* range_flag, const int32_t* dest, void* stream) {

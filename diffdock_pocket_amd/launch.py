@@ -411,7 +411,7 @@ def stage_a(x, n_rows, offs, nb, W, out, rows=None, rows_cnt=None, out_rows=None
     n_in, ncols = W.shape[1], W.shape[2]
     if n_rows == 0:
         return
-    if gh is not None and gh_fmt == 1:     # plane form 1 (fp16 hi + e4m3 lo pieces): rows of `ldo` floats (packing.gh3_ld), shorter than ncols
+    if gh is not None and gh_fmt == 1:     # plane form 1 (fp16 hi + continuation bytes): rows of `ldo` floats (packing.gh3_ld = 6 ncols / 8)
         L.check(lib.ddp_stage_a_gh3(x.data_ptr(), x.stride(0), n_rows, ptr(rows), ptr(rows_cnt), out_rows if out_rows is not None else n_rows,
                                     offs, nb, W.data_ptr(), ptr(Wh), n_in, ncols, out.data_ptr(), int(ldo), ptr(_RANGE_FLAG), gh.data_ptr(),
                                     stream()), "ddp_stage_a_gh3")

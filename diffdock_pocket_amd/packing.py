@@ -653,14 +653,14 @@ def gh_ld(hid: int, gcp: int) -> int:
     return (((hid + 7) // 8 * 8 + 1) * gcp + 31) // 32 * 32
 
 
-GH3_LO_SCALE = 512.0     # include/ddp_hip.h DDP_GH3_LO_SCALE: the e4m3 lo bytes of plane form 1 hold (V - hi) * 512
+GH3_FP32_COLS = (0, 1, 4, 5, 2, 6)     # plane form 1: product column (inside its 8-column group) of the j-th fp32 value a group stores
 
 
 def gh3_ld(hid: int, gcp: int) -> int:
-    """DDP_GH3_LD: floats per node of a G array in plane form 1 (fp16 hi + e4m3 lo pieces: 24 bytes per 8 values; Gb as 6 fp32 values per
-    32-byte group; 32 bytes of scratch for the product's padding groups; 128-byte aligned rows)."""
+    """DDP_GH3_LD: floats per node of a G array in plane form 1 (fp16 hi + a continuation byte: 24 bytes per 8 values; Gb as 6 fp32 values
+    per 24-byte group; whole 384-byte pieces = 16 groups = the four column blocks of a stage-A wave)."""
     n8 = (hid + 7) // 8
-    return (n8 * gcp * 24 + (gcp + 5) // 6 * 32 + 32 + 127) // 128 * 32
+    return (n8 * gcp + (gcp + 5) // 6 + 15) // 16 * 96
 
 
 def factor_weights_gh(spec: "ConvSpec", weight: torch.Tensor, bias: torch.Tensor, fmt: int = 0, form: int = 0):
@@ -669,8 +669,9 @@ def factor_weights_gh(spec: "ConvSpec", weight: torch.Tensor, bias: torch.Tensor
     columns of a part are zero), then Gb per padded column, then zero padding to DDP_GH_LD.  ddp_stage_a_gh writes the groups of a row
     as unified fp16 hi/lo planes, every part a contiguous tile [k8][c][plane][8] (ddp_conv_task_t::gh): the plane scale ROWS_SG rides in
     the G columns, the accumulator scale ROWS_SH ROWS_SG in the Gb columns.
-    fmt = 1 (plane form 1, ddp_stage_a_gh3): the same plane groups, then Gb in groups of SIX values per 8 product columns (a group's second
-    piece is an 8-byte store; columns 6, 7 stay zero), then zero padding to a multiple of 32 columns; the output row is gh3_ld floats.
+    fmt = 1 (plane form 1, ddp_stage_a_gh3): the same plane groups, then Gb in groups of SIX values per 8 product columns (the j-th value
+    of a group at product column GH3_FP32_COLS[j]: stage A stores those six, in that order), then zero padding to a multiple of 128 columns;
+    the output row is gh3_ld = 6 columns / 8 floats.
     Returns ([Wg0, Wg1], [in_off0, in_off1], [part widths of slot 0, of slot 1])."""
     ns16 = h2_steps(spec)
     assert ns16 > 0
@@ -695,7 +696,7 @@ def factor_weights_gh(spec: "ConvSpec", weight: torch.Tensor, bias: torch.Tensor
             Bm[:, b.g_col0:b.g_col0 + b.n] = bias[rows] * b.scale
         parts = gh_parts(spec, slot)
         gcp = sum(p[4] for p in parts)
-        ld = gh_ld(spec.hid, gcp) if fmt != 1 else (8 * (n8 * gcp + (gcp + 5) // 6) + 31) // 32 * 32
+        ld = gh_ld(spec.hid, gcp) if fmt != 1 else gh3_ld(spec.hid, gcp) // 6 * 8
         Wfull = torch.zeros(n_in, ld)
         Wk = W[:, kp].reshape(n_in, n8, 8, gc)                                                       # [u, k8, i, column]
         for _, _, c0, w, wp, cum in parts:
@@ -706,7 +707,7 @@ def factor_weights_gh(spec: "ConvSpec", weight: torch.Tensor, bias: torch.Tensor
                 Wfull[:, 8 * n8 * gcp + cum:8 * n8 * gcp + cum + w] = Bm[:, c0:c0 + w] * (ROWS_SH * ROWS_SG)
             else:
                 cpad = cum + torch.arange(w)                                                         # padded column of the slot
-                Wfull[:, 8 * n8 * gcp + 8 * (cpad // 6) + cpad % 6] = Bm[:, c0:c0 + w] * (ROWS_SH * ROWS_SG)
+                Wfull[:, 8 * n8 * gcp + 8 * (cpad // 6) + torch.tensor(GH3_FP32_COLS)[cpad % 6]] = Bm[:, c0:c0 + w] * (ROWS_SH * ROWS_SG)
         Wg[slot], offs[slot], widths[slot] = Wfull.contiguous(), blks[0].g_in_off, [p[4] for p in parts]
     return Wg, offs, widths
 
@@ -721,25 +722,13 @@ def gh_dest_table(widths: Sequence[int], n8: int, ncols: int, fmt: int = 0) -> t
     tab = torch.empty((ng, 2), dtype=torch.int32)
     g = torch.arange(ng, dtype=torch.int64)
     if fmt == 1:
-        # plane form 1: part p's tile starts at byte 24 n8 cum_p: hi piece of group (k8, c) at + 16 (k8 w_p + c), lo piece (8 e4m3 bytes) at
-        # + 16 n8 w_p + 8 (k8 w_p + c); Gb group j (6 values) at byte 24 n8 gcp + 32 j; the product's padding groups go to the scratch slot
+        # plane form 1: EVERY group g of the product sits at byte 24 g of the row (ddp_stage_a_gh3 reads bit 0 of [g][0] only: a plane group;
+        # the offsets are written for the record: 6 g floats, the group's 8 bytes behind its 16)
         gcp = sum(widths)
-        ngb = (gcp + 5) // 6
-        gb0 = 24 * n8 * gcp
-        assert 8 * (n8 * gcp + ngb) <= ncols
-        tab[:, 0] = (gb0 + 32 * ngb) // 4
-        tab[:, 1] = (gb0 + 32 * ngb) // 4 + 4
-        cum = 0
-        for w in widths:
-            gs = n8 * cum
-            gl = torch.arange(n8 * w, dtype=torch.int64)
-            base = 24 * n8 * cum
-            tab[gs:gs + n8 * w, 0] = ((base + 16 * gl) // 4 + 1).int()
-            tab[gs:gs + n8 * w, 1] = ((base + 16 * n8 * w + 8 * gl) // 4).int()
-            cum += w
-        j = torch.arange(ngb, dtype=torch.int64)
-        tab[n8 * gcp:n8 * gcp + ngb, 0] = ((gb0 + 32 * j) // 4).int()
-        tab[n8 * gcp:n8 * gcp + ngb, 1] = ((gb0 + 32 * j) // 4 + 4).int()
+        assert 8 * (n8 * gcp + (gcp + 5) // 6) <= ncols and ncols % 128 == 0
+        tab[:, 0] = (6 * g).int()
+        tab[:, 1] = (6 * g + 4).int()
+        tab[:n8 * gcp, 0] += 1
         return tab
     tab[:, 0] = (8 * g).int()
     tab[:, 1] = (8 * g + 4).int()

@@ -553,7 +553,7 @@ class TensorProductScoreModel(nn.Module):
         # plane form of the factorised convs' G (property g_planes3); DDP_G_PLANES3 = 0 / 1 in the environment sets the default of every model
         # built in the process (the parity suites under the other form: profiles/r06_g3byte_parity.txt)
         self.rows_mfma16 = os.environ.get("DDP_ROWS_MFMA16", ROWS_MFMA16_DEFAULT) == "1"
-        self.g_planes3 = os.environ.get("DDP_G_PLANES3", G_PLANES3_DEFAULT) == "1"      # (switches rows_mfma16 off: see the property)
+        self.g_planes3 = os.environ.get("DDP_G_PLANES3", G_PLANES3_DEFAULT) == "1"
 
     # ---- checkpoint compatibility -------------------------------------------------------------
     _IGNORED_PREFIXES = ("final_tp_tor.", "final_tp_sc_tor.", "tor_bond_conv.tp.", "sc_tor_bond_conv.tp.")
@@ -707,19 +707,17 @@ class TensorProductScoreModel(nn.Module):
     @property
     def g_planes3(self):
         """Plane form of the factorised convs' G (ddp_conv_task_t::gh_fmt).  False: fp16 hi + fp16 lo words, 4 bytes per value, 22 significant
-        bits.  True: fp16 hi + OCP e4m3 lo bytes (ddp_stage_a_gh3), 3 bytes per value, 15 - 16 significant bits: a quarter less of the step's
-        G round trip through HBM (written by stage A, read once by ddp_conv_rows); |32 G| must stay below 2048 (range flag -> the fp32
-        form, like every other value the split forms cannot hold).  Changing it drops the packed weights and captured steps; switching it ON
-        also switches rows_mfma16 off (only the round-5 kernel reads this form).  Measured in round 6: FAILS the 1e-4 bar
-        (profiles/r06_g3byte_parity.txt) - for experiments only."""
+        bits.  True: fp16 hi (truncated) + a continuation byte (ddp_stage_a_gh3), 3 bytes per value, 19 significant bits: a quarter less of
+        the step's G round trip through HBM (written by stage A, read once by ddp_conv_rows), and stage A leaves whole 128-byte lines.
+        Precision: 3.5e-6 worst on the scores of the golden cases, where the 22-bit planes give 5.5e-6 (the floor the rest of the path
+        sets; profiles/r06_g19bit_precision.txt).  Changing it drops the packed weights and captured steps.  (ABI 16 had an e4m3 byte in
+        this place: 15 - 16 bits, 2.4e-4 - outside the bar; profiles/r06_g3byte_parity.txt.)"""
         return bool(self.__dict__.get("_g_planes3", False))
 
     @g_planes3.setter
     def g_planes3(self, value):
         value = bool(value)
         if value != self.g_planes3:
-            if value and self.rows_mfma16:
-                self.rows_mfma16 = False      # (the e4m3 form is read by the round-5 kernel only: csrc/ddp_conv_rows.hip)
             self.__dict__["_g_planes3"] = value
             self._stage_a_stacks = {}
             for m_ in self.modules():
@@ -734,15 +732,13 @@ class TensorProductScoreModel(nn.Module):
         """Operand images of the row-stationary conv kernel (ddp_conv_task_t::rows_form).  True: every tile product on
         v_mfma_f32_16x16x32_f16 (csrc/ddp_conv_rows16.hip); False: v_mfma_f32_32x32x16_f16 (csrc/ddp_conv_rows.hip).  Same arithmetic per
         product (unified fp16 hi/lo planes, fp32 accumulation), other summation order inside a k-step: results agree to fp32 rounding, not
-        bit for bit.  Changing it drops the packed weights and captured steps.  Excludes g_planes3."""
+        bit for bit.  Changing it drops the packed weights and captured steps."""
         return bool(self.__dict__.get("_rows_mfma16", False))
 
     @rows_mfma16.setter
     def rows_mfma16(self, value):
         value = bool(value)
         if value != self.rows_mfma16:
-            if value and self.g_planes3:
-                raise NotImplementedError("rows_mfma16 reads G in plane form 0 (g_planes3 must be off)")
             self.__dict__["_rows_mfma16"] = value
             self._stage_a_stacks = {}
             for m_ in self.modules():

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DDP_ABI_VERSION 16
+#define DDP_ABI_VERSION 17
 #define DDP_EINVAL (-1)   /* bad argument (shape not supported, null pointer, ...) */
 #define DDP_ELIMIT (-2)   /* exceeds a compiled-in limit (see DDP_MAX_*) */
 
@@ -159,11 +159,13 @@ typedef struct {
   const void* gh[2];
   /* Plane form of gh (ABI 16; all tasks of a launch carry the same):
    *  0  as above - hi and lo words of a column side by side, 32 bytes per 8 values, DDP_GH_LD floats per node;
-   *  1  "fp16 + e4m3": a part's tile is [k8][c < wp] 16-byte hi pieces (8 fp16 words fp16(V)), then [k8][c < wp] 8-byte lo pieces: 8 OCP
-   *     e4m3 bytes of (V - hi) * DDP_GH3_LO_SCALE - 24 bytes per 8 values, 15 - 16 significant bits (|err| <= 2^-16 |V|; below
-   *     |V| = 2^-3 the lo byte is an e4m3 subnormal: absolute 2^-19), |V| < 2048 or the range flag is raised; behind the tiles Gb per padded
-   *     column c of the slot as fp32 at byte 32 (c / 6) + 4 (c % 6) (stage A stores 6 values per 8-column group), 32 bytes of scratch,
-   *     padding to 128 bytes: DDP_GH3_LD floats per node.  Written by ddp_stage_a_gh3. */
+   *  1  "fp16 + a continuation byte" (ABI 17): the unit (k8, c) of a part's tile is 24 bytes - 8 fp16 hi words, then 8 bytes - with
+   *     V = hi + sign(hi) 2^E(hi) u8 / 2^18: hi = V rounded to 19 significant bits and TRUNCATED to fp16, u8 = the next 8 mantissa bits
+   *     (19 significant bits, |err| <= 2^-19 |V| for |V| >= 2^-14; below, hi alone: absolute 2^-24); the units of a part [k8][c < wp] one
+   *     after the other, the parts one after the other (unit g of the row at byte 24 g), then Gb per padded column c of the slot as fp32 at
+   *     byte 24 (units + c / 6) + 4 (c % 6), padding to whole 384-byte pieces: DDP_GH3_LD floats per node.  Written by ddp_stage_a_gh3,
+   *     read by rows_form 1 only.  (ABI 16 had an e4m3 byte there: 15 - 16 bits, 2.4e-4 on the scores - outside the path's 1e-4,
+   *     profiles/r06_g3byte_parity.txt; the 19-bit form: 3.5e-6, profiles/r06_g19bit_precision.txt.) */
   int32_t gh_fmt;
   /* Operand images of wsh / gh / the kernel's h (ABI 16; all tasks of a launch carry the same):
    *  0  v_mfma_f32_32x32x16_f16 (csrc/ddp_conv_rows.hip): wsh fragments [ks][plane] of [hh][column 32][8 halves], k of the fc.3 tiles and of gh
@@ -172,7 +174,7 @@ typedef struct {
    *     [plane], each [k group g < 4][column n < 16][8 halves] = plane(W)[column 16 ct + n][k = 32 s + 8 g + i]; the k order of the fc.3 tiles and
    *     of gh is the NATURAL one (gh: the same bytes per node as form 0, k8 group = k / 8), and fc.0's OUTPUT columns are placed inside every
    *     32-column stream tile t so that the transposed fc1 product leaves h in that k order: h column 32 t + 8 g + i sits at position
-   *     16 (i / 4) + 4 g + i % 4 of the tile (DDP_ROWS16_POS; bias words in position order).  gh_fmt must be 0. */
+   *     16 (i / 4) + 4 g + i % 4 of the tile (DDP_ROWS16_POS; bias words in position order).  gh_fmt 0 or 1 (form 0: gh_fmt 0 only). */
   int32_t rows_form;
 } ddp_conv_task_t;
 /* plane scales of ddp_conv_rows' operands: edge_attr_ (split in the kernel), fc.0 / fc.3 weights (task.wsh), h = relu(fc1) (split in
@@ -185,8 +187,7 @@ typedef struct {
 #define DDP_ROWS_KPERM(ks, hh, i) (32 * ((ks) >> 1) + ((8 * ((ks) & 1) + (i)) & 3) + 8 * ((8 * ((ks) & 1) + (i)) >> 2) + 4 * (hh))
 /* position inside a 32-column fc.0 stream tile of the h column with in-tile index j = 8 g + i (rows_form 1) */
 #define DDP_ROWS16_POS(j) (16 * (((j) & 7) >> 2) + 4 * ((j) >> 3) + ((j) & 3))
-#define DDP_GH3_LO_SCALE 512
-#define DDP_GH3_LD(hid, gcp) ((((((hid) + 7) / 8) * (gcp) * 24 + (((gcp) + 5) / 6) * 32 + 32 + 127) / 128) * 32)   /* floats per node, plane form 1 */
+#define DDP_GH3_LD(hid, gcp) ((((((hid) + 7) / 8) * (gcp) + ((gcp) + 5) / 6 + 15) / 16) * 96)   /* floats per node, plane form 1: 6 per 8-column group, 16 groups per piece */
 #define DDP_GH_LD(hid, gcp) ((((((hid) + 7) / 8) * 8 + 1) * (gcp) + 31) / 32 * 32)   /* floats per node of a G array in plane form, gcp = padded columns */
 /* Fused fc -> tensor product -> per-edge message for up to 9 convs that share one shape.
  * All tasks of one call share `shape` (factorised and plain convs therefore go in separate calls).
@@ -411,10 +412,11 @@ int ddp_stage_a_gh(const float* x, int ldx, int nrows, const int32_t* rows, cons
                    int nbatch, const float* w, const void* w_h2, int k, int ncols, float* out, int ldo, int32_t* range_flag,
                    const int32_t* dest, void* stream);
 
-/* ... in plane form 1 of ddp_conv_task_t::gh (gh_fmt = 1: fp16 hi + e4m3 lo pieces).  The product's columns are ordered as for
- * ddp_stage_a_gh, but a group's second piece is 8 bytes: dest[b][g][1] is then the float offset (even) of the 8 e4m3 bytes of a plane group,
- * or of values 4, 5 of an fp32 group (Gb: 6 values per group, the host leaves product columns 6, 7 of such a group zero); ldo = DDP_GH3_LD
- * floats per row (shorter than ncols).  |V| >= 2048 raises range_flag.  ABI 16. */
+/* ... in plane form 1 of ddp_conv_task_t::gh (gh_fmt = 1: fp16 hi + a continuation byte, 24 bytes per 8-column group).  The product's
+ * columns are ordered as for ddp_stage_a_gh; group g of the product (8 columns) leaves at byte 24 g of the row: a plane group as 8 hi words
+ * + 8 bytes, an fp32 group (Gb, padding) as SIX values - product columns 0, 1, 4, 5, 2, 6 of the group in that order, columns 3 and 7 are
+ * not stored (packing.factor_weights_gh(fmt = 1) places Gb accordingly).  Of dest only bit 0 of [b][g][0] is read (a plane group);
+ * ncols % 128 == 0, ldo = 6 ncols / 8 = DDP_GH3_LD floats per row, a multiple of 32.  |V| > 65504 raises range_flag.  ABI 17. */
 int ddp_stage_a_gh3(const float* x, int ldx, int nrows, const int32_t* rows, const int32_t* nrows_dev, int out_rows, const int32_t* offs,
                     int nbatch, const float* w, const void* w_h2, int k, int ncols, float* out, int ldo, int32_t* range_flag,
                     const int32_t* dest, void* stream);

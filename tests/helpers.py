@@ -168,7 +168,7 @@ class PyGLikeBatch:
 def decode_gh_rows(rows, widths, hid, fmt):
     """Decodes G rows in the plane forms of ddp_conv_task_t::gh (include/ddp_hip.h) back to fp64: rows [N, ld] float32 (the bytes stage A
     wrote) -> (V [N, n8, gcp, 8] = the plane values hi + lo per k8 group, padded column and k slot; Gb [N, gcp]).  fmt 0: hi / lo fp16 words
-    side by side; fmt 1: 16-byte hi pieces, then 8-byte pieces of OCP e4m3 bytes holding (V - hi) * 512.  Test infrastructure: written from
+    side by side; fmt 1: 24-byte units of 8 hi words (V truncated) and 8 continuation bytes (19 significant bits).  Test infrastructure: written from
     the header's description of the layouts, independently of packing.gh_dest_table."""
     import numpy as np
     import torch
@@ -178,13 +178,6 @@ def decode_gh_rows(rows, widths, hid, fmt):
     V = np.zeros((N, n8, gcp, 8), dtype=np.float64)
     Gb = np.zeros((N, gcp), dtype=np.float64)
 
-    def e4m3(b):
-        b = b.astype(np.int64)
-        s, e, m = (b >> 7) & 1, (b >> 3) & 15, b & 7
-        v = np.where(e == 0, m / 8.0 * 2.0 ** -6, (1.0 + m / 8.0) * 2.0 ** (e.astype(np.float64) - 7.0))
-        v = np.where((e == 15) & (m == 7), np.nan, v)
-        return np.where(s == 1, -v, v)
-
     cum = 0
     for w in widths:
         if fmt == 0:
@@ -193,9 +186,14 @@ def decode_gh_rows(rows, widths, hid, fmt):
             hi = t[:, :, :, 0].copy().view(np.float16).astype(np.float64)
             lo = t[:, :, :, 1].copy().view(np.float16).astype(np.float64)
         else:
+            # plane form 1 (ABI 17): unit (k8, c) = 8 fp16 hi words + 8 continuation bytes; V = hi + sign(hi) 2^E(hi) u8 / 2^18, zero exponent: hi
             base = n8 * cum * 24
-            hi = raw[:, base:base + n8 * w * 16].reshape(N, n8, w, 16).copy().view(np.float16).astype(np.float64)
-            lo = e4m3(raw[:, base + n8 * w * 16:base + n8 * w * 24].reshape(N, n8, w, 8)) / 512.0
+            t = raw[:, base:base + n8 * w * 24].reshape(N, n8, w, 24)
+            hw = t[..., :16].copy().view(np.uint16)
+            hi = hw.view(np.float16).astype(np.float64)
+            e = ((hw >> 10) & 31).astype(np.int64)
+            mag = np.where(e > 0, np.ldexp(t[..., 16:].astype(np.float64), e - 15 - 18), 0.0)
+            lo = np.where((hw >> 15) == 1, -mag, mag)
         V[:, :, cum:cum + w] = hi + lo
         cum += w
     f32 = raw.view(np.float32)
@@ -204,5 +202,5 @@ def decode_gh_rows(rows, widths, hid, fmt):
     else:
         g0 = 24 * n8 * gcp // 4
         c = np.arange(gcp)
-        Gb[:] = f32[:, g0 + 8 * (c // 6) + c % 6]
+        Gb[:] = f32[:, g0 + 6 * (c // 6) + c % 6]
     return torch.from_numpy(V), torch.from_numpy(Gb)

@@ -242,7 +242,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.ddp_abi_version.restype = ctypes.c_int
-    assert lib.ddp_abi_version() == L.load().ddp_abi_version() == 16
+    assert lib.ddp_abi_version() == L.load().ddp_abi_version() == 17
     assert ctypes.sizeof(L.ConvShape) == 11 * 4 + 4 * (11 * 4 + 3 * 12) + 4 + 4 * 4 + 4 * 2 * 20
 
 
@@ -557,8 +557,9 @@ def test_smooth_edge_weight_matches_the_oracle_and_tolerates_unfilled_list_entri
 def test_g_plane_forms_host_side_against_the_decoder(fmt):
     """The two plane forms of a factorised conv's G (ddp_conv_task_t::gh_fmt; include/ddp_hip.h): packing.factor_weights_gh orders the
     product's columns, packing.gh_dest_table says where the two pieces of every 8-column group go, the kernel's drain is one conversion
-    per group.  Emulated here on the CPU exactly as csrc/ddp_gemm.hip drains (a plane group: 8 fp16 hi words + the lo piece - 8 fp16 words,
-    or 8 e4m3 bytes of (V - hi) x 512 in form 1; any other group: its first 4, and second 4 - form 1: 2 - fp32 values), and read back with
+    per group.  Emulated here on the CPU exactly as csrc/ddp_gemm.hip drains (form 0: a plane group = 8 fp16 hi words + 8 fp16 lo words at the
+    table's two places, any other group its 8 fp32 values; form 1: group g at byte 24 g - a plane group = the fp32 pattern + 0x10 truncated to
+    fp16 and its mantissa bits 12 .. 5, any other group the six fp32 values of product columns 0, 1, 4, 5, 2, 6), and read back with
     tests/helpers.decode_gh_rows, which is written from the header's description of the BYTES alone: the decoded planes must be the fp64
     product (to the forms' precision), the Gb columns exact, and the row lengths DDP_GH_LD / DDP_GH3_LD."""
     import numpy as np
@@ -579,7 +580,7 @@ def test_g_plane_forms_host_side_against_the_decoder(fmt):
         gcp = sum(widths[slot])
         ncols = W.shape[1]
         ld = P.gh3_ld(hid, gcp) if fmt == 1 else P.gh_ld(hid, gcp)
-        assert ncols % 32 == 0 and (ncols == ld if fmt != 1 else (ld * 4) % 128 == 0 and ld < ncols)
+        assert ncols % 32 == 0 and (ncols == ld if fmt != 1 else ncols % 128 == 0 and ld == 6 * ncols // 8 and (ld * 4) % 384 == 0)
         tab = P.gh_dest_table(widths[slot], n8, ncols, fmt=fmt)
         x = torch.randn(7, W.shape[0], generator=g)
         prod = (x.double() @ W.double()).float()                              # what the block's accumulator holds (fp32)
@@ -587,18 +588,27 @@ def test_g_plane_forms_host_side_against_the_decoder(fmt):
         for gi in range(ncols // 8):
             v = prod[:, 8 * gi:8 * gi + 8]
             o0, o1, plane = int(tab[gi, 0]) & ~3, int(tab[gi, 1]), int(tab[gi, 0]) & 1
-            if plane:
+            if fmt == 1:
+                assert int(tab[gi, 0]) & ~1 == 6 * gi
+                if plane:
+                    b = v.contiguous().numpy().view(np.uint32) + np.uint32(0x10)
+                    sgn, e, m = (b >> 31).astype(np.int64), ((b >> 23) & 0xff).astype(np.int64), (b & 0x7fffff).astype(np.int64)
+                    e16 = e - 112
+                    hw = np.where(e16 >= 1, (e16 << 10) | (m >> 13), (m | 0x800000) >> np.minimum(14 - e16, 40))     # (truncation, subnormal results too)
+                    hw = np.where(e == 0, 0, hw) | (sgn << 15)
+                    raw[:, 24 * gi:24 * gi + 16] = hw.astype(np.uint16).view(np.uint8).reshape(7, 16)
+                    raw[:, 24 * gi + 16:24 * gi + 24] = ((b >> 5) & 0xff).astype(np.uint8)
+                else:
+                    six = v[:, list(P.GH3_FP32_COLS)].contiguous().numpy()
+                    raw[:, 24 * gi:24 * gi + 24] = six.view(np.uint8).reshape(7, 24)
+            elif plane:
                 hi = v.to(torch.float16)
                 rest = v - hi.float()
                 raw[:, 4 * o0:4 * o0 + 16] = hi.numpy().view(np.uint8).reshape(7, 16)
-                if fmt == 1:
-                    raw[:, 4 * o1:4 * o1 + 8] = (rest * P.GH3_LO_SCALE).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
-                else:
-                    raw[:, 4 * o1:4 * o1 + 16] = rest.to(torch.float16).numpy().view(np.uint8).reshape(7, 16)
+                raw[:, 4 * o1:4 * o1 + 16] = rest.to(torch.float16).numpy().view(np.uint8).reshape(7, 16)
             else:
                 raw[:, 4 * o0:4 * o0 + 16] = v[:, :4].contiguous().numpy().view(np.uint8).reshape(7, 16)
-                n2 = 2 if fmt == 1 else 4
-                raw[:, 4 * o1:4 * o1 + 4 * n2] = v[:, 4:4 + n2].contiguous().numpy().view(np.uint8).reshape(7, 4 * n2)
+                raw[:, 4 * o1:4 * o1 + 16] = v[:, 4:8].contiguous().numpy().view(np.uint8).reshape(7, 16)
         rows = torch.from_numpy(raw.view(np.float32).copy())
         V, Gb = decode_gh_rows(rows, widths[slot], hid, fmt)
         # the same planes and bias columns as form 0's right-hand side gives (its column order is the documented one)
@@ -610,7 +620,7 @@ def test_g_plane_forms_host_side_against_the_decoder(fmt):
             wantV[:, :, cum:cum + w] = want[:, 8 * n8 * cum:8 * n8 * (cum + w)].reshape(7, n8, w, 8)
             cum += w
         wantB = want[:, 8 * n8 * gcp:8 * n8 * gcp + gcp]
-        tolV = 2.0 ** -21 * wantV.abs() + 2.0 ** -24 if fmt != 1 else 2.0 ** -15 * wantV.abs() + 2.0 ** -18
+        tolV = 2.0 ** -21 * wantV.abs() + 2.0 ** -24 if fmt != 1 else 2.0 ** -19 * wantV.abs() + 2.0 ** -24
         assert bool(((V - wantV).abs() <= tolV + 1e-6 * wantV.abs()).all()), (fmt, slot, float((V - wantV).abs().max()))
         # (the Gb columns of the padded parts only: the others are zero on both sides)
         assert bool(((Gb - wantB).abs() <= 1e-6 * wantB.abs() + 1e-9).all()), (fmt, slot)
@@ -678,9 +688,9 @@ def test_rows_kernel_operand_images_of_the_16x16x32_form():
 
 
 def test_rows_kernel_options_are_consistent(monkeypatch):
-    """model.rows_mfma16 (the row-stationary conv kernel on v_mfma_f32_16x16x32_f16: the default) and model.g_planes3 (G in three bytes: only
-    the round-5 kernel reads it): switching the second on switches the first off, the first refuses to come on beside the second, both
-    setters drop the packed weights (epoch) and tell the conv layers; the environment sets the defaults."""
+    """model.rows_mfma16 (the row-stationary conv kernel on v_mfma_f32_16x16x32_f16) and model.g_planes3 (G in three bytes per value, 19
+    significant bits): independent of each other since ABI 17 (both kernels read both plane forms), both setters drop the packed weights
+    (epoch) and tell the conv layers; the environment sets the defaults."""
     from diffdock_pocket_amd.score_model import TensorProductConvLayer, TensorProductScoreModel
     from oracle.cases import CASES
     case = CASES["cfg2_small"]
@@ -691,19 +701,23 @@ def test_rows_kernel_options_are_consistent(monkeypatch):
     monkeypatch.delenv("DDP_G_PLANES3", raising=False)
     m = TensorProductScoreModel(**kw)
     convs = [c for c in m.modules() if isinstance(c, TensorProductConvLayer)]
-    assert m.rows_mfma16 and not m.g_planes3 and all(getattr(c, "rows_form", 0) == 1 and getattr(c, "gh_fmt", 0) == 0 for c in convs)
+    from diffdock_pocket_amd.score_model import G_PLANES3_DEFAULT, ROWS_MFMA16_DEFAULT
+    d3, d16 = G_PLANES3_DEFAULT == "1", ROWS_MFMA16_DEFAULT == "1"
+    assert m.rows_mfma16 == d16 and m.g_planes3 == d3
+    assert all(getattr(c, "rows_form", 0) == int(d16) and getattr(c, "gh_fmt", 0) == int(d3) for c in convs)
     e0 = m.__dict__.get("_packed_epoch", 0)
-    m.g_planes3 = True
-    assert m.g_planes3 and not m.rows_mfma16 and all(c.rows_form == 0 and c.gh_fmt == 1 for c in convs)
-    assert m.__dict__["_packed_epoch"] > e0
-    with pytest.raises(NotImplementedError):
-        m.rows_mfma16 = True
-    m.g_planes3 = False
-    m.rows_mfma16 = True
-    assert all(c.rows_form == 1 and c.gh_fmt == 0 for c in convs)
-    monkeypatch.setenv("DDP_ROWS_MFMA16", "0")
-    assert not TensorProductScoreModel(**kw).rows_mfma16
-    monkeypatch.setenv("DDP_G_PLANES3", "1")
-    monkeypatch.setenv("DDP_ROWS_MFMA16", "1")
-    m2 = TensorProductScoreModel(**kw)
-    assert m2.g_planes3 and not m2.rows_mfma16
+    m.g_planes3 = not d3
+    assert m.g_planes3 != d3 and m.rows_mfma16 == d16 and all(c.rows_form == int(d16) and c.gh_fmt == int(not d3) for c in convs)
+    e1 = m.__dict__["_packed_epoch"]
+    assert e1 > e0
+    m.rows_mfma16 = not d16
+    assert m.__dict__["_packed_epoch"] > e1 and all(c.rows_form == int(not d16) and c.gh_fmt == int(not d3) for c in convs)
+    m.g_planes3 = d3
+    m.rows_mfma16 = d16
+    assert all(c.rows_form == int(d16) and c.gh_fmt == int(d3) for c in convs)
+    for v3 in ("0", "1"):
+        for v16 in ("0", "1"):
+            monkeypatch.setenv("DDP_G_PLANES3", v3)
+            monkeypatch.setenv("DDP_ROWS_MFMA16", v16)
+            m2 = TensorProductScoreModel(**kw)
+            assert m2.g_planes3 == (v3 == "1") and m2.rows_mfma16 == (v16 == "1")

@@ -49,8 +49,9 @@ def main():
                                                          None, dest.data_ptr(), st), "a"))
         gbg = nb * N * ncg * 4 / 1e9
         print(f"{name}: plane form (ddp_stage_a_gh) {gbg:.2f} GB out: {t_gh:.3f} ms ({gbg / t_gh:.2f} TB/s)")
-        # plane form 1 (fp16 hi + e4m3 lo pieces, ddp_stage_a_gh3): 24 bytes per 8 values
-        nc3, ld3 = (8 * (23 * 72 + 12) + 31) // 32 * 32, gh3_ld(180, 72)
+        # plane form 1 (fp16 hi + continuation bytes, ddp_stage_a_gh3): 24 bytes per 8 values
+        ld3 = gh3_ld(180, 72)
+        nc3 = ld3 // 6 * 8
         wg3 = torch.randn(nb, k, nc3, device=dev)
         wgh3 = split_h2(wg3, unified_scale=0.5)
         outg3 = torch.empty(nb, N, ld3, device=dev)
