@@ -149,7 +149,7 @@ class _PackedConv:
                  "wsh", "bsp", "wgh", "gh_groups", "gh_ld", "gh_fmt", "rows_form")     # (the last six: ddp_conv_rows' weight stream and stage-A right-hand sides)
 
 
-G_PLANES3_DEFAULT = "0"      # model.g_planes3 unless DDP_G_PLANES3 says otherwise
+G_PLANES3_DEFAULT = "1"      # model.g_planes3 unless DDP_G_PLANES3 says otherwise (round 6, late: the 19-bit form is the default)
 ROWS_MFMA16_DEFAULT = "1"    # model.rows_mfma16 unless DDP_ROWS_MFMA16 says otherwise (round 6: 15.5 against 16.1 ms per 40-sample step)
 
 

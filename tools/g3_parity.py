@@ -1,5 +1,6 @@
-"""Round 6, VERDICT item 3: the 3-byte G plane (model.g_planes3: fp16 hi + e4m3 lo, 15 - 16 significant bits) MEASURED against the path's
-1e-4 bar instead of argued away.  For every golden case whose factorised convs run through ddp_conv_rows (size classes ns = 60 / 32):
+"""Round 6, VERDICT item 3: the 3-byte G plane (model.g_planes3) MEASURED against the path's 1e-4 bar instead of argued away - first with
+an e4m3 byte (ABI 16: 15 - 16 significant bits, FAILED: profiles/r06_g3byte_parity.txt), then as fp16 hi + continuation byte (ABI 17: 19
+bits, the default since: profiles/r06_g19bit_parity.txt).  For every golden case whose factorised convs run through ddp_conv_rows (size classes ns = 60 / 32):
 forward scores against the CPU oracle in both plane forms (tests/test_gpu_parity.py::test_forward_matches_oracle_and_golden's measure:
 max |d| / max |ref| per output); the cfg2 job of 2 samples x 20 steps
 against the oracle-driven CPU sampler (test_cfg2_job_end_to_end_against_the_cpu_sampler's measure).  Prints profiles/r06_g3byte_parity.txt.
@@ -31,7 +32,7 @@ FORMS = tuple(int(v) for v in (sys.argv[sys.argv.index("--forms") + 1] if "--for
 def main():
     dev = torch.device("cuda:0")
     worst = {0: 0.0, 1: 0.0}
-    print("# forward scores against the CPU oracle, max |d| / max |ref| per output; plane form 0 (fp16 + fp16, shipped) | form 1 (fp16 + e4m3)")
+    print("# forward scores against the CPU oracle, max |d| / max |ref| per output; plane form 0 (fp16 + fp16) | form 1 (fp16 + continuation byte)")
     for name, case in CASES.items():
         _, gold, batch, sd = case_inputs(name)
         kw = dict(case.model_kwargs())
