@@ -477,9 +477,8 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 // the row tile in LDS (32 rows x the 384 bytes of the wave's 16 groups: no fp32 park, no re-read for the conversion), and behind the row
 // tile's fourth block the wave copies the image out with twelve 16-byte store instructions of WHOLE 128-byte lines (8 rows x 384 bytes per
 // three instructions).  Needs ncols % 128 == 0 (a wave's four blocks are all there or none is) and ldo = 6 ncols / 8.
-// The waves of this form run FREE: every wave fetches and splits the rows' operand fragments itself (x is small and sits in L2; the split
-// costs a wave ~100 instructions per row tile), so there is no shared x tile and no barrier in the loop - a wave's drain burst overlaps the
-// other waves' products instead of all four draining at once.
+// (Measured and dropped: the waves running FREE - every wave fetching and splitting its own operand fragments, no shared x tile, no barrier
+// in the loop - 1.05 instead of 0.89 ms on the atom stack, the step 15.2 instead of 14.3 ms: four times the split work, 22 spilled registers.)
 template <int KT, bool GH = false, bool G3 = false>
 __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(const float* __restrict__ x, int ldx, int nrows,
                                                                               const int32_t* __restrict__ rows,
@@ -497,7 +496,7 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
   constexpr int NV = (32 * KT / 4 + DDP_GEMM_THREADS - 1) / DDP_GEMM_THREADS;
   constexpr int TS = 36;
   constexpr int RS3 = 392;                                     // G3: bytes per row of a wave's row-tile image (384 + 8: 98 words, two-way banks at most)
-  __shared__ __attribute__((aligned(16))) _Float16 xt[G3 ? 1 : 2][2][G3 ? 8 : 32 * XS];
+  __shared__ __attribute__((aligned(16))) _Float16 xt[2][2][32 * XS];
   __shared__ __attribute__((aligned(16))) float st[G3 ? 1 : 4][2][G3 ? 4 : 32 * TS];
   __shared__ __attribute__((aligned(16))) char g3t[G3 ? 4 : 1][G3 ? 32 * RS3 : 16];
   const int z = (int)blockIdx.z, tid = (int)threadIdx.x;
@@ -514,7 +513,7 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
         wr[t][p][s2] = *reinterpret_cast<const h8*>(wh + (((((size_t)z * 2 + p) * NS + s2) * 2 + hh) * ncols + c) * 8);
   }
   // the k padding [KT, KP) of both x buffers is zero for good
-  if constexpr (KP > KT && !G3) {
+  if constexpr (KP > KT) {
     for (int i = tid; i < 2 * 2 * 32 * (KP - KT); i += DDP_GEMM_THREADS) {
       const int kk = i % (KP - KT), rr = (i / (KP - KT)) % 32, bp = i / ((KP - KT) * 32);
       xt[bp / 2][bp % 2][rr * XS + KT + kk] = (_Float16)0.f;
@@ -548,11 +547,18 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
       gh_sp[t] = (d[0] & 1) != 0;
     }
   }
-  // G3: which of the wave's 16 groups are plane groups (bit 4 t + q)
+  // G3: which of the wave's 16 groups are plane groups (bit 4 t + q), and where lane i = 64 j + lane of a drain instruction j < 3 reads /
+  // writes: 8 rows x 24 16-byte pieces per three instructions
   unsigned sp3 = 0u;
+  int g3_rr[3] = {0, 0, 0}, g3_pc[3] = {0, 0, 0};
   if constexpr (G3) {
     const int g = min(col0 + 8 * (lane & 15), ncols - 8) >> 3;
     sp3 = (unsigned)__ballot((gh_dest[((size_t)z * (ncols >> 3) + g) * 2] & 1) != 0) & 0xffffu;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      g3_rr[j] = (64 * j + lane) / 24;
+      g3_pc[j] = (64 * j + lane) % 24;
+    }
   }
   for (int R0 = (int)blockIdx.y * mrows; R0 < nrows; R0 += (int)gridDim.y * mrows) {
   const int R1 = min(nrows, R0 + mrows);
@@ -734,22 +740,14 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
       *reinterpret_cast<uint32_t*>(tl + 24 * q + 16 + 4 * hh) = sp ? lo : __builtin_bit_cast(uint32_t, v2);
     }
   };
-  // G3: the row tile's image leaves - twelve 16-byte stores of whole lines (lane i = 64 j + lane of instruction j < 3 of a row group moves
-  // piece i % 24 of row i / 24: 8 rows x 24 pieces per three instructions); rows behind the tile's last repeat it (identical data)
+  // G3: the row tile's image leaves - twelve 16-byte stores of whole lines; rows behind the tile's last repeat it (identical data)
   auto drain3 = [&](int myrow, int nr) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const char* img = g3t[G3 ? wave : 0];
     float* __restrict__ oc = ob + 6 * (col0 >> 3);
-    int g3_rr[3], g3_pc[3];      // (recomputed per drain: six registers that do not live through the products)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      g3_rr[j] = (64 * j + lane) / 24;
-      g3_pc[j] = (64 * j + lane) % 24;
-    }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      __builtin_amdgcn_sched_barrier(0);      // (three pieces in flight at a time)
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int rl = min(8 * p + g3_rr[j], nr - 1);
@@ -760,66 +758,8 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         *reinterpret_cast<u32x4*>(oc + (size_t)ri * ldo + 4 * g3_pc[j]) = u32x4{lo8[0], lo8[1], hi8[0], hi8[1]};
       }
-    }
     __builtin_amdgcn_wave_barrier();
   };
-  if constexpr (G3) {
-    // the wave's own operand fragments of a row tile: lane (row r, hh) holds k = 16 s2 + 8 hh + 0..7 of its row, hi and lo planes
-    f32x4 xr[2 * NS];
-    auto xfetch3 = [&](int row0) {
-      const int ri = min(row0 + r, nrows - 1);
-      const float* __restrict__ p = xb + (size_t)(rows ? rows[ri] : ri) * ldx;
-#pragma unroll
-      for (int i = 0; i < 2 * NS; ++i) {
-        const int k0 = min(16 * (i >> 1) + 8 * hh + 4 * (i & 1), KT - 4);      // (KT % 4 == 0; a quad behind the row's k range: zeroed in the split)
-        xr[i] = *reinterpret_cast<const f32x4*>(p + k0);
-      }
-    };
-    float x_max = 0.f;
-    h8 a[2][NS];
-    auto xsplit3 = [&]() {
-#pragma unroll
-      for (int s2 = 0; s2 < NS; ++s2) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const bool in = 16 * s2 + 8 * hh + 4 * (e >> 2) < KT;
-          const float f = in ? xr[2 * s2 + (e >> 2)][e & 3] * (float)DDP_GH_SX : 0.f;
-          x_max = fmaxf(x_max, fabsf(f));
-          const _Float16 h = (_Float16)f;
-          a[0][s2][e] = h;
-          a[1][s2][e] = (_Float16)(f - (float)h);
-        }
-        __builtin_amdgcn_sched_barrier(0);     // (one k-step at a time: the split of all four at once costs 37 spilled registers)
-      }
-    };
-    if (col0 < ncols) {                                // (wave-uniform; ncols % 128 == 0: all four blocks or none)
-      xfetch3(R0);
-      xsplit3();
-      for (int row0 = R0; row0 < R1; row0 += 32) {
-        const bool more = row0 + 32 < R1;
-        const int ri = min(row0 + r, R1 - 1);
-        const int myrow = rows ? rows[ri] : ri;
-#pragma unroll
-        for (int t = 0; t < CT; ++t) {
-          block3(t, a);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_sched_barrier(0);             // (the next tile's fragments take the registers this tile's leave: not earlier)
-        if (more) {                                    // (one branch: the fragments in flight live from here to their split, nowhere else)
-          xfetch3(row0 + 32);                          // (in flight while the image leaves)
-          __builtin_amdgcn_sched_barrier(0);
-          drain3(myrow, R1 - row0);
-          __builtin_amdgcn_sched_barrier(0);
-          xsplit3();
-        } else {
-          drain3(myrow, R1 - row0);
-        }
-      }
-      // (outside the fp16 range, or NaN: reported, not saturated)
-      if (!(x_max <= 65504.f) && range_flag) *range_flag = 1;
-    }
-    continue;
-  }
   fetch(R0);
   park(0);
   __syncthreads();
@@ -841,6 +781,18 @@ __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(con
       blk_ri[p] = rows ? rows[ri] : ri;
     }
     const int nr = R1 - row0;
+    if constexpr (G3) {
+      if (col0 < ncols) {                              // (wave-uniform; ncols % 128 == 0: all four blocks or none)
+        const int ri = min(row0 + r, R1 - 1);
+        const int myrow = rows ? rows[ri] : ri;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) block3(t, a);
+        drain3(myrow, nr);
+      }
+      if (more) park(buf ^ 1);
+      __syncthreads();
+      continue;
+    }
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
       if (col0 + 32 * t >= ncols) continue;           // (wave-uniform: a column block beyond the array)
@@ -883,11 +835,6 @@ static int stage_a_impl(const float* x, int ldx, int nrows, const int32_t* rows,
     return ddp_fail(DDP_EINVAL, "ddp_stage_a: ncols / nrows / ldo");
   if (gh_dest && gh_fmt == 1 && ((ncols & 127) != 0 || (ldo & 31) != 0))
     return ddp_fail(DDP_EINVAL, "ddp_stage_a_gh3: ncols % 128 == 0 (a wave's four column blocks), ldo % 32 == 0 (whole 128-byte lines)");
-  if (gh_dest && gh_fmt == 1) {     // (its waves fetch their operand fragments as 16-byte quads)
-    bool al = (ldx & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0;
-    for (int i = 0; i < nbatch && offs; ++i) al = al && (offs[i] & 3) == 0;
-    if (!al) return ddp_fail(DDP_EINVAL, "ddp_stage_a_gh3: x 16-byte aligned, ldx % 4 == 0, offs % 4 == 0");
-  }
   if (nbatch == 0 || nrows == 0) return 0;
   if (!x || !offs || !w || !out) return ddp_fail(DDP_EINVAL, "ddp_stage_a: null argument");
   if ((reinterpret_cast<size_t>(x) & 3) || (reinterpret_cast<size_t>(out) & 7))   // scalar loads: dword aligned
