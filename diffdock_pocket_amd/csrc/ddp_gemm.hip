@@ -478,7 +478,8 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 // tile's fourth block the wave copies the image out with twelve 16-byte store instructions of WHOLE 128-byte lines (8 rows x 384 bytes per
 // three instructions).  Needs ncols % 128 == 0 (a wave's four blocks are all there or none is) and ldo = 6 ncols / 8.
 // (Measured and dropped: the waves running FREE - every wave fetching and splitting its own operand fragments, no shared x tile, no barrier
-// in the loop - 1.05 instead of 0.89 ms on the atom stack, the step 15.2 instead of 14.3 ms: four times the split work, 22 spilled registers.)
+// in the loop - 1.05 instead of 0.89 ms on the atom stack, the step 15.2 instead of 14.3 ms: four times the split work, 22 spilled registers;
+// the image leaving one row group behind each k-step of the NEXT tile's first block instead of as a burst - 0.92 ms, the step 14.7 ms.)
 template <int KT, bool GH = false, bool G3 = false>
 __global__ __launch_bounds__(DDP_GEMM_THREADS, 2) void ddp_stage_a_h2_kernel(const float* __restrict__ x, int ldx, int nrows,
                                                                               const int32_t* __restrict__ rows,
