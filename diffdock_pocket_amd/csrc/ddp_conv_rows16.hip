@@ -39,6 +39,7 @@
 #define R16_ET 128
 #define R16_FS 36     // floats per feature row F[u * C + c][edge]
 #define R16_NP 3      // pieces per stream tile (one ring slot each)
+#define R16_FROWS 72  // feature rows a wave holds at a time (a block with more - the direct convs: 80 features x 3 components - builds them in chunks)
 #define R16_SX ((float)DDP_ROWS_SX)
 #define R16_SW ((float)DDP_ROWS_SW)
 #define R16_SH ((float)DDP_ROWS_SH)
@@ -51,9 +52,11 @@ typedef __amdgpu_buffer_rsrc_t R16Stream;
 struct R16Launch {
   ConvLaunch L;
   int nts;         // stream tiles per conv (fc.0 tiles + fc.3 tiles of all segments)
+  int bias_tiles;  // stream tiles whose bias words sit in the LDS table (all, or fc.0's: ddp_conv_task_t::rows_bias_k)
   int bias_bytes;  // LDS bytes of the bias table behind the ring
   int priv_bytes;  // LDS bytes of a wave's private area
   int aux_off;     // byte offset of the per-edge tables inside it
+  int frows;       // feature rows of the private area (<= R16_FROWS)
 };
 static_assert(sizeof(ConvLaunch) + 16 <= 4096, "the launch descriptor travels as a kernel argument");
 struct R16Aux {
@@ -167,6 +170,45 @@ __device__ __forceinline__ void r16_build_features(const ddp_block_t& B, const d
           F[(u * 3 + 1) * FS + e] = (az[i] * sx - ax[i] * sz) * inv_sqrt2;
           F[(u * 3 + 2) * FS + e] = (ax[i] * sy - ay[i] * sx) * inv_sqrt2;
         }
+      }
+    }
+    ubase += cnt;
+  }
+}
+
+// ... the features [u0, u1) of a block of ANY kinds, rows (u - u0) C + c: the chunks of a block whose features do not fit the private area at
+// once (the direct convs; build_features of ddp_conv_common.h over a range, for one wave: lane = (edge, half))
+__device__ __forceinline__ void r16_build_features_range(const ddp_block_t& B, const ddp_conv_task_t& T, const R16Aux* aux, float* F, int lane,
+                                                         int u0, int u1) {
+  constexpr int FS = R16_FS;
+  const int e = lane & 31, half = lane >> 5;
+  const float* __restrict__ xrow = T.x_src + (size_t)aux->src[e] * T.ldx_src;
+  const float s0 = aux->sh[e][0], sx = aux->sh[e][1], sy = aux->sh[e][2], sz = aux->sh[e][3];
+  const float inv_sqrt3 = 0.57735026918962576f, inv_sqrt2 = 0.70710678118654752f;
+  int ubase = 0;
+  for (int si = 0; si < B.nseg; ++si) {
+    const int kind = B.seg[si].kind, off = B.seg[si].in_off, cnt = B.seg[si].count;
+    const int lo = max(0, u0 - ubase), hi = min(cnt, u1 - ubase);
+    for (int ul = lo + half; ul < hi; ul += 2) {
+      const int u = ubase + ul - u0;
+      if (kind == DDP_F_SCALAR_S0) {
+        F[u * FS + e] = xrow[off + ul] * s0;
+      } else if (kind == DDP_F_DOT) {
+        F[u * FS + e] = (xrow[off + 3 * ul] * sx + xrow[off + 3 * ul + 1] * sy + xrow[off + 3 * ul + 2] * sz) * inv_sqrt3;
+      } else if (kind == DDP_F_SCALAR_S1) {
+        const float a = xrow[off + ul];
+        F[(u * 3 + 0) * FS + e] = a * sx;
+        F[(u * 3 + 1) * FS + e] = a * sy;
+        F[(u * 3 + 2) * FS + e] = a * sz;
+      } else if (kind == DDP_F_VEC_S0) {
+        F[(u * 3 + 0) * FS + e] = xrow[off + 3 * ul] * s0;
+        F[(u * 3 + 1) * FS + e] = xrow[off + 3 * ul + 1] * s0;
+        F[(u * 3 + 2) * FS + e] = xrow[off + 3 * ul + 2] * s0;
+      } else {  // DDP_F_CROSS: a x s1 / sqrt(2)
+        const float ax = xrow[off + 3 * ul], ay = xrow[off + 3 * ul + 1], az = xrow[off + 3 * ul + 2];
+        F[(u * 3 + 0) * FS + e] = (ay * sz - az * sy) * inv_sqrt2;
+        F[(u * 3 + 1) * FS + e] = (az * sx - ax * sz) * inv_sqrt2;
+        F[(u * 3 + 2) * FS + e] = (ax * sy - ay * sx) * inv_sqrt2;
       }
     }
     ubase += cnt;
@@ -416,7 +458,7 @@ __device__ __forceinline__ void r16_g_runs(const ddp_conv_shape_t& S, const R16G
 // tiles (vector-input features), then the message columns
 template <int NS, int C, int GF>
 __device__ __forceinline__ int r16_segment(const R16Launch& RL, const ddp_block_t& B, int bi, int part, const ddp_conv_task_t& T, const h8 (&ah)[NS],
-                                           const h8 (&al)[NS], f32x4* ring, const float* lbias, int t, const float* F, const R16Aux* aux, unsigned rmask,
+                                           const h8 (&al)[NS], f32x4* ring, const float* lbias, int t, float* F, const R16Aux* aux, unsigned rmask,
                                            int src_reg, int nvw, int wave, int lane) {
   const ddp_conv_shape_t& S = RL.L.shape;
   const int n = lane & 15, g = lane >> 4;
@@ -452,12 +494,23 @@ __device__ __forceinline__ int r16_segment(const R16Launch& RL, const ddp_block_
 
   // ---- the segment's stream tiles (vector-input features)
   const int cnt = (B.ntiles == 0 || B.U == 0) ? 0 : (B.nsub > 1 ? B.U : (B.U + B.ups - 1) / B.ups);
+  // a block whose U C feature rows do not fit the private area builds them chunk by chunk: tpc tiles (tpc upt features) per chunk
+  const int upt = (B.nsub > 1) ? 1 : B.ups;                      // features per tile
+  const bool chunked = B.U * C > RL.frows;
+  const int tpc = chunked ? max(1, RL.frows / (C * upt)) : cnt;
+  int u0 = 0;
   for (int j = 0; j < cnt; ++j, ++t) {
     constexpr int KPP = NS / R16_NP, PIECE_Q = 2 * KPP * 64;
+    if (chunked && j % tpc == 0) {
+      u0 = j * upt;
+      r16_build_features_range(B, T, aux, F, lane, u0, min(B.U, u0 + tpc * upt));
+    }
     f32x4 acc[4];
     r16_stream_step<NS, 0>(ring, wsh, t, RL.nts, wave, lane);
     {
-      const float b0 = lbias[t * 32 + n], b1 = lbias[t * 32 + 16 + n];
+      // (rows_bias_k: the tile's bias is its k row `hid`, times h[hid] = 1)
+      const bool bt = t < RL.bias_tiles;
+      const float b0 = bt ? lbias[t * 32 + n] : 0.f, b1 = bt ? lbias[t * 32 + 16 + n] : 0.f;
       acc[0] = r16_splat4(b0);
       acc[1] = r16_splat4(b1);
       acc[2] = r16_splat4(b0);
@@ -473,7 +526,7 @@ __device__ __forceinline__ int r16_segment(const R16Launch& RL, const ddp_block_
     for (int ct = 0; ct < 2; ++ct) {
       int u = (B.nsub > 1) ? j : j * B.ups + us[ct];
       if (!(valid[ct] && u < B.U)) u = 0;
-      const float* frow = F + (u * C) * R16_FS + 4 * g;
+      const float* frow = F + ((u - u0) * C) * R16_FS + 4 * g;
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -574,7 +627,7 @@ __global__ __launch_bounds__(R16_NT, 2) void ddp_conv_rows16_kernel(const R16Lau
   // ---- request tiles 0 / 1 of the stream; the tiles' bias words: one table in LDS for the whole kernel
   r16_request_piece<NS>(ring, wsh, 0, R16_NP * RL.nts, 0, wave, lane);
   r16_request_piece<NS>(ring, wsh, 1, R16_NP * RL.nts, 1, wave, lane);
-  for (int i = tid; i < RL.nts * 32; i += R16_NT) lbias[i] = T.bsp[i];
+  for (int i = tid; i < RL.bias_tiles * 32; i += R16_NT) lbias[i] = T.bsp[i];
   // ---- edge_attr_ of the wave's edges as B-operand fragments: lane (edge n of tile et, g) holds k = 32 s + 8 g + i.  hi plane in registers,
   // lo plane in the wave's private LDS area (each lane reads back what it wrote); image index 2 s + et
   h8 xh[NS];
@@ -692,7 +745,7 @@ __global__ __launch_bounds__(R16_NT, 2) void ddp_conv_rows16_kernel(const R16Lau
   // ---- the segments: blocks in order, the 32-column parts of a block in order
   for (int bi = 0; bi < S.nblocks; ++bi) {
     const ddp_block_t& B = S.blk[bi];
-    if (B.ntiles > 0 && B.U > 0) {
+    if (B.ntiles > 0 && B.U > 0 && B.U * B.C <= RL.frows) {
       bool fast = true;     // (vector-input segments of at most 16 features: the factorised shapes of nv <= 16)
       for (int si = 0; si < B.nseg; ++si)
         fast = fast && B.seg[si].count <= 16 && (B.seg[si].kind == DDP_F_DOT || B.seg[si].kind == DDP_F_VEC_S0 || B.seg[si].kind == DDP_F_CROSS);
@@ -734,6 +787,8 @@ int ddp_conv_rows16_launch(const ddp_conv_shape_t* shape, const ddp_conv_task_t*
     const ddp_conv_task_t& T = tasks[i];
     if (T.n_edges <= 0) continue;
     if (T.gh_fmt != tasks[0].gh_fmt || (unsigned)T.gh_fmt > 1u) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: the tasks of a launch carry one plane form of G (gh_fmt 0 or 1)");
+    if (T.rows_bias_k != tasks[0].rows_bias_k || (unsigned)T.rows_bias_k > 1u || (T.rows_bias_k && (shape->hid & 15) == 0))
+      return ddp_fail(DDP_EINVAL, "ddp_conv_rows: rows_bias_k is 0 or 1 for all tasks of a launch and needs hid % 16 != 0");
     if (T.n_edges_dev) L.dev_counts = 1;
     L.tile_start[L.ntasks] = tiles;
     L.task[L.ntasks] = T;
@@ -743,6 +798,8 @@ int ddp_conv_rows16_launch(const ddp_conv_shape_t* shape, const ddp_conv_task_t*
   L.tile_start[L.ntasks] = tiles;
   if (tiles == 0) return 0;
   RL.nts = nts;
+  if (frows > R16_FROWS) frows = R16_FROWS;          // (larger blocks build their features in chunks)
+  RL.frows = frows;
   int fbytes = frows * R16_FS * 4;
   fbytes = (fbytes + 127) / 128 * 128;
   RL.aux_off = fbytes;
@@ -750,7 +807,8 @@ int ddp_conv_rows16_launch(const ddp_conv_shape_t* shape, const ddp_conv_task_t*
   if (priv < NS * 1024) priv = NS * 1024;          // the lo plane of edge_attr_ during fc1
   priv = (priv + 127) / 128 * 128;
   RL.priv_bytes = priv;
-  RL.bias_bytes = (nts * 128 + 127) / 128 * 128;
+  RL.bias_tiles = tasks[0].rows_bias_k ? nct1 : nts;
+  RL.bias_bytes = (RL.bias_tiles * 128 + 127) / 128 * 128;
   size_t lds_bytes = (size_t)2 * (NS * 1024) + RL.bias_bytes + (size_t)R16_NW * priv;
   if (2 * lds_bytes > 160 * 1024) return ddp_fail(DDP_ELIMIT, "ddp_conv_rows: LDS budget of two workgroups per CU exceeded (too many vector features per block)");
   if ((size_t)ddp_shape_rows_min_lds > lds_bytes) lds_bytes = (size_t)ddp_shape_rows_min_lds;

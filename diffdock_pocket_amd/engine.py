@@ -963,7 +963,12 @@ class ForwardEngine:
                 if prof_on:
                     nb_d += node_bytes(l, k)
                 segs = [(e[ek], csr.eid, ns, ns), (x_recv, csr.recv, ldx, ns), (x_src, csr.src, ldx, ns)]
-                tasks.append(K.make_task(pkc, x_src, ldx, csr, sh[ek], segs, msg))
+                # (model.direct_rows: through the row-stationary kernel - 128-edge workgroups stream the fc.3 tiles once per 128 edges)
+                pkr = m.conv_layers[9 * l + k].packed_rows_direct(dev)
+                if pkr is not None and K.rows_mode(pkr):
+                    tasks.append(K.make_task(pkr, x_src, ldx, csr, sh[ek], segs, msg, rows=True))
+                else:
+                    tasks.append(K.make_task(pkc, x_src, ldx, csr, sh[ek], segs, msg))
             P.tasks, P.nb_d = tasks, nb_d
             return tasks
 

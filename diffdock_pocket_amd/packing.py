@@ -532,11 +532,23 @@ def bn_affine(out_mul_blocks: Sequence[Tuple[int, int, bool]], running_mean, run
     return torch.cat(scales).float(), torch.cat(shifts).float()
 
 # ------------------------------------------------------------------------------------------------ row-stationary kernel (ddp_conv_rows)
+def spec_form1_chunks(spec: "ConvSpec") -> bool:
+    """Feature chunks exist in the 16x16x32 form of the rows kernel only, which is also the only one the direct convs run through."""
+    return not spec.factorized
+
+
+def rows_bias_in_k(spec: "ConvSpec") -> bool:
+    """ddp_conv_task_t::rows_bias_k: a DIRECT conv (every feature a stream tile: hundreds of tiles, whose bias table alone would take the
+    LDS of two workgroups) carries the fc.3 bias in the padding k row `hid` of its tiles - possible where hid is not a multiple of 16."""
+    return (not spec.factorized) and spec.hid % 16 != 0
+
+
 def rows_supported(spec: "ConvSpec") -> bool:
-    """Shapes ddp_conv_rows runs: factorised convs of the size classes ns = 60 / 32 (f_in = hid = 180 / 96: the README's large and small
-    score models) whose per-wave feature rows fit the kernel's LDS plan."""
+    """Shapes ddp_conv_rows runs: convs of the size classes ns = 60 / 32 (f_in = hid = 180 / 96: the README's large and small score
+    models) whose per-wave feature rows and bias table fit the kernel's LDS plan - the factorised convs, and (round 6, rows_form 1 only) the
+    direct ones where the bias can ride in k (rows_bias_in_k: hid = 180)."""
     ns16 = h2_steps(spec)
-    if not spec.factorized or ns16 not in (12, 6):
+    if ns16 not in (12, 6) or (not spec.factorized and not rows_bias_in_k(spec)):
         return False
     # the host entry's block checks (csrc/ddp_conv_rows.hip, ddp_conv_rows): shapes it would refuse keep the 32-edge kernel instead of
     # failing at launch
@@ -546,8 +558,10 @@ def rows_supported(spec: "ConvSpec") -> bool:
         if b.nsub < 1 or b.nsub > 2 or b.ups < 1 or (b.nsub > 1) != (b.n > 32) or (b.nsub == 1 and b.ups != 32 // b.n):
             return False
     frows = max([b.U * b.C for b in spec.blocks if b.U > 0] + [0])
+    if spec_form1_chunks(spec):
+        frows = min(frows, 72)          # (csrc/ddp_conv_rows16.hip R16_FROWS: larger blocks build their features in chunks; rows_form 1 only)
     priv = max((frows * 36 * 4 + 127) // 128 * 128 + 1408 + 2048, ns16 * 1024)
-    nts = spec.nct1 + sum(len(t) for _, _, t in rows_segments(spec))
+    nts = spec.nct1 if rows_bias_in_k(spec) else spec.nct1 + sum(len(t) for _, _, t in rows_segments(spec))     # (tiles of the bias table)
     # two 4-wave workgroups per CU: ring of one tile's pieces + bias table + four private areas each
     return 2 * (2 * ns16 * 1024 + (nts * 128 + 127) // 128 * 128 + 4 * ((priv + 127) // 128 * 128)) <= 160 * 1024
 
@@ -582,21 +596,26 @@ def rows_segments(spec: "ConvSpec"):
     return segs
 
 
-def rows_stream(spec: "ConvSpec", w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, form: int = 0):
+def rows_stream(spec: "ConvSpec", w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, form: int = 0, bias_in_k: bool = False):
     """(wsh, bsp) of ddp_conv_task_t for ddp_conv_rows: fc.0's nct1 column tiles (natural k order: their K is edge_attr_), then the fc.3
     tiles of `spec` (block scale folded in) segment by segment with the k index permuted by rows_kperm; UNIFIED fp16 hi/lo planes of
     ROWS_SW w per tile (_pack_tiles_h2), the bias words fp32 [tiles, 32] at the scale of their tile's accumulator (fc.0: ROWS_SW ROWS_SX,
     fc.3: ROWS_SH ROWS_SW).
     form = 1 (ddp_conv_task_t::rows_form, csrc/ddp_conv_rows16.hip): the same stream in the operand images of v_mfma_f32_16x16x32_f16
     (_pack_tiles_16): fc.0's output columns placed by rows16_pos inside every 32-column tile (bias words in the same positions), the k of
-    the fc.3 tiles in natural order."""
+    the fc.3 tiles in natural order.
+    bias_in_k (ddp_conv_task_t::rows_bias_k, form 1): fc.0 gets an output column `hid` with zero weights and bias 1 (h[hid] = relu(1) = 1),
+    every fc.3 tile its bias as k row `hid`; the bias words of the fc.3 tiles are zero."""
     ns16 = h2_steps(spec)
     assert ns16 > 0
     hid, f_in = w1.shape
+    assert not bias_in_k or (form == 1 and hid < 16 * ns16 and hid < spec.nct1 * 32)
     W1c = torch.zeros(spec.nct1 * 32, f_in)
     W1c[:hid] = w1.detach().float().cpu()
     b1c = torch.zeros(spec.nct1 * 32)
     b1c[:hid] = b1.detach().float().cpu() * (ROWS_SW * ROWS_SX)
+    if bias_in_k:
+        b1c[hid] = 1.0 * (ROWS_SW * ROWS_SX)
     if form == 1:
         pos = rows16_pos(spec.nct1 * 32)
         W1p, b1p = torch.zeros_like(W1c), torch.zeros_like(b1c)
@@ -623,12 +642,14 @@ def rows_stream(spec: "ConvSpec", w1: torch.Tensor, b1: torch.Tensor, w2: torch.
         Wall = torch.cat(cols, 0)                                   # [ntiles * 32, hid]
         Wp = torch.zeros(Wall.shape[0], 16 * ns16)
         Wp[:, :spec.hid] = Wall
+        if bias_in_k:
+            Wp[:, spec.hid] = torch.cat(bcols, 0)
         if form == 1:
             t2 = _pack_tiles_16(Wp, ns16, ROWS_SW).reshape(Wall.shape[0] // 32, -1)[order]      # (natural k)
         else:
             Wp = Wp[:, rows_kperm(ns16)]                                # fragment slot -> permuted k
             t2 = _pack_tiles_h2(Wp, ns16, ROWS_SW).reshape(Wall.shape[0] // 32, -1)[order]
-        bs2 = torch.cat(bcols, 0).reshape(-1, 32)[order] * (ROWS_SH * ROWS_SW)
+        bs2 = torch.cat(bcols, 0).reshape(-1, 32)[order] * (0.0 if bias_in_k else ROWS_SH * ROWS_SW)
         return torch.cat([t1, t2], 0).reshape(-1).contiguous(), torch.cat([b1c.reshape(-1, 32), bs2], 0).contiguous()
     return t1.reshape(-1).contiguous(), b1c.reshape(-1, 32).contiguous()
 

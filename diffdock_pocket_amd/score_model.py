@@ -146,10 +146,11 @@ def _mlp(n_in, n_hidden, n_out, dropout):
 
 class _PackedConv:
     __slots__ = ("w1p", "b1p", "w2p", "b2p", "bn_scale", "bn_shift", "wg", "bg", "g_in_off", "w1h", "w2h",
-                 "wsh", "bsp", "wgh", "gh_groups", "gh_ld", "gh_fmt", "rows_form")     # (the last six: ddp_conv_rows' weight stream and stage-A right-hand sides)
+                 "wsh", "bsp", "wgh", "gh_groups", "gh_ld", "gh_fmt", "rows_form", "rows_bias_k")     # (the last seven: ddp_conv_rows' weight stream and stage-A right-hand sides)
 
 
 G_PLANES3_DEFAULT = "1"      # model.g_planes3 unless DDP_G_PLANES3 says otherwise (round 6, late: the 19-bit form is the default)
+DIRECT_ROWS_DEFAULT = "1"    # model.direct_rows unless DDP_DIRECT_ROWS says otherwise (round 6, late)
 ROWS_MFMA16_DEFAULT = "1"    # model.rows_mfma16 unless DDP_ROWS_MFMA16 says otherwise (round 6: 15.5 against 16.1 ms per 40-sample step)
 
 
@@ -167,6 +168,7 @@ class TensorProductConvLayer(nn.Module):
         self.batch_norm = IrrepsBatchNorm(out_blocks) if batch_norm else None
         self._packed: Optional[_PackedConv] = None
         self._packed_g: Optional[_PackedConv] = None
+        self._packed_d = None           # (packed(), its copy with the direct conv's weight stream): packed_rows_direct
 
     def packed_g(self, device) -> _PackedConv:
         """Weights for the factorised path: fc.3 tiles of the vector-input features only + the GEMM right-hand sides
@@ -190,6 +192,7 @@ class TensorProductConvLayer(nn.Module):
             # the 128-edge row-stationary kernel (ddp_conv_rows; size classes ns = 60 / 32): the fc.0 / fc.3 tiles as one stream in the
             # kernel's k order, and stage-A right-hand sides whose product ddp_stage_a_gh writes as fp16 hi/lo planes
             pk.wsh = pk.bsp = pk.wgh = pk.gh_groups = pk.gh_ld = None
+            pk.rows_bias_k = 0
             pk.gh_fmt = int(getattr(self, "gh_fmt", 0))     # plane form of G (ddp_conv_task_t::gh_fmt; set by the model: g_planes3)
             pk.rows_form = int(getattr(self, "rows_form", 0))   # operand images of the rows kernel (ddp_conv_task_t::rows_form: rows_mfma16)
             if P.rows_supported(self.spec_g):
@@ -254,8 +257,34 @@ class TensorProductConvLayer(nn.Module):
             if P.h2_steps(self.spec) > 0:
                 pk.w1h = P.pack_fc1_h2(self.spec, self.fc[0].weight).to(device)
                 pk.w2h = P.pack_fc2_h2(self.spec, self.fc[3].weight).to(device)
+            pk.wsh = pk.bsp = pk.wgh = pk.gh_groups = pk.gh_ld = None
+            pk.gh_fmt, pk.rows_form, pk.rows_bias_k = 0, 0, 0
             self._packed = pk
+            self._packed_d = None
         return self._packed
+
+    def packed_rows_direct(self, device) -> Optional[_PackedConv]:
+        """The DIRECT conv through the row-stationary kernel (round 6: rows_form 1, the fc.3 bias in the padding k row - packing.rows_stream(
+        bias_in_k)): packed() plus the weight stream, built on first use (8 MB per conv: only the convs that run direct get one).  None where
+        the option is off, the shape is not one of the kernel's, or a weight / bias lies beyond the unified planes' range (ddp_conv_messages
+        then)."""
+        base = self.packed(device)
+        if not (bool(getattr(self, "direct_rows", False)) and int(getattr(self, "rows_form", 0)) == 1 and not self.spec.factorized
+                and P.rows_supported(self.spec)):
+            return None
+        if getattr(self, "_packed_d", None) is None or self._packed_d[0] is not base:
+            pk = _PackedConv()
+            for name in ("w1p", "b1p", "w2p", "b2p", "bn_scale", "bn_shift", "w1h", "w2h"):
+                setattr(pk, name, getattr(base, name))
+            pk.wsh = pk.bsp = pk.wgh = pk.gh_groups = pk.gh_ld = None
+            pk.gh_fmt, pk.rows_form, pk.rows_bias_k = 0, 1, 1
+            try:
+                wsh, bsp = P.rows_stream(self.spec, self.fc[0].weight, self.fc[0].bias, self.fc[3].weight, self.fc[3].bias, form=1, bias_in_k=True)
+                pk.wsh, pk.bsp = wsh.to(device), bsp.to(device)
+            except NotImplementedError:
+                pk = None
+            self._packed_d = (base, pk)
+        return self._packed_d[1]
 
     def forward(self, node_attr, edge_index, edge_attr, edge_sh, out_nodes=None, reduce="mean", edge_weight=1.0,
                 factorized=False):
@@ -553,6 +582,7 @@ class TensorProductScoreModel(nn.Module):
         # plane form of the factorised convs' G (property g_planes3); DDP_G_PLANES3 = 0 / 1 in the environment sets the default of every model
         # built in the process (the parity suites under the other form: profiles/r06_g3byte_parity.txt)
         self.rows_mfma16 = os.environ.get("DDP_ROWS_MFMA16", ROWS_MFMA16_DEFAULT) == "1"
+        self.direct_rows = os.environ.get("DDP_DIRECT_ROWS", DIRECT_ROWS_DEFAULT) == "1"
         self.g_planes3 = os.environ.get("DDP_G_PLANES3", G_PLANES3_DEFAULT) == "1"
 
     # ---- checkpoint compatibility -------------------------------------------------------------
@@ -745,7 +775,28 @@ class TensorProductScoreModel(nn.Module):
                 if isinstance(m_, TensorProductConvLayer):
                     m_.rows_form = 1 if value else 0
                     m_._packed_g = None
+                    m_._packed = None
             self.__dict__["_rows_checked_epoch"] = None
+            self.__dict__["_packed_epoch"] = self.__dict__.get("_packed_epoch", 0) + 1
+
+    @property
+    def direct_rows(self):
+        """The layers' DIRECT convs (receptor<-atom: one edge per atom, nothing to factorise) through the row-stationary kernel as well
+        (csrc/ddp_conv_rows16.hip: every feature a stream tile, the fc.3 bias in the padding k row - ddp_conv_task_t::rows_bias_k), where
+        the shape allows it (rows_mfma16 on, hid = 180); False: ddp_conv_messages (64-edge workgroups).  Changing it drops the packed weights
+        and captured steps."""
+        return bool(self.__dict__.get("_direct_rows", False))
+
+    @direct_rows.setter
+    def direct_rows(self, value):
+        value = bool(value)
+        if value != self.direct_rows:
+            self.__dict__["_direct_rows"] = value
+            for m_ in self.modules():
+                if isinstance(m_, TensorProductConvLayer):
+                    m_.direct_rows = value
+                    m_._packed_g = None
+                    m_._packed = None
             self.__dict__["_packed_epoch"] = self.__dict__.get("_packed_epoch", 0) + 1
 
     def rows_all_or_none(self, device):

@@ -176,6 +176,11 @@ typedef struct {
    *     32-column stream tile t so that the transposed fc1 product leaves h in that k order: h column 32 t + 8 g + i sits at position
    *     16 (i / 4) + 4 g + i % 4 of the tile (DDP_ROWS16_POS; bias words in position order).  gh_fmt 0 or 1 (form 0: gh_fmt 0 only). */
   int32_t rows_form;
+  /* ABI 17, rows_form 1 only.  1: the bias words of the fc.3 stream tiles ride in the tiles themselves - k row `hid` of every fc.3 tile holds the
+   * tile's bias, fc.0's output column `hid` is the constant 1 (zero weights, bias word 1 at the tile's scale: h[hid] = relu(1)), bsp rows of the
+   * fc.3 tiles are zero and not read; needs hid % 16 != 0 (a padding k).  The kernel then keeps only fc.0's bias words in LDS: shapes with
+   * hundreds of stream tiles (the DIRECT convs: every feature is a stream tile) fit two workgroups per CU.  packing.rows_stream(bias_in_k). */
+  int32_t rows_bias_k;
 } ddp_conv_task_t;
 /* plane scales of ddp_conv_rows' operands: edge_attr_ (split in the kernel), fc.0 / fc.3 weights (task.wsh), h = relu(fc1) (split in
  * the kernel), G (task.gh).  Ranges |edge_attr_|, |h| < 4094, |w| < 255, |G| < 2047; absolute floors 2^-29, 2^-33, 2^-30. */
