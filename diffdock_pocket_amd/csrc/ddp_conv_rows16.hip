@@ -456,7 +456,7 @@ __device__ __forceinline__ void r16_g_runs(const ddp_conv_shape_t& S, const R16G
 
 // One segment = one 32-column part of one weight block's output columns: the factorised features (G runs), then the segment's stream
 // tiles (vector-input features), then the message columns
-template <int NS, int C, int GF>
+template <int NS, int C, int GF, bool DIRECT>
 __device__ __forceinline__ int r16_segment(const R16Launch& RL, const ddp_block_t& B, int bi, int part, const ddp_conv_task_t& T, const h8 (&ah)[NS],
                                            const h8 (&al)[NS], f32x4* ring, const float* lbias, int t, float* F, const R16Aux* aux, unsigned rmask,
                                            int src_reg, int nvw, int wave, int lane) {
@@ -484,12 +484,14 @@ __device__ __forceinline__ int r16_segment(const R16Launch& RL, const ddp_block_
   for (int c = 0; c < C; ++c) res[c] = splat16(0.f);
 
   // ---- factorised features
-  if (B.g_slot >= 0 && rmask != 0u) {
-    const R16GPart PA = r16_gpart_of<GF>(S, T, bi, part);
-    if (PA.nmine > 16)
-      r16_g_runs<NS, C, 2, GF>(S, PA, ah, al, aux, rmask, src_reg, lane, res);
-    else
-      r16_g_runs<NS, C, 1, GF>(S, PA, ah, al, aux, rmask, src_reg, lane, res);
+  if constexpr (!DIRECT) {
+    if (B.g_slot >= 0 && rmask != 0u) {
+      const R16GPart PA = r16_gpart_of<GF>(S, T, bi, part);
+      if (PA.nmine > 16)
+        r16_g_runs<NS, C, 2, GF>(S, PA, ah, al, aux, rmask, src_reg, lane, res);
+      else
+        r16_g_runs<NS, C, 1, GF>(S, PA, ah, al, aux, rmask, src_reg, lane, res);
+    }
   }
 
   // ---- the segment's stream tiles (vector-input features)
@@ -576,8 +578,10 @@ __device__ __forceinline__ int r16_segment(const R16Launch& RL, const ddp_block_
   return t;
 }
 
-template <int SZ, int GF>
-__global__ __launch_bounds__(R16_NT, 2) void ddp_conv_rows16_kernel(const R16Launch RL) {
+// (DIRECT: a shape without factorised blocks - the layers' direct convs, every feature a stream tile: the G runs are compiled out and the
+// kernel carries a name of its own, ddp_conv_rows16_direct_kernel, so that profiles keep the two kinds of launch apart)
+template <int SZ, int GF, bool DIRECT>
+__device__ __forceinline__ void r16_body(const R16Launch& RL) {
   constexpr int NS = H2Class<SZ>::NS, NS2 = NS / 2, RING_Q = 2 * NS * 64;     // the ring holds one tile's worth of pieces
   constexpr int NQ = SZ / 4;     // 16-byte quads per edge_attr_ segment (ns floats each)
   static_assert(NS > 0 && NS % (2 * R16_NP) == 0 && SZ % 4 == 0, "size classes whose k16 steps split into R16_NP pieces of whole k32 steps");
@@ -757,11 +761,20 @@ __global__ __launch_bounds__(R16_NT, 2) void ddp_conv_rows16_kernel(const R16Lau
     const int nparts = (B.n + 31) >> 5;
     for (int part = 0; part < nparts; ++part) {
       if (B.C == 1)
-        t = r16_segment<NS, 1, GF>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane);
+        t = r16_segment<NS, 1, GF, DIRECT>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane);
       else
-        t = r16_segment<NS, 3, GF>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane);
+        t = r16_segment<NS, 3, GF, DIRECT>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane);
     }
   }
+}
+
+template <int SZ, int GF>
+__global__ __launch_bounds__(R16_NT, 2) void ddp_conv_rows16_kernel(const R16Launch RL) {
+  r16_body<SZ, GF, false>(RL);
+}
+template <int SZ>
+__global__ __launch_bounds__(R16_NT, 2) void ddp_conv_rows16_direct_kernel(const R16Launch RL) {
+  r16_body<SZ, 0, true>(RL);
 }
 
 // ------------------------------------------------------------------------------------------------ host (called by ddp_conv_rows for rows_form = 1)
@@ -812,21 +825,31 @@ int ddp_conv_rows16_launch(const ddp_conv_shape_t* shape, const ddp_conv_task_t*
   size_t lds_bytes = (size_t)2 * (NS * 1024) + RL.bias_bytes + (size_t)R16_NW * priv;
   if (2 * lds_bytes > 160 * 1024) return ddp_fail(DDP_ELIMIT, "ddp_conv_rows: LDS budget of two workgroups per CU exceeded (too many vector features per block)");
   if ((size_t)ddp_shape_rows_min_lds > lds_bytes) lds_bytes = (size_t)ddp_shape_rows_min_lds;
-  static int lds_have[4] = {0, 0, 0, 0};
+  static int lds_have[6] = {0, 0, 0, 0, 0, 0};
   hipError_t err;
   const int gf = tasks[0].gh_fmt;
+  const bool direct = shape->g_cols[0] == 0 && shape->g_cols[1] == 0;
 #define R16_LAUNCH(SZ_, GF_, I_)                                                                                             \
   {                                                                                                                          \
     err = ddp_need_lds(reinterpret_cast<const void*>(ddp_conv_rows16_kernel<SZ_, GF_>), (int)lds_bytes, &lds_have[I_]);      \
     if (err != hipSuccess) return ddp_fail_hip(err, "hipFuncSetAttribute(conv rows16)");                                    \
     hipLaunchKernelGGL((ddp_conv_rows16_kernel<SZ_, GF_>), dim3(tiles), dim3(R16_NT), lds_bytes, (hipStream_t)stream, RL);   \
   }
-  if (sc == 60) {
+#define R16_LAUNCH_D(SZ_, I_)                                                                                                \
+  {                                                                                                                          \
+    err = ddp_need_lds(reinterpret_cast<const void*>(ddp_conv_rows16_direct_kernel<SZ_>), (int)lds_bytes, &lds_have[I_]);    \
+    if (err != hipSuccess) return ddp_fail_hip(err, "hipFuncSetAttribute(conv rows16)");                                    \
+    hipLaunchKernelGGL((ddp_conv_rows16_direct_kernel<SZ_>), dim3(tiles), dim3(R16_NT), lds_bytes, (hipStream_t)stream, RL); \
+  }
+  if (direct) {
+    if (sc == 60) R16_LAUNCH_D(60, 4) else R16_LAUNCH_D(32, 5)
+  } else if (sc == 60) {
     if (gf == 1) R16_LAUNCH(60, 1, 2) else R16_LAUNCH(60, 0, 0)
   } else {
     if (gf == 1) R16_LAUNCH(32, 1, 3) else R16_LAUNCH(32, 0, 1)
   }
 #undef R16_LAUNCH
+#undef R16_LAUNCH_D
   err = hipGetLastError();
   if (err != hipSuccess) return ddp_fail_hip(err, "ddp_conv_rows (16x16x32 form) launch");
   return 0;

@@ -89,7 +89,7 @@ class ConvProfiler:
         self.tags.append(tag)
         self.h2.append(bool(h2))     # the launch ran the fp16 hi/lo split form of the fc products
         # (rows: 1 = ddp_conv_rows_kernel, the v_mfma_f32_32x32x16_f16 form; 2 = ddp_conv_rows16_kernel, the 16x16x32 form)
-        self.kernel.append(("ddp_conv_rows16_kernel" if int(rows) == 2 else "ddp_conv_rows_kernel") if rows else
+        self.kernel.append((("ddp_conv_rows16_kernel" if spec.factorized else "ddp_conv_rows16_direct_kernel") if int(rows) == 2 else "ddp_conv_rows_kernel") if rows else
                            "ddp_conv32_kernel" if spec.factorized else "ddp_conv_messages_kernel")
         self.specs.append((spec, flops_spec or spec))
         self.counts.append(tasks_counts)

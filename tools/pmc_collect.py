@@ -27,7 +27,7 @@ import sys
 
 import pandas as pd
 
-CONV = ["ddp_conv_rows16_kernel", "ddp_conv_rows_kernel", "ddp_conv32_kernel", "ddp_conv_messages_kernel"]
+CONV = ["ddp_conv_rows16_kernel", "ddp_conv_rows16_direct_kernel", "ddp_conv_rows_kernel", "ddp_conv32_kernel", "ddp_conv_messages_kernel"]
 OTHER = ["ddp_stage_a_h2_kernel", "ddp_stage_a_mfma_kernel", "ddp_segment_reduce4_kernel", "ddp_segment_reduce_kernel", "ddp_edge_featurize", "ddp_radius", "ddp_knn", "ddp_pose_update"]
 
 

@@ -9,7 +9,7 @@ import sys
 import pandas as pd
 
 d = sys.argv[1]
-want = sys.argv[2:] or ["ddp_conv_rows16_kernel", "ddp_conv_rows_kernel", "ddp_conv32_kernel", "ddp_conv_messages_kernel", "ddp_stage_a_h2_kernel", "ddp_stage_a_mfma_kernel"]
+want = sys.argv[2:] or ["ddp_conv_rows16_kernel", "ddp_conv_rows16_direct_kernel", "ddp_conv_rows_kernel", "ddp_conv32_kernel", "ddp_conv_messages_kernel", "ddp_stage_a_h2_kernel", "ddp_stage_a_mfma_kernel"]
 f = max(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
 c = pd.read_csv(f)
 out = {}
