@@ -354,7 +354,7 @@ __device__ __forceinline__ constexpr unsigned rows_gfrag_lo(int kq, int NS, int 
 // the lo plane of a fragment as the B operand: plane form 0 holds the 8 fp16 words, plane form 1 eight continuation bytes - lo = sign(hi)
 // 2^E(hi) u8 / 2^18: the byte in the mantissa of 2^-8 (0x1C00 | u8), minus 2^-8, times the hi word's sign-and-exponent bits; four packed
 // instructions per pair of values (csrc/ddp_conv_rows16.hip, r16_lo_of: the same)
-typedef float f32x2r __attribute__((ext_vector_type(2)));
+typedef unsigned int f32x2r __attribute__((ext_vector_type(2)));      // (eight continuation bytes: two words, never used as floats)
 template <int GF>
 struct RowsLoT { typedef f32x4 type; };
 template <>
@@ -369,7 +369,7 @@ __device__ __forceinline__ h8 rows_lo_operand(const typename RowsLoT<GF>::type v
     u32x4r out;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const unsigned x = __builtin_amdgcn_perm(0x1c1c1c1cu, __builtin_bit_cast(unsigned, v[i >> 1]), (i & 1) ? 0x07030602u : 0x05010400u);
+      const unsigned x = __builtin_amdgcn_perm(0x1c1c1c1cu, v[i >> 1], (i & 1) ? 0x07030602u : 0x05010400u);
       const h2 y = __builtin_bit_cast(h2, x) - c;
       out[i] = __builtin_bit_cast(unsigned, y * __builtin_bit_cast(h2, hw[i] & 0xfc00fc00u));
     }

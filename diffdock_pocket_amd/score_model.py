@@ -317,7 +317,12 @@ class TensorProductConvLayer(nn.Module):
             task = _make_task(pk, x, x.shape[1], so, sh, segs, msg, g=g, rows=rows)
             _launch_convs(self.spec_g, [task], flops_spec=self.spec)
         else:
-            task = _make_task(self.packed(dev), x, x.shape[1], csr, sh, [(ea, csr.eid, ea.shape[1], ea.shape[1])], msg)
+            pkr = self.packed_rows_direct(dev) if ea.shape[1] % 12 == 0 else None      # (the row-stationary kernel's direct form: direct_rows)
+            if pkr is not None and K.rows_mode(pkr):
+                w3 = ea.shape[1] // 3
+                task = _make_task(pkr, x, x.shape[1], csr, sh, [(ea[:, i * w3:], csr.eid, ea.shape[1], w3) for i in range(3)], msg, rows=True)
+            else:
+                task = _make_task(self.packed(dev), x, x.shape[1], csr, sh, [(ea, csr.eid, ea.shape[1], ea.shape[1])], msg)
             _launch_convs(self.spec, [task])
         out = torch.zeros((n_out, self.spec.d_out), device=dev, dtype=torch.float32)
         _launch_reduce(out, self.spec.d_out, n_out, self.spec.d_out, [(msg, csr, self.packed(dev))], accumulate=False)

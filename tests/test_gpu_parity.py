@@ -636,10 +636,13 @@ def test_forward_is_deterministic():
                                               # vector blocks wider than one 16-column tile of the row-stationary kernel (nv > 16): two column tiles in
                                               # their G runs, layer 0 without and layer 1 with stream tiles (24 features: the general feature path)
                                               (60, 20, 0, 150, 9), (32, 24, 1, 170, 11)])
-@pytest.mark.parametrize("factorized", [False, True])
-def test_single_conv_layer(ns, nv, layer, E, N, factorized):
+@pytest.mark.parametrize("factorized,form,fmt", [(False, 0, 0), (False, 1, 0), (True, 1, 1), (True, 1, 0), (True, 0, 1), (True, 0, 0)])
+def test_single_conv_layer(ns, nv, layer, E, N, factorized, form, fmt):
     """TensorProductConvLayer.forward with the reference call signature (models/score_model.py:108) on ragged
-    edge sets: partial tiles, receivers without edges, repeated receivers."""
+    edge sets: partial tiles, receivers without edges, repeated receivers.  Factorised: through both forms of the row-stationary kernel
+    (ddp_conv_task_t::rows_form: 1 = v_mfma_f32_16x16x32_f16, the model's default) and both plane forms of G (gh_fmt: 1 = fp16 hi +
+    continuation byte, the model's default) where the shape is one of that kernel's - a stand-alone layer has no model to set them; direct
+    with form 1: through ddp_conv_rows16_direct_kernel (model.direct_rows: every feature a stream tile, the bias in k, feature chunks)."""
     from diffdock_pocket_amd import packing as P
     from diffdock_pocket_amd.score_model import TensorProductConvLayer
     torch.manual_seed(ns + layer + E)
@@ -661,7 +664,14 @@ def test_single_conv_layer(ns, nv, layer, E, N, factorized):
     want = OracleScoreModel(cfg, sd)._conv("c", cfg.irreps(layer), cfg.irreps(layer + 1), x, ei, ea, sh)
     dev = _dev()
     conv = conv.to(dev)
+    conv.rows_form, conv.gh_fmt = form, fmt
+    conv.direct_rows = bool(form) and not factorized      # (False, 1, 0): the DIRECT conv through ddp_conv_rows16_direct_kernel where the shape allows it (ns = 60)
     got = conv(x.to(dev), ei.to(dev), ea.to(dev), sh.to(dev), factorized=factorized).cpu()
+    if conv.direct_rows and ns == 60:
+        assert conv.packed_rows_direct(dev) is not None and conv.packed_rows_direct(dev).rows_bias_k == 1
+    if factorized and ns in (60, 32) and P.rows_supported(conv.spec_g):
+        pk = conv.packed_g(dev)
+        assert pk.wsh is not None and pk.rows_form == form and pk.gh_fmt == fmt      # (it ran through the kernel form and plane form asked for)
     assert got.shape == want.shape
     assert rel_err(got, want) < 2e-5, rel_err(got, want)
     # empty edge set: scalar zero, like the reference (models/score_model.py:109-111)
@@ -669,8 +679,9 @@ def test_single_conv_layer(ns, nv, layer, E, N, factorized):
     assert z.dim() == 0 and float(z) == 0.0
 
 
+@pytest.mark.parametrize("form,fmt", [(1, 1), (0, 0)])
 @pytest.mark.parametrize("mag", [1.0, 1e-2, 1e-4])
-def test_rows_kernel_operand_planes_at_small_magnitudes(mag):
+def test_rows_kernel_operand_planes_at_small_magnitudes(mag, form, fmt):
     """ddp_conv_rows computes on UNIFIED fp16 hi/lo planes (V = v 2^s = hi + lo, both halves at one scale: include/ddp_hip.h DDP_ROWS_S*):
     22 significant bits while lo is a normal fp16 number, an ABSOLUTE floor of 2^-25 / 2^s per operand element below that (2^-29 for
     edge_attr_ and h, 2^-33 for the fc weights, 2^-30 for G).  Asserted here on a factorised ns = 60 conv whose edge_attr_ AND node
@@ -695,6 +706,7 @@ def test_rows_kernel_operand_planes_at_small_magnitudes(mag):
     want = OracleScoreModel(cfg, sd)._conv("c", cfg.irreps(layer), cfg.irreps(layer + 1), x, ei, ea, sh)
     dev = _dev()
     conv = conv.to(dev)
+    conv.rows_form, conv.gh_fmt = form, fmt      # (1, 1: the model's defaults - the 16x16x32 kernel, G as fp16 hi + continuation byte: absolute 2^-24 / 32 on G below |32 G| = 2^-14)
     assert K.CONV_ROWS and conv.packed_g(dev).wsh is not None      # (the row-stationary kernel's weight stream exists: this conv runs through it)
     got = conv(x.to(dev), ei.to(dev), ea.to(dev), sh.to(dev), factorized=True).cpu()
     rows_was = K.CONV_ROWS
