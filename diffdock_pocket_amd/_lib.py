@@ -53,7 +53,7 @@ class ConvTask(C.Structure):
                 ("seg_n", C.c_int32 * DDP_MAX_SEGS), ("w1p", C.c_void_p), ("b1p", C.c_void_p), ("w2p", C.c_void_p),
                 ("b2p", C.c_void_p), ("msg", C.c_void_p), ("g", C.c_void_p * 2),
                 ("pos", C.c_void_p), ("n_edges_dev", C.c_void_p), ("w1h", C.c_void_p), ("w2h", C.c_void_p), ("h2_range_flag", C.c_void_p),
-                ("wsh", C.c_void_p), ("bsp", C.c_void_p), ("gh", C.c_void_p * 2), ("gh_fmt", C.c_int32), ("rows_form", C.c_int32), ("rows_bias_k", C.c_int32)]
+                ("wsh", C.c_void_p), ("bsp", C.c_void_p), ("gh", C.c_void_p * 2), ("gh_fmt", C.c_int32), ("rows_form", C.c_int32), ("rows_bias_k", C.c_int32), ("rows_seg0", C.c_int32), ("rows_seg1", C.c_int32), ("rows_nts", C.c_int32)]
 
 
 class ReduceSrc(C.Structure):

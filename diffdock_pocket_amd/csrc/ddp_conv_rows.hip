@@ -949,7 +949,8 @@ extern "C" int ddp_conv_rows(const ddp_conv_shape_t* shape, const ddp_conv_task_
     if (gfmt >= 0 && T.gh_fmt != gfmt) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: the tasks of a launch carry G in ONE plane form");
     gfmt = T.gh_fmt;
     if (T.rows_form != 0 && T.rows_form != 1) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: task.rows_form must be 0 or 1");
-    if (T.rows_bias_k != 0 && T.rows_form != 1) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: task.rows_bias_k needs rows_form 1");
+    if ((T.rows_bias_k != 0 || T.rows_seg0 != 0 || T.rows_seg1 != 0 || T.rows_nts != 0) && T.rows_form != 1)
+      return ddp_fail(DDP_EINVAL, "ddp_conv_rows: task.rows_bias_k / rows_seg0 / rows_seg1 / rows_nts need rows_form 1");
     if (form >= 0 && T.rows_form != form) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: the tasks of a launch carry ONE form of operand images");
     form = T.rows_form;
     if (T.n_edges_dev) L.dev_counts = 1;

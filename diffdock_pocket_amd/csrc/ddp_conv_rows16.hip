@@ -459,10 +459,10 @@ __device__ __forceinline__ void r16_g_runs(const ddp_conv_shape_t& S, const R16G
 template <int NS, int C, int GF, bool DIRECT>
 __device__ __forceinline__ int r16_segment(const R16Launch& RL, const ddp_block_t& B, int bi, int part, const ddp_conv_task_t& T, const h8 (&ah)[NS],
                                            const h8 (&al)[NS], f32x4* ring, const float* lbias, int t, float* F, const R16Aux* aux, unsigned rmask,
-                                           int src_reg, int nvw, int wave, int lane) {
+                                           int src_reg, int nvw, int wave, int lane, int nts) {
   const ddp_conv_shape_t& S = RL.L.shape;
   const int n = lane & 15, g = lane >> 4;
-  const R16Stream wsh = r16_stream_of(T.wsh, RL.nts, 2 * NS * 1024);
+  const R16Stream wsh = r16_stream_of(T.wsh, nts, 2 * NS * 1024);
   // lane -> (output channel, feature slot) of the segment's tiles, per 16-column tile ct: column 16 ct + n of the 32-column tile
   int ncol[2], us[2];
   bool valid[2];
@@ -508,7 +508,7 @@ __device__ __forceinline__ int r16_segment(const R16Launch& RL, const ddp_block_
       r16_build_features_range(B, T, aux, F, lane, u0, min(B.U, u0 + tpc * upt));
     }
     f32x4 acc[4];
-    r16_stream_step<NS, 0>(ring, wsh, t, RL.nts, wave, lane);
+    r16_stream_step<NS, 0>(ring, wsh, t, nts, wave, lane);
     {
       // (rows_bias_k: the tile's bias is its k row `hid`, times h[hid] = 1)
       const bool bt = t < RL.bias_tiles;
@@ -519,9 +519,9 @@ __device__ __forceinline__ int r16_segment(const R16Launch& RL, const ddp_block_
       acc[3] = r16_splat4(b1);
     }
     r16_piece<NS, 0>(ring, ah, al, lane, acc);                      // (piece p of every tile sits in slot p)
-    r16_stream_step<NS, 1>(ring, wsh, t, RL.nts, wave, lane);
+    r16_stream_step<NS, 1>(ring, wsh, t, nts, wave, lane);
     r16_piece<NS, 1>(ring + PIECE_Q, ah, al, lane, acc);
-    r16_stream_step<NS, 2>(ring, wsh, t, RL.nts, wave, lane);
+    r16_stream_step<NS, 2>(ring, wsh, t, nts, wave, lane);
     r16_piece<NS, 2>(ring + 2 * PIECE_Q, ah, al, lane, acc);
     // the feature contraction in the D layout: out[c][row, column] += F[(u c)][row] * acc[row, column]
 #pragma unroll
@@ -596,7 +596,8 @@ __device__ __forceinline__ void r16_body(const R16Launch& RL) {
   f32x4* ring = reinterpret_cast<f32x4*>(lds);
   float* lbias = lds + RING_Q * 4;                                        // [nts][32] bias words of the stream tiles
   char* priv = reinterpret_cast<char*>(lds) + RING_Q * 16 + RL.bias_bytes + (size_t)wave * RL.priv_bytes;
-  const R16Stream wsh = r16_stream_of(T.wsh, RL.nts, 2 * NS * 1024);
+  const int nts = (T.rows_nts > 0) ? T.rows_nts : RL.nts;      // stream tiles of THIS task (a task of a segment range has a stream of its own)
+  const R16Stream wsh = r16_stream_of(T.wsh, nts, 2 * NS * 1024);
   const int nvw = max(0, min(32, nvalid - 32 * wave));      // valid edges of this wave
 
   // ---- the wave's edges (rows behind the last valid one repeat it: every load stays in bounds, nothing of theirs is stored).  Per-edge
@@ -629,8 +630,8 @@ __device__ __forceinline__ void r16_body(const R16Launch& RL) {
   }
 
   // ---- request tiles 0 / 1 of the stream; the tiles' bias words: one table in LDS for the whole kernel
-  r16_request_piece<NS>(ring, wsh, 0, R16_NP * RL.nts, 0, wave, lane);
-  r16_request_piece<NS>(ring, wsh, 1, R16_NP * RL.nts, 1, wave, lane);
+  r16_request_piece<NS>(ring, wsh, 0, R16_NP * nts, 0, wave, lane);
+  r16_request_piece<NS>(ring, wsh, 1, R16_NP * nts, 1, wave, lane);
   for (int i = tid; i < RL.bias_tiles * 32; i += R16_NT) lbias[i] = T.bsp[i];
   // ---- edge_attr_ of the wave's edges as B-operand fragments: lane (edge n of tile et, g) holds k = 32 s + 8 g + i.  hi plane in registers,
   // lo plane in the wave's private LDS area (each lane reads back what it wrote); image index 2 s + et
@@ -678,9 +679,9 @@ __device__ __forceinline__ void r16_body(const R16Launch& RL) {
 #pragma unroll
     for (int pc = 0; pc < R16_NP; ++pc) {
       constexpr int KPP = NS / R16_NP, KP2 = KPP / 2, PIECE_Q = 2 * KPP * 64;
-      if (pc == 0) r16_stream_step<NS, 0>(ring, wsh, t, RL.nts, wave, lane);
-      else if (pc == 1) r16_stream_step<NS, 1>(ring, wsh, t, RL.nts, wave, lane);
-      else r16_stream_step<NS, 2>(ring, wsh, t, RL.nts, wave, lane);
+      if (pc == 0) r16_stream_step<NS, 0>(ring, wsh, t, nts, wave, lane);
+      else if (pc == 1) r16_stream_step<NS, 1>(ring, wsh, t, nts, wave, lane);
+      else r16_stream_step<NS, 2>(ring, wsh, t, nts, wave, lane);
       if (pc == 0) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -746,9 +747,17 @@ __device__ __forceinline__ void r16_body(const R16Launch& RL) {
     }
   }
 
-  // ---- the segments: blocks in order, the 32-column parts of a block in order
+  // ---- the segments: blocks in order, the 32-column parts of a block in order; a task of a segment RANGE (ddp_conv_task_t::rows_seg0 / 1)
+  // walks only those - its weight stream holds only their tiles
+  const int seg0 = T.rows_seg0, seg1 = (T.rows_seg1 > 0) ? T.rows_seg1 : 0x7fffffff;
+  int sgi = 0;
   for (int bi = 0; bi < S.nblocks; ++bi) {
     const ddp_block_t& B = S.blk[bi];
+    const int nparts = (B.n + 31) >> 5;
+    if (sgi >= seg1 || sgi + nparts <= seg0) {      // (none of the block's parts is this task's)
+      sgi += nparts;
+      continue;
+    }
     if (B.ntiles > 0 && B.U > 0 && B.U * B.C <= RL.frows) {
       bool fast = true;     // (vector-input segments of at most 16 features: the factorised shapes of nv <= 16)
       for (int si = 0; si < B.nseg; ++si)
@@ -758,12 +767,12 @@ __device__ __forceinline__ void r16_body(const R16Launch& RL) {
       else
         build_features<32, 2>(B, T, aux->src, aux->sh, F, lane);
     }
-    const int nparts = (B.n + 31) >> 5;
-    for (int part = 0; part < nparts; ++part) {
+    for (int part = 0; part < nparts; ++part, ++sgi) {
+      if (sgi < seg0 || sgi >= seg1) continue;
       if (B.C == 1)
-        t = r16_segment<NS, 1, GF, DIRECT>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane);
+        t = r16_segment<NS, 1, GF, DIRECT>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane, nts);
       else
-        t = r16_segment<NS, 3, GF, DIRECT>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane);
+        t = r16_segment<NS, 3, GF, DIRECT>(RL, B, bi, part, T, ah, al, ring, lbias, t, F, aux, rmask, src, nvw, wave, lane, nts);
     }
   }
 }
@@ -800,6 +809,9 @@ int ddp_conv_rows16_launch(const ddp_conv_shape_t* shape, const ddp_conv_task_t*
     const ddp_conv_task_t& T = tasks[i];
     if (T.n_edges <= 0) continue;
     if (T.gh_fmt != tasks[0].gh_fmt || (unsigned)T.gh_fmt > 1u) return ddp_fail(DDP_EINVAL, "ddp_conv_rows: the tasks of a launch carry one plane form of G (gh_fmt 0 or 1)");
+    if (T.rows_seg0 < 0 || T.rows_seg1 < 0 || T.rows_nts < 0 || (T.rows_seg1 > 0 && (T.rows_seg1 <= T.rows_seg0 || T.rows_nts < nct1)) ||
+        (T.rows_nts > nts) || (T.rows_seg1 > 0 && !T.rows_bias_k))      // (a range's bias table is fc.0's: rows_bias_k)
+      return ddp_fail(DDP_EINVAL, "ddp_conv_rows: task.rows_seg0 / rows_seg1 / rows_nts");
     if (T.rows_bias_k != tasks[0].rows_bias_k || (unsigned)T.rows_bias_k > 1u || (T.rows_bias_k && (shape->hid & 15) == 0))
       return ddp_fail(DDP_EINVAL, "ddp_conv_rows: rows_bias_k is 0 or 1 for all tasks of a launch and needs hid % 16 != 0");
     if (T.n_edges_dev) L.dev_counts = 1;

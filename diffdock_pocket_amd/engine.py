@@ -964,9 +964,15 @@ class ForwardEngine:
                     nb_d += node_bytes(l, k)
                 segs = [(e[ek], csr.eid, ns, ns), (x_recv, csr.recv, ldx, ns), (x_src, csr.src, ldx, ns)]
                 # (model.direct_rows: through the row-stationary kernel - 128-edge workgroups stream the fc.3 tiles once per 128 edges)
-                pkr = m.conv_layers[9 * l + k].packed_rows_direct(dev)
-                if pkr is not None and K.rows_mode(pkr):
-                    tasks.append(K.make_task(pkr, x_src, ldx, csr, sh[ek], segs, msg, rows=True))
+                # one conv as several tasks of segment ranges where 128-edge workgroups of all its tiles would not fill the chip's 512 slots
+                nsplit = max(1, min(m.direct_rows_max_split, -(-512 // max(1, -(-csr.n_edges // 128)))))
+                pkr = m.conv_layers[9 * l + k].packed_rows_direct(dev, nsplit) if nsplit > 1 else m.conv_layers[9 * l + k].packed_rows_direct(dev)
+                if pkr is not None and all(K.rows_mode(p_) for p_ in (pkr if nsplit > 1 else [pkr])):
+                    for i_, p_ in enumerate(pkr if nsplit > 1 else [pkr]):
+                        t_ = K.make_task(p_, x_src, ldx, csr, sh[ek], segs, msg, rows=True)
+                        if i_:
+                            t_._count = (0, None)      # (the profiler counts a conv's edges once)
+                        tasks.append(t_)
                 else:
                     tasks.append(K.make_task(pkc, x_src, ldx, csr, sh[ek], segs, msg))
             P.tasks, P.nb_d = tasks, nb_d

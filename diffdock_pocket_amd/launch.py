@@ -269,6 +269,8 @@ def make_task(pk, x_src, ldx_src, view: EdgeView, sh, segs, msg, g=None, rows=Fa
     t.gh_fmt = int(getattr(pk, "gh_fmt", 0)) if rows else 0
     t.rows_form = int(getattr(pk, "rows_form", 0)) if rows else 0
     t.rows_bias_k = int(getattr(pk, "rows_bias_k", 0)) if rows else 0
+    t.rows_seg0, t.rows_seg1 = (int(v) for v in getattr(pk, "rows_seg", (0, 0))) if rows else (0, 0)
+    t.rows_nts = int(getattr(pk, "rows_nts", 0)) if rows else 0
     t._rows = bool(rows)
     t.pos = _p(view.pos)
     t.n_edges_dev = _p(view.cnt)

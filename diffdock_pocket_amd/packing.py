@@ -596,7 +596,25 @@ def rows_segments(spec: "ConvSpec"):
     return segs
 
 
-def rows_stream(spec: "ConvSpec", w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, form: int = 0, bias_in_k: bool = False):
+def rows_split_segments(spec: "ConvSpec", nsplit: int):
+    """[(seg0, seg1, fc.3 tiles)]: the shape's output segments (rows_segments order) cut into at most nsplit contiguous ranges, the largest
+    range as small as possible (ddp_conv_task_t::rows_seg0 / rows_seg1: one conv spread over several workgroups per 128 edges)."""
+    import itertools
+    counts = [len(t) for _, _, t in rows_segments(spec)]
+    n = len(counts)
+    nsplit = max(1, min(nsplit, n))
+    best = None
+    for cuts in itertools.combinations(range(1, n), nsplit - 1):
+        edges = (0,) + cuts + (n,)
+        sums = [sum(counts[a:b]) for a, b in zip(edges[:-1], edges[1:])]
+        if best is None or max(sums) < best[0]:
+            best = (max(sums), edges, sums)
+    _, edges, sums = best
+    return [(a, b, c) for a, b, c in zip(edges[:-1], edges[1:], sums)]
+
+
+def rows_stream(spec: "ConvSpec", w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, form: int = 0, bias_in_k: bool = False,
+                seg_range=None):
     """(wsh, bsp) of ddp_conv_task_t for ddp_conv_rows: fc.0's nct1 column tiles (natural k order: their K is edge_attr_), then the fc.3
     tiles of `spec` (block scale folded in) segment by segment with the k index permuted by rows_kperm; UNIFIED fp16 hi/lo planes of
     ROWS_SW w per tile (_pack_tiles_h2), the bias words fp32 [tiles, 32] at the scale of their tile's accumulator (fc.0: ROWS_SW ROWS_SX,
@@ -605,7 +623,8 @@ def rows_stream(spec: "ConvSpec", w1: torch.Tensor, b1: torch.Tensor, w2: torch.
     (_pack_tiles_16): fc.0's output columns placed by rows16_pos inside every 32-column tile (bias words in the same positions), the k of
     the fc.3 tiles in natural order.
     bias_in_k (ddp_conv_task_t::rows_bias_k, form 1): fc.0 gets an output column `hid` with zero weights and bias 1 (h[hid] = relu(1) = 1),
-    every fc.3 tile its bias as k row `hid`; the bias words of the fc.3 tiles are zero."""
+    every fc.3 tile its bias as k row `hid`; the bias words of the fc.3 tiles are zero.
+    seg_range = (seg0, seg1): fc.0's tiles followed by the tiles of those segments only (ddp_conv_task_t::rows_seg0 / rows_seg1)."""
     ns16 = h2_steps(spec)
     assert ns16 > 0
     hid, f_in = w1.shape
@@ -637,7 +656,10 @@ def rows_stream(spec: "ConvSpec", w1: torch.Tensor, b1: torch.Tensor, w2: torch.
         bc[valid] = b2[rows[valid]] * b.scale
         cols.append(Wc)
         bcols.append(bc)
-    order = [t for _, _, tiles in rows_segments(spec) for t in tiles]
+    segs = rows_segments(spec)
+    if seg_range is not None:
+        segs = segs[seg_range[0]:seg_range[1]]
+    order = [t for _, _, tiles in segs for t in tiles]
     if order:
         Wall = torch.cat(cols, 0)                                   # [ntiles * 32, hid]
         Wp = torch.zeros(Wall.shape[0], 16 * ns16)

@@ -146,7 +146,7 @@ def _mlp(n_in, n_hidden, n_out, dropout):
 
 class _PackedConv:
     __slots__ = ("w1p", "b1p", "w2p", "b2p", "bn_scale", "bn_shift", "wg", "bg", "g_in_off", "w1h", "w2h",
-                 "wsh", "bsp", "wgh", "gh_groups", "gh_ld", "gh_fmt", "rows_form", "rows_bias_k")     # (the last seven: ddp_conv_rows' weight stream and stage-A right-hand sides)
+                 "wsh", "bsp", "wgh", "gh_groups", "gh_ld", "gh_fmt", "rows_form", "rows_bias_k", "rows_seg", "rows_nts")     # (the last seven: ddp_conv_rows' weight stream and stage-A right-hand sides)
 
 
 G_PLANES3_DEFAULT = "1"      # model.g_planes3 unless DDP_G_PLANES3 says otherwise (round 6, late: the 19-bit form is the default)
@@ -192,7 +192,7 @@ class TensorProductConvLayer(nn.Module):
             # the 128-edge row-stationary kernel (ddp_conv_rows; size classes ns = 60 / 32): the fc.0 / fc.3 tiles as one stream in the
             # kernel's k order, and stage-A right-hand sides whose product ddp_stage_a_gh writes as fp16 hi/lo planes
             pk.wsh = pk.bsp = pk.wgh = pk.gh_groups = pk.gh_ld = None
-            pk.rows_bias_k = 0
+            pk.rows_bias_k, pk.rows_seg, pk.rows_nts = 0, (0, 0), 0
             pk.gh_fmt = int(getattr(self, "gh_fmt", 0))     # plane form of G (ddp_conv_task_t::gh_fmt; set by the model: g_planes3)
             pk.rows_form = int(getattr(self, "rows_form", 0))   # operand images of the rows kernel (ddp_conv_task_t::rows_form: rows_mfma16)
             if P.rows_supported(self.spec_g):
@@ -258,33 +258,49 @@ class TensorProductConvLayer(nn.Module):
                 pk.w1h = P.pack_fc1_h2(self.spec, self.fc[0].weight).to(device)
                 pk.w2h = P.pack_fc2_h2(self.spec, self.fc[3].weight).to(device)
             pk.wsh = pk.bsp = pk.wgh = pk.gh_groups = pk.gh_ld = None
-            pk.gh_fmt, pk.rows_form, pk.rows_bias_k = 0, 0, 0
+            pk.gh_fmt, pk.rows_form, pk.rows_bias_k, pk.rows_seg, pk.rows_nts = 0, 0, 0, (0, 0), 0
             self._packed = pk
             self._packed_d = None
         return self._packed
 
-    def packed_rows_direct(self, device) -> Optional[_PackedConv]:
+    def packed_rows_direct(self, device, nsplit: int = 1):
         """The DIRECT conv through the row-stationary kernel (round 6: rows_form 1, the fc.3 bias in the padding k row - packing.rows_stream(
-        bias_in_k)): packed() plus the weight stream, built on first use (8 MB per conv: only the convs that run direct get one).  None where
-        the option is off, the shape is not one of the kernel's, or a weight / bias lies beyond the unified planes' range (ddp_conv_messages
-        then)."""
+        bias_in_k)): packed() plus the weight stream, built on first use (8 MB per conv: only the convs that run direct get one).  nsplit > 1:
+        a LIST of packs, one per range of output segments (packing.rows_split_segments; each with fc.0's tiles and its own segments' tiles:
+        ddp_conv_task_t::rows_seg0 / rows_seg1 / rows_nts) - the tasks of one conv spread over several workgroups per 128 edges; nsplit = 1:
+        the one pack.  None where the option is off, the shape is not one of the kernel's, or a weight / bias lies beyond the unified planes'
+        range (ddp_conv_messages then)."""
         base = self.packed(device)
         if not (bool(getattr(self, "direct_rows", False)) and int(getattr(self, "rows_form", 0)) == 1 and not self.spec.factorized
                 and P.rows_supported(self.spec)):
             return None
         if getattr(self, "_packed_d", None) is None or self._packed_d[0] is not base:
-            pk = _PackedConv()
-            for name in ("w1p", "b1p", "w2p", "b2p", "bn_scale", "bn_shift", "w1h", "w2h"):
-                setattr(pk, name, getattr(base, name))
-            pk.wsh = pk.bsp = pk.wgh = pk.gh_groups = pk.gh_ld = None
-            pk.gh_fmt, pk.rows_form, pk.rows_bias_k = 0, 1, 1
-            try:
-                wsh, bsp = P.rows_stream(self.spec, self.fc[0].weight, self.fc[0].bias, self.fc[3].weight, self.fc[3].bias, form=1, bias_in_k=True)
-                pk.wsh, pk.bsp = wsh.to(device), bsp.to(device)
-            except NotImplementedError:
-                pk = None
-            self._packed_d = (base, pk)
-        return self._packed_d[1]
+            self._packed_d = (base, {})
+        cache = self._packed_d[1]
+        ranges = P.rows_split_segments(self.spec, nsplit) if nsplit > 1 else [None]
+        key = len(ranges)
+        if key not in cache:
+            pks = []
+            for rg in ranges:
+                pk = _PackedConv()
+                for name in ("w1p", "b1p", "w2p", "b2p", "bn_scale", "bn_shift", "w1h", "w2h"):
+                    setattr(pk, name, getattr(base, name))
+                pk.wsh = pk.bsp = pk.wgh = pk.gh_groups = pk.gh_ld = None
+                pk.gh_fmt, pk.rows_form, pk.rows_bias_k = 0, 1, 1
+                pk.rows_seg, pk.rows_nts = ((rg[0], rg[1]), self.spec.nct1 + rg[2]) if rg is not None else ((0, 0), 0)
+                try:
+                    wsh, bsp = P.rows_stream(self.spec, self.fc[0].weight, self.fc[0].bias, self.fc[3].weight, self.fc[3].bias, form=1, bias_in_k=True,
+                                             seg_range=None if rg is None else (rg[0], rg[1]))
+                    pk.wsh, pk.bsp = wsh.to(device), bsp.to(device)
+                    pks.append(pk)
+                except NotImplementedError:
+                    pks = None
+                    break
+            cache[key] = pks
+        pks = cache[key]
+        if pks is None:
+            return None
+        return pks if nsplit > 1 else pks[0]
 
     def forward(self, node_attr, edge_index, edge_attr, edge_sh, out_nodes=None, reduce="mean", edge_weight=1.0,
                 factorized=False):
@@ -588,6 +604,9 @@ class TensorProductScoreModel(nn.Module):
         # built in the process (the parity suites under the other form: profiles/r06_g3byte_parity.txt)
         self.rows_mfma16 = os.environ.get("DDP_ROWS_MFMA16", ROWS_MFMA16_DEFAULT) == "1"
         self.direct_rows = os.environ.get("DDP_DIRECT_ROWS", DIRECT_ROWS_DEFAULT) == "1"
+        # a direct conv through the rows kernel as up to this many tasks of segment ranges where its 128-edge workgroups would not fill the chip
+        # (engine.direct_tasks: ceil(512 / workgroups), at most this; 1 = never split)
+        self.direct_rows_max_split = int(os.environ.get("DDP_DIRECT_SPLIT", "6"))
         self.g_planes3 = os.environ.get("DDP_G_PLANES3", G_PLANES3_DEFAULT) == "1"
 
     # ---- checkpoint compatibility -------------------------------------------------------------

@@ -181,6 +181,11 @@ typedef struct {
    * fc.3 tiles are zero and not read; needs hid % 16 != 0 (a padding k).  The kernel then keeps only fc.0's bias words in LDS: shapes with
    * hundreds of stream tiles (the DIRECT convs: every feature is a stream tile) fit two workgroups per CU.  packing.rows_stream(bias_in_k). */
   int32_t rows_bias_k;
+  /* ABI 17, rows_form 1 only.  A task may cover a RANGE of the shape's output segments (block, 32-column part; in the order the kernel walks
+   * them): segments [rows_seg0, rows_seg1) - 0, 0 = all.  wsh / bsp then hold fc.0's tiles followed by the tiles of THOSE segments only,
+   * rows_nts tiles in all (0 = the shape's count).  Several tasks with the same edges and msg and disjoint ranges = one conv spread over
+   * several workgroups per 128 edges (the direct convs of small batches: 340 tiles per workgroup otherwise); every range recomputes fc1. */
+  int32_t rows_seg0, rows_seg1, rows_nts;
 } ddp_conv_task_t;
 /* plane scales of ddp_conv_rows' operands: edge_attr_ (split in the kernel), fc.0 / fc.3 weights (task.wsh), h = relu(fc1) (split in
  * the kernel), G (task.gh).  Ranges |edge_attr_|, |h| < 4094, |w| < 255, |G| < 2047; absolute floors 2^-29, 2^-33, 2^-30. */
