@@ -964,8 +964,10 @@ class ForwardEngine:
                     nb_d += node_bytes(l, k)
                 segs = [(e[ek], csr.eid, ns, ns), (x_recv, csr.recv, ldx, ns), (x_src, csr.src, ldx, ns)]
                 # (model.direct_rows: through the row-stationary kernel - 128-edge workgroups stream the fc.3 tiles once per 128 edges)
-                # one conv as several tasks of segment ranges where 128-edge workgroups of all its tiles would not fill the chip's 512 slots
-                nsplit = max(1, min(m.direct_rows_max_split, -(-512 // max(1, -(-csr.n_edges // 128)))))
+                # one conv as several tasks of segment ranges where its 128-edge workgroups would leave most of the chip empty (measured: 44
+                # workgroups of 340 tiles - the 5-sample shard - 0.36 -> 0.155 ms per launch as six ranges; 347 workgroups - 40 samples - gain
+                # nothing from two ranges, profiles/r06_direct_rows_ab.txt): ceil(256 / workgroups) ranges, at most direct_rows_max_split
+                nsplit = max(1, min(m.direct_rows_max_split, -(-256 // max(1, -(-csr.n_edges // 128)))))
                 pkr = m.conv_layers[9 * l + k].packed_rows_direct(dev, nsplit) if nsplit > 1 else m.conv_layers[9 * l + k].packed_rows_direct(dev)
                 if pkr is not None and all(K.rows_mode(p_) for p_ in (pkr if nsplit > 1 else [pkr])):
                     for i_, p_ in enumerate(pkr if nsplit > 1 else [pkr]):

@@ -721,3 +721,41 @@ def test_rows_kernel_options_are_consistent(monkeypatch):
             monkeypatch.setenv("DDP_ROWS_MFMA16", v16)
             m2 = TensorProductScoreModel(**kw)
             assert m2.g_planes3 == (v3 == "1") and m2.rows_mfma16 == (v16 == "1")
+
+
+def test_direct_conv_weight_streams_of_segment_ranges():
+    """ddp_conv_task_t::rows_seg0 / rows_seg1 / rows_nts (a direct conv as several tasks of output-segment ranges, each with a weight stream of
+    its own): packing.rows_split_segments cuts the shape's segments into contiguous ranges that cover them once, the largest as small as
+    possible; the ranges' streams (fc.0's tiles, then the range's tiles) put together are the whole stream; with bias_in_k the fc.3 bias words
+    are zero, k row `hid` of every fc.3 tile holds the tile's bias and fc.0's output column `hid` is the constant 1."""
+    from diffdock_pocket_amd import packing as P
+    g = torch.Generator().manual_seed(3)
+    ns, nv, layer = 60, 10, 3
+    spec = P.faster_tp_spec(P.irreps_muls(ns, nv, layer), P.irreps_muls(ns, nv, layer + 1), 3 * ns)
+    assert not spec.factorized and P.rows_bias_in_k(spec) and P.rows_supported(spec)
+    hid = 3 * ns
+    w1, b1 = torch.randn(hid, hid, generator=g) * 0.07, torch.randn(hid, generator=g) * 0.1
+    w2, b2 = torch.randn(spec.weight_numel, hid, generator=g) * 0.07, torch.randn(spec.weight_numel, generator=g) * 0.1
+    counts = [len(t) for _, _, t in P.rows_segments(spec)]
+    for n in (1, 2, 3, 6, 9):
+        rg = P.rows_split_segments(spec, n)
+        assert len(rg) == min(n, len(counts)) and rg[0][0] == 0 and rg[-1][1] == len(counts)
+        assert all(a[1] == b[0] for a, b in zip(rg[:-1], rg[1:])) and [c for _, _, c in rg] == [sum(counts[a:b]) for a, b, _ in rg]
+    assert [c for _, _, c in P.rows_split_segments(spec, 2)] == [167, 167]
+    whole, bs = P.rows_stream(spec, w1, b1, w2, b2, form=1, bias_in_k=True)
+    tile = 2 * 12 * 1024 // 2                      # halves per tile (NS = 12)
+    whole = whole.reshape(-1, tile)
+    n1 = spec.nct1
+    assert whole.shape[0] == n1 + sum(counts) and bs.shape == (n1 + sum(counts), 32)
+    assert float(bs[n1:].abs().max()) == 0.0 and float(bs[:n1].abs().max()) > 0.0
+    parts = []
+    for a, b, c in P.rows_split_segments(spec, 3):
+        w, bsp = P.rows_stream(spec, w1, b1, w2, b2, form=1, bias_in_k=True, seg_range=(a, b))
+        w = w.reshape(-1, tile)
+        assert w.shape[0] == n1 + c and torch.equal(w[:n1], whole[:n1]) and torch.equal(bsp[:n1], bs[:n1])
+        parts.append(w[n1:])
+    assert torch.equal(torch.cat(parts), whole[n1:])
+    # the constant-1 column of fc.0: position DDP_ROWS16_POS of h column `hid` inside its tile carries the bias word 1 x ROWS_SW ROWS_SX
+    t_, j_ = hid // 32, hid % 32
+    pos = 16 * ((j_ & 7) >> 2) + 4 * (j_ >> 3) + (j_ & 3)
+    assert float(bs[t_, pos]) == P.ROWS_SW * P.ROWS_SX
