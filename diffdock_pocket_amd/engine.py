@@ -951,6 +951,9 @@ class ForwardEngine:
             """The direct convs (receptor<-atom: one edge per atom, nothing to factorise): no stage A."""
             l, spec = P.l, P.spec
             tasks, nb_d = [], 0.0
+            # (the launch holds at most DDP_MAX_TASKS tasks: several direct convs in it - factorize_min_degree = 0 - share them)
+            n_direct = sum(1 for k, (csr, so_k, x_src) in P.per.items() if not (so_k is not None or (k == 3 and P.c1 is not None)) and csr.n_edges > 0)
+            split_cap = max(1, L.DDP_MAX_TASKS // max(1, n_direct))
             for k, (csr, so_k, x_src) in P.per.items():
                 if so_k is not None or (k == 3 and P.c1 is not None):
                     continue
@@ -967,7 +970,7 @@ class ForwardEngine:
                 # one conv as several tasks of segment ranges where its 128-edge workgroups would leave most of the chip empty (measured: 44
                 # workgroups of 340 tiles - the 5-sample shard - 0.36 -> 0.155 ms per launch as six ranges; 347 workgroups - 40 samples - gain
                 # nothing from two ranges, profiles/r06_direct_rows_ab.txt): ceil(256 / workgroups) ranges, at most direct_rows_max_split
-                nsplit = max(1, min(m.direct_rows_max_split, -(-256 // max(1, -(-csr.n_edges // 128)))))
+                nsplit = max(1, min(m.direct_rows_max_split, split_cap, -(-256 // max(1, -(-csr.n_edges // 128)))))
                 pkr = m.conv_layers[9 * l + k].packed_rows_direct(dev, nsplit) if nsplit > 1 else m.conv_layers[9 * l + k].packed_rows_direct(dev)
                 if pkr is not None and all(K.rows_mode(p_) for p_ in (pkr if nsplit > 1 else [pkr])):
                     for i_, p_ in enumerate(pkr if nsplit > 1 else [pkr]):
