@@ -627,7 +627,7 @@ def main(argv=None):
         line = {"metric": "ligand poses/sec (40 samples x 20 steps) on 3dpf", "value": poses / elapsed, "unit": "poses/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                 "higher_is_better": True, "scaling": scaling if world > 1 else None, "vs_baseline": None,
-                "dtype": "f32 (fc and G products: fp16 hi/lo split of both operands on v_mfma_f32_16x16x32_f16 - the row-stationary conv kernel - and v_mfma_f32_32x32x16_f16, fp32 accumulate; the exact fp32 MFMA form is timed in other_workloads)", "data": "synthetic",
+                "dtype": "f32 (fc and G products: fp16 hi/lo split of both operands on v_mfma_f32_16x16x32_f16 - the row-stationary conv kernel - and v_mfma_f32_32x32x16_f16, fp32 accumulate; G between its two kernels as fp16 hi + continuation byte = 19 significant bits; the exact fp32 MFMA form is timed in other_workloads)", "data": "synthetic",
                 "config": {"workload": f"3dpf ({sampler.n_l} lig atoms, 139 residues, {sampler.n_a} pocket atoms), "
                                        f"{n_total} samples over {world} GPU(s) ({n_local} on rank 0) x 20-step schedule, score model "
                                        f"{args.cfg} (ns={kw['ns']} nv={kw['nv']} L={kw['num_conv_layers']}), "

@@ -157,14 +157,14 @@ typedef struct {
   const void* wsh;
   const float* bsp;
   const void* gh[2];
-  /* Plane form of gh (ABI 16; all tasks of a launch carry the same):
+  /* Plane form of gh (ABI 16, form 1 redefined in ABI 17; all tasks of a launch carry the same):
    *  0  as above - hi and lo words of a column side by side, 32 bytes per 8 values, DDP_GH_LD floats per node;
    *  1  "fp16 + a continuation byte" (ABI 17): the unit (k8, c) of a part's tile is 24 bytes - 8 fp16 hi words, then 8 bytes - with
    *     V = hi + sign(hi) 2^E(hi) u8 / 2^18: hi = V rounded to 19 significant bits and TRUNCATED to fp16, u8 = the next 8 mantissa bits
    *     (19 significant bits, |err| <= 2^-19 |V| for |V| >= 2^-14; below, hi alone: absolute 2^-24); the units of a part [k8][c < wp] one
    *     after the other, the parts one after the other (unit g of the row at byte 24 g), then Gb per padded column c of the slot as fp32 at
    *     byte 24 (units + c / 6) + 4 (c % 6), padding to whole 384-byte pieces: DDP_GH3_LD floats per node.  Written by ddp_stage_a_gh3,
-   *     read by rows_form 1 only.  (ABI 16 had an e4m3 byte there: 15 - 16 bits, 2.4e-4 on the scores - outside the path's 1e-4,
+   *     read by both forms of the rows kernel.  (ABI 16 had an e4m3 byte there: 15 - 16 bits, 2.4e-4 on the scores - outside the path's 1e-4,
    *     profiles/r06_g3byte_parity.txt; the 19-bit form: 3.5e-6, profiles/r06_g19bit_precision.txt.) */
   int32_t gh_fmt;
   /* Operand images of wsh / gh / the kernel's h (ABI 16; all tasks of a launch carry the same):
@@ -174,7 +174,7 @@ typedef struct {
    *     [plane], each [k group g < 4][column n < 16][8 halves] = plane(W)[column 16 ct + n][k = 32 s + 8 g + i]; the k order of the fc.3 tiles and
    *     of gh is the NATURAL one (gh: the same bytes per node as form 0, k8 group = k / 8), and fc.0's OUTPUT columns are placed inside every
    *     32-column stream tile t so that the transposed fc1 product leaves h in that k order: h column 32 t + 8 g + i sits at position
-   *     16 (i / 4) + 4 g + i % 4 of the tile (DDP_ROWS16_POS; bias words in position order).  gh_fmt 0 or 1 (form 0: gh_fmt 0 only). */
+   *     16 (i / 4) + 4 g + i % 4 of the tile (DDP_ROWS16_POS; bias words in position order).  gh_fmt 0 or 1 in either form. */
   int32_t rows_form;
   /* ABI 17, rows_form 1 only.  1: the bias words of the fc.3 stream tiles ride in the tiles themselves - k row `hid` of every fc.3 tile holds the
    * tile's bias, fc.0's output column `hid` is the constant 1 (zero weights, bias word 1 at the tile's scale: h[hid] = relu(1)), bsp rows of the
