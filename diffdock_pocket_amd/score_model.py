@@ -529,7 +529,8 @@ class TensorProductScoreModel(nn.Module):
         self.split_rows_launch = True
         self.shape_early_rows = False           # the early launch at ONE workgroup per CU beside stage A of the atom rows (measured: off)
         self.split_rows_min_g_bytes = 3.0e9     # ... where stage A of the atom rows writes at least this much (engine._layers): 4.7 GB at
-        # 40 samples of cfg2; at 20 samples (2.4 GB) the second launch cost 0.1 - 0.2 of 9.2 ms, on the README's small model (1.4 GB) 0.3 of 3.2
+        # 40 samples of cfg2 (3.6 GB in the 3-byte plane form); at 20 samples (2.4 GB; 1.8) the second launch cost 0.1 - 0.2 of 9.2 ms, on the
+        # README's small model (1.4 GB) 0.3 of 3.2
         # The front's independent chains side by side (parallel branches of the captured step; same kernels, same arguments, same bits):
         # [node encoders -> edge embeddings] beside [neighbour searches -> CSR / source-ordered views], and - rigid receptor - the index
         # lists of the work eliminations (first read by layer 1) beside stage A + the 32-edge conv launch of layer 0 (engine._front,
