@@ -621,6 +621,33 @@ def test_forward_direct_path_matches_too(name):
         assert rel_err(g.float().cpu(), gold["outputs"][k]) < TOL, (name, k)
 
 
+@pytest.mark.parametrize("name", ["cfg2_small", "cfg2_full_noflex"])
+def test_direct_convs_as_tasks_of_segment_ranges_change_no_bit(name):
+    """model.direct_rows: the layers' direct convs through ddp_conv_rows16_direct_kernel; model.direct_rows_max_split = n: each of them as up
+    to n tasks of output-segment ranges (ddp_conv_task_t::rows_seg0 / rows_seg1 / rows_nts, a weight stream per range).  Every output column
+    is computed by exactly one task from the same tiles in the same order, so the scores of n = 2, 3, 6 are those of n = 1 BIT FOR BIT; and
+    against ddp_conv_messages (direct_rows off: 2048-scaled planes, 64-edge workgroups) within the path's tolerance of the golden outputs."""
+    case, gold, batch, sd = case_inputs(name)
+    dev = _dev()
+    outs = {}
+    for n in (1, 2, 3, 6):
+        model = _model_for(case, sd)
+        assert model.direct_rows and model.rows_mfma16
+        model.direct_rows_max_split = n
+        outs[n] = [t.clone() for t in model(case.make_batch().to(dev))]
+        for g, k in zip(outs[n], ("tr", "rot", "tor", "sc_tor")):
+            if gold["outputs"][k].numel():
+                assert rel_err(g.float().cpu(), gold["outputs"][k]) < TOL, (name, n, k)
+    for n in (2, 3, 6):
+        assert all(torch.equal(a, b) for a, b in zip(outs[1], outs[n])), (name, n)
+    model = _model_for(case, sd)
+    model.direct_rows = False
+    off = model(case.make_batch().to(dev))
+    for g, k in zip(off, ("tr", "rot", "tor", "sc_tor")):
+        if gold["outputs"][k].numel():
+            assert rel_err(g.float().cpu(), gold["outputs"][k]) < TOL, (name, "direct_rows off", k)
+
+
 def test_forward_is_deterministic():
     case, gold, batch, sd = case_inputs("cfg1_full")
     model = _model_for(case, sd)
