@@ -169,6 +169,11 @@ class TensorProductConvLayer(nn.Module):
         self._packed: Optional[_PackedConv] = None
         self._packed_g: Optional[_PackedConv] = None
         self._packed_d = None           # (packed(), its copy with the direct conv's weight stream): packed_rows_direct
+        # which forms of the row-stationary kernel a layer runs through: a model sets these on its layers (rows_mfma16, g_planes3,
+        # direct_rows); a stand-alone layer takes the same defaults
+        self.rows_form = 1 if os.environ.get("DDP_ROWS_MFMA16", ROWS_MFMA16_DEFAULT) == "1" else 0
+        self.gh_fmt = 1 if os.environ.get("DDP_G_PLANES3", G_PLANES3_DEFAULT) == "1" else 0
+        self.direct_rows = os.environ.get("DDP_DIRECT_ROWS", DIRECT_ROWS_DEFAULT) == "1"
 
     def packed_g(self, device) -> _PackedConv:
         """Weights for the factorised path: fc.3 tiles of the vector-input features only + the GEMM right-hand sides
